@@ -1,0 +1,99 @@
+"""ctypes binding of libspk_hip.so (C ABI: include/spk.h).
+
+There is deliberately NO fallback: if the library is missing or a tensor is not on a HIP device
+the call raises.  PyTorch is used only for device memory and streams.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import threading
+
+import torch
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(HERE, "libspk_hip.so")
+
+# epilogue flags (include/spk.h)
+EPI_BIAS, EPI_NOISE, EPI_LRELU, EPI_STYLE, CONV_UPSAMPLE2X, EPI_ACCUM = 1, 2, 4, 8, 16, 32
+
+c_float_p = C.c_void_p  # device pointers travel as integers
+
+
+class Conv3x3Desc(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("w_packed", C.c_void_p), ("bias", C.c_void_p), ("noise_w", C.c_void_p),
+                ("noise", C.c_void_p), ("style", C.c_void_p), ("y", C.c_void_p),
+                ("B", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("style_stride", C.c_int32), ("flags", C.c_uint32), ("lrelu_slope", C.c_float),
+                ("in_scale", C.c_float), ("config", C.c_int32)]
+
+
+_PROTOTYPES = {
+    "spk_version": (C.c_char_p, []),
+    "spk_last_error": (C.c_char_p, []),
+    "spk_conv3x3_num_configs": (C.c_int, []),
+    "spk_conv3x3_pick_config": (C.c_int, [C.c_int] * 5),
+    "spk_conv3x3_config_info": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "spk_conv3x3_packed_floats": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
+    "spk_conv3x3_pack_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "spk_conv3x3_fwd": (C.c_int, [C.POINTER(Conv3x3Desc), C.c_void_p]),
+    "spk_fc_fwd": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
+                             C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    "spk_bias_noise_style_fwd": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                           C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "spk_conv1x1_small_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
+                                        C.c_int64, C.c_float, C.c_void_p]),
+    "spk_upsample2x_bilinear_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
+}
+
+_lib = None
+_lock = threading.Lock()
+
+
+class SpkError(RuntimeError):
+    pass
+
+
+def exported_symbols():
+    """Names every entry point include/spk.h declares (used by the CPU-side ABI test)."""
+    return sorted(_PROTOTYPES)
+
+
+def lib():
+    """Load (once) and return the ctypes handle; raises if the HIP library has not been built."""
+    global _lib
+    if _lib is None:
+        with _lock:
+            if _lib is None:
+                if not os.path.exists(LIB_PATH):
+                    raise SpkError(f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; "
+                                   f"g.build()'` (hipcc --offload-arch=gfx950). There is no CPU fallback.")
+                h = C.CDLL(LIB_PATH)
+                for name, (res, args) in _PROTOTYPES.items():
+                    fn = getattr(h, name)
+                    fn.restype = res
+                    fn.argtypes = args
+                _lib = h
+    return _lib
+
+
+def check(code: int, what: str):
+    if code != 0:
+        raise SpkError(f"{what} failed ({code}): {lib().spk_last_error().decode()}")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dptr(t, name="tensor"):
+    """Device pointer of a contiguous fp32 HIP tensor (None -> NULL)."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise SpkError(f"{name}: expected a HIP device tensor, got {t.device} -- speak-hack_amd has no CPU path")
+    if t.dtype != torch.float32:
+        raise SpkError(f"{name}: expected float32, got {t.dtype}")
+    if not t.is_contiguous():
+        raise SpkError(f"{name}: expected a contiguous tensor")
+    return t.data_ptr()

@@ -1,0 +1,159 @@
+// HBM-bound streaming kernels around the conv core: decoder prologue, toRGB 1x1, stand-alone
+// bilinear x2.  All are one pass over the data with 16-byte per-lane accesses where the shape
+// allows.  See include/spk.h for the reference call sites each replaces.
+#include "spk_common.hpp"
+
+#include <algorithm>
+
+namespace {
+
+// y[b,c,p] = (x[b*xbs + c*HW + p] + bias[c] + noise_w[c]*noise[b,p]) * (s0[b,c]+1) + s1[b,c]
+__global__ __launch_bounds__(256) void bias_noise_style_kernel(const float* __restrict__ cin, long long xbs,
+                                                              const float* __restrict__ bias,
+                                                            const float* __restrict__ nw, const float* __restrict__ noise,
+                                                            const float* __restrict__ style, long long style_stride,
+                                                            float* __restrict__ y, int B, int C, int HW) {
+    const long long total = (long long)B * C * HW;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int p = (int)(idx % HW);
+        const int c = (int)((idx / HW) % C);
+        const int b = (int)(idx / ((long long)HW * C));
+        float v = cin[(size_t)b * xbs + (size_t)c * HW + p];
+        if (bias) v += bias[c];
+        if (noise) v += nw[c] * noise[(size_t)b * HW + p];
+        if (style) {
+            const float* st = style + (size_t)b * style_stride;
+            v = v * (st[c] + 1.f) + st[C + c];
+        }
+        y[idx] = v;
+    }
+}
+
+// 1x1 conv with O <= 4 outputs.  VEC: each thread owns 4 consecutive pixels.
+template <bool VEC>
+__global__ __launch_bounds__(256) void conv1x1_small_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                           const float* __restrict__ bias, float* __restrict__ y, int C,
+                                                           int O, long long HW, float in_scale) {
+    extern __shared__ float w_s[];  // [O][C]
+    for (int i = threadIdx.x; i < O * C; i += blockDim.x) w_s[i] = w[i] * in_scale;
+    __syncthreads();
+    const int b = blockIdx.y;
+    const float* xb = x + (size_t)b * C * HW;
+    float* yb = y + (size_t)b * O * HW;
+    if (VEC) {
+        const long long n4 = HW / 4;
+        for (long long p4 = (long long)blockIdx.x * blockDim.x + threadIdx.x; p4 < n4;
+             p4 += (long long)gridDim.x * blockDim.x) {
+            float4 acc[4];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                const float bo = (bias && o < O) ? bias[o] : 0.f;
+                acc[o] = make_float4(bo, bo, bo, bo);
+            }
+#pragma unroll 8
+            for (int c = 0; c < C; ++c) {
+                const float4 xv = reinterpret_cast<const float4*>(xb + (size_t)c * HW)[p4];
+#pragma unroll
+                for (int o = 0; o < 4; ++o) {
+                    if (o < O) {
+                        const float wv = w_s[o * C + c];
+                        acc[o].x += wv * xv.x; acc[o].y += wv * xv.y; acc[o].z += wv * xv.z; acc[o].w += wv * xv.w;
+                    }
+                }
+            }
+#pragma unroll
+            for (int o = 0; o < 4; ++o)
+                if (o < O) reinterpret_cast<float4*>(yb + (size_t)o * HW)[p4] = acc[o];
+        }
+    } else {
+        for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < HW;
+             p += (long long)gridDim.x * blockDim.x) {
+            float acc[4];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) acc[o] = (bias && o < O) ? bias[o] : 0.f;
+            for (int c = 0; c < C; ++c) {
+                const float xv = xb[(size_t)c * HW + p];
+#pragma unroll
+                for (int o = 0; o < 4; ++o)
+                    if (o < O) acc[o] += w_s[o * C + c] * xv;
+            }
+#pragma unroll
+            for (int o = 0; o < 4; ++o)
+                if (o < O) yb[(size_t)o * HW + p] = acc[o];
+        }
+    }
+}
+
+// bilinear x2, align_corners=False (torch area_pixel_compute_source_index with scale 0.5)
+__global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                        long long planes, int Hin, int Win) {
+    const int Ho = 2 * Hin, Wo = 2 * Win;
+    const long long total = planes * Ho * Wo;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
+         idx += (long long)gridDim.x * blockDim.x) {
+        const int ux = (int)(idx % Wo);
+        const int uy = (int)((idx / Wo) % Ho);
+        const long long pl = idx / ((long long)Wo * Ho);
+        const float sy = fmaxf(0.5f * (uy + 0.5f) - 0.5f, 0.f), sx = fmaxf(0.5f * (ux + 0.5f) - 0.5f, 0.f);
+        const int iy0 = (int)sy, ix0 = (int)sx;
+        const int iy1 = min(iy0 + 1, Hin - 1), ix1 = min(ix0 + 1, Win - 1);
+        const float ly1 = sy - iy0, lx1 = sx - ix0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+        const float* s = x + (size_t)pl * Hin * Win;
+        y[idx] = ly0 * (lx0 * s[iy0 * Win + ix0] + lx1 * s[iy0 * Win + ix1]) +
+                 ly1 * (lx0 * s[iy1 * Win + ix0] + lx1 * s[iy1 * Win + ix1]);
+    }
+}
+
+inline unsigned stream_grid(long long work_items, int threads) {
+    const long long blocks = (work_items + threads - 1) / threads;
+    return (unsigned)std::max(1ll, std::min(blocks, 256ll * 8));
+}
+
+}  // namespace
+
+extern "C" {
+
+int spk_bias_noise_style_fwd(const float* x, int64_t x_batch_stride, const float* bias, const float* noise_w,
+                             const float* noise, const float* style, int64_t style_stride, float* y, int B, int C,
+                             int HW, void* stream) {
+    SPK_REQUIRE(x && y, "bias_noise_style: null pointer");
+    SPK_REQUIRE(B > 0 && C > 0 && HW > 0, "bias_noise_style: bad shape");
+    SPK_REQUIRE(!noise || noise_w, "bias_noise_style: noise without noise_w");
+    hipLaunchKernelGGL(bias_noise_style_kernel, dim3(stream_grid((long long)B * C * HW, 256)), dim3(256), 0,
+                       (hipStream_t)stream, x, (long long)x_batch_stride, bias, noise_w, noise, style,
+                       (long long)style_stride, y, B, C, HW);
+    return spk::check_launch("bias_noise_style_kernel");
+}
+
+int spk_conv1x1_small_fwd(const float* x, const float* w, const float* bias, float* y, int B, int C, int O, int64_t HW,
+                          float in_scale, void* stream) {
+    SPK_REQUIRE(x && w && y, "conv1x1_small: null pointer");
+    SPK_REQUIRE(B > 0 && C > 0 && O > 0 && O <= 4 && HW > 0, "conv1x1_small: bad shape (O must be <= 4)");
+    SPK_REQUIRE((size_t)O * C * sizeof(float) <= 48 * 1024, "conv1x1_small: weight too large for LDS");
+    const bool vec = (HW % 4 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0);
+    const size_t lds = (size_t)O * C * sizeof(float);
+    if (vec) {
+        dim3 grid(stream_grid(HW / 4, 256), (unsigned)B);
+        hipLaunchKernelGGL(conv1x1_small_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, x, w, bias, y, C, O,
+                           (long long)HW, in_scale);
+    } else {
+        dim3 grid(stream_grid(HW, 256), (unsigned)B);
+        hipLaunchKernelGGL(conv1x1_small_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, x, w, bias, y, C, O,
+                           (long long)HW, in_scale);
+    }
+    return spk::check_launch("conv1x1_small_kernel");
+}
+
+int spk_upsample2x_bilinear_fwd(const float* x, float* y, int64_t planes, int Hin, int Win, void* stream) {
+    SPK_REQUIRE(x && y, "upsample2x: null pointer");
+    SPK_REQUIRE(planes > 0 && Hin > 0 && Win > 0, "upsample2x: bad shape");
+    hipLaunchKernelGGL(upsample2x_kernel, dim3(stream_grid(planes * 4ll * Hin * Win, 256)), dim3(256), 0,
+                       (hipStream_t)stream, x, y, (long long)planes, Hin, Win);
+    return spk::check_launch("upsample2x_kernel");
+}
+
+const char* spk_version(void) { return "spk-hip 0.1 (gfx950)"; }
+const char* spk_last_error(void) { return spk::err_buf(); }
+
+}  // extern "C"

@@ -1,0 +1,192 @@
+"""Host-side mirror of the reference's live decoder (``styleganv1.py:448-635``): same class names,
+constructor arguments, ``forward`` signatures and ``state_dict`` keys, but every forward runs on the
+HIP kernels of libspk_hip.so.  The reference's per-op chain
+
+    up -> conv3x3 -> +bias -> +noise -> lrelu -> *(s0+1)+s1          (styleganv1.py:624-633)
+
+is ONE kernel launch per half-block here (ops.conv3x3_fused); the 13 style affines and the mapping
+stack run on the weight-streaming FC kernel.
+
+Differences a caller can observe, all opt-in or device-side only:
+  * every ``forward`` that draws noise accepts an optional explicit ``noise``/``noises`` argument
+    (the reference draws ``torch.randn`` inside ``ApplyNoise.forward``, styleganv1.py:454-455);
+    without it noise is drawn on the device exactly as the reference does;
+  * no DEBUG f-string logging on the hot path (the reference formats ~20 strings per forward).
+There is no CPU path: a CPU tensor raises (``_lib.SpkError``).
+"""
+from __future__ import annotations
+
+import logging
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+LRELU = 0.2
+
+
+class FC(nn.Module):
+    """``FC`` (styleganv1.py:471-495): y = lrelu_0.2(x @ (W*w_lrmul)^T + b*b_lrmul)."""
+
+    def __init__(self, in_channels, out_channels, gain=2 ** 0.5, use_wscale=False, lrmul=1.0, bias=True):
+        super().__init__()
+        he_std = gain * in_channels ** (-0.5)
+        if use_wscale:
+            init_std, self.w_lrmul = 1.0 / lrmul, he_std * lrmul
+        else:
+            init_std, self.w_lrmul = he_std / lrmul, lrmul
+        self.weight = nn.Parameter(torch.randn(out_channels, in_channels) * init_std)
+        if bias:
+            self.bias = nn.Parameter(torch.zeros(out_channels))
+            self.b_lrmul = lrmul
+        else:
+            self.bias = None
+            self.b_lrmul = 1.0
+
+    def forward(self, x):
+        lead = x.shape[:-1]
+        y = ops.fc(x.reshape(-1, x.shape[-1]), self.weight, self.bias, self.w_lrmul, self.b_lrmul, LRELU)
+        return y.view(*lead, -1)
+
+
+class ApplyNoise(nn.Module):
+    """``ApplyNoise`` (styleganv1.py:448-456).  Stand-alone use only; inside the network the noise
+    add is part of the conv epilogue."""
+
+    def __init__(self, channels):
+        super().__init__()
+        self.weight = nn.Parameter(torch.zeros(channels))
+
+    def forward(self, x, noise):
+        if noise is None:
+            noise = torch.randn(x.size(0), 1, x.size(2), x.size(3), device=x.device, dtype=x.dtype)
+        return ops.bias_noise_style(x.contiguous(), x.size(0), noise_w=self.weight,
+                                    noise=noise.to(x.device).contiguous())
+
+
+class ApplyStyle(nn.Module):
+    """``ApplyStyle`` (styleganv1.py:458-468): x*(s0+1)+s1 with [s0|s1] = FC_gain1(latent)."""
+
+    def __init__(self, latent_size, channels, use_wscale):
+        super().__init__()
+        self.linear = FC(latent_size, channels * 2, gain=1.0, use_wscale=use_wscale)
+
+    def style(self, latent):
+        return self.linear(latent)
+
+    def forward(self, x, latent):
+        return ops.bias_noise_style(x.contiguous(), x.size(0), style=self.style(latent))
+
+
+class SynthesisBlock(nn.Module):
+    """``SynthesisBlock`` (styleganv1.py:612-635): two fused launches."""
+
+    def __init__(self, in_channels, out_channels, resolution):
+        super().__init__()
+        self.conv1 = nn.Conv2d(in_channels, out_channels, kernel_size=3, padding=1)
+        self.conv2 = nn.Conv2d(out_channels, out_channels, kernel_size=3, padding=1)
+        self.noise1 = ApplyNoise(out_channels)
+        self.noise2 = ApplyNoise(out_channels)
+        self.style_mod1 = ApplyStyle(512, out_channels, use_wscale=True)
+        self.style_mod2 = ApplyStyle(512, out_channels, use_wscale=True)
+        self.upsample = nn.Upsample(scale_factor=2, mode="bilinear", align_corners=False)
+        self.out_channels = out_channels
+        self._pk1, self._pk2 = ops.PackedConvWeight(), ops.PackedConvWeight()
+
+    def _half(self, x, conv, pk, noise_mod, noise, style, upsample):
+        B, Cin, Hs, Ws = x.shape
+        H, W = (2 * Hs, 2 * Ws) if upsample else (Hs, Ws)
+        if noise is None:
+            noise = torch.randn(B, 1, H, W, device=x.device, dtype=torch.float32)
+        cfg = ops.conv3x3_pick_config(B, Cin, self.out_channels, H, W)
+        return ops.conv3x3_fused(x, pk.get(conv.weight, cfg), self.out_channels, bias=conv.bias,
+                                 noise_w=noise_mod.weight, noise=noise, style=style, upsample=upsample,
+                                 lrelu_slope=LRELU, config=cfg)
+
+    def forward(self, x, w, noise1=None, noise2=None, styles=None):
+        """``w`` is [B,2,512].  ``styles`` (optional) = precomputed ([B,2C],[B,2C]) affine outputs."""
+        if styles is None:
+            styles = (self.style_mod1.style(w[:, 0]), self.style_mod2.style(w[:, 1]))
+        x = self._half(x.contiguous(), self.conv1, self._pk1, self.noise1, noise1, styles[0], True)
+        x = self._half(x, self.conv2, self._pk2, self.noise2, noise2, styles[1], False)
+        return x
+
+
+class SynthesisNetwork(nn.Module):
+    """``SynthesisNetwork`` (styleganv1.py:569-610)."""
+
+    def __init__(self, resolution=256, fmap_base=8192, fmap_max=512):
+        super().__init__()
+        self.resolution_log2 = int(math.log2(resolution))
+        self.num_layers = self.resolution_log2 * 2 - 2
+
+        def nf(stage):
+            return min(int(fmap_base / (2.0 ** stage)), fmap_max)
+
+        self.const_input = nn.Parameter(torch.ones(1, nf(1), 4, 4))
+        self.bias = nn.Parameter(torch.zeros(nf(1)))
+        self.style_mod = ApplyStyle(512, nf(1), use_wscale=True)
+        self.noise_input1 = ApplyNoise(nf(1))
+        self.layers = nn.ModuleList(
+            SynthesisBlock(nf(res - 2), nf(res - 1), res) for res in range(3, self.resolution_log2 + 1))
+        self.to_rgb = nn.Conv2d(nf(self.resolution_log2 - 1), 3, kernel_size=1)
+        self.logger = logging.getLogger(__name__)
+
+    def noise_shapes(self, batch):
+        shapes = [(batch, 1, 4, 4)]
+        for i in range(len(self.layers)):
+            s = 8 << i
+            shapes += [(batch, 1, s, s)] * 2
+        return shapes
+
+    def forward(self, w, noises=None):
+        """``w``: [B, num_layers, 512]; ``noises``: optional list of the 2*len(layers)+1 noise
+        tensors in call order (drawn on the device when omitted, as the reference does)."""
+        B = w.size(0)
+        w = w.contiguous()
+        if noises is None:
+            noises = [torch.randn(s, device=w.device, dtype=torch.float32) for s in self.noise_shapes(B)]
+        elif len(noises) != 2 * len(self.layers) + 1:
+            raise ValueError(f"expected {2 * len(self.layers) + 1} noise tensors, got {len(noises)}")
+        x = ops.const_prologue(self.const_input, self.bias, self.noise_input1.weight, noises[0],
+                               self.style_mod.style(w[:, 0]), B)
+        for i, layer in enumerate(self.layers):
+            x = layer(x, w[:, 2 * i + 1:2 * i + 3], noises[1 + 2 * i], noises[2 + 2 * i])
+        return ops.conv1x1_small(x, self.to_rgb.weight, self.to_rgb.bias)
+
+
+class StyleGenerator(nn.Module):
+    """``StyleGenerator`` (styleganv1.py:497-567): mapping -> broadcast -> truncation (a plain
+    scale of rows [:cutoff], :540-543) -> train-only style mixing (:547-554) -> synthesis."""
+
+    def __init__(self, input_dim=6144, latent_dim=512, mapping_layers=8, style_mixing_prob=0.9,
+                 truncation_psi=0.7, truncation_cutoff=8):
+        super().__init__()
+        self.input_dim = input_dim
+        self.latent_dim = latent_dim
+        self.style_mixing_prob = style_mixing_prob
+        self.truncation_psi = truncation_psi
+        self.truncation_cutoff = truncation_cutoff
+        self.mapping = nn.Sequential(*[FC(input_dim if i == 0 else latent_dim, latent_dim, lrmul=0.01, use_wscale=True)
+                                       for i in range(mapping_layers)])
+        self.synthesis = SynthesisNetwork()
+        self.bn = None
+        self.logger = logging.getLogger(__name__)
+
+    def forward(self, features, noises=None):
+        L = self.synthesis.num_layers
+        w = self.mapping(features).unsqueeze(1).repeat(1, L, 1)
+        if self.truncation_psi and self.truncation_cutoff:
+            coefs = torch.ones_like(w)
+            coefs[:, :self.truncation_cutoff] *= self.truncation_psi
+            w = coefs * w
+        if self.training and self.style_mixing_prob > 0:
+            # host RNG draws in the reference's order: rand(1), randn_like(features), randint
+            if torch.rand(1) < self.style_mixing_prob:
+                with torch.no_grad():
+                    w2 = self.mapping(torch.randn_like(features)).unsqueeze(1).repeat(1, L, 1)
+                    mix_layer = torch.randint(1, w.size(1), (1,)).item()
+                    w[:, mix_layer:] = w2[:, mix_layer:]
+        return self.synthesis(w, noises)

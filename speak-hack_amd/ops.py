@@ -1,0 +1,167 @@
+"""Thin Python launchers over the C ABI (include/spk.h).  Forward primitives; every output buffer is
+a torch allocation (caching allocator, so no hipMalloc in steady state) and every launch goes on
+torch's current HIP stream.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+# --------------------------------------------------------------------------------------------------
+class PackedConvWeight:
+    """A [Cout,Cin,3,3] weight re-laid for one tile config of the MFMA conv kernel
+    ([co_tile][ci_chunk][tap][ci][co], zero padded).  Re-packed when the source parameter changes
+    (its autograd version counter / storage pointer), e.g. after an optimizer step."""
+
+    def __init__(self):
+        self._cache = {}
+
+    def get(self, weight: torch.Tensor, config: int, transpose_flip: bool = False) -> torch.Tensor:
+        key = (config, transpose_flip)
+        stamp = (weight.data_ptr(), weight._version, tuple(weight.shape))
+        hit = self._cache.get(key)
+        if hit is not None and hit[0] == stamp:
+            return hit[1]
+        packed = pack_conv3x3_weight(weight.detach(), config, transpose_flip)
+        self._cache[key] = (stamp, packed)
+        return packed
+
+    def clear(self):
+        self._cache.clear()
+
+
+def conv3x3_pick_config(B, Cin, Cout, H, W) -> int:
+    return L.lib().spk_conv3x3_pick_config(B, Cin, Cout, H, W)
+
+
+def conv3x3_config_info(config: int):
+    co, ci, px = C.c_int(), C.c_int(), C.c_int()
+    L.check(L.lib().spk_conv3x3_config_info(config, C.byref(co), C.byref(ci), C.byref(px)), "spk_conv3x3_config_info")
+    return co.value, ci.value, px.value
+
+
+def pack_conv3x3_weight(weight: torch.Tensor, config: int, transpose_flip: bool = False) -> torch.Tensor:
+    Cout, Cin, kh, kw = weight.shape
+    if (kh, kw) != (3, 3):
+        raise L.SpkError(f"pack_conv3x3_weight: expected a 3x3 kernel, got {kh}x{kw}")
+    n = L.lib().spk_conv3x3_packed_floats(config, Cout if transpose_flip else Cin, Cin if transpose_flip else Cout)
+    if n <= 0:
+        raise L.SpkError("spk_conv3x3_packed_floats: bad arguments")
+    out = torch.empty(n, device=weight.device, dtype=torch.float32)
+    L.check(L.lib().spk_conv3x3_pack_weights(L.dptr(weight.contiguous(), "weight"), L.dptr(out), Cin, Cout, config,
+                                             1 if transpose_flip else 0, L.stream_ptr()), "spk_conv3x3_pack_weights")
+    return out
+
+
+def conv3x3_fused(x, w_packed, Cout: int, *, bias=None, noise_w=None, noise=None, style=None, style_stride=None,
+                  upsample=False, lrelu_slope=None, in_scale=1.0, config=-1, out=None, accumulate=False):
+    """y = style(lrelu(conv3x3(up?(x)) * in_scale + bias + noise_w*noise)) -- one launch.
+
+    ``style`` is a tensor whose row ``b`` (stride ``style_stride`` floats, default its row length)
+    holds [s0(Cout) | s1(Cout)].  ``upsample``: x is [B,Cin,H/2,W/2] and is bilinearly upsampled x2
+    on the fly.  Stages whose operands are None are skipped.
+    """
+    B, Cin, Hs, Ws = x.shape
+    H, W = (2 * Hs, 2 * Ws) if upsample else (Hs, Ws)
+    if out is None:
+        out = torch.empty((B, Cout, H, W), device=x.device, dtype=torch.float32)
+    flags = 0
+    if bias is not None:
+        flags |= L.EPI_BIAS
+    if noise is not None:
+        if noise_w is None or noise.numel() != B * H * W:
+            raise L.SpkError(f"conv3x3_fused: noise must be [B,1,H,W]={B, 1, H, W}, got {tuple(noise.shape)}")
+        flags |= L.EPI_NOISE
+    if lrelu_slope is not None:
+        flags |= L.EPI_LRELU
+    if style is not None:
+        if style_stride is None:
+            style_stride = style.stride(0) if style.dim() == 2 else 2 * Cout
+        flags |= L.EPI_STYLE
+    if upsample:
+        flags |= L.CONV_UPSAMPLE2X
+    if accumulate:
+        flags |= L.EPI_ACCUM
+    d = L.Conv3x3Desc(x=L.dptr(x, "x"), w_packed=L.dptr(w_packed, "w_packed"), bias=L.dptr(bias, "bias"),
+                      noise_w=L.dptr(noise_w, "noise_w") if noise is not None else None,
+                      noise=L.dptr(noise, "noise"), style=_style_ptr(style), y=L.dptr(out, "out"),
+                      B=B, Cin=Cin, Cout=Cout, H=H, W=W, style_stride=int(style_stride or 0), flags=flags,
+                      lrelu_slope=float(lrelu_slope if lrelu_slope is not None else 1.0), in_scale=float(in_scale),
+                      config=int(config))
+    L.check(L.lib().spk_conv3x3_fwd(C.byref(d), L.stream_ptr()), "spk_conv3x3_fwd")
+    return out
+
+
+def _style_ptr(style):
+    """Style rows may be a strided view (a column block of the batched style buffer)."""
+    if style is None:
+        return None
+    if not style.is_cuda or style.dtype != torch.float32 or style.stride(-1) != 1:
+        raise L.SpkError("style: expected a float32 HIP tensor with unit inner stride")
+    return style.data_ptr()
+
+
+def fc(x, weight, bias=None, wmul=1.0, bmul=1.0, slope=1.0, out=None):
+    """out[b,o] = act(wmul * <x[b], weight[o]> + bmul*bias[o]); x may be a row-strided 2-D view."""
+    if x.dim() != 2 or x.stride(1) != 1:
+        raise L.SpkError("fc: x must be 2-D with unit inner stride")
+    B, I = x.shape
+    O = weight.shape[0]
+    if weight.shape[1] != I:
+        raise L.SpkError(f"fc: weight {tuple(weight.shape)} does not match input width {I}")
+    if out is None:
+        out = torch.empty((B, O), device=x.device, dtype=torch.float32)
+    if out.stride(1) != 1:
+        raise L.SpkError("fc: out must have unit inner stride")
+    if not x.is_cuda or x.dtype != torch.float32:
+        raise L.SpkError(f"fc: expected a float32 HIP tensor, got {x.dtype} on {x.device} (no CPU path)")
+    L.check(L.lib().spk_fc_fwd(x.data_ptr(), x.stride(0), L.dptr(weight, "weight"), L.dptr(bias, "bias"),
+                               out.data_ptr(), out.stride(0), B, I, O, float(wmul), float(bmul), float(slope),
+                               L.stream_ptr()), "spk_fc_fwd")
+    return out
+
+
+def bias_noise_style(x, B: int, bias=None, noise_w=None, noise=None, style=None):
+    """y = (x + bias + noise_w*noise) * (s0+1) + s1 -> [B,C,H,W]; x is [B,C,H,W] or a [1,C,H,W]
+    constant broadcast over the batch.  Any of bias / noise / style may be None."""
+    xb, Cc, H, W = x.shape
+    if xb not in (1, B):
+        raise L.SpkError(f"bias_noise_style: batch {xb} does not broadcast to {B}")
+    if noise is not None and noise.numel() != B * H * W:
+        raise L.SpkError(f"bias_noise_style: noise must be [B,1,H,W], got {tuple(noise.shape)}")
+    out = torch.empty((B, Cc, H, W), device=x.device, dtype=torch.float32)
+    L.check(L.lib().spk_bias_noise_style_fwd(L.dptr(x, "x"), 0 if xb == 1 and B > 1 else Cc * H * W,
+                                             L.dptr(bias, "bias"),
+                                             L.dptr(noise_w, "noise_w") if noise is not None else None,
+                                             L.dptr(noise, "noise"), _style_ptr(style),
+                                             style.stride(0) if style is not None else 0, L.dptr(out), B, Cc, H * W,
+                                             L.stream_ptr()), "spk_bias_noise_style_fwd")
+    return out
+
+
+def const_prologue(const_in, bias, noise_w, noise, style, B: int):
+    """styleganv1.py:596-599 in one launch."""
+    return bias_noise_style(const_in, B, bias, noise_w, noise, style)
+
+
+def conv1x1_small(x, weight, bias=None, in_scale=1.0):
+    """1x1 conv to <= 4 channels (toRGB)."""
+    B, Cc, H, W = x.shape
+    O = weight.shape[0]
+    out = torch.empty((B, O, H, W), device=x.device, dtype=torch.float32)
+    L.check(L.lib().spk_conv1x1_small_fwd(L.dptr(x, "x"), L.dptr(weight.reshape(O, Cc), "weight"), L.dptr(bias, "bias"),
+                                          L.dptr(out), B, Cc, O, H * W, float(in_scale), L.stream_ptr()),
+            "spk_conv1x1_small_fwd")
+    return out
+
+
+def upsample2x_bilinear(x):
+    B, Cc, H, W = x.shape
+    out = torch.empty((B, Cc, 2 * H, 2 * W), device=x.device, dtype=torch.float32)
+    L.check(L.lib().spk_upsample2x_bilinear_fwd(L.dptr(x, "x"), L.dptr(out), B * Cc, H, W, L.stream_ptr()),
+            "spk_upsample2x_bilinear_fwd")
+    return out

@@ -1,0 +1,89 @@
+"""CPU-side checks of the drop-in boundary: the C-ABI library builds for gfx950, loads, and
+exports every symbol include/spk.h declares (no compute calls -- there is no GPU here); the
+host-side module mirrors keep the reference's state_dict layout; CPU tensors are refused."""
+import ctypes
+import importlib
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    import __graft_entry__ as ge
+    ge.build()
+    return importlib.import_module("speak-hack_amd")
+
+
+def header_symbols():
+    src = open(os.path.join(ROOT, "include", "spk.h")).read()
+    src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+    return sorted(set(re.findall(r"\b(spk_[a-z0-9_]+)\s*\(", src)))
+
+
+def test_library_exports_every_declared_symbol(pkg):
+    lib = ctypes.CDLL(pkg._lib.LIB_PATH)
+    syms = header_symbols()
+    assert len(syms) >= 10
+    for s in syms:
+        assert hasattr(lib, s), f"{s} declared in include/spk.h but not exported"
+    assert sorted(pkg._lib.exported_symbols()) == syms, "ctypes prototypes out of sync with include/spk.h"
+    assert b"gfx950" in pkg._lib.lib().spk_version()
+
+
+def test_host_side_queries_and_argument_errors(pkg):
+    lib = pkg._lib.lib()
+    n = lib.spk_conv3x3_num_configs()
+    assert n >= 4
+    for cfg in range(n):
+        co, ci, px = pkg.ops.conv3x3_config_info(cfg)
+        assert co % 32 == 0 and px % 32 == 0 and ci % 2 == 0
+        # packed image is zero-padded up to whole tiles
+        assert lib.spk_conv3x3_packed_floats(cfg, 3, 5) == -(-5 // co) * -(-3 // ci) * 9 * ci * co
+    assert lib.spk_conv3x3_packed_floats(99, 3, 5) < 0
+    # error behaviour: negative code + message, never an exception/abort from C
+    assert lib.spk_conv3x3_fwd(None, None) < 0
+    assert b"null" in lib.spk_last_error()
+    assert lib.spk_fc_fwd(None, 0, None, None, None, 0, 1, 1, 1, 1.0, 1.0, 1.0, None) < 0
+
+
+def test_decoder_state_dict_layout_matches_reference(pkg):
+    """Key layout and shapes of SURVEY.md 8(b) (83 tensors, 26,076,867 parameters)."""
+    g = pkg.StyleGenerator(6144)
+    sd = g.state_dict()
+    assert len(sd) == 83
+    assert sum(p.numel() for p in g.parameters()) == 26076867
+    assert tuple(sd["mapping.0.weight"].shape) == (512, 6144)
+    assert tuple(sd["synthesis.const_input"].shape) == (1, 512, 4, 4)
+    assert tuple(sd["synthesis.style_mod.linear.weight"].shape) == (1024, 512)
+    assert tuple(sd["synthesis.layers.3.conv1.weight"].shape) == (256, 512, 3, 3)
+    assert tuple(sd["synthesis.layers.5.style_mod2.linear.bias"].shape) == (128,)
+    assert tuple(sd["synthesis.to_rgb.weight"].shape) == (3, 64, 1, 1)
+    assert g.input_dim == 6144 and g.synthesis.num_layers == 14
+    assert pkg.SynthesisNetwork(resolution=512).num_layers == 16
+    # the top-level drop-in module exposes the reference's names
+    import styleganv1
+    assert styleganv1.StyleGenerator is pkg.StyleGenerator
+
+
+def test_no_cpu_fallback(pkg):
+    g = pkg.StyleGenerator(6144).eval()
+    with pytest.raises(RuntimeError, match="HIP|device|CPU"):
+        with torch.no_grad():
+            g(torch.zeros(1, 6144))
+
+
+def test_product_path_never_imports_oracle():
+    """The shipped package must not reach into oracle/ (test infrastructure)."""
+    pk = os.path.join(ROOT, "speak-hack_amd")
+    for dirpath, _, files in os.walk(pk):
+        for f in files:
+            if f.endswith((".py", ".hip", ".hpp", ".h")):
+                text = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
+    for f in ("styleganv1.py",):
+        assert "oracle" not in open(os.path.join(ROOT, f)).read()

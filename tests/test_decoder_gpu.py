@@ -1,0 +1,201 @@
+"""GPU parity tests proper: the HIP path (through the C ABI) against the CPU oracle on the same
+seeded inputs, and against the committed golden vectors produced by the reference.
+
+Tolerance: the conv runs on the exact-fp32 MFMA pipe (an fmaf chain), so the only difference from
+the oracle is summation order: TOL = 2e-5 rel-L2 per op / block, 1e-4 end to end (13 stacked
+layers) -- the north-star bound is 1e-3.
+"""
+import importlib
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2
+from oracle import decoder_ref as R
+from oracle.weights_recipe import fill_state_dict, recipe_input, recipe_noises, recipe_tensor
+
+pytestmark = pytest.mark.gpu
+TOL_OP = 2e-5
+TOL_E2E = 1e-4
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    assert torch.cuda.is_available(), "gpu tests need a HIP device"
+    p = importlib.import_module("speak-hack_amd")
+    p._lib.lib()  # must load: no fallback
+    return p
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+def T(a):
+    return torch.from_numpy(np.asarray(a))
+
+
+# ------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [
+    (2, 16, 8, 12, 12),      # ragged: H,W not powers of two, Cout < tile, Cin = 2 chunks
+    (1, 3, 5, 7, 9),         # tiny odd everything, Cin < CI_T
+    (3, 24, 40, 8, 8),       # several images per pixel tile, batch not a multiple of TB
+    (2, 64, 64, 32, 32),
+    (1, 128, 64, 64, 64),
+    (2, 20, 130, 16, 40),    # Cout just over one 128-tile, non-square
+    (1, 8, 32, 4, 4),        # 4x4 (ProGAN initial conv)
+])
+@pytest.mark.parametrize("config", [-1, 0, 1, 2, 3])
+def test_conv3x3_plain_all_configs(pkg, dev, B, Cin, Cout, H, W, config):
+    x = recipe_input(f"cv.x.{B}.{Cin}.{H}.{W}", (B, Cin, H, W))
+    w = recipe_tensor(f"cv.{Cout}.{Cin}.weight", (Cout, Cin, 3, 3))
+    b = recipe_tensor(f"cv.{Cout}.bias", (Cout,))
+    ref = F.conv2d(x, w, b, padding=1)
+    cfg = config if config >= 0 else pkg.ops.conv3x3_pick_config(B, Cin, Cout, H, W)
+    wp = pkg.ops.pack_conv3x3_weight(w.to(dev), cfg)
+    y = pkg.ops.conv3x3_fused(x.to(dev), wp, Cout, bias=b.to(dev), config=cfg)
+    assert rel_l2(y, ref) < TOL_OP
+
+
+@pytest.mark.parametrize("B,Cin,Cout,Hs", [(2, 16, 8, 6), (1, 128, 64, 16), (3, 32, 96, 4), (1, 6, 6, 1), (2, 64, 32, 32)])
+def test_conv3x3_fused_upsample_epilogue(pkg, dev, B, Cin, Cout, Hs):
+    """up x2 -> conv -> bias -> noise -> lrelu -> style, one launch, vs the oracle's op chain."""
+    tag = f"cvf.{B}.{Cin}.{Cout}.{Hs}"
+    x = recipe_input(tag + ".x", (B, Cin, Hs, Hs))
+    w = recipe_tensor(tag + ".weight", (Cout, Cin, 3, 3))
+    b = recipe_tensor(tag + ".bias", (Cout,))
+    nw = recipe_tensor(tag + ".noise.weight", (Cout,))
+    nz = recipe_input(tag + ".nz", (B, 1, 2 * Hs, 2 * Hs))
+    st = recipe_input(tag + ".style", (B, 2 * Cout))
+    ref = F.conv2d(R.upsample2x_bilinear(x), w, b, padding=1)
+    ref = F.leaky_relu(R.apply_noise(ref, nw, nz), 0.2)
+    ref = ref * (st[:, :Cout].view(B, Cout, 1, 1) + 1.0) + st[:, Cout:].view(B, Cout, 1, 1)
+    for cfg in range(4):
+        wp = pkg.ops.pack_conv3x3_weight(w.to(dev), cfg)
+        y = pkg.ops.conv3x3_fused(x.to(dev), wp, Cout, bias=b.to(dev), noise_w=nw.to(dev), noise=nz.to(dev),
+                                  style=st.to(dev), upsample=True, lrelu_slope=0.2, config=cfg)
+        assert rel_l2(y, ref) < TOL_OP, cfg
+
+
+def test_conv3x3_transpose_flip_is_data_gradient(pkg, dev):
+    """The transpose_flip packing turns the same kernel into the conv's adjoint (dgrad)."""
+    B, Cin, Cout, H = 2, 24, 40, 10
+    x = recipe_input("dg.x", (B, Cin, H, H)).requires_grad_(True)
+    w = recipe_tensor("dg.weight", (Cout, Cin, 3, 3))
+    gy = recipe_input("dg.gy", (B, Cout, H, H))
+    F.conv2d(x, w, padding=1).backward(gy)
+    cfg = 2
+    wp = pkg.ops.pack_conv3x3_weight(w.to(dev), cfg, transpose_flip=True)
+    gx = pkg.ops.conv3x3_fused(gy.to(dev), wp, Cin, config=cfg)
+    assert rel_l2(gx, x.grad) < TOL_OP
+
+
+def test_fc_matches_oracle_and_golden(pkg, dev, golden):
+    g = golden("decoder_ops.npz")
+    for tag, gain, wscale, lrmul, has_bias in [("fc_map", 2 ** 0.5, True, 0.01, True),
+                                               ("fc_style", 1.0, True, 1.0, True),
+                                               ("fc_plain", 2 ** 0.5, False, 1.0, False)]:
+        O, I = g[f"{tag}.gw"].shape
+        m = pkg.FC(I, O, gain=gain, use_wscale=wscale, lrmul=lrmul, bias=has_bias)
+        m.load_state_dict(fill_state_dict(m.state_dict(), prefix=tag + "."))
+        y = m.to(dev)(T(g[f"{tag}.x"]).to(dev))
+        assert rel_l2(y, g[f"{tag}.y"]) < TOL_OP, tag
+    # batch > 8 (two passes over the weight row) and the 6144-wide first mapping layer
+    x = recipe_input("fcbig.x", (11, 6144))
+    w = recipe_tensor("fcbig.weight", (96, 6144), 1.0)
+    b = recipe_tensor("fcbig.bias", (96,))
+    ref = R.fc(x, w, b, 0.02, 0.5)
+    y = pkg.ops.fc(x.to(dev), w.to(dev), b.to(dev), 0.02, 0.5, 0.2)
+    assert rel_l2(y, ref) < TOL_OP
+
+
+def test_noise_style_upsample_modules(pkg, dev, golden):
+    g = golden("decoder_ops.npz")
+    C = g["an.x"].shape[1]
+    m = pkg.ApplyNoise(C)
+    m.load_state_dict(fill_state_dict(m.state_dict(), prefix="an."))
+    assert rel_l2(m.to(dev)(T(g["an.x"]).to(dev), T(g["an.noise"]).to(dev)), g["an.y"]) < TOL_OP
+    m = pkg.ApplyStyle(16, C, use_wscale=True)
+    m.load_state_dict(fill_state_dict(m.state_dict(), prefix="as."))
+    assert rel_l2(m.to(dev)(T(g["as.x"]).to(dev), T(g["as.lat"]).to(dev)), g["as.y"]) < TOL_OP
+    for tag in ("up_a", "up_b", "up_c"):
+        assert rel_l2(pkg.ops.upsample2x_bilinear(T(g[f"{tag}.x"]).to(dev)), g[f"{tag}.y"]) < TOL_OP
+
+
+def test_synthesis_block_goldens(pkg, dev, golden):
+    g = golden("decoder_blocks.npz")
+    for tag, cin, cout, B, hin in [("blk512", 512, 512, 2, 4), ("blk128_64", 128, 64, 1, 16), ("blk16_8", 16, 8, 3, 6)]:
+        m = pkg.SynthesisBlock(cin, cout, 3)
+        m.load_state_dict(fill_state_dict(m.state_dict(), prefix=tag + "."))
+        m.to(dev)
+        x = recipe_input(tag + ".x", (B, cin, hin, hin)).to(dev)
+        w = recipe_input(tag + ".w", (B, 2, 512)).to(dev)
+        n1 = recipe_input(tag + ".n1", (B, 1, 2 * hin, 2 * hin)).to(dev)
+        n2 = recipe_input(tag + ".n2", (B, 1, 2 * hin, 2 * hin)).to(dev)
+        with torch.no_grad():
+            y = m(x, w, n1, n2)
+        assert rel_l2(y, g[f"{tag}.y"]) < TOL_OP, tag
+
+
+def _generator(pkg, dev, prefix="Gd."):
+    g = pkg.StyleGenerator(6144).eval()
+    sd = fill_state_dict(g.state_dict(), prefix=prefix)
+    g.load_state_dict(sd)
+    return g.to(dev), sd
+
+
+def test_style_generator_golden_frame(pkg, dev, golden):
+    """BASELINE config 1 input, the reference's own output as the expected value."""
+    g, _ = _generator(pkg, dev)
+    with torch.no_grad():
+        y = g(recipe_input("e2e.features", (1, 6144)).to(dev), [n.to(dev) for n in recipe_noises("e2e", 1, 256)])
+    assert y.shape == (1, 3, 256, 256)
+    assert rel_l2(y, golden("decoder_e2e_256.npz")["y"]) < TOL_E2E
+    gb = golden("decoder_e2e_256_b2.npz")
+    with torch.no_grad():
+        feats = recipe_input("e2e_b2.features", (2, 6144)).to(dev)
+        assert rel_l2(g.mapping(feats), gb["w"]) < TOL_OP
+        y = g(feats, [n.to(dev) for n in recipe_noises("e2e_b2", 2, 256)])
+    assert rel_l2(y[..., ::4, ::4], gb["y_s4"]) < TOL_E2E
+    assert rel_l2(y[..., 96:160, 96:160], gb["y_crop"]) < TOL_E2E
+
+
+def test_style_generator_batch8_vs_oracle(pkg, dev):
+    """BASELINE config 2 (the benchmarked workload): B=8, 256^2, forward."""
+    g, sd = _generator(pkg, dev)
+    feats = recipe_input("cfg2.features", (8, 6144))
+    noises = recipe_noises("cfg2", 8, 256)
+    with torch.no_grad():
+        y = g(feats.to(dev), [n.to(dev) for n in noises])
+        ref = R.style_generator(feats, sd, noises)
+    assert y.shape == (8, 3, 256, 256)
+    assert rel_l2(y, ref) < TOL_E2E
+    # size-independent property: frames are independent -> any sub-batch reproduces its rows exactly
+    with torch.no_grad():
+        y3 = g(feats[3:4].to(dev), [n[3:4].to(dev) for n in noises])
+    assert rel_l2(y3, y[3:4]) < 1e-6
+
+
+def test_synthesis_512_golden(pkg, dev, golden):
+    gold = golden("decoder_e2e_512.npz")
+    s = pkg.SynthesisNetwork(resolution=512).eval()
+    s.load_state_dict(fill_state_dict(s.state_dict(), prefix="Gd512.synthesis."))
+    s.to(dev)
+    with torch.no_grad():
+        y = s(recipe_input("e2e512.w", (1, 16, 512)).to(dev), [n.to(dev) for n in recipe_noises("e2e512", 1, 512)])
+    assert y.shape == (1, 3, 512, 512)
+    assert rel_l2(y[..., ::8, ::8], gold["y_s8"]) < TOL_E2E
+    assert rel_l2(y[..., 224:288, 224:288], gold["y_crop"]) < TOL_E2E
+
+
+def test_noise_default_draw_and_errors(pkg, dev):
+    """noise=None draws on the device (reference behaviour); CPU tensors are refused loudly."""
+    g, _ = _generator(pkg, dev)
+    with torch.no_grad():
+        y = g(recipe_input("nd.features", (1, 6144)).to(dev))
+    assert torch.isfinite(y).all()
+    with pytest.raises(RuntimeError):
+        pkg.ops.fc(torch.zeros(2, 8), torch.zeros(4, 8))
