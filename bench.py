@@ -1,0 +1,182 @@
+#!/usr/bin/env python3
+"""Headline benchmark: generator frames/s at 256^2, batch 8 per GPU (BASELINE.json metric,
+configs[1]: StyleGAN synthesis forward only, batch 8, 1x MI355X).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+
+A step = one ``StyleGenerator.forward`` (mapping + 13 style affines + prologue + 12 fused 3x3 conv
+launches + toRGB) over one batch of 8 synthetic [6144] latents, inputs and weights resident in HBM,
+noise drawn on the device inside the step as the reference does (styleganv1.py:455).  fp32
+end to end (exact-f32 MFMA).  N > 1: launched by torch.distributed.run, one rank per GPU, each rank
+an independent replica on its own batch (the forward path has no exchange step -- SURVEY.md 8e);
+barrier + synchronize on both sides of the timed region, MAX over ranks, rank 0 prints ONE JSON line.
+
+Extra objects in the line:
+  roofline     -- the dominant kernel (conv3x3_kernel, MFMA-bound): algorithmic conv FLOPs per
+                  step / conv kernel time per step, timed live with HIP events on the launch stream.
+  cpu_baseline -- the CPU oracle (a port of the reference's algorithm, parity-pinned to it) timed
+                  on this box's host cores on the same B=8 workload (rank 0, N=1 only).
+"""
+from __future__ import annotations
+
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+BATCH = 8
+RES = 256
+F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+
+
+def decoder_conv_flops(batch, resolution=RES):
+    """Algorithmic FLOPs (2*MAC) of the twelve 3x3 convs per step -- SURVEY.md 8(d): 56.17 GFLOP/frame."""
+    total, res, cin = 0, 8, 512
+    while res <= resolution:
+        cout = min(int(8192 / (2.0 ** (res.bit_length() - 2))), 512)
+        total += 2 * 9 * res * res * (cin * cout + cout * cout)
+        cin, res = cout, res * 2
+    return total * batch
+
+
+def host_cores():
+    """Cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()
+        if quota != "max":
+            n = min(n, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        pass
+    return max(1, min(n, int(os.environ.get("SPK_CPU_THREADS", n))))
+
+
+def cpu_baseline(threads):
+    """Oracle (port) on the host cores: 1 warm-up + 3 timed B=8 forwards."""
+    from oracle import decoder_ref as R
+    from oracle.weights_recipe import recipe_input, recipe_noises
+    pkg = importlib.import_module("speak-hack_amd")
+    torch.set_num_threads(threads)
+    g = pkg.StyleGenerator(6144)
+    sd = {k: v.detach().clone() for k, v in g.state_dict().items()}
+    feats = recipe_input("bench.cpu.features", (BATCH, 6144))
+    noises = recipe_noises("bench.cpu", BATCH, RES)
+    times = []
+    with torch.no_grad():
+        for i in range(4):
+            t0 = time.perf_counter()
+            R.style_generator(feats, sd, noises)
+            times.append(time.perf_counter() - t0)
+    times = sorted(times[1:])
+    med = times[len(times) // 2]
+    return {"value": round(BATCH / med, 3), "unit": "frames/s", "cores": threads, "kind": "port",
+            "sample": f"oracle.decoder_ref.style_generator, B={BATCH}, 256^2, fp32, median of 3 after 1 warm-up "
+                      f"({med * 1e3:.0f} ms/step)"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.gpus > 1 and world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    pkg = importlib.import_module("speak-hack_amd")
+    pkg._lib.lib()
+    torch.manual_seed(1 + rank)
+    gen = pkg.StyleGenerator(6144).eval().to(dev)          # random-init weights of the architecture
+    with torch.no_grad():                                   # default init zeroes the noise weights; wake them up
+        for n, p in gen.named_parameters():
+            if "noise" in n:
+                p.normal_(0, 0.1)
+    feats = torch.randn(BATCH, 6144, device=dev)            # synthetic latents, resident in HBM
+
+    def step():
+        return gen(feats)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            step()
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step()
+        barrier()
+        elapsed = time.perf_counter() - t0
+        if dist is not None:
+            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            elapsed = float(t.item())
+
+        # ---- roofline of the dominant kernel: HIP events around every conv launch (same stream) ----
+        pkg.ops.CONV_EVENTS = []
+        prof_steps = 5
+        for _ in range(prof_steps):
+            step()
+        torch.cuda.synchronize()
+        conv_ms = sum(a.elapsed_time(b) for a, b in pkg.ops.CONV_EVENTS) / prof_steps
+        n_launch = len(pkg.ops.CONV_EVENTS) // prof_steps
+        pkg.ops.CONV_EVENTS = None
+
+    if rank == 0:
+        flops = decoder_conv_flops(BATCH)
+        achieved = flops / (conv_ms * 1e-3) / 1e12
+        ms_per_step = elapsed / args.steps * 1e3
+        line = {
+            "metric": "generator frames/sec at 256^2, batch 8/GPU",
+            "value": round(world * BATCH * args.steps / elapsed, 2),
+            "unit": "frames/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 4),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "StyleGAN decoder (styleganv1.StyleGenerator) 256^2 forward only, batch 8/GPU, "
+                                   "fp32, random-init weights, synthetic [8,6144] latents, device-drawn noise",
+                       "global_batch": BATCH * world, "resolution": RES,
+                       "parallelism": f"replicas x{world} (no data-path collective)"},
+            "roofline": {"bound": "mfma", "kernel": "conv3x3_kernel (f32 MFMA implicit GEMM, fused epilogue)",
+                         "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "launches_per_step": n_launch, "conv_ms_per_step": round(conv_ms, 4),
+                         "conv_share_of_step": round(conv_ms / ms_per_step, 3),
+                         "algorithmic_gflop_per_step": round(flops / 1e9, 2)},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline(host_cores())
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

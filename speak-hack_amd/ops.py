@@ -10,6 +10,10 @@ import torch
 
 from . import _lib as L
 
+# bench.py sets this to a list to collect (start, end) HIP-event pairs around every conv launch
+# (events are recorded on torch's current stream, the one the kernel is launched on).
+CONV_EVENTS = None
+
 
 # --------------------------------------------------------------------------------------------------
 class PackedConvWeight:
@@ -92,7 +96,13 @@ def conv3x3_fused(x, w_packed, Cout: int, *, bias=None, noise_w=None, noise=None
                       B=B, Cin=Cin, Cout=Cout, H=H, W=W, style_stride=int(style_stride or 0), flags=flags,
                       lrelu_slope=float(lrelu_slope if lrelu_slope is not None else 1.0), in_scale=float(in_scale),
                       config=int(config))
+    if CONV_EVENTS is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
     L.check(L.lib().spk_conv3x3_fwd(C.byref(d), L.stream_ptr()), "spk_conv3x3_fwd")
+    if CONV_EVENTS is not None:
+        e1.record()
+        CONV_EVENTS.append((e0, e1))
     return out
 
 
