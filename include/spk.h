@@ -66,6 +66,9 @@ typedef struct spk_conv3x3_desc {
     float lrelu_slope;
     float in_scale;          /* multiplies the result of the contraction before bias (1.0 = none) */
     int32_t config;          /* tile config id, 0..spk_conv3x3_num_configs()-1, or -1 = auto */
+    int32_t ksplit;          /* slices of the input-channel range (split-K); 0 = auto, 1 = none */
+    void*   workspace;       /* device scratch for split-K partial sums (may be NULL if not needed) */
+    int64_t workspace_bytes; /* its size; see spk_conv3x3_workspace_bytes */
 } spk_conv3x3_desc;
 
 int spk_conv3x3_num_configs(void);
@@ -75,6 +78,9 @@ int spk_conv3x3_pick_config(int B, int Cin, int Cout, int H, int W);
 int spk_conv3x3_config_info(int config, int* co_tile, int* ci_tile, int* pix_tile);
 /* number of floats of the packed image of a [Cout,Cin,3,3] weight for `config` */
 int64_t spk_conv3x3_packed_floats(int config, int Cin, int Cout);
+/* bytes of scratch spk_conv3x3_fwd needs for this problem (0 when it will not split K; <0 = bad args).
+ * config = -1 / ksplit = 0 ask for the library's own choices. */
+int64_t spk_conv3x3_workspace_bytes(int config, int ksplit, int B, int Cin, int Cout, int H, int W);
 /* w[Cout,Cin,3,3] -> packed [co_tile][ci_chunk][tap][ci][co] (zero padded).
  * transpose_flip != 0 packs the data-gradient operator instead: w'[ci,co,ky,kx] = w[co,ci,2-ky,2-kx]
  * (then the packed image is that of a [Cin,Cout,3,3] weight).

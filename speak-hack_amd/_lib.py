@@ -25,7 +25,8 @@ class Conv3x3Desc(C.Structure):
                 ("noise", C.c_void_p), ("style", C.c_void_p), ("y", C.c_void_p),
                 ("B", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
                 ("style_stride", C.c_int32), ("flags", C.c_uint32), ("lrelu_slope", C.c_float),
-                ("in_scale", C.c_float), ("config", C.c_int32)]
+                ("in_scale", C.c_float), ("config", C.c_int32), ("ksplit", C.c_int32),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
 
 
 _PROTOTYPES = {
@@ -35,6 +36,7 @@ _PROTOTYPES = {
     "spk_conv3x3_pick_config": (C.c_int, [C.c_int] * 5),
     "spk_conv3x3_config_info": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "spk_conv3x3_packed_floats": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
+    "spk_conv3x3_workspace_bytes": (C.c_int64, [C.c_int] * 7),
     "spk_conv3x3_pack_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "spk_conv3x3_fwd": (C.c_int, [C.POINTER(Conv3x3Desc), C.c_void_p]),
     "spk_fc_fwd": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,

@@ -10,17 +10,36 @@
 //   D  : v_mfma_f32_32x32x2_f32, col = lane&31 = pixel (x-contiguous -> 128-B coalesced NCHW
 //        stores), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) = output channel.
 // One workgroup = WM x WN waves; each wave owns MT x NT accumulator tiles of 32co x 32pix.
-// The f32 MFMA is bit-for-bit an fmaf chain (exact fp32), 64 cycles/SIMD per instruction, so the
-// kernel is matrix-pipe bound as long as staging overlaps (>=2 workgroups per CU).
+//
+// Pipeline: LDS is double buffered.  While the waves run the 9*CI_T/2 MFMA k-steps of chunk c out
+// of buffer c&1, the global loads of chunk c+1 (weights: 16-B loads of one contiguous packed
+// block; input: per-lane gathers whose addresses, validity and bilinear codes were computed once
+// at kernel start) are already in flight into registers; they are written to buffer (c+1)&1 after
+// the k-steps, followed by the only barrier of the chunk.  The f32 MFMA is 64 cycles/SIMD per
+// instruction, so all of the staging issue fits in its shadow.
+//
+// Split-K: gridDim.z slices the ci-chunk range; slices write raw partial sums to a workspace and
+// splitk_epilogue_kernel reduces them in a fixed order (bitwise reproducible) and applies the
+// epilogue.  Used for the low-resolution layers, whose output tiles alone cannot fill 256 CUs.
 //
 // Replaces the ATen call sites listed at spk_conv3x3_fwd in include/spk.h.
 #include "spk_common.hpp"
 
 #include <algorithm>
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 namespace {
+
+template <int I, int N, class F>
+__device__ __forceinline__ void spk_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        spk_static_for<I + 1, N>(f);
+    }
+}
 
 struct ConvArgs {
     const float* x;
@@ -29,12 +48,13 @@ struct ConvArgs {
     const float* noise_w;
     const float* noise;
     const float* style;
-    float* y;
+    float* y;   // output, or the split-K workspace [ksplit][B][Cout][H][W]
     int B, Cin, Cout, H, W;  // output spatial size
     int Hs, Ws;              // source spatial size (H/2, W/2 when upsampling)
     int lgTW, lgTH, lgTB;    // log2 of the pixel-tile geometry
     int tiles_x, tiles_y;
-    int n_chunks;
+    int n_chunks;            // ceil(Cin / CI_T)
+    int chunks_per_split;
     int style_stride;
     unsigned flags;
     float slope, in_scale;
@@ -46,14 +66,27 @@ struct Cfg {
     static constexpr int NW = WM * WN, NTHREADS = NW * 64;
     static constexpr int CO_T = WM * MT * 32, PIX_T = WN * NT * 32;
     static constexpr int W_FLOATS = 9 * CI_T * CO_T;
-    static constexpr int JMAX = PIX_T >= 256 ? 6 : (PIX_T >= 128 ? 4 : 3);
+    static constexpr int WV = (W_FLOATS / 4 + NTHREADS - 1) / NTHREADS;  // float4 per thread per chunk
+    // register slots (64 input elements each) a wave prefetches per chunk
+    static constexpr int NSLOT_FULL = PIX_T >= 256 ? 11 : (PIX_T >= 128 ? 7 : 5);   // for CI_T = 8
+    static constexpr int NSLOT = (NSLOT_FULL * CI_T + 7) / 8;
+    // fragment prefetch distance in k-steps: about 256 MFMA cycles of cover for the ds_read latency
+    static constexpr int PD = MT * NT >= 4 ? 1 : (MT * NT >= 2 ? 2 : 4);
 };
+
+// slot descriptor bits
+constexpr unsigned D_VALID = 1u;        // element is inside the image (else: zero padding)
+constexpr unsigned D_CI_SHIFT = 1;      // 4 bits: ci within the chunk
+constexpr unsigned D_DX = 1u << 5;      // bilinear: second tap is one column to the right
+constexpr unsigned D_DY = 1u << 6;      // bilinear: second row is one source row below
+constexpr unsigned D_LX_SHIFT = 7;      // 2 bits: lambda code (0: 0, 1: 0.25, 2: 0.75)
+constexpr unsigned D_LY_SHIFT = 9;
+
+__device__ __forceinline__ float lambda_of(unsigned code) { return code == 0 ? 0.f : (code == 1 ? 0.25f : 0.75f); }
 
 template <class C, bool UPS>
 __global__ __launch_bounds__(C::NTHREADS) void conv3x3_kernel(const ConvArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* const w_s = smem;
-    float* const in_s = smem + C::W_FLOATS;
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -63,6 +96,8 @@ __global__ __launch_bounds__(C::NTHREADS) void conv3x3_kernel(const ConvArgs p) 
 
     const int TW = 1 << p.lgTW, TH = 1 << p.lgTH, TB = 1 << p.lgTB;
     const int PW = TW + 2, PLANE = (TH + 2) * PW;
+    const int IN_FLOATS = C::CI_T * TB * PLANE;
+    const int BUF_FLOATS = C::W_FLOATS + ((IN_FLOATS + 3) & ~3);
     int bx = blockIdx.x;
     const int tx = bx % p.tiles_x;
     bx /= p.tiles_x;
@@ -70,48 +105,60 @@ __global__ __launch_bounds__(C::NTHREADS) void conv3x3_kernel(const ConvArgs p) 
     const int tbi = bx / p.tiles_y;
     const int b0 = tbi << p.lgTB, y0 = ty << p.lgTH, x0 = tx << p.lgTW;
     const int co_tile0 = blockIdx.y * C::CO_T;
+    const int c_begin = blockIdx.z * p.chunks_per_split;
+    const int c_end = min(p.n_chunks, c_begin + p.chunks_per_split);
 
-    // ---- per-lane gather descriptors of one (ci, tb) input plane: fixed for the whole kernel ----
-    int g_off[C::JMAX];
-    int g_dy[UPS ? C::JMAX : 1], g_dx[UPS ? C::JMAX : 1];
-    float g_ly[UPS ? C::JMAX : 1], g_lx[UPS ? C::JMAX : 1];
-    unsigned g_valid = 0;
+    // ---- per-lane gather slots: wave w owns planes [w*ppw, (w+1)*ppw), contiguous in LDS ----
+    const int ppw = (C::CI_T * TB) / C::NW;
+    const int wave_elems = ppw * PLANE;
+    const size_t src_plane = (size_t)p.Hs * p.Ws;
+    int s_off[C::NSLOT];
+    unsigned s_desc[C::NSLOT];
 #pragma unroll
-    for (int j = 0; j < C::JMAX; ++j) {
-        const int pidx = lane + 64 * j;
-        g_off[j] = 0;
-        if (UPS) { g_dy[j] = 0; g_dx[j] = 0; g_ly[j] = 0.f; g_lx[j] = 0.f; }
-        if (pidx < PLANE) {
+    for (int s = 0; s < C::NSLOT; ++s) {
+        s_off[s] = 0;
+        s_desc[s] = 0;
+        const int e = s * 64 + lane;
+        if (e < wave_elems) {
+            const int pl = e / PLANE, pidx = e - pl * PLANE;
+            const int q = wave * ppw + pl;
+            const int ci = q >> p.lgTB, tb = q & (TB - 1);
             const int r = pidx / PW, c = pidx - r * PW;
             const int uy = y0 + r - 1, ux = x0 + c - 1;
-            const bool v = uy >= 0 && uy < p.H && ux >= 0 && ux < p.W;
-            if (v) {
-                g_valid |= 1u << j;
+            unsigned d = (unsigned)ci << D_CI_SHIFT;
+            if (uy >= 0 && uy < p.H && ux >= 0 && ux < p.W && b0 + tb < p.B) {
+                d |= D_VALID;
+                int goff;
                 if (!UPS) {
-                    g_off[j] = uy * p.W + ux;
+                    goff = uy * p.W + ux;
                 } else {
-                    // torch area_pixel_compute_source_index(scale=0.5, align_corners=False)
-                    const float sy = fmaxf(0.5f * (uy + 0.5f) - 0.5f, 0.f);
-                    const float sx = fmaxf(0.5f * (ux + 0.5f) - 0.5f, 0.f);
-                    const int iy0 = (int)sy, ix0 = (int)sx;
-                    const int iy1 = min(iy0 + 1, p.Hs - 1), ix1 = min(ix0 + 1, p.Ws - 1);
-                    g_off[j] = iy0 * p.Ws + ix0;
-                    g_dy[j] = (iy1 - iy0) * p.Ws;
-                    g_dx[j] = ix1 - ix0;
-                    g_ly[j] = sy - (float)iy0;
-                    g_lx[j] = sx - (float)ix0;
+                    // torch area_pixel_compute_source_index(scale=0.5, align_corners=False):
+                    // src = max(0.5*(dst+0.5)-0.5, 0); lambdas are exactly 0, 0.25 or 0.75
+                    const int iy0 = uy == 0 ? 0 : (uy - 1) >> 1, ix0 = ux == 0 ? 0 : (ux - 1) >> 1;
+                    const unsigned ly = uy == 0 ? 0u : ((uy & 1) ? 1u : 2u);
+                    const unsigned lx = ux == 0 ? 0u : ((ux & 1) ? 1u : 2u);
+                    if (iy0 + 1 < p.Hs) d |= D_DY;
+                    if (ix0 + 1 < p.Ws) d |= D_DX;
+                    d |= (lx << D_LX_SHIFT) | (ly << D_LY_SHIFT);
+                    goff = iy0 * p.Ws + ix0;
                 }
+                s_off[s] = (int)((size_t)(tb * p.Cin + ci) * src_plane) + goff;
+            } else {
+                s_off[s] = ci * (int)src_plane;  // masked at store time; any address inside the tensor will do
             }
+            s_desc[s] = d;
         }
     }
+    const float* xblk = p.x + (size_t)b0 * p.Cin * src_plane;
 
     // ---- per-lane fragment addresses ----
     int b_off[C::NT];
 #pragma unroll
     for (int n = 0; n < C::NT; ++n) {
         const int pt = (wn * C::NT + n) * 32 + l32;
-        const int px = pt & (TW - 1), py = (pt >> p.lgTW) & (TH - 1), tb = pt >> (p.lgTW + p.lgTH);
-        b_off[n] = half * TB * PLANE + tb * PLANE + py * PW + px;
+        const int px = pt & (TW - 1), py = (pt >> p.lgTW) & (TH - 1);
+        const int tb = min(pt >> (p.lgTW + p.lgTH), TB - 1);  // pixel groups beyond the tile idle (results dropped)
+        b_off[n] = C::W_FLOATS + half * TB * PLANE + tb * PLANE + py * PW + px;
     }
     const int a_off = half * C::CO_T + wm * C::MT * 32 + l32;
     const int ci_stride2 = 2 * TB * PLANE;
@@ -124,77 +171,152 @@ __global__ __launch_bounds__(C::NTHREADS) void conv3x3_kernel(const ConvArgs p) 
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-    const size_t src_plane = (size_t)p.Hs * p.Ws;
-    const float4* wsrc = reinterpret_cast<const float4*>(p.wp) + (size_t)blockIdx.y * p.n_chunks * (C::W_FLOATS / 4);
+    const f32x4* wsrc = reinterpret_cast<const f32x4*>(p.wp) +
+                         ((size_t)blockIdx.y * p.n_chunks + c_begin) * (C::W_FLOATS / 4);
 
-    for (int chunk = 0; chunk < p.n_chunks; ++chunk) {
-        __syncthreads();  // everyone is done reading the previous chunk
-        // weights: one contiguous 9*CI_T*CO_T block per (co_tile, chunk)
-        for (int i = tid; i < C::W_FLOATS / 4; i += C::NTHREADS) reinterpret_cast<float4*>(w_s)[i] = wsrc[i];
-        wsrc += C::W_FLOATS / 4;
-        // input planes (zero-filled halo / out-of-range channels and images)
-        for (int q = wave; q < C::CI_T * TB; q += C::NW) {
-            const int ci = q >> p.lgTB, tb = q & (TB - 1);
-            const int cig = chunk * C::CI_T + ci, b = b0 + tb;
-            const bool pv = (cig < p.Cin) && (b < p.B);
-            const float* src = p.x + ((size_t)(pv ? b : 0) * p.Cin + (pv ? cig : 0)) * src_plane;
-            float* dst = in_s + q * PLANE;
-#pragma unroll
-            for (int j = 0; j < C::JMAX; ++j) {
-                const int pidx = lane + 64 * j;
-                if (pidx < PLANE) {
-                    float v = 0.f;
-                    if (pv && ((g_valid >> j) & 1u)) {
-                        if (!UPS) {
-                            v = src[g_off[j]];
-                        } else {
-                            const float* s0 = src + g_off[j];
-                            const float v00 = s0[0], v01 = s0[g_dx[j]];
-                            const float v10 = s0[g_dy[j]], v11 = s0[g_dy[j] + g_dx[j]];
-                            const float lx1 = g_lx[j], lx0 = 1.f - lx1, ly1 = g_ly[j], ly0 = 1.f - ly1;
-                            v = ly0 * (lx0 * v00 + lx1 * v01) + ly1 * (lx0 * v10 + lx1 * v11);
-                        }
-                    }
-                    dst[pidx] = v;
+    // prefetch registers
+    f32x4 wreg[C::WV];
+    float xin[UPS ? 4 * C::NSLOT : C::NSLOT];
+
+    // staging is written as macros (not lambdas / functions) so that the prefetch arrays stay in
+    // registers: every index is a compile-time constant after unrolling.
+#define SPK_ISSUE_LOADS(chunk_)                                                                               \
+    {                                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < C::WV; ++i) {                                                   \
+            const int idx = tid + i * C::NTHREADS;                                                            \
+            if (C::W_FLOATS / 4 % C::NTHREADS == 0 || idx < C::W_FLOATS / 4) wreg[i] = wsrc[idx];             \
+        }                                                                                                     \
+        wsrc += C::W_FLOATS / 4;                                                                              \
+        const float* xc = xblk + (size_t)(chunk_) * C::CI_T * src_plane;                                      \
+        const int ci_left_ = p.Cin - (chunk_) * C::CI_T;                                                      \
+        _Pragma("unroll") for (int s = 0; s < C::NSLOT; ++s) {                                                \
+            /* unconditional loads from always-valid addresses; masking happens at LDS-store time.            \
+               Channels past Cin (zero-padded last chunk) are folded onto channel 0 of the chunk. */          \
+            const unsigned d = s_desc[s];                                                                     \
+            const int ci_ = (int)((d >> D_CI_SHIFT) & 15u);                                                   \
+            const int off_ = s_off[s] - (ci_ >= ci_left_ ? ci_ * (int)src_plane : 0);                         \
+            if (!UPS) {                                                                                       \
+                xin[s] = xc[off_];                                                                            \
+            } else {                                                                                          \
+                const float* s0 = xc + off_;                                                                  \
+                const int dx = (d & D_DX) ? 1 : 0, dy = (d & D_DY) ? p.Ws : 0;                                \
+                xin[4 * s + 0] = s0[0];                                                                       \
+                xin[4 * s + 1] = s0[dx];                                                                      \
+                xin[4 * s + 2] = s0[dy];                                                                      \
+                xin[4 * s + 3] = s0[dy + dx];                                                                 \
+            }                                                                                                 \
+        }                                                                                                     \
+    }
+
+#define SPK_STORE_LDS(buf_, chunk_)                                                                           \
+    {                                                                                                         \
+        float* const sbuf = (buf_);                                                                           \
+        const int ci_left = p.Cin - (chunk_) * C::CI_T; /* channels of this chunk that exist */               \
+        _Pragma("unroll") for (int i = 0; i < C::WV; ++i) {                                                   \
+            const int idx = tid + i * C::NTHREADS;                                                            \
+            if (C::W_FLOATS / 4 % C::NTHREADS == 0 || idx < C::W_FLOATS / 4)                                  \
+                reinterpret_cast<f32x4*>(sbuf)[idx] = wreg[i];                                                \
+        }                                                                                                     \
+        float* dst = sbuf + C::W_FLOATS + wave * wave_elems;                                                  \
+        _Pragma("unroll") for (int s = 0; s < C::NSLOT; ++s) {                                                \
+            const int e = s * 64 + lane;                                                                      \
+            if (e < wave_elems) {                                                                             \
+                float v;                                                                                      \
+                const unsigned d = s_desc[s];                                                                 \
+                const bool ok = (d & D_VALID) && (int)((d >> D_CI_SHIFT) & 15u) < ci_left;                    \
+                if (!UPS) {                                                                                   \
+                    v = xin[s];                                                                               \
+                } else {                                                                                      \
+                    const float lx1 = lambda_of((d >> D_LX_SHIFT) & 3u), ly1 = lambda_of((d >> D_LY_SHIFT) & 3u); \
+                    const float lx0 = 1.f - lx1, ly0 = 1.f - ly1;                                             \
+                    v = ly0 * (lx0 * xin[4 * s] + lx1 * xin[4 * s + 1]) +                                     \
+                        ly1 * (lx0 * xin[4 * s + 2] + lx1 * xin[4 * s + 3]);                                  \
+                }                                                                                             \
+                dst[e] = ok ? v : 0.f;                                                                        \
+            }                                                                                                 \
+        }                                                                                                     \
+    }
+
+    if (c_begin < c_end) {
+        SPK_ISSUE_LOADS(c_begin);
+        SPK_STORE_LDS(smem, c_begin);
+    }
+    __syncthreads();
+
+    for (int chunk = c_begin; chunk < c_end; ++chunk) {
+        const float* buf = smem + ((chunk - c_begin) & 1) * BUF_FLOATS;
+        const bool more = chunk + 1 < c_end;
+        if (more) SPK_ISSUE_LOADS(chunk + 1);
+
+        // k-steps: step = (tap, kk).  Fragments are read PD steps ahead of the MFMAs that use them
+        // (register ring, all indices static after unrolling) so LDS latency hides under the MFMAs;
+        // sched_group_barrier pins the ds_read / MFMA interleave the source states.
+        {
+            constexpr int STEPS = 9 * (C::CI_T / 2);
+            constexpr int PD = C::PD;
+            float fa[PD + 1][C::MT], fb[PD + 1][C::NT];
+#define SPK_LOAD_FRAG(step_)                                                                                  \
+    {                                                                                                         \
+        constexpr int tap_ = (step_) / (C::CI_T / 2), kk_ = (step_) % (C::CI_T / 2);                          \
+        const int tapoff_ = (tap_ / 3) * PW + (tap_ % 3);                                                     \
+        _Pragma("unroll") for (int m = 0; m < C::MT; ++m)                                                     \
+            fa[(step_) % (PD + 1)][m] = buf[a_off + (tap_ * C::CI_T + 2 * kk_) * C::CO_T + m * 32];           \
+        _Pragma("unroll") for (int n = 0; n < C::NT; ++n)                                                     \
+            fb[(step_) % (PD + 1)][n] = buf[b_off[n] + kk_ * ci_stride2 + tapoff_];                           \
+    }
+            spk_static_for<0, PD>([&](auto i) { SPK_LOAD_FRAG(decltype(i)::value); });
+            spk_static_for<0, STEPS>([&](auto i) {
+                constexpr int st = decltype(i)::value;
+                if constexpr (st + PD < STEPS) {
+                    SPK_LOAD_FRAG(st + PD);
+                    __builtin_amdgcn_sched_group_barrier(0x100, C::MT + C::NT, 0);
                 }
-            }
-        }
-        __syncthreads();
-
-#pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int tapoff = (tap / 3) * PW + (tap % 3);
-#pragma unroll
-            for (int kk = 0; kk < C::CI_T / 2; ++kk) {
-                float a[C::MT], bv[C::NT];
-#pragma unroll
-                for (int m = 0; m < C::MT; ++m) a[m] = w_s[a_off + (tap * C::CI_T + 2 * kk) * C::CO_T + m * 32];
-#pragma unroll
-                for (int n = 0; n < C::NT; ++n) bv[n] = in_s[b_off[n] + kk * ci_stride2 + tapoff];
 #pragma unroll
                 for (int m = 0; m < C::MT; ++m)
 #pragma unroll
                     for (int n = 0; n < C::NT; ++n)
-                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[m], bv[n], acc[m][n], 0, 0, 0);
-            }
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[st % (PD + 1)][m], fb[st % (PD + 1)][n],
+                                                                        acc[m][n], 0, 0, 0);
+                __builtin_amdgcn_sched_group_barrier(0x8, C::MT * C::NT, 0);
+            });
+#undef SPK_LOAD_FRAG
         }
+
+        if (more) SPK_STORE_LDS(smem + (((chunk - c_begin) & 1) ^ 1) * BUF_FLOATS, chunk + 1);
+        __syncthreads();
     }
 
-    // ---- fused epilogue: *in_scale -> +bias -> +noise_w*noise -> lrelu -> *(s0+1)+s1 -> store ----
+#undef SPK_ISSUE_LOADS
+#undef SPK_STORE_LDS
+
+    // ---- epilogue ----
+    const bool split = gridDim.z > 1;
     const bool f_bias = p.flags & SPK_EPI_BIAS, f_noise = p.flags & SPK_EPI_NOISE;
     const bool f_lrelu = p.flags & SPK_EPI_LRELU, f_style = p.flags & SPK_EPI_STYLE;
     const bool f_accum = p.flags & SPK_EPI_ACCUM;
+    const size_t HW = (size_t)p.H * p.W;
+    float* ybase = p.y + (split ? (size_t)blockIdx.z * p.B * p.Cout * HW : 0);
 #pragma unroll
     for (int n = 0; n < C::NT; ++n) {
         const int pt = (wn * C::NT + n) * 32 + l32;
         const int px = pt & (TW - 1), py = (pt >> p.lgTW) & (TH - 1), tb = pt >> (p.lgTW + p.lgTH);
         const int b = b0 + tb, yy = y0 + py, xx = x0 + px;
-        const bool pvalid = b < p.B && yy < p.H && xx < p.W;
+        const bool pvalid = tb < TB && b < p.B && yy < p.H && xx < p.W;
         if (!pvalid) continue;
         const size_t pix = (size_t)yy * p.W + xx;
-        const float nz = f_noise ? p.noise[(size_t)b * p.H * p.W + pix] : 0.f;
+        float* yb = ybase + (size_t)b * p.Cout * HW + pix;
+        if (split) {  // raw partial sums; splitk_epilogue_kernel finishes
+#pragma unroll
+            for (int m = 0; m < C::MT; ++m)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co_tile0 + (wm * C::MT + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (co < p.Cout) yb[(size_t)co * HW] = acc[m][n][r];
+                }
+            continue;
+        }
+        const float nz = f_noise ? p.noise[(size_t)b * HW + pix] : 0.f;
         const float* st = f_style ? p.style + (size_t)b * p.style_stride : nullptr;
-        float* yb = p.y + (size_t)b * p.Cout * p.H * p.W + pix;
 #pragma unroll
         for (int m = 0; m < C::MT; ++m) {
 #pragma unroll
@@ -206,12 +328,38 @@ __global__ __launch_bounds__(C::NTHREADS) void conv3x3_kernel(const ConvArgs p) 
                     if (f_noise) v += p.noise_w[co] * nz;
                     if (f_lrelu) v = v > 0.f ? v : v * p.slope;
                     if (f_style) v = v * (st[co] + 1.f) + st[p.Cout + co];
-                    float* dst = yb + (size_t)co * p.H * p.W;
+                    float* dst = yb + (size_t)co * HW;
                     if (f_accum) v += *dst;
                     *dst = v;
                 }
             }
         }
+    }
+}
+
+// y = epi( sum_z ws[z] ) -- fixed summation order, one element per thread
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const ConvArgs p, const float* __restrict__ ws, int ksplit) {
+    const size_t HW = (size_t)p.H * p.W;
+    const size_t total = (size_t)p.B * p.Cout * HW;
+    const bool f_bias = p.flags & SPK_EPI_BIAS, f_noise = p.flags & SPK_EPI_NOISE;
+    const bool f_lrelu = p.flags & SPK_EPI_LRELU, f_style = p.flags & SPK_EPI_STYLE;
+    const bool f_accum = p.flags & SPK_EPI_ACCUM;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        float v = 0.f;
+        for (int z = 0; z < ksplit; ++z) v += ws[(size_t)z * total + idx];
+        const size_t pix = idx % HW;
+        const int co = (int)((idx / HW) % p.Cout);
+        const int b = (int)(idx / (HW * p.Cout));
+        v *= p.in_scale;
+        if (f_bias) v += p.bias[co];
+        if (f_noise) v += p.noise_w[co] * p.noise[(size_t)b * HW + pix];
+        if (f_lrelu) v = v > 0.f ? v : v * p.slope;
+        if (f_style) {
+            const float* st = p.style + (size_t)b * p.style_stride;
+            v = v * (st[co] + 1.f) + st[p.Cout + co];
+        }
+        if (f_accum) v += p.y[idx];
+        p.y[idx] = v;
     }
 }
 
@@ -236,11 +384,83 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
 
 // ---- tile configs -------------------------------------------------------------------------------
 //                WM WN MT NT CI_T       CO_T  PIX_T
-typedef Cfg<2, 2, 2, 2, 8> Cfg0;  //  128   128   large layers
+typedef Cfg<2, 2, 2, 2, 8> Cfg0;  //  128   128   general
 typedef Cfg<1, 4, 2, 2, 8> Cfg1;  //   64   256   Cout <= 64, many pixels
-typedef Cfg<2, 2, 1, 1, 8> Cfg2;  //   64    64   small layers (more workgroups)
+typedef Cfg<2, 2, 1, 1, 8> Cfg2;  //   64    64   small problems
 typedef Cfg<1, 4, 1, 1, 8> Cfg3;  //   32   128   Cout <= 32
-constexpr int kNumConfigs = 4;
+typedef Cfg<2, 2, 2, 2, 4> Cfg4;  //  128   128   half-depth chunks: 43 KiB LDS -> 2-3 workgroups per CU
+typedef Cfg<1, 4, 2, 2, 4> Cfg5;  //   64   256   half-depth chunks
+constexpr int kNumConfigs = 6;
+
+struct Geometry {
+    int TW, TH, TB, PLANE, tiles_x, tiles_y, tiles_b, n_chunks, co_tiles;
+    size_t lds_bytes;
+    bool ok;
+};
+
+template <class C>
+Geometry geometry(int B, int Cin, int Cout, int H, int W) {
+    Geometry g;
+    g.TW = std::min(32, spk::pow2_ceil(W));
+    g.TH = std::min(C::PIX_T / g.TW, spk::pow2_ceil(H));
+    g.TB = C::PIX_T / (g.TW * g.TH);
+    // the wave's share of the input tile must fit its prefetch slots
+    auto slots = [&]() { return spk::ceil_div(C::CI_T * g.TB / C::NW * (g.TH + 2) * (g.TW + 2), 64); };
+    while (slots() > C::NSLOT && g.TB > 1 && (C::CI_T * (g.TB / 2)) % C::NW == 0) g.TB >>= 1;  // idle pixel groups
+    while (slots() > C::NSLOT && g.TH > 1) g.TH >>= 1;
+    g.PLANE = (g.TH + 2) * (g.TW + 2);
+    g.ok = slots() <= C::NSLOT && (C::CI_T * g.TB) % C::NW == 0;
+    g.tiles_x = spk::ceil_div(W, g.TW);
+    g.tiles_y = spk::ceil_div(H, g.TH);
+    g.tiles_b = spk::ceil_div(B, g.TB);
+    g.n_chunks = spk::ceil_div(Cin, C::CI_T);
+    g.co_tiles = spk::ceil_div(Cout, C::CO_T);
+    const size_t in_floats = ((size_t)C::CI_T * g.TB * g.PLANE + 3) & ~(size_t)3;
+    g.lds_bytes = 2 * (C::W_FLOATS + in_floats) * sizeof(float);
+    if (g.lds_bytes > 160 * 1024) g.ok = false;
+    return g;
+}
+
+Geometry geometry_cfg(int cfg, int B, int Cin, int Cout, int H, int W) {
+    switch (cfg) {
+        case 0: return geometry<Cfg0>(B, Cin, Cout, H, W);
+        case 1: return geometry<Cfg1>(B, Cin, Cout, H, W);
+        case 2: return geometry<Cfg2>(B, Cin, Cout, H, W);
+        case 3: return geometry<Cfg3>(B, Cin, Cout, H, W);
+        case 4: return geometry<Cfg4>(B, Cin, Cout, H, W);
+        default: return geometry<Cfg5>(B, Cin, Cout, H, W);
+    }
+}
+
+// number of ci-chunk slices so that the grid fills the chip
+int pick_ksplit(const Geometry& g) {
+    const long long tiles = (long long)g.tiles_x * g.tiles_y * g.tiles_b * g.co_tiles;
+    int ks = 1;
+    while (tiles * ks < 512 && g.n_chunks / (ks * 2) >= 4 && ks < 64) ks *= 2;
+    return ks;
+}
+
+int resolve_ksplit(const Geometry& g, int requested, int* chunks_per_split) {
+    int ks = requested > 0 ? requested : pick_ksplit(g);
+    ks = std::max(1, std::min(ks, g.n_chunks));
+    const int cps = spk::ceil_div(g.n_chunks, ks);
+    if (chunks_per_split) *chunks_per_split = cps;
+    return spk::ceil_div(g.n_chunks, cps);
+}
+
+template <class C>
+int set_lds_attr(bool ups, size_t lds) {
+    // dynamic LDS above 64 KiB needs the attribute raised; done once per instantiation
+    static bool raised[2] = {false, false};
+    if (lds <= 64 * 1024 || raised[ups]) return SPK_OK;
+    hipError_t e = ups ? hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<C, true>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)
+                       : hipFuncSetAttribute(reinterpret_cast<const void*>(&conv3x3_kernel<C, false>),
+                                             hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if (e != hipSuccess) return spk::fail(SPK_ELAUNCH, "hipFuncSetAttribute(LDS): %s", hipGetErrorString(e));
+    raised[ups] = true;
+    return SPK_OK;
+}
 
 template <class C>
 int run(const spk_conv3x3_desc* d, hipStream_t stream) {
@@ -255,25 +475,35 @@ int run(const spk_conv3x3_desc* d, hipStream_t stream) {
     } else {
         a.Hs = d->H; a.Ws = d->W;
     }
-    int TW = std::min(32, spk::pow2_ceil(d->W));
-    int TH = std::min(C::PIX_T / TW, spk::pow2_ceil(d->H));
-    while ((TH + 2) * (TW + 2) > 64 * C::JMAX && TH > 1) TH >>= 1;
-    const int TB = C::PIX_T / (TW * TH);
-    const int PLANE = (TH + 2) * (TW + 2);
-    SPK_REQUIRE(PLANE <= 64 * C::JMAX, "conv3x3: tile plane %d too large", PLANE);
-    a.lgTW = spk::ilog2(TW); a.lgTH = spk::ilog2(TH); a.lgTB = spk::ilog2(TB);
-    a.tiles_x = spk::ceil_div(d->W, TW); a.tiles_y = spk::ceil_div(d->H, TH);
-    const int tiles_b = spk::ceil_div(d->B, TB);
-    a.n_chunks = spk::ceil_div(d->Cin, C::CI_T);
+    const Geometry g = geometry<C>(d->B, d->Cin, d->Cout, d->H, d->W);
+    SPK_REQUIRE(g.ok, "conv3x3: config does not fit this shape (%dx%d, B=%d)", d->H, d->W, d->B);
+    SPK_REQUIRE((size_t)g.TB * d->Cin * a.Hs * a.Ws < (1ull << 31), "conv3x3: image group too large for 32-bit offsets");
+    a.lgTW = spk::ilog2(g.TW); a.lgTH = spk::ilog2(g.TH); a.lgTB = spk::ilog2(g.TB);
+    a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y;
+    a.n_chunks = g.n_chunks;
     a.style_stride = d->style_stride; a.flags = d->flags; a.slope = d->lrelu_slope; a.in_scale = d->in_scale;
-    const size_t lds = (size_t)(C::W_FLOATS + C::CI_T * TB * PLANE) * sizeof(float);
-    SPK_REQUIRE(lds <= 64 * 1024, "conv3x3: LDS request %zu > 64 KiB", lds);
-    const long long gx = (long long)a.tiles_x * a.tiles_y * tiles_b;
+    const int ksplit = resolve_ksplit(g, d->ksplit, &a.chunks_per_split);
+    const size_t out_floats = (size_t)d->B * d->Cout * d->H * d->W;
+    if (ksplit > 1) {
+        SPK_REQUIRE(d->workspace && (size_t)d->workspace_bytes >= ksplit * out_floats * sizeof(float),
+                    "conv3x3: split-K x%d needs a %zu-byte workspace (see spk_conv3x3_workspace_bytes)", ksplit,
+                    ksplit * out_floats * sizeof(float));
+        a.y = static_cast<float*>(d->workspace);
+    }
+    int rc = set_lds_attr<C>(ups, g.lds_bytes);
+    if (rc != SPK_OK) return rc;
+    const long long gx = (long long)g.tiles_x * g.tiles_y * g.tiles_b;
     SPK_REQUIRE(gx < (1ll << 31), "conv3x3: grid too large");
-    dim3 grid((unsigned)gx, (unsigned)spk::ceil_div(d->Cout, C::CO_T));
-    if (ups) hipLaunchKernelGGL((conv3x3_kernel<C, true>), grid, dim3(C::NTHREADS), lds, stream, a);
-    else     hipLaunchKernelGGL((conv3x3_kernel<C, false>), grid, dim3(C::NTHREADS), lds, stream, a);
-    return spk::check_launch("conv3x3_kernel");
+    dim3 grid((unsigned)gx, (unsigned)g.co_tiles, (unsigned)ksplit);
+    if (ups) hipLaunchKernelGGL((conv3x3_kernel<C, true>), grid, dim3(C::NTHREADS), g.lds_bytes, stream, a);
+    else     hipLaunchKernelGGL((conv3x3_kernel<C, false>), grid, dim3(C::NTHREADS), g.lds_bytes, stream, a);
+    rc = spk::check_launch("conv3x3_kernel");
+    if (rc != SPK_OK || ksplit == 1) return rc;
+    a.y = d->y;
+    const unsigned blocks = (unsigned)std::min<size_t>((out_floats + 255) / 256, 256 * 8);
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, stream, a,
+                       static_cast<const float*>(d->workspace), ksplit);
+    return spk::check_launch("splitk_epilogue_kernel");
 }
 
 void config_dims(int cfg, int* co_t, int* ci_t, int* pix_t) {
@@ -283,6 +513,8 @@ void config_dims(int cfg, int* co_t, int* ci_t, int* pix_t) {
         case 1: co = Cfg1::CO_T; ci = Cfg1::CI_T; px = Cfg1::PIX_T; break;
         case 2: co = Cfg2::CO_T; ci = Cfg2::CI_T; px = Cfg2::PIX_T; break;
         case 3: co = Cfg3::CO_T; ci = Cfg3::CI_T; px = Cfg3::PIX_T; break;
+        case 4: co = Cfg4::CO_T; ci = Cfg4::CI_T; px = Cfg4::PIX_T; break;
+        case 5: co = Cfg5::CO_T; ci = Cfg5::CI_T; px = Cfg5::PIX_T; break;
     }
     if (co_t) *co_t = co;
     if (ci_t) *ci_t = ci;
@@ -296,12 +528,19 @@ extern "C" {
 int spk_conv3x3_num_configs(void) { return kNumConfigs; }
 
 int spk_conv3x3_pick_config(int B, int Cin, int Cout, int H, int W) {
-    (void)Cin;
+    // Measured on MI355X (tools/bench_conv.py, profiles/): the half-depth-chunk configs (4, 5) win on
+    // every decoder layer because 2-3 workgroups fit a CU and cover each other's barriers/epilogues.
     const long long pixels = (long long)B * H * W;
-    if (Cout <= 32) return 3;
-    if (Cout <= 64) return pixels >= 256ll * 1024 ? 1 : 2;
-    const long long wgs0 = (long long)spk::ceil_div(Cout, 128) * ((pixels + 127) / 128);
-    return wgs0 >= 512 ? 0 : 2;
+    int want;
+    if (Cout <= 32) want = 3;
+    else if (Cout <= 64) want = pixels >= 64 * 1024 ? 5 : 2;
+    else want = pixels >= 2048 ? 4 : 2;
+    // fall back along a fixed order if the preferred config cannot host the shape
+    static const int order[6][6] = {{0, 4, 2, 3, 1, 5}, {1, 5, 2, 3, 0, 4}, {2, 3, 4, 0, 5, 1},
+                                    {3, 2, 4, 0, 5, 1}, {4, 0, 2, 3, 5, 1}, {5, 1, 2, 3, 4, 0}};
+    for (int i = 0; i < 6; ++i)
+        if (geometry_cfg(order[want][i], B, Cin, Cout, H, W).ok) return order[want][i];
+    return want;
 }
 
 int spk_conv3x3_config_info(int config, int* co_tile, int* ci_tile, int* pix_tile) {
@@ -315,6 +554,16 @@ int64_t spk_conv3x3_packed_floats(int config, int Cin, int Cout) {
     int co_t, ci_t;
     config_dims(config, &co_t, &ci_t, nullptr);
     return (int64_t)spk::ceil_div(Cout, co_t) * spk::ceil_div(Cin, ci_t) * 9 * ci_t * co_t;
+}
+
+int64_t spk_conv3x3_workspace_bytes(int config, int ksplit, int B, int Cin, int Cout, int H, int W) {
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return -1;
+    if (config < 0) config = spk_conv3x3_pick_config(B, Cin, Cout, H, W);
+    if (config >= kNumConfigs) return -1;
+    const Geometry g = geometry_cfg(config, B, Cin, Cout, H, W);
+    if (!g.ok) return -1;
+    const int ks = resolve_ksplit(g, ksplit, nullptr);
+    return ks > 1 ? (int64_t)ks * B * Cout * H * W * (int64_t)sizeof(float) : 0;
 }
 
 int spk_conv3x3_pack_weights(const float* w, float* w_packed, int Cin, int Cout, int config, int transpose_flip,
@@ -350,6 +599,8 @@ int spk_conv3x3_fwd(const spk_conv3x3_desc* d, void* stream) {
         case 1: return run<Cfg1>(d, s);
         case 2: return run<Cfg2>(d, s);
         case 3: return run<Cfg3>(d, s);
+        case 4: return run<Cfg4>(d, s);
+        case 5: return run<Cfg5>(d, s);
         default: return spk::fail(SPK_EINVAL, "conv3x3: bad config %d", cfg);
     }
 }

@@ -42,6 +42,11 @@ def conv3x3_pick_config(B, Cin, Cout, H, W) -> int:
     return L.lib().spk_conv3x3_pick_config(B, Cin, Cout, H, W)
 
 
+def conv3x3_config_fits(config: int, B, Cin, Cout, H, W) -> bool:
+    """Whether tile config ``config`` can host this problem (some configs cannot tile tiny images)."""
+    return L.lib().spk_conv3x3_workspace_bytes(int(config), 1, B, Cin, Cout, H, W) >= 0
+
+
 def conv3x3_config_info(config: int):
     co, ci, px = C.c_int(), C.c_int(), C.c_int()
     L.check(L.lib().spk_conv3x3_config_info(config, C.byref(co), C.byref(ci), C.byref(px)), "spk_conv3x3_config_info")
@@ -61,8 +66,21 @@ def pack_conv3x3_weight(weight: torch.Tensor, config: int, transpose_flip: bool 
     return out
 
 
+_workspaces = {}
+
+
+def _workspace(device, nbytes: int):
+    """Per-device scratch for split-K partial sums, grown on demand (stream-ordered reuse: every
+    consumer of the scratch is enqueued on the same stream right behind its producer)."""
+    ws = _workspaces.get(device)
+    if ws is None or ws.numel() * 4 < nbytes:
+        ws = torch.empty((nbytes + 3) // 4, device=device, dtype=torch.float32)
+        _workspaces[device] = ws
+    return ws
+
+
 def conv3x3_fused(x, w_packed, Cout: int, *, bias=None, noise_w=None, noise=None, style=None, style_stride=None,
-                  upsample=False, lrelu_slope=None, in_scale=1.0, config=-1, out=None, accumulate=False):
+                  upsample=False, lrelu_slope=None, in_scale=1.0, config=-1, ksplit=0, out=None, accumulate=False):
     """y = style(lrelu(conv3x3(up?(x)) * in_scale + bias + noise_w*noise)) -- one launch.
 
     ``style`` is a tensor whose row ``b`` (stride ``style_stride`` floats, default its row length)
@@ -90,12 +108,19 @@ def conv3x3_fused(x, w_packed, Cout: int, *, bias=None, noise_w=None, noise=None
         flags |= L.CONV_UPSAMPLE2X
     if accumulate:
         flags |= L.EPI_ACCUM
+    if config < 0:
+        config = L.lib().spk_conv3x3_pick_config(B, Cin, Cout, H, W)
+    ws_bytes = L.lib().spk_conv3x3_workspace_bytes(int(config), int(ksplit), B, Cin, Cout, H, W)
+    if ws_bytes < 0:
+        raise L.SpkError(f"conv3x3_fused: config {config} cannot host shape {(B, Cin, Cout, H, W)}")
+    ws = _workspace(x.device, ws_bytes) if ws_bytes > 0 else None
     d = L.Conv3x3Desc(x=L.dptr(x, "x"), w_packed=L.dptr(w_packed, "w_packed"), bias=L.dptr(bias, "bias"),
                       noise_w=L.dptr(noise_w, "noise_w") if noise is not None else None,
                       noise=L.dptr(noise, "noise"), style=_style_ptr(style), y=L.dptr(out, "out"),
                       B=B, Cin=Cin, Cout=Cout, H=H, W=W, style_stride=int(style_stride or 0), flags=flags,
                       lrelu_slope=float(lrelu_slope if lrelu_slope is not None else 1.0), in_scale=float(in_scale),
-                      config=int(config))
+                      config=int(config), ksplit=int(ksplit), workspace=ws.data_ptr() if ws is not None else None,
+                      workspace_bytes=ws.numel() * 4 if ws is not None else 0)
     if CONV_EVENTS is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()

@@ -48,16 +48,19 @@ def T(a):
     (2, 20, 130, 16, 40),    # Cout just over one 128-tile, non-square
     (1, 8, 32, 4, 4),        # 4x4 (ProGAN initial conv)
 ])
-@pytest.mark.parametrize("config", [-1, 0, 1, 2, 3])
+@pytest.mark.parametrize("config", [-1, 0, 1, 2, 3, 4, 5])
 def test_conv3x3_plain_all_configs(pkg, dev, B, Cin, Cout, H, W, config):
     x = recipe_input(f"cv.x.{B}.{Cin}.{H}.{W}", (B, Cin, H, W))
     w = recipe_tensor(f"cv.{Cout}.{Cin}.weight", (Cout, Cin, 3, 3))
     b = recipe_tensor(f"cv.{Cout}.bias", (Cout,))
     ref = F.conv2d(x, w, b, padding=1)
     cfg = config if config >= 0 else pkg.ops.conv3x3_pick_config(B, Cin, Cout, H, W)
+    if not pkg.ops.conv3x3_config_fits(cfg, B, Cin, Cout, H, W):
+        pytest.skip("tile config cannot host this shape (the auto pick never selects it)")
     wp = pkg.ops.pack_conv3x3_weight(w.to(dev), cfg)
-    y = pkg.ops.conv3x3_fused(x.to(dev), wp, Cout, bias=b.to(dev), config=cfg)
-    assert rel_l2(y, ref) < TOL_OP
+    for ksplit in (1, 0, 3):     # none / auto / forced odd split (ragged last slice)
+        y = pkg.ops.conv3x3_fused(x.to(dev), wp, Cout, bias=b.to(dev), config=cfg, ksplit=ksplit)
+        assert rel_l2(y, ref) < TOL_OP, ksplit
 
 
 @pytest.mark.parametrize("B,Cin,Cout,Hs", [(2, 16, 8, 6), (1, 128, 64, 16), (3, 32, 96, 4), (1, 6, 6, 1), (2, 64, 32, 32)])
@@ -73,11 +76,17 @@ def test_conv3x3_fused_upsample_epilogue(pkg, dev, B, Cin, Cout, Hs):
     ref = F.conv2d(R.upsample2x_bilinear(x), w, b, padding=1)
     ref = F.leaky_relu(R.apply_noise(ref, nw, nz), 0.2)
     ref = ref * (st[:, :Cout].view(B, Cout, 1, 1) + 1.0) + st[:, Cout:].view(B, Cout, 1, 1)
-    for cfg in range(4):
+    hosted = 0
+    for cfg in range(6):
+        if not pkg.ops.conv3x3_config_fits(cfg, B, Cin, Cout, 2 * Hs, 2 * Hs):
+            continue
+        hosted += 1
         wp = pkg.ops.pack_conv3x3_weight(w.to(dev), cfg)
-        y = pkg.ops.conv3x3_fused(x.to(dev), wp, Cout, bias=b.to(dev), noise_w=nw.to(dev), noise=nz.to(dev),
-                                  style=st.to(dev), upsample=True, lrelu_slope=0.2, config=cfg)
-        assert rel_l2(y, ref) < TOL_OP, cfg
+        for ksplit in (1, 2):
+            y = pkg.ops.conv3x3_fused(x.to(dev), wp, Cout, bias=b.to(dev), noise_w=nw.to(dev), noise=nz.to(dev),
+                                      style=st.to(dev), upsample=True, lrelu_slope=0.2, config=cfg, ksplit=ksplit)
+            assert rel_l2(y, ref) < TOL_OP, (cfg, ksplit)
+    assert hosted >= 2
 
 
 def test_conv3x3_transpose_flip_is_data_gradient(pkg, dev):
@@ -176,7 +185,8 @@ def test_style_generator_batch8_vs_oracle(pkg, dev):
     # size-independent property: frames are independent -> any sub-batch reproduces its rows exactly
     with torch.no_grad():
         y3 = g(feats[3:4].to(dev), [n[3:4].to(dev) for n in noises])
-    assert rel_l2(y3, y[3:4]) < 1e-6
+    # (to summation order: the split-K factor is chosen from the grid size, which depends on the batch)
+    assert rel_l2(y3, y[3:4]) < 1e-5
 
 
 def test_synthesis_512_golden(pkg, dev, golden):
