@@ -148,6 +148,12 @@ def main():
         pkg.ops.CONV_EVENTS = None
 
     if rank == 0:
+        traffic = None
+        try:   # HBM bytes per conv launch from the committed PMC pass of this same command
+            with open(os.path.join(ROOT, "profiles", "conv_traffic.json")) as f:
+                traffic = json.load(f)["bytes_per_launch"]
+        except (OSError, KeyError, ValueError):
+            pass
         flops = decoder_conv_flops(BATCH)
         achieved = flops / (conv_ms * 1e-3) / 1e12
         ms_per_step = elapsed / args.steps * 1e3
@@ -165,7 +171,7 @@ def main():
                        "parallelism": f"replicas x{world} (no data-path collective)"},
             "roofline": {"bound": "mfma", "kernel": "conv3x3_kernel (f32 MFMA implicit GEMM, fused epilogue)",
                          "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                          "launches_per_step": n_launch, "conv_ms_per_step": round(conv_ms, 4),
                          "conv_share_of_step": round(conv_ms / ms_per_step, 3),
                          "algorithmic_gflop_per_step": round(flops / 1e9, 2)},
