@@ -31,70 +31,86 @@ extern "C" {
 #define SPK_ELAUNCH      -2   /* HIP reported a launch error */
 #define SPK_EUNSUPPORTED -3
 
-/* epilogue flags of spk_conv3x3_desc.flags */
+/* flags of spk_conv2d_desc.flags */
 #define SPK_EPI_BIAS   1u
 #define SPK_EPI_NOISE  2u
 #define SPK_EPI_LRELU  4u
 #define SPK_EPI_STYLE  8u
-#define SPK_CONV_UPSAMPLE2X 16u   /* input is [B,Cin,H/2,W/2]; bilinear x2 is applied while staging */
-#define SPK_EPI_ACCUM  32u        /* y += result (used by weight-gradient / residual paths) */
+#define SPK_CONV_UPSAMPLE2X 16u      /* input is bilinearly upsampled x2 while staging (3x3 stride 1 only) */
+#define SPK_EPI_ACCUM  32u           /* y += result */
+#define SPK_EPI_STATS  64u           /* stats[0:Cout] += sum_bhw y, stats[Cout:2Cout] += sum_bhw y^2 (fp64) */
+#define SPK_CONV_IN_AFFINE_RELU 128u /* x' = max(x*in_scale[ci] + in_shift[ci], 0) applied while staging */
 
 const char* spk_version(void);
 const char* spk_last_error(void);
 
-/* ---- 3x3 convolution, stride 1, zero pad 1, fp32 on the f32 MFMA pipe ------------------------
- * y[b,co,h,w] = epi( sum_{ci,ky,kx} w[co,ci,ky,kx] * xin[b,ci,h+ky-1,w+kx-1] )
- * epi(v) = style( lrelu( v + bias[co] + noise_w[co]*noise[b,0,h,w] ) ),
- * style(v) = v*(style[b*style_stride + co] + 1) + style[b*style_stride + Cout + co]
- * Each stage of epi is enabled by its SPK_EPI_* flag.  With SPK_CONV_UPSAMPLE2X, xin is the
- * bilinear x2 (align_corners=False) upsampling of x[B,Cin,H/2,W/2], formed on the fly.
+/* ---- 2-D convolution on the f32 MFMA pipe -----------------------------------------------------------
+ * Kernel sizes 1x1, 3x3, 7x7; stride 1 or 2; zero padding (k-1)/2; fp32, exact (fmaf-chain) arithmetic.
+ *   y[b,co,h,w] = epi( out_scale * sum_{ci,ky,kx} w[co,ci,ky,kx] * xin[b,ci,h*s+ky-p,w*s+kx-p] )
+ *   epi(v) = style( lrelu( v + bias[co] + noise_w[co]*noise[b,0,h,w] ) ),
+ *   style(v) = v*(style[b*style_stride + co] + 1) + style[b*style_stride + Cout + co]
+ * Each stage of epi is enabled by its SPK_EPI_* flag.  xin is x, or (SPK_CONV_UPSAMPLE2X) the bilinear x2
+ * (align_corners=False) upsampling of x formed on the fly, or (SPK_CONV_IN_AFFINE_RELU) max(x*a+b, 0)
+ * with per-input-channel a, b -- the producer's BatchNorm + ReLU, never materialised.
  * replaces: styleganv1.py:624-628 (upsample, conv1, noise1, leaky_relu, style_mod1) and
  *           styleganv1.py:630-633 (conv2, noise2, leaky_relu, style_mod2) -- one launch each;
- *           stylegan.py:45-46 (WSConv2d: in_scale folds the x*scale pre-multiply).
- * Weights must first be packed for the chosen tile config with spk_conv3x3_pack_weights. */
-typedef struct spk_conv3x3_desc {
-    const float* x;          /* [B,Cin,H,W] (or [B,Cin,H/2,W/2] with SPK_CONV_UPSAMPLE2X) */
-    const float* w_packed;   /* from spk_conv3x3_pack_weights, same `config` */
+ *           stylegan.py:45-46 (WSConv2d: out_scale folds the x*scale pre-multiply);
+ *           every nn.Conv2d of the torchvision ResNet-50 trunk built at model.py:60-62 (7x7 s2 stem,
+ *           1x1 / 3x3 bottleneck convs, 1x1 s2 downsample) with the following BatchNorm2d statistics
+ *           pass (SPK_EPI_STATS) and the preceding BatchNorm2d+ReLU application folded in.
+ * Weights must first be packed for the chosen tile config with spk_conv2d_pack_weights. */
+typedef struct spk_conv2d_desc {
+    const float* x;          /* [B,Cin,Hin,Win] */
+    const float* w_packed;   /* from spk_conv2d_pack_weights, same kernel size and `config` */
     const float* bias;       /* [Cout] or NULL */
     const float* noise_w;    /* [Cout] or NULL */
     const float* noise;      /* [B,1,H,W] or NULL */
     const float* style;      /* row b at style + b*style_stride: [s0(Cout) | s1(Cout)] or NULL */
+    const float* in_scale;   /* [Cin] (SPK_CONV_IN_AFFINE_RELU) or NULL */
+    const float* in_shift;   /* [Cin] */
+    double*      stats;      /* [2*Cout] (SPK_EPI_STATS) or NULL; caller zeroes it */
     float*       y;          /* [B,Cout,H,W] */
-    int32_t B, Cin, Cout, H, W;   /* H, W: OUTPUT spatial size */
+    int32_t B, Cin, Cout;
+    int32_t H, W;            /* OUTPUT spatial size */
+    int32_t Hin, Win;        /* input spatial size (H = 2*Hin with SPK_CONV_UPSAMPLE2X, else (Hin+2p-k)/s+1) */
+    int32_t kh, kw, stride;
     int32_t style_stride;    /* in floats */
     uint32_t flags;
     float lrelu_slope;
-    float in_scale;          /* multiplies the result of the contraction before bias (1.0 = none) */
-    int32_t config;          /* tile config id, 0..spk_conv3x3_num_configs()-1, or -1 = auto */
+    float out_scale;         /* multiplies the contraction before bias (1.0 = none) */
+    int32_t config;          /* tile config id, or -1 = auto */
     int32_t ksplit;          /* slices of the input-channel range (split-K); 0 = auto, 1 = none */
     void*   workspace;       /* device scratch for split-K partial sums (may be NULL if not needed) */
-    int64_t workspace_bytes; /* its size; see spk_conv3x3_workspace_bytes */
-} spk_conv3x3_desc;
+    int64_t workspace_bytes; /* its size; see spk_conv2d_workspace_bytes */
+} spk_conv2d_desc;
 
-int spk_conv3x3_num_configs(void);
-/* tile config chosen by the heuristic for this problem (what `config = -1` resolves to) */
-int spk_conv3x3_pick_config(int B, int Cin, int Cout, int H, int W);
+int spk_conv2d_num_configs(void);
+/* whether tile config `config` is built for this kernel size / stride */
+int spk_conv2d_config_valid(int config, int kh, int kw, int stride);
+/* tile config chosen by the heuristic for this problem (what `config = -1` resolves to); H, W = output size */
+int spk_conv2d_pick_config(int kh, int kw, int stride, int B, int Cin, int Cout, int H, int W);
 /* CO_T / CI_T / PIX_T of a config (any out pointer may be NULL) */
-int spk_conv3x3_config_info(int config, int* co_tile, int* ci_tile, int* pix_tile);
-/* number of floats of the packed image of a [Cout,Cin,3,3] weight for `config` */
-int64_t spk_conv3x3_packed_floats(int config, int Cin, int Cout);
-/* bytes of scratch spk_conv3x3_fwd needs for this problem (0 when it will not split K; <0 = bad args).
- * config = -1 / ksplit = 0 ask for the library's own choices. */
-int64_t spk_conv3x3_workspace_bytes(int config, int ksplit, int B, int Cin, int Cout, int H, int W);
-/* w[Cout,Cin,3,3] -> packed [co_tile][ci_chunk][tap][ci][co] (zero padded).
- * transpose_flip != 0 packs the data-gradient operator instead: w'[ci,co,ky,kx] = w[co,ci,2-ky,2-kx]
- * (then the packed image is that of a [Cin,Cout,3,3] weight).
+int spk_conv2d_config_info(int config, int* co_tile, int* ci_tile, int* pix_tile);
+/* number of floats of the packed image of a [Cout,Cin,kh,kw] weight for `config` (<0 = bad args) */
+int64_t spk_conv2d_packed_floats(int config, int kh, int kw, int Cin, int Cout);
+/* bytes of scratch spk_conv2d_fwd needs for this problem (0 when it will not split K; <0 = the config cannot
+ * host the shape).  config = -1 / ksplit = 0 ask for the library's own choices. */
+int64_t spk_conv2d_workspace_bytes(int config, int ksplit, int kh, int kw, int stride, int B, int Cin, int Cout,
+                                   int H, int W);
+/* w[Cout,Cin,kh,kw] -> packed [co_tile][ci_chunk][tap][ci][co] (zero padded).
+ * transpose_flip != 0 packs the data-gradient operator instead: w'[ci,co,ky,kx] = w[co,ci,kh-1-ky,kw-1-kx]
+ * (then the packed image is that of a [Cin,Cout,kh,kw] weight).
  * replaces: nothing in the reference (layout change private to this library). */
-int spk_conv3x3_pack_weights(const float* w, float* w_packed, int Cin, int Cout, int config,
-                             int transpose_flip, void* stream);
-int spk_conv3x3_fwd(const spk_conv3x3_desc* desc, void* stream);
+int spk_conv2d_pack_weights(const float* w, float* w_packed, int kh, int kw, int Cin, int Cout, int config,
+                            int transpose_flip, void* stream);
+int spk_conv2d_fwd(const spk_conv2d_desc* desc, void* stream);
 
 /* ---- fully connected + LeakyReLU ---------------------------------------------------------------
  * out[b,o] = act( wmul * sum_i x[b*x_stride + i] * w[o*I + i] + bmul * bias[o] ),
  * act(v) = v > 0 ? v : slope*v  (slope = 1 => identity).
  * replaces: styleganv1.py:489-495 (FC.forward: F.linear with runtime w_lrmul/b_lrmul + leaky_relu),
  *           used by the mapping stack :513-518,:532 and by every ApplyStyle :461,:464;
- *           stylegan.py:20-21 (WSLinear). */
+ *           stylegan.py:20-21 (WSLinear); model.py:121-122 (Cm = nn.Linear(2048, 8)). */
 int spk_fc_fwd(const float* x, int64_t x_stride, const float* w, const float* bias, float* out,
                int64_t out_stride, int B, int I, int O, float wmul, float bmul, float slope, void* stream);
 
@@ -117,6 +133,28 @@ int spk_conv1x1_small_fwd(const float* x, const float* w, const float* bias, flo
 /* ---- bilinear x2 upsampling (align_corners = False) -----------------------------------------------
  * replaces: styleganv1.py:621,624 (nn.Upsample) / stylegan.py:168 (F.interpolate) when used un-fused. */
 int spk_upsample2x_bilinear_fwd(const float* x, float* y, int64_t planes, int Hin, int Win, void* stream);
+
+/* ---- BatchNorm2d pieces (torchvision ResNet-50 trunk, model.py:60-62) ------------------------------
+ * spk_bn_finalize: turns the fp64 batch sums a conv epilogue accumulated (SPK_EPI_STATS) into the affine
+ *   the consumer applies: mean = S/N, var = SS/N - mean^2 (biased), scale = gamma*rsqrt(var+eps),
+ *   shift = beta - mean*scale; and (momentum > 0) updates running_mean / running_var (unbiased var) as
+ *   nn.BatchNorm2d does in training mode.  With stats = NULL (eval mode) the running statistics are used.
+ *   save_mean / save_invstd ([C], may be NULL) keep the batch statistics for the backward pass.
+ * replaces: the statistics half of F.batch_norm for every bn1/bn2/bn3/downsample.1 of the trunk. */
+int spk_bn_finalize(const double* stats, int64_t count, const float* gamma, const float* beta, float* running_mean,
+                    float* running_var, float momentum, float eps, float* scale, float* shift, float* save_mean,
+                    float* save_invstd, int C, void* stream);
+/* y = [relu]( a*sa[c] + ba[c] + (b ? b*sb[c] + bb[c] : 0) ): BatchNorm apply (+ residual add) (+ ReLU).
+ * sb/bb NULL = identity on b.  replaces: bn3 + `out += identity` + relu at the end of every torchvision
+ * Bottleneck.forward, bn1+relu of the stem (with b = NULL). */
+int spk_bn_add_relu_fwd(const float* a, const float* sa, const float* ba, const float* b, const float* sb,
+                        const float* bb, float* y, int B, int C, int64_t HW, int relu, void* stream);
+/* 3x3 stride-2 pad-1 max pooling; with in_scale/in_shift != NULL the input is max(x*s[c]+b[c],0) formed on the
+ * fly (stem bn1+relu folded).  replaces: resnet50.maxpool (children()[3], model.py:62). */
+int spk_maxpool3x3s2_fwd(const float* x, const float* in_scale, const float* in_shift, float* y, int B, int C,
+                         int Hin, int Win, void* stream);
+/* y[b,c] = mean_hw x[b,c,:,:].  replaces: resnet50.avgpool = AdaptiveAvgPool2d(1) (children()[8]). */
+int spk_global_avgpool_fwd(const float* x, float* y, int64_t planes, int64_t HW, void* stream);
 
 #ifdef __cplusplus
 }

@@ -74,6 +74,29 @@ def fill_state_dict(sd: dict, prefix: str = "", wscale_convs: bool = False) -> d
     return out
 
 
+def resnet_trunk_state_dict(prefix: str) -> dict:
+    """Recipe state dict of one ResNet-50 trunk (torchvision Sequential keys, oracle.resnet_ref):
+    conv weights He-scaled, BN gamma = 1 + 0.2 N, beta = 0.1 N, running_mean = 0.1 N,
+    running_var = 0.5 + |N| (positive), num_batches_tracked = 0."""
+    from .resnet_ref import trunk_param_shapes
+    sd = {}
+    for k, shp in trunk_param_shapes().items():
+        key = prefix + k
+        if k.endswith("num_batches_tracked"):
+            sd[k] = torch.zeros((), dtype=torch.long)
+        elif k.endswith("running_var"):
+            sd[k] = recipe_tensor(key, shp, 1.0).abs() + 0.5
+        elif k.endswith("running_mean"):
+            sd[k] = recipe_tensor(key, shp, 0.1)
+        elif len(shp) == 1 and k.endswith("weight"):
+            sd[k] = 1.0 + recipe_tensor(key, shp, 0.2)
+        elif len(shp) == 1:
+            sd[k] = recipe_tensor(key, shp, 0.1)
+        else:
+            sd[k] = recipe_tensor(key, shp)          # conv: sqrt(2 / fan_in)
+    return sd
+
+
 def recipe_input(name: str, shape, dist: str = "normal") -> torch.Tensor:
     rs = _rs("input:" + name)
     if dist == "normal":

@@ -15,30 +15,41 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(HERE, "libspk_hip.so")
 
 # epilogue flags (include/spk.h)
-EPI_BIAS, EPI_NOISE, EPI_LRELU, EPI_STYLE, CONV_UPSAMPLE2X, EPI_ACCUM = 1, 2, 4, 8, 16, 32
+EPI_BIAS, EPI_NOISE, EPI_LRELU, EPI_STYLE, CONV_UPSAMPLE2X, EPI_ACCUM, EPI_STATS, CONV_IN_AFFINE_RELU = \
+    1, 2, 4, 8, 16, 32, 64, 128
 
 c_float_p = C.c_void_p  # device pointers travel as integers
 
 
-class Conv3x3Desc(C.Structure):
+class Conv2dDesc(C.Structure):
+    """Mirror of spk_conv2d_desc (include/spk.h)."""
     _fields_ = [("x", C.c_void_p), ("w_packed", C.c_void_p), ("bias", C.c_void_p), ("noise_w", C.c_void_p),
-                ("noise", C.c_void_p), ("style", C.c_void_p), ("y", C.c_void_p),
+                ("noise", C.c_void_p), ("style", C.c_void_p), ("in_scale", C.c_void_p), ("in_shift", C.c_void_p),
+                ("stats", C.c_void_p), ("y", C.c_void_p),
                 ("B", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("Hin", C.c_int32), ("Win", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32),
                 ("style_stride", C.c_int32), ("flags", C.c_uint32), ("lrelu_slope", C.c_float),
-                ("in_scale", C.c_float), ("config", C.c_int32), ("ksplit", C.c_int32),
+                ("out_scale", C.c_float), ("config", C.c_int32), ("ksplit", C.c_int32),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
 
 
 _PROTOTYPES = {
     "spk_version": (C.c_char_p, []),
     "spk_last_error": (C.c_char_p, []),
-    "spk_conv3x3_num_configs": (C.c_int, []),
-    "spk_conv3x3_pick_config": (C.c_int, [C.c_int] * 5),
-    "spk_conv3x3_config_info": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
-    "spk_conv3x3_packed_floats": (C.c_int64, [C.c_int, C.c_int, C.c_int]),
-    "spk_conv3x3_workspace_bytes": (C.c_int64, [C.c_int] * 7),
-    "spk_conv3x3_pack_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
-    "spk_conv3x3_fwd": (C.c_int, [C.POINTER(Conv3x3Desc), C.c_void_p]),
+    "spk_conv2d_num_configs": (C.c_int, []),
+    "spk_conv2d_config_valid": (C.c_int, [C.c_int] * 4),
+    "spk_conv2d_pick_config": (C.c_int, [C.c_int] * 8),
+    "spk_conv2d_config_info": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    "spk_conv2d_packed_floats": (C.c_int64, [C.c_int] * 5),
+    "spk_conv2d_workspace_bytes": (C.c_int64, [C.c_int] * 10),
+    "spk_conv2d_pack_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
+                                          C.c_void_p]),
+    "spk_conv2d_fwd": (C.c_int, [C.POINTER(Conv2dDesc), C.c_void_p]),
+    "spk_bn_finalize": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
+                                  C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "spk_bn_add_relu_fwd": (C.c_int, [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_int64, C.c_int, C.c_void_p]),
+    "spk_maxpool3x3s2_fwd": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p]),
+    "spk_global_avgpool_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     "spk_fc_fwd": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
                              C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "spk_bias_noise_style_fwd": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,

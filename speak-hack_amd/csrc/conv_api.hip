@@ -1,0 +1,237 @@
+// C-ABI entry points of the conv family (include/spk.h), config tables / heuristics, the split-K
+// finishing kernel and the weight packer.  The MFMA kernel template lives in conv_mfma_f32.hpp and
+// is instantiated in conv_inst_*.hip.
+#include "conv_mfma_f32.hpp"
+
+namespace spkconv {
+
+// y = epi( sum_z ws[z] ): fixed summation order (bitwise reproducible), one element per thread.
+// BN statistics: a wave whose 64 elements share one output channel reduces with a butterfly and issues
+// one fp64 atomic; ragged waves fall back to per-lane atomics.
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const ConvArgs p, const float* __restrict__ ws, int ksplit) {
+    const size_t HW = (size_t)p.H * p.W;
+    const size_t total = (size_t)p.B * p.Cout * HW;
+    const bool f_bias = p.flags & SPK_EPI_BIAS, f_noise = p.flags & SPK_EPI_NOISE;
+    const bool f_lrelu = p.flags & SPK_EPI_LRELU, f_style = p.flags & SPK_EPI_STYLE;
+    const bool f_accum = p.flags & SPK_EPI_ACCUM, f_stats = p.flags & SPK_EPI_STATS;
+    const size_t nthreads = (size_t)gridDim.x * blockDim.x;
+    const size_t rounds = (total + nthreads - 1) / nthreads;
+    for (size_t it = 0; it < rounds; ++it) {   // every lane runs every round (wave-wide shuffles below)
+        const size_t idx = it * nthreads + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+        const bool in = idx < total;
+        float v = 0.f;
+        int co = -1;
+        if (in) {
+            for (int z = 0; z < ksplit; ++z) v += ws[(size_t)z * total + idx];
+            const size_t pix = idx % HW;
+            co = (int)((idx / HW) % p.Cout);
+            const int b = (int)(idx / (HW * p.Cout));
+            v *= p.out_scale;
+            if (f_bias) v += p.bias[co];
+            if (f_noise) v += p.noise_w[co] * p.noise[(size_t)b * HW + pix];
+            if (f_lrelu) v = v > 0.f ? v : v * p.slope;
+            if (f_style) {
+                const float* st = p.style + (size_t)b * p.style_stride;
+                v = v * (st[co] + 1.f) + st[p.Cout + co];
+            }
+            if (f_accum) v += p.y[idx];
+            p.y[idx] = v;
+        }
+        if (f_stats) {
+            const int co0 = __shfl(co, 0);
+            if (__all(co == co0) && co0 >= 0) {
+                float s = v, ss = v * v;
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) {
+                    s += __shfl_xor(s, off);
+                    ss += __shfl_xor(ss, off);
+                }
+                if ((threadIdx.x & 63) == 0) {
+                    atomicAdd(p.stats + co0, (double)s);
+                    atomicAdd(p.stats + p.Cout + co0, (double)ss);
+                }
+            } else if (in) {
+                atomicAdd(p.stats + co, (double)v);
+                atomicAdd(p.stats + p.Cout + co, (double)v * v);
+            }
+        }
+    }
+}
+
+int launch_splitk_epilogue(const ConvArgs& a, const float* ws, int ksplit, hipStream_t stream) {
+    const size_t out_floats = (size_t)a.B * a.Cout * a.H * a.W;
+    const unsigned blocks = (unsigned)std::min<size_t>((out_floats + 255) / 256, 256 * 8);
+    hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, stream, a, ws, ksplit);
+    return spk::check_launch("splitk_epilogue_kernel");
+}
+
+__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int taps, int Cin_orig,
+                                    int opCin, int opCout, int CO_T, int CI_T, int n_chunks, int tf, long long total) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    long long t = idx;
+    const int co_in = (int)(t % CO_T); t /= CO_T;
+    const int ci = (int)(t % CI_T); t /= CI_T;
+    const int tap = (int)(t % taps); t /= taps;
+    const int chunk = (int)(t % n_chunks);
+    const int cot = (int)(t / n_chunks);
+    const int co = cot * CO_T + co_in, cig = chunk * CI_T + ci;
+    float v = 0.f;
+    if (co < opCout && cig < opCin) {
+        if (!tf) v = w[((size_t)co * Cin_orig + cig) * taps + tap];
+        else     v = w[((size_t)cig * Cin_orig + co) * taps + (taps - 1 - tap)];
+    }
+    wp[idx] = v;
+}
+
+struct CfgDims { int co_t, ci_t, pix_t; };
+static const CfgDims kDims[kNumConfigs] = {
+    {Cfg0::CO_T, Cfg0::CI_T, Cfg0::PIX_T},   {Cfg1::CO_T, Cfg1::CI_T, Cfg1::PIX_T},   {Cfg2::CO_T, Cfg2::CI_T, Cfg2::PIX_T},
+    {Cfg3::CO_T, Cfg3::CI_T, Cfg3::PIX_T},   {Cfg4::CO_T, Cfg4::CI_T, Cfg4::PIX_T},   {Cfg5::CO_T, Cfg5::CI_T, Cfg5::PIX_T},
+    {Cfg6::CO_T, Cfg6::CI_T, Cfg6::PIX_T},   {Cfg7::CO_T, Cfg7::CI_T, Cfg7::PIX_T},   {Cfg8::CO_T, Cfg8::CI_T, Cfg8::PIX_T},
+    {Cfg9::CO_T, Cfg9::CI_T, Cfg9::PIX_T},   {Cfg10::CO_T, Cfg10::CI_T, Cfg10::PIX_T}, {Cfg11::CO_T, Cfg11::CI_T, Cfg11::PIX_T}};
+
+static bool supported_kernel(int kh, int kw, int stride) {
+    return kh == kw && (kh == 1 || kh == 3 || kh == 7) && (stride == 1 || stride == 2) && !(kh == 7 && stride == 1);
+}
+
+static bool config_valid(int cfg, int kh, int kw, int stride) {
+    if (!supported_kernel(kh, kw, stride) || cfg < 0 || cfg >= kNumConfigs) return false;
+    if (kh == 1) return cfg >= 8;
+    if (kh == 3 && stride == 1) return cfg <= 7;
+    return cfg >= 4 && cfg <= 7;  // 3x3 s2, 7x7 s2
+}
+
+template <int KH, int S>
+static Geometry geom_k(int cfg, int B, int Cin, int Cout, int H, int W) {
+    switch (cfg) {
+        case 0: return geometry<Cfg0, KH, KH, S>(B, Cin, Cout, H, W);
+        case 1: return geometry<Cfg1, KH, KH, S>(B, Cin, Cout, H, W);
+        case 2: return geometry<Cfg2, KH, KH, S>(B, Cin, Cout, H, W);
+        case 3: return geometry<Cfg3, KH, KH, S>(B, Cin, Cout, H, W);
+        case 4: return geometry<Cfg4, KH, KH, S>(B, Cin, Cout, H, W);
+        case 5: return geometry<Cfg5, KH, KH, S>(B, Cin, Cout, H, W);
+        case 6: return geometry<Cfg6, KH, KH, S>(B, Cin, Cout, H, W);
+        case 7: return geometry<Cfg7, KH, KH, S>(B, Cin, Cout, H, W);
+        case 8: return geometry<Cfg8, KH, KH, S>(B, Cin, Cout, H, W);
+        case 9: return geometry<Cfg9, KH, KH, S>(B, Cin, Cout, H, W);
+        case 10: return geometry<Cfg10, KH, KH, S>(B, Cin, Cout, H, W);
+        default: return geometry<Cfg11, KH, KH, S>(B, Cin, Cout, H, W);
+    }
+}
+
+static Geometry geometry_any(int kh, int stride, int cfg, int B, int Cin, int Cout, int H, int W) {
+    Geometry g;
+    if (!config_valid(cfg, kh, kh, stride)) { g.ok = false; return g; }
+    if (kh == 1) return stride == 1 ? geom_k<1, 1>(cfg, B, Cin, Cout, H, W) : geom_k<1, 2>(cfg, B, Cin, Cout, H, W);
+    if (kh == 3) return stride == 1 ? geom_k<3, 1>(cfg, B, Cin, Cout, H, W) : geom_k<3, 2>(cfg, B, Cin, Cout, H, W);
+    return geom_k<7, 2>(cfg, B, Cin, Cout, H, W);
+}
+
+// Heuristic from measurements on MI355X (tools/bench_conv.py, profiles/): the shallow-chunk configs
+// win on every decoder layer because 2-3 workgroups fit a CU and cover each other's barriers and
+// epilogues; the wide-pixel tile for Cout <= 64; the small tile when the whole problem is small.
+static int pick_config(int kh, int stride, int B, int Cin, int Cout, int H, int W) {
+    const long long pixels = (long long)B * H * W;
+    const int shape = Cout <= 32 ? 3 : (Cout <= 64 ? (pixels >= 64 * 1024 ? 1 : 2) : (pixels >= 2048 ? 0 : 2));
+    const int base = kh == 1 ? 8 : 4;            // 1x1 -> ids 8-11; everything else prefers ids 4-7
+    const int lo = kh == 1 ? 8 : (kh == 3 && stride == 1 ? 0 : 4), hi = kh == 1 ? 11 : 7;
+    const int want = base + shape;
+    if (geometry_any(kh, stride, want, B, Cin, Cout, H, W).ok) return want;
+    static const int alt[4][3] = {{2, 3, 1}, {2, 3, 0}, {3, 0, 1}, {2, 0, 1}};
+    for (int i = 0; i < 3; ++i) {
+        const int c = base + alt[shape][i];
+        if (geometry_any(kh, stride, c, B, Cin, Cout, H, W).ok) return c;
+    }
+    for (int c = lo; c <= hi; ++c)
+        if (geometry_any(kh, stride, c, B, Cin, Cout, H, W).ok) return c;
+    return want;
+}
+
+}  // namespace spkconv
+
+using namespace spkconv;
+
+extern "C" {
+
+int spk_conv2d_num_configs(void) { return kNumConfigs; }
+
+int spk_conv2d_config_valid(int config, int kh, int kw, int stride) { return config_valid(config, kh, kw, stride) ? 1 : 0; }
+
+int spk_conv2d_pick_config(int kh, int kw, int stride, int B, int Cin, int Cout, int H, int W) {
+    SPK_REQUIRE(supported_kernel(kh, kw, stride), "conv2d: unsupported kernel %dx%d stride %d", kh, kw, stride);
+    SPK_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0, "conv2d: bad shape");
+    return pick_config(kh, stride, B, Cin, Cout, H, W);
+}
+
+int spk_conv2d_config_info(int config, int* co_tile, int* ci_tile, int* pix_tile) {
+    SPK_REQUIRE(config >= 0 && config < kNumConfigs, "conv2d: bad config %d", config);
+    if (co_tile) *co_tile = kDims[config].co_t;
+    if (ci_tile) *ci_tile = kDims[config].ci_t;
+    if (pix_tile) *pix_tile = kDims[config].pix_t;
+    return SPK_OK;
+}
+
+int64_t spk_conv2d_packed_floats(int config, int kh, int kw, int Cin, int Cout) {
+    if (config < 0 || config >= kNumConfigs || Cin <= 0 || Cout <= 0 || kh <= 0 || kw <= 0) return -1;
+    const CfgDims& c = kDims[config];
+    return (int64_t)spk::ceil_div(Cout, c.co_t) * spk::ceil_div(Cin, c.ci_t) * kh * kw * c.ci_t * c.co_t;
+}
+
+int64_t spk_conv2d_workspace_bytes(int config, int ksplit, int kh, int kw, int stride, int B, int Cin, int Cout,
+                                   int H, int W) {
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || !supported_kernel(kh, kw, stride)) return -1;
+    if (config < 0) config = pick_config(kh, stride, B, Cin, Cout, H, W);
+    const Geometry g = geometry_any(kh, stride, config, B, Cin, Cout, H, W);
+    if (!g.ok) return -1;
+    const int ks = resolve_ksplit(g, ksplit, nullptr);
+    return ks > 1 ? (int64_t)ks * B * Cout * H * W * (int64_t)sizeof(float) : 0;
+}
+
+int spk_conv2d_pack_weights(const float* w, float* w_packed, int kh, int kw, int Cin, int Cout, int config,
+                            int transpose_flip, void* stream) {
+    SPK_REQUIRE(w && w_packed, "pack_weights: null pointer");
+    SPK_REQUIRE(config >= 0 && config < kNumConfigs, "pack_weights: bad config %d", config);
+    SPK_REQUIRE(Cin > 0 && Cout > 0 && kh > 0 && kw > 0, "pack_weights: bad shape");
+    const CfgDims& c = kDims[config];
+    const int opCin = transpose_flip ? Cout : Cin, opCout = transpose_flip ? Cin : Cout;
+    const int n_chunks = spk::ceil_div(opCin, c.ci_t);
+    const long long total = (long long)spk::ceil_div(opCout, c.co_t) * n_chunks * kh * kw * c.ci_t * c.co_t;
+    const int threads = 256;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((total + threads - 1) / threads)), dim3(threads), 0,
+                       (hipStream_t)stream, w, w_packed, kh * kw, Cin, opCin, opCout, c.co_t, c.ci_t, n_chunks,
+                       transpose_flip ? 1 : 0, total);
+    return spk::check_launch("pack_weights_kernel");
+}
+
+int spk_conv2d_fwd(const spk_conv2d_desc* d, void* stream) {
+    SPK_REQUIRE(d, "conv2d: null descriptor");
+    SPK_REQUIRE(d->x && d->w_packed && d->y, "conv2d: null tensor pointer");
+    SPK_REQUIRE(d->B > 0 && d->Cin > 0 && d->Cout > 0 && d->H > 0 && d->W > 0 && d->Hin > 0 && d->Win > 0, "conv2d: bad shape");
+    SPK_REQUIRE(supported_kernel(d->kh, d->kw, d->stride), "conv2d: unsupported kernel %dx%d stride %d", d->kh, d->kw, d->stride);
+    const bool ups = d->flags & SPK_CONV_UPSAMPLE2X, aff = d->flags & SPK_CONV_IN_AFFINE_RELU;
+    SPK_REQUIRE(!(ups && aff), "conv2d: UPSAMPLE2X and IN_AFFINE_RELU are exclusive");
+    SPK_REQUIRE(!ups || (d->kh == 3 && d->stride == 1), "conv2d: UPSAMPLE2X needs a 3x3 stride-1 kernel");
+    const int pad = (d->kh - 1) / 2;
+    if (ups) SPK_REQUIRE(d->H == 2 * d->Hin && d->W == 2 * d->Win, "conv2d: upsampled output must be 2x the input (%dx%d vs %dx%d)", d->H, d->W, d->Hin, d->Win);
+    else SPK_REQUIRE(d->H == (d->Hin + 2 * pad - d->kh) / d->stride + 1 && d->W == (d->Win + 2 * pad - d->kw) / d->stride + 1,
+                     "conv2d: output size %dx%d does not match input %dx%d (k=%d s=%d)", d->H, d->W, d->Hin, d->Win, d->kh, d->stride);
+    SPK_REQUIRE(!(d->flags & SPK_EPI_BIAS) || d->bias, "conv2d: SPK_EPI_BIAS without bias");
+    SPK_REQUIRE(!(d->flags & SPK_EPI_NOISE) || (d->noise && d->noise_w), "conv2d: SPK_EPI_NOISE without noise");
+    SPK_REQUIRE(!(d->flags & SPK_EPI_STYLE) || d->style, "conv2d: SPK_EPI_STYLE without style");
+    SPK_REQUIRE(!(d->flags & SPK_EPI_STATS) || d->stats, "conv2d: SPK_EPI_STATS without stats");
+    SPK_REQUIRE(!aff || (d->in_scale && d->in_shift), "conv2d: IN_AFFINE_RELU without in_scale/in_shift");
+    SPK_REQUIRE((long long)d->B * d->Cout * d->H * d->W < (1ll << 40), "conv2d: tensor too large");
+    int cfg = d->config;
+    if (cfg < 0) cfg = pick_config(d->kh, d->stride, d->B, d->Cin, d->Cout, d->H, d->W);
+    SPK_REQUIRE(config_valid(cfg, d->kh, d->kw, d->stride), "conv2d: config %d is not built for %dx%d stride %d", cfg, d->kh, d->kw, d->stride);
+    spk_conv2d_desc dd = *d;
+    dd.config = cfg;
+    const int mode = ups ? MODE_UPSAMPLE : (aff ? MODE_AFFINE_RELU : MODE_PLAIN);
+    hipStream_t s = (hipStream_t)stream;
+    if (d->kh == 1) return run_1x1(d->stride, cfg, mode, &dd, s);
+    if (d->kh == 3 && d->stride == 1) return cfg <= 3 ? run_3x3s1_a(cfg, mode, &dd, s) : run_3x3s1_b(cfg, mode, &dd, s);
+    return run_3x3s2_7x7s2(d->kh, cfg, mode, &dd, s);
+}
+
+}  // extern "C"

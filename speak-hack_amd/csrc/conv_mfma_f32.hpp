@@ -1,0 +1,506 @@
+// 2-D convolution (KHxKW in {1x1, 3x3, 7x7}, stride 1 or 2, zero pad (K-1)/2) as an LDS-staged implicit
+// GEMM on the gfx950 f32 MFMA pipe.  One kernel template serves the StyleGAN decoder (3x3 s1 with the
+// bilinear x2 upsampling folded into staging and the bias/noise/LeakyReLU/style epilogue) and the
+// ResNet-50 trunk (1x1 / 3x3 / 7x7, stride 1/2, the producer's BatchNorm+ReLU folded into staging as a
+// per-channel affine, BatchNorm batch statistics accumulated in the epilogue).
+//
+// GEMM view (per image group):  D[co][pix] = sum_k A[co][k] * Bm[k][pix],  k = (tap, ci)
+//   A  = weights, pre-packed [co_tile][ci_chunk][tap][ci][co]  (co contiguous -> conflict-free
+//        ds_read_b32 of the A fragment: lane l reads A[i = l&31][k = l>>5])
+//   Bm = input window; the tile's input planes (with halo) sit in LDS as [ci][tb][PH][PW];
+//        lane l reads Bm[k = l>>5][j = l&31] = 32 consecutive output pixels (stride S apart in LDS)
+//   D  : v_mfma_f32_32x32x2_f32, col = lane&31 = pixel (x-contiguous -> 128-B coalesced NCHW
+//        stores), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) = output channel.
+// One workgroup = WM x WN waves; each wave owns MT x NT accumulator tiles of 32co x 32pix.
+//
+// Pipeline: LDS is double buffered.  While the waves run the KH*KW*CI_T/2 MFMA k-steps of chunk c out
+// of buffer c&1, the global loads of chunk c+1 (weights: 16-B loads of one contiguous packed block;
+// input: per-lane gathers whose addresses, validity and bilinear codes were computed once at kernel
+// start) are in flight into registers; they are written to buffer (c+1)&1 after the k-steps, followed
+// by the only barrier of the chunk.  Fragments are read PD k-steps ahead of the MFMAs that use them.
+// The f32 MFMA is 64 cycles/SIMD per instruction (an exact fmaf chain), so staging issue fits in its
+// shadow; 2-3 workgroups per CU cover each other's barriers and epilogues.
+//
+// Split-K: gridDim.z slices the ci-chunk range; slices write raw partial sums to a workspace and
+// splitk_epilogue_kernel reduces them in a fixed order and applies the epilogue.
+#pragma once
+#include "spk_common.hpp"
+
+#include <algorithm>
+#include <type_traits>
+
+namespace spkconv {
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+enum Mode { MODE_PLAIN = 0, MODE_UPSAMPLE = 1, MODE_AFFINE_RELU = 2 };
+
+template <int I, int N, class F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
+struct ConvArgs {
+    const float* x;
+    const float* wp;
+    const float* bias;
+    const float* noise_w;
+    const float* noise;
+    const float* style;
+    const float* in_scale;   // MODE_AFFINE_RELU: per input channel
+    const float* in_shift;
+    double* stats;           // [2*Cout] sum / sum of squares of y (SPK_EPI_STATS)
+    float* y;                // output, or the split-K workspace [ksplit][B][Cout][H][W]
+    int B, Cin, Cout, H, W;  // output spatial size
+    int Hs, Ws;              // source tensor spatial size
+    int lgTW, lgTH, lgTB;    // log2 of the pixel-tile geometry
+    int tiles_x, tiles_y;
+    int n_chunks;            // ceil(Cin / CI_T)
+    int chunks_per_split;
+    int style_stride;
+    unsigned flags;
+    float slope, out_scale;
+};
+
+template <int WM_, int WN_, int MT_, int NT_, int CIT_>
+struct Cfg {
+    static constexpr int WM = WM_, WN = WN_, MT = MT_, NT = NT_, CI_T = CIT_;
+    static constexpr int NW = WM * WN, NTHREADS = NW * 64;
+    static constexpr int CO_T = WM * MT * 32, PIX_T = WN * NT * 32;
+    // fragment prefetch distance in k-steps: about 256 MFMA cycles of cover for the ds_read latency
+    static constexpr int PD = MT * NT >= 4 ? 1 : (MT * NT >= 2 ? 2 : 4);
+};
+
+// compile-time shape of one (config, kernel size, stride) instantiation
+template <class C, int KH, int KW, int S>
+struct Shape {
+    static constexpr int TAPS = KH * KW, PAD = (KH - 1) / 2;
+    static constexpr int W_FLOATS = TAPS * C::CI_T * C::CO_T;
+    static constexpr int WV = (W_FLOATS / 4 + C::NTHREADS - 1) / C::NTHREADS;  // 16-B loads per thread per chunk
+    static constexpr int STEPS = TAPS * (C::CI_T / 2);
+    // largest input plane of a tile (TW = 32): register slots (64 elements each) a wave prefetches
+    static constexpr int PH_MAX = (C::PIX_T / 32 - 1) * S + KH, PW_MAX = 31 * S + KW;
+    static constexpr int PPW = C::CI_T / C::NW > 0 ? C::CI_T / C::NW : 1;
+    static constexpr int NSLOT = (PPW * PH_MAX * PW_MAX + 63) / 64;
+};
+
+// slot descriptor bits
+constexpr unsigned D_VALID = 1u;        // element is inside the image (else: zero padding)
+constexpr unsigned D_CI_SHIFT = 1;      // 6 bits: ci within the chunk
+constexpr unsigned D_DX = 1u << 7;      // bilinear: second tap is one column to the right
+constexpr unsigned D_DY = 1u << 8;      // bilinear: second row is one source row below
+constexpr unsigned D_LX_SHIFT = 9;      // 2 bits: lambda code (0: 0, 1: 0.25, 2: 0.75)
+constexpr unsigned D_LY_SHIFT = 11;
+
+__device__ __forceinline__ float lambda_of(unsigned code) { return code == 0 ? 0.f : (code == 1 ? 0.25f : 0.75f); }
+
+template <class C, int KH, int KW, int S, int MODE>
+__global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
+    using SH = Shape<C, KH, KW, S>;
+    constexpr bool UPS = MODE == MODE_UPSAMPLE, AFF = MODE == MODE_AFFINE_RELU;
+    constexpr int NSLOT = SH::NSLOT, W_FLOATS = SH::W_FLOATS, WV = SH::WV, PAD = SH::PAD;
+    static_assert(!UPS || S == 1, "upsample folding needs stride 1");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l32 = lane & 31;
+    const int wm = wave / C::WN, wn = wave % C::WN;
+
+    const int TW = 1 << p.lgTW, TH = 1 << p.lgTH, TB = 1 << p.lgTB;
+    const int PW = (TW - 1) * S + KW, PLANE = ((TH - 1) * S + KH) * PW;
+    const int IN_FLOATS = C::CI_T * TB * PLANE;
+    const int BUF_FLOATS = W_FLOATS + ((IN_FLOATS + 3) & ~3);
+    int bx = blockIdx.x;
+    const int tx = bx % p.tiles_x;
+    bx /= p.tiles_x;
+    const int ty = bx % p.tiles_y;
+    const int tbi = bx / p.tiles_y;
+    const int b0 = tbi << p.lgTB, y0 = ty << p.lgTH, x0 = tx << p.lgTW;
+    const int co_tile0 = blockIdx.y * C::CO_T;
+    const int c_begin = blockIdx.z * p.chunks_per_split;
+    const int c_end = min(p.n_chunks, c_begin + p.chunks_per_split);
+    // extent of the (virtual) input image the taps index: the x2-upsampled image in MODE_UPSAMPLE
+    const int Hv = UPS ? 2 * p.Hs : p.Hs, Wv = UPS ? 2 * p.Ws : p.Ws;
+
+    // ---- per-lane gather slots: wave w owns planes [w*ppw, (w+1)*ppw), contiguous in LDS ----
+    const int ppw = (C::CI_T * TB) / C::NW;
+    const int wave_elems = ppw * PLANE;
+    const size_t src_plane = (size_t)p.Hs * p.Ws;
+    int s_off[NSLOT];
+    unsigned s_desc[NSLOT];
+#pragma unroll
+    for (int s = 0; s < NSLOT; ++s) {
+        s_off[s] = 0;
+        s_desc[s] = 0;
+        const int e = s * 64 + lane;
+        if (e < wave_elems) {
+            const int pl = e / PLANE, pidx = e - pl * PLANE;
+            const int q = wave * ppw + pl;
+            const int ci = q >> p.lgTB, tb = q & (TB - 1);
+            const int r = pidx / PW, c = pidx - r * PW;
+            const int uy = y0 * S + r - PAD, ux = x0 * S + c - PAD;
+            unsigned d = (unsigned)ci << D_CI_SHIFT;
+            if (uy >= 0 && uy < Hv && ux >= 0 && ux < Wv && b0 + tb < p.B) {
+                d |= D_VALID;
+                int goff;
+                if (!UPS) {
+                    goff = uy * p.Ws + ux;
+                } else {
+                    // torch area_pixel_compute_source_index(scale=0.5, align_corners=False):
+                    // src = max(0.5*(dst+0.5)-0.5, 0); lambdas are exactly 0, 0.25 or 0.75
+                    const int iy0 = uy == 0 ? 0 : (uy - 1) >> 1, ix0 = ux == 0 ? 0 : (ux - 1) >> 1;
+                    const unsigned ly = uy == 0 ? 0u : ((uy & 1) ? 1u : 2u);
+                    const unsigned lx = ux == 0 ? 0u : ((ux & 1) ? 1u : 2u);
+                    if (iy0 + 1 < p.Hs) d |= D_DY;
+                    if (ix0 + 1 < p.Ws) d |= D_DX;
+                    d |= (lx << D_LX_SHIFT) | (ly << D_LY_SHIFT);
+                    goff = iy0 * p.Ws + ix0;
+                }
+                s_off[s] = (int)((size_t)(tb * p.Cin + ci) * src_plane) + goff;
+            } else {
+                s_off[s] = ci * (int)src_plane;  // masked at store time; any address inside the tensor will do
+            }
+            s_desc[s] = d;
+        }
+    }
+    const float* xblk = p.x + (size_t)b0 * p.Cin * src_plane;
+
+    // ---- per-lane fragment addresses ----
+    int b_off[C::NT];
+#pragma unroll
+    for (int n = 0; n < C::NT; ++n) {
+        const int pt = (wn * C::NT + n) * 32 + l32;
+        const int px = pt & (TW - 1), py = (pt >> p.lgTW) & (TH - 1);
+        const int tb = min(pt >> (p.lgTW + p.lgTH), TB - 1);  // pixel groups beyond the tile idle (results dropped)
+        b_off[n] = W_FLOATS + half * TB * PLANE + tb * PLANE + py * S * PW + px * S;
+    }
+    const int a_off = half * C::CO_T + wm * C::MT * 32 + l32;
+    const int ci_stride2 = 2 * TB * PLANE;
+
+    f32x16 acc[C::MT][C::NT];
+#pragma unroll
+    for (int m = 0; m < C::MT; ++m)
+#pragma unroll
+        for (int n = 0; n < C::NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    const f32x4* wsrc = reinterpret_cast<const f32x4*>(p.wp) + ((size_t)blockIdx.y * p.n_chunks + c_begin) * (W_FLOATS / 4);
+
+    // prefetch registers
+    f32x4 wreg[WV];
+    float xin[UPS ? 4 * NSLOT : NSLOT];
+    float xsc[AFF ? NSLOT : 1], xsh[AFF ? NSLOT : 1];
+
+    // staging is written as macros (not lambdas / functions) so that the prefetch arrays stay in
+    // registers: every index is a compile-time constant after unrolling.
+#define SPK_ISSUE_LOADS(chunk_)                                                                               \
+    {                                                                                                         \
+        _Pragma("unroll") for (int i = 0; i < WV; ++i) {                                                      \
+            const int idx = tid + i * C::NTHREADS;                                                            \
+            if (W_FLOATS / 4 % C::NTHREADS == 0 || idx < W_FLOATS / 4) wreg[i] = wsrc[idx];                   \
+        }                                                                                                     \
+        wsrc += W_FLOATS / 4;                                                                                 \
+        const float* xc = xblk + (size_t)(chunk_) * C::CI_T * src_plane;                                      \
+        const int ci_left_ = p.Cin - (chunk_) * C::CI_T;                                                      \
+        _Pragma("unroll") for (int s = 0; s < NSLOT; ++s) {                                                   \
+            /* unconditional loads from always-valid addresses; masking happens at LDS-store time.            \
+               Channels past Cin (zero-padded last chunk) are folded onto channel 0 of the chunk. */          \
+            const unsigned d = s_desc[s];                                                                     \
+            const int ci_ = (int)((d >> D_CI_SHIFT) & 63u);                                                   \
+            const bool past_ = ci_ >= ci_left_;                                                               \
+            const int off_ = s_off[s] - (past_ ? ci_ * (int)src_plane : 0);                                   \
+            if (!UPS) {                                                                                       \
+                xin[s] = xc[off_];                                                                            \
+            } else {                                                                                          \
+                const float* s0 = xc + off_;                                                                  \
+                const int dx = (d & D_DX) ? 1 : 0, dy = (d & D_DY) ? p.Ws : 0;                                \
+                xin[4 * s + 0] = s0[0];                                                                       \
+                xin[4 * s + 1] = s0[dx];                                                                      \
+                xin[4 * s + 2] = s0[dy];                                                                      \
+                xin[4 * s + 3] = s0[dy + dx];                                                                 \
+            }                                                                                                 \
+            if (AFF) {                                                                                        \
+                const int cg_ = (chunk_) * C::CI_T + (past_ ? 0 : ci_);                                       \
+                xsc[s] = p.in_scale[cg_];                                                                     \
+                xsh[s] = p.in_shift[cg_];                                                                     \
+            }                                                                                                 \
+        }                                                                                                     \
+    }
+
+#define SPK_STORE_LDS(buf_, chunk_)                                                                           \
+    {                                                                                                         \
+        float* const sbuf = (buf_);                                                                           \
+        const int ci_left = p.Cin - (chunk_) * C::CI_T; /* channels of this chunk that exist */               \
+        _Pragma("unroll") for (int i = 0; i < WV; ++i) {                                                      \
+            const int idx = tid + i * C::NTHREADS;                                                            \
+            if (W_FLOATS / 4 % C::NTHREADS == 0 || idx < W_FLOATS / 4)                                        \
+                reinterpret_cast<f32x4*>(sbuf)[idx] = wreg[i];                                                \
+        }                                                                                                     \
+        float* dst = sbuf + W_FLOATS + wave * wave_elems;                                                     \
+        _Pragma("unroll") for (int s = 0; s < NSLOT; ++s) {                                                   \
+            const int e = s * 64 + lane;                                                                      \
+            if (e < wave_elems) {                                                                             \
+                float v;                                                                                      \
+                const unsigned d = s_desc[s];                                                                 \
+                const bool ok = (d & D_VALID) && (int)((d >> D_CI_SHIFT) & 63u) < ci_left;                    \
+                if (!UPS) {                                                                                   \
+                    v = xin[s];                                                                               \
+                } else {                                                                                      \
+                    const float lx1 = lambda_of((d >> D_LX_SHIFT) & 3u), ly1 = lambda_of((d >> D_LY_SHIFT) & 3u); \
+                    const float lx0 = 1.f - lx1, ly0 = 1.f - ly1;                                             \
+                    v = ly0 * (lx0 * xin[4 * s] + lx1 * xin[4 * s + 1]) +                                     \
+                        ly1 * (lx0 * xin[4 * s + 2] + lx1 * xin[4 * s + 3]);                                  \
+                }                                                                                             \
+                if (AFF) v = fmaxf(v * xsc[s] + xsh[s], 0.f);                                                 \
+                dst[e] = ok ? v : 0.f;                                                                        \
+            }                                                                                                 \
+        }                                                                                                     \
+    }
+
+    if (c_begin < c_end) {
+        SPK_ISSUE_LOADS(c_begin);
+        SPK_STORE_LDS(smem, c_begin);
+    }
+    __syncthreads();
+
+    for (int chunk = c_begin; chunk < c_end; ++chunk) {
+        const float* buf = smem + ((chunk - c_begin) & 1) * BUF_FLOATS;
+        const bool more = chunk + 1 < c_end;
+        if (more) SPK_ISSUE_LOADS(chunk + 1);
+
+        // k-steps: step = (tap, kk).  Fragments are read PD steps ahead of the MFMAs that use them
+        // (register ring, all indices static after unrolling) so LDS latency hides under the MFMAs;
+        // sched_group_barrier pins the ds_read / MFMA interleave the source states.
+        // Large kernels (7x7) keep the tap-row loop rolled: ROWS runtime iterations of KW*CI_T/2 static steps.
+        {
+            constexpr bool ROWLOOP = KH * KW > 9;
+            constexpr int ROWS = ROWLOOP ? KH : 1;
+            constexpr int STEPS = SH::STEPS / ROWS;
+            constexpr int PD = C::PD < STEPS ? C::PD : STEPS - 1;
+            float fa[PD + 1][C::MT], fb[PD + 1][C::NT];
+#pragma unroll 1
+            for (int row = 0; row < ROWS; ++row) {
+                const float* abuf = buf + row * (KW * C::CI_T * C::CO_T);
+                const float* bbuf = buf + row * PW;
+#define SPK_LOAD_FRAG(step_)                                                                                  \
+    {                                                                                                         \
+        constexpr int tap_ = (step_) / (C::CI_T / 2), kk_ = (step_) % (C::CI_T / 2);                          \
+        const int tapoff_ = (tap_ / KW) * PW + (tap_ % KW);                                                   \
+        _Pragma("unroll") for (int m = 0; m < C::MT; ++m)                                                     \
+            fa[(step_) % (PD + 1)][m] = abuf[a_off + (tap_ * C::CI_T + 2 * kk_) * C::CO_T + m * 32];          \
+        _Pragma("unroll") for (int n = 0; n < C::NT; ++n)                                                     \
+            fb[(step_) % (PD + 1)][n] = bbuf[b_off[n] + kk_ * ci_stride2 + tapoff_];                          \
+    }
+                static_for<0, PD>([&](auto i) { SPK_LOAD_FRAG(decltype(i)::value); });
+                static_for<0, STEPS>([&](auto i) {
+                    constexpr int st = decltype(i)::value;
+                    if constexpr (st + PD < STEPS) {
+                        SPK_LOAD_FRAG(st + PD);
+                        __builtin_amdgcn_sched_group_barrier(0x100, C::MT + C::NT, 0);
+                    }
+#pragma unroll
+                    for (int m = 0; m < C::MT; ++m)
+#pragma unroll
+                        for (int n = 0; n < C::NT; ++n)
+                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[st % (PD + 1)][m], fb[st % (PD + 1)][n],
+                                                                            acc[m][n], 0, 0, 0);
+                    __builtin_amdgcn_sched_group_barrier(0x8, C::MT * C::NT, 0);
+                });
+#undef SPK_LOAD_FRAG
+            }
+        }
+
+        if (more) SPK_STORE_LDS(smem + (((chunk - c_begin) & 1) ^ 1) * BUF_FLOATS, chunk + 1);
+        __syncthreads();
+    }
+#undef SPK_ISSUE_LOADS
+#undef SPK_STORE_LDS
+
+    // ---- epilogue ----
+    const bool split = gridDim.z > 1;
+    const bool f_bias = p.flags & SPK_EPI_BIAS, f_noise = p.flags & SPK_EPI_NOISE;
+    const bool f_lrelu = p.flags & SPK_EPI_LRELU, f_style = p.flags & SPK_EPI_STYLE;
+    const bool f_accum = p.flags & SPK_EPI_ACCUM, f_stats = (p.flags & SPK_EPI_STATS) && !split;
+    const size_t HW = (size_t)p.H * p.W;
+    float* ybase = p.y + (split ? (size_t)blockIdx.z * p.B * p.Cout * HW : 0);
+    // per pixel group: validity, output offset, noise value, style row
+    bool pv[C::NT];
+    size_t poff[C::NT];
+    float nz[C::NT];
+    const float* st[C::NT];
+#pragma unroll
+    for (int n = 0; n < C::NT; ++n) {
+        const int pt = (wn * C::NT + n) * 32 + l32;
+        const int px = pt & (TW - 1), py = (pt >> p.lgTW) & (TH - 1), tb = pt >> (p.lgTW + p.lgTH);
+        const int b = b0 + tb, yy = y0 + py, xx = x0 + px;
+        pv[n] = tb < TB && b < p.B && yy < p.H && xx < p.W;
+        const size_t pix = (size_t)yy * p.W + xx;
+        poff[n] = pv[n] ? (size_t)b * p.Cout * HW + pix : 0;
+        nz[n] = (f_noise && pv[n] && !split) ? p.noise[(size_t)b * HW + pix] : 0.f;
+        st[n] = (f_style && pv[n]) ? p.style + (size_t)b * p.style_stride : nullptr;
+    }
+#pragma unroll
+    for (int m = 0; m < C::MT; ++m) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co_tile0 + (wm * C::MT + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const bool cv = co < p.Cout;
+            float ssum = 0.f, ssq = 0.f;
+            if (cv) {
+                const float bb = (f_bias && !split) ? p.bias[co] : 0.f;
+                const float nwc = (f_noise && !split) ? p.noise_w[co] : 0.f;
+#pragma unroll
+                for (int n = 0; n < C::NT; ++n) {
+                    if (!pv[n]) continue;
+                    float* dst = ybase + poff[n] + (size_t)co * HW;
+                    if (split) {  // raw partial sums; splitk_epilogue_kernel finishes
+                        *dst = acc[m][n][r];
+                        continue;
+                    }
+                    float v = acc[m][n][r] * p.out_scale + bb;
+                    if (f_noise) v += nwc * nz[n];
+                    if (f_lrelu) v = v > 0.f ? v : v * p.slope;
+                    if (f_style) v = v * (st[n][co] + 1.f) + st[n][p.Cout + co];
+                    if (f_accum) v += *dst;
+                    *dst = v;
+                    ssum += v;
+                    ssq += v * v;
+                }
+            }
+            if (f_stats) {  // wave-uniform flag: every lane takes part in the butterfly
+#pragma unroll
+                for (int off = 16; off >= 1; off >>= 1) {
+                    ssum += __shfl_xor(ssum, off);
+                    ssq += __shfl_xor(ssq, off);
+                }
+                if (l32 == 0 && cv) {
+                    atomicAdd(p.stats + co, (double)ssum);
+                    atomicAdd(p.stats + p.Cout + co, (double)ssq);
+                }
+            }
+        }
+    }
+}
+
+// ---- host side -------------------------------------------------------------------------------------
+struct Geometry {
+    int TW, TH, TB, PLANE, tiles_x, tiles_y, tiles_b, n_chunks, co_tiles;
+    size_t lds_bytes;
+    bool ok;
+};
+
+template <class C, int KH, int KW, int S>
+Geometry geometry(int B, int Cin, int Cout, int H, int W) {
+    using SH = Shape<C, KH, KW, S>;
+    Geometry g;
+    g.TW = std::min(32, spk::pow2_ceil(W));
+    g.TH = std::min(C::PIX_T / g.TW, spk::pow2_ceil(H));
+    g.TB = C::PIX_T / (g.TW * g.TH);
+    auto plane = [&]() { return ((g.TH - 1) * S + KH) * ((g.TW - 1) * S + KW); };
+    // the wave's share of the input tile must fit its prefetch slots
+    auto slots = [&]() { return spk::ceil_div(C::CI_T * g.TB / C::NW * plane(), 64); };
+    while (slots() > SH::NSLOT && g.TB > 1 && (C::CI_T * (g.TB / 2)) % C::NW == 0) g.TB >>= 1;  // idle pixel groups
+    while (slots() > SH::NSLOT && g.TH > 1) g.TH >>= 1;
+    g.PLANE = plane();
+    g.ok = slots() <= SH::NSLOT && (C::CI_T * g.TB) % C::NW == 0 && C::CI_T <= 64;
+    g.tiles_x = spk::ceil_div(W, g.TW);
+    g.tiles_y = spk::ceil_div(H, g.TH);
+    g.tiles_b = spk::ceil_div(B, g.TB);
+    g.n_chunks = spk::ceil_div(Cin, C::CI_T);
+    g.co_tiles = spk::ceil_div(Cout, C::CO_T);
+    const size_t in_floats = ((size_t)C::CI_T * g.TB * g.PLANE + 3) & ~(size_t)3;
+    g.lds_bytes = 2 * (SH::W_FLOATS + in_floats) * sizeof(float);
+    if (g.lds_bytes > 160 * 1024) g.ok = false;
+    return g;
+}
+
+// number of ci-chunk slices so that the grid fills the chip (about 2 workgroups per CU)
+inline int pick_ksplit(const Geometry& g) {
+    const long long tiles = (long long)g.tiles_x * g.tiles_y * g.tiles_b * g.co_tiles;
+    int ks = 1;
+    while (tiles * ks < 512 && g.n_chunks / (ks * 2) >= 4 && ks < 64) ks *= 2;
+    return ks;
+}
+
+inline int resolve_ksplit(const Geometry& g, int requested, int* chunks_per_split) {
+    int ks = requested > 0 ? requested : pick_ksplit(g);
+    ks = std::max(1, std::min(ks, g.n_chunks));
+    const int cps = spk::ceil_div(g.n_chunks, ks);
+    if (chunks_per_split) *chunks_per_split = cps;
+    return spk::ceil_div(g.n_chunks, cps);
+}
+
+int launch_splitk_epilogue(const ConvArgs& a, const float* ws, int ksplit, hipStream_t stream);
+
+// Fill ConvArgs from the public descriptor, pick geometry / split-K, launch (and the split-K epilogue).
+template <class C, int KH, int KW, int S, int MODE>
+int run(const spk_conv2d_desc* d, hipStream_t stream) {
+    ConvArgs a;
+    a.x = d->x; a.wp = d->w_packed; a.bias = d->bias; a.noise_w = d->noise_w; a.noise = d->noise;
+    a.style = d->style; a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.stats = d->stats; a.y = d->y;
+    a.B = d->B; a.Cin = d->Cin; a.Cout = d->Cout; a.H = d->H; a.W = d->W; a.Hs = d->Hin; a.Ws = d->Win;
+    const Geometry g = geometry<C, KH, KW, S>(d->B, d->Cin, d->Cout, d->H, d->W);
+    SPK_REQUIRE(g.ok, "conv2d: config %d does not fit this shape (%dx%d, B=%d)", d->config, d->H, d->W, d->B);
+    SPK_REQUIRE((size_t)g.TB * d->Cin * a.Hs * a.Ws < (1ull << 31), "conv2d: image group too large for 32-bit offsets");
+    a.lgTW = spk::ilog2(g.TW); a.lgTH = spk::ilog2(g.TH); a.lgTB = spk::ilog2(g.TB);
+    a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y;
+    a.n_chunks = g.n_chunks;
+    a.style_stride = d->style_stride; a.flags = d->flags; a.slope = d->lrelu_slope; a.out_scale = d->out_scale;
+    const int ksplit = resolve_ksplit(g, d->ksplit, &a.chunks_per_split);
+    const size_t out_floats = (size_t)d->B * d->Cout * d->H * d->W;
+    if (ksplit > 1) {
+        SPK_REQUIRE(d->workspace && (size_t)d->workspace_bytes >= ksplit * out_floats * sizeof(float),
+                    "conv2d: split-K x%d needs a %zu-byte workspace (see spk_conv2d_workspace_bytes)", ksplit,
+                    ksplit * out_floats * sizeof(float));
+        a.y = static_cast<float*>(d->workspace);
+    }
+    auto kern = &conv_kernel<C, KH, KW, S, MODE>;
+    if (g.lds_bytes > 64 * 1024) {  // dynamic LDS above 64 KiB needs the attribute raised (once)
+        static bool raised = false;
+        if (!raised) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return spk::fail(SPK_ELAUNCH, "hipFuncSetAttribute(LDS): %s", hipGetErrorString(e));
+            raised = true;
+        }
+    }
+    const long long gx = (long long)g.tiles_x * g.tiles_y * g.tiles_b;
+    SPK_REQUIRE(gx < (1ll << 31), "conv2d: grid too large");
+    dim3 grid((unsigned)gx, (unsigned)g.co_tiles, (unsigned)ksplit);
+    hipLaunchKernelGGL(kern, grid, dim3(C::NTHREADS), g.lds_bytes, stream, a);
+    int rc = spk::check_launch("conv_kernel");
+    if (rc != SPK_OK || ksplit == 1) return rc;
+    a.y = d->y;
+    return launch_splitk_epilogue(a, static_cast<const float*>(d->workspace), ksplit, stream);
+}
+
+// ---- tile configs ------------------------------------------------------------------------------------
+//                 WM WN MT NT CI_T      CO_T  PIX_T  used by
+typedef Cfg<2, 2, 2, 2, 8> Cfg0;   //  128   128   3x3 s1
+typedef Cfg<1, 4, 2, 2, 8> Cfg1;   //   64   256   3x3 s1
+typedef Cfg<2, 2, 1, 1, 8> Cfg2;   //   64    64   3x3 s1
+typedef Cfg<1, 4, 1, 1, 8> Cfg3;   //   32   128   3x3 s1
+typedef Cfg<2, 2, 2, 2, 4> Cfg4;   //  128   128   3x3 s1/s2, 7x7 s2   (half-depth chunks: 2-3 WGs per CU)
+typedef Cfg<1, 4, 2, 2, 4> Cfg5;   //   64   256   3x3 s1/s2, 7x7 s2
+typedef Cfg<2, 2, 1, 1, 4> Cfg6;   //   64    64   3x3 s1/s2, 7x7 s2
+typedef Cfg<1, 4, 1, 1, 4> Cfg7;   //   32   128   3x3 s1/s2, 7x7 s2
+typedef Cfg<2, 2, 2, 2, 32> Cfg8;  //  128   128   1x1 s1/s2
+typedef Cfg<1, 4, 2, 2, 16> Cfg9;  //   64   256   1x1 s1/s2
+typedef Cfg<2, 2, 1, 1, 32> Cfg10; //   64    64   1x1 s1/s2
+typedef Cfg<1, 4, 1, 1, 32> Cfg11; //   32   128   1x1 s1/s2
+constexpr int kNumConfigs = 12;
+
+// per-family dispatchers, one translation unit each (parallel compilation)
+int run_3x3s1_a(int cfg, int mode, const spk_conv2d_desc* d, hipStream_t s);  // ids 0-3
+int run_3x3s1_b(int cfg, int mode, const spk_conv2d_desc* d, hipStream_t s);  // ids 4-7
+int run_3x3s2_7x7s2(int kh, int cfg, int mode, const spk_conv2d_desc* d, hipStream_t s);  // ids 4-7
+int run_1x1(int stride, int cfg, int mode, const spk_conv2d_desc* d, hipStream_t s);      // ids 8-11
+
+}  // namespace spkconv

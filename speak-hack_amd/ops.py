@@ -17,7 +17,7 @@ CONV_EVENTS = None
 
 # --------------------------------------------------------------------------------------------------
 class PackedConvWeight:
-    """A [Cout,Cin,3,3] weight re-laid for one tile config of the MFMA conv kernel
+    """A [Cout,Cin,k,k] weight re-laid for one tile config of the MFMA conv kernel
     ([co_tile][ci_chunk][tap][ci][co], zero padded).  Re-packed when the source parameter changes
     (its autograd version counter / storage pointer), e.g. after an optimizer step."""
 
@@ -30,7 +30,7 @@ class PackedConvWeight:
         hit = self._cache.get(key)
         if hit is not None and hit[0] == stamp:
             return hit[1]
-        packed = pack_conv3x3_weight(weight.detach(), config, transpose_flip)
+        packed = pack_conv_weight(weight.detach(), config, transpose_flip)
         self._cache[key] = (stamp, packed)
         return packed
 
@@ -38,31 +38,34 @@ class PackedConvWeight:
         self._cache.clear()
 
 
-def conv3x3_pick_config(B, Cin, Cout, H, W) -> int:
-    return L.lib().spk_conv3x3_pick_config(B, Cin, Cout, H, W)
+def conv2d_pick_config(k, stride, B, Cin, Cout, H, W) -> int:
+    """Tile config the library's heuristic picks; H, W are the OUTPUT size."""
+    cfg = L.lib().spk_conv2d_pick_config(k, k, stride, B, Cin, Cout, H, W)
+    if cfg < 0:
+        raise L.SpkError(f"spk_conv2d_pick_config: {L.lib().spk_last_error().decode()}")
+    return cfg
 
 
-def conv3x3_config_fits(config: int, B, Cin, Cout, H, W) -> bool:
-    """Whether tile config ``config`` can host this problem (some configs cannot tile tiny images)."""
-    return L.lib().spk_conv3x3_workspace_bytes(int(config), 1, B, Cin, Cout, H, W) >= 0
+def conv2d_config_fits(config: int, k, stride, B, Cin, Cout, H, W) -> bool:
+    """Whether tile config ``config`` is built for this kernel and can host this problem."""
+    return L.lib().spk_conv2d_workspace_bytes(int(config), 1, k, k, stride, B, Cin, Cout, H, W) >= 0
 
 
-def conv3x3_config_info(config: int):
+def conv2d_config_info(config: int):
     co, ci, px = C.c_int(), C.c_int(), C.c_int()
-    L.check(L.lib().spk_conv3x3_config_info(config, C.byref(co), C.byref(ci), C.byref(px)), "spk_conv3x3_config_info")
+    L.check(L.lib().spk_conv2d_config_info(config, C.byref(co), C.byref(ci), C.byref(px)), "spk_conv2d_config_info")
     return co.value, ci.value, px.value
 
 
-def pack_conv3x3_weight(weight: torch.Tensor, config: int, transpose_flip: bool = False) -> torch.Tensor:
+def pack_conv_weight(weight: torch.Tensor, config: int, transpose_flip: bool = False) -> torch.Tensor:
     Cout, Cin, kh, kw = weight.shape
-    if (kh, kw) != (3, 3):
-        raise L.SpkError(f"pack_conv3x3_weight: expected a 3x3 kernel, got {kh}x{kw}")
-    n = L.lib().spk_conv3x3_packed_floats(config, Cout if transpose_flip else Cin, Cin if transpose_flip else Cout)
+    n = L.lib().spk_conv2d_packed_floats(config, kh, kw, Cout if transpose_flip else Cin, Cin if transpose_flip else Cout)
     if n <= 0:
-        raise L.SpkError("spk_conv3x3_packed_floats: bad arguments")
+        raise L.SpkError("spk_conv2d_packed_floats: bad arguments")
     out = torch.empty(n, device=weight.device, dtype=torch.float32)
-    L.check(L.lib().spk_conv3x3_pack_weights(L.dptr(weight.contiguous(), "weight"), L.dptr(out), Cin, Cout, config,
-                                             1 if transpose_flip else 0, L.stream_ptr()), "spk_conv3x3_pack_weights")
+    L.check(L.lib().spk_conv2d_pack_weights(L.dptr(weight.contiguous(), "weight"), L.dptr(out), kh, kw, Cin, Cout,
+                                            config, 1 if transpose_flip else 0, L.stream_ptr()),
+            "spk_conv2d_pack_weights")
     return out
 
 
@@ -79,16 +82,25 @@ def _workspace(device, nbytes: int):
     return ws
 
 
-def conv3x3_fused(x, w_packed, Cout: int, *, bias=None, noise_w=None, noise=None, style=None, style_stride=None,
-                  upsample=False, lrelu_slope=None, in_scale=1.0, config=-1, ksplit=0, out=None, accumulate=False):
-    """y = style(lrelu(conv3x3(up?(x)) * in_scale + bias + noise_w*noise)) -- one launch.
+def conv_out_size(n, k, stride):
+    return (n + 2 * ((k - 1) // 2) - k) // stride + 1
 
-    ``style`` is a tensor whose row ``b`` (stride ``style_stride`` floats, default its row length)
-    holds [s0(Cout) | s1(Cout)].  ``upsample``: x is [B,Cin,H/2,W/2] and is bilinearly upsampled x2
-    on the fly.  Stages whose operands are None are skipped.
+
+def conv2d_fused(x, w_packed, Cout: int, k: int = 3, stride: int = 1, *, bias=None, noise_w=None, noise=None,
+                 style=None, style_stride=None, upsample=False, lrelu_slope=None, out_scale=1.0, in_affine=None,
+                 stats=None, config=-1, ksplit=0, out=None, accumulate=False):
+    """y = style(lrelu(conv_kxk(in(x)) * out_scale + bias + noise_w*noise)) -- one launch.
+
+    ``in``: identity; or bilinear x2 (``upsample``; x is [B,Cin,H/2,W/2]); or ``max(x*a+b, 0)`` per
+    input channel (``in_affine=(a, b)``: the producer's BatchNorm+ReLU, folded into staging).
+    ``style``: rows [s0(Cout) | s1(Cout)] with row stride ``style_stride``.  ``stats``: fp64 [2*Cout],
+    accumulates sum / sum of squares of y over (b,h,w) (BatchNorm batch statistics).
     """
     B, Cin, Hs, Ws = x.shape
-    H, W = (2 * Hs, 2 * Ws) if upsample else (Hs, Ws)
+    if upsample:
+        H, W = 2 * Hs, 2 * Ws
+    else:
+        H, W = conv_out_size(Hs, k, stride), conv_out_size(Ws, k, stride)
     if out is None:
         out = torch.empty((B, Cout, H, W), device=x.device, dtype=torch.float32)
     flags = 0
@@ -96,7 +108,7 @@ def conv3x3_fused(x, w_packed, Cout: int, *, bias=None, noise_w=None, noise=None
         flags |= L.EPI_BIAS
     if noise is not None:
         if noise_w is None or noise.numel() != B * H * W:
-            raise L.SpkError(f"conv3x3_fused: noise must be [B,1,H,W]={B, 1, H, W}, got {tuple(noise.shape)}")
+            raise L.SpkError(f"conv2d_fused: noise must be [B,1,H,W]={B, 1, H, W}, got {tuple(noise.shape)}")
         flags |= L.EPI_NOISE
     if lrelu_slope is not None:
         flags |= L.EPI_LRELU
@@ -108,27 +120,54 @@ def conv3x3_fused(x, w_packed, Cout: int, *, bias=None, noise_w=None, noise=None
         flags |= L.CONV_UPSAMPLE2X
     if accumulate:
         flags |= L.EPI_ACCUM
+    if in_affine is not None:
+        flags |= L.CONV_IN_AFFINE_RELU
+    if stats is not None:
+        if stats.dtype != torch.float64 or stats.numel() != 2 * Cout or not stats.is_cuda:
+            raise L.SpkError("conv2d_fused: stats must be a float64 HIP tensor of 2*Cout elements")
+        flags |= L.EPI_STATS
     if config < 0:
-        config = L.lib().spk_conv3x3_pick_config(B, Cin, Cout, H, W)
-    ws_bytes = L.lib().spk_conv3x3_workspace_bytes(int(config), int(ksplit), B, Cin, Cout, H, W)
+        config = conv2d_pick_config(k, stride, B, Cin, Cout, H, W)
+    ws_bytes = L.lib().spk_conv2d_workspace_bytes(int(config), int(ksplit), k, k, stride, B, Cin, Cout, H, W)
     if ws_bytes < 0:
-        raise L.SpkError(f"conv3x3_fused: config {config} cannot host shape {(B, Cin, Cout, H, W)}")
+        raise L.SpkError(f"conv2d_fused: config {config} cannot host k={k} s={stride} shape {(B, Cin, Cout, H, W)}")
     ws = _workspace(x.device, ws_bytes) if ws_bytes > 0 else None
-    d = L.Conv3x3Desc(x=L.dptr(x, "x"), w_packed=L.dptr(w_packed, "w_packed"), bias=L.dptr(bias, "bias"),
-                      noise_w=L.dptr(noise_w, "noise_w") if noise is not None else None,
-                      noise=L.dptr(noise, "noise"), style=_style_ptr(style), y=L.dptr(out, "out"),
-                      B=B, Cin=Cin, Cout=Cout, H=H, W=W, style_stride=int(style_stride or 0), flags=flags,
-                      lrelu_slope=float(lrelu_slope if lrelu_slope is not None else 1.0), in_scale=float(in_scale),
-                      config=int(config), ksplit=int(ksplit), workspace=ws.data_ptr() if ws is not None else None,
-                      workspace_bytes=ws.numel() * 4 if ws is not None else 0)
+    d = L.Conv2dDesc(x=L.dptr(x, "x"), w_packed=L.dptr(w_packed, "w_packed"), bias=L.dptr(bias, "bias"),
+                     noise_w=L.dptr(noise_w, "noise_w") if noise is not None else None,
+                     noise=L.dptr(noise, "noise"), style=_style_ptr(style),
+                     in_scale=L.dptr(in_affine[0], "in_scale") if in_affine is not None else None,
+                     in_shift=L.dptr(in_affine[1], "in_shift") if in_affine is not None else None,
+                     stats=stats.data_ptr() if stats is not None else None, y=L.dptr(out, "out"),
+                     B=B, Cin=Cin, Cout=Cout, H=H, W=W, Hin=Hs, Win=Ws, kh=k, kw=k, stride=stride,
+                     style_stride=int(style_stride or 0), flags=flags,
+                     lrelu_slope=float(lrelu_slope if lrelu_slope is not None else 1.0), out_scale=float(out_scale),
+                     config=int(config), ksplit=int(ksplit), workspace=ws.data_ptr() if ws is not None else None,
+                     workspace_bytes=ws.numel() * 4 if ws is not None else 0)
     if CONV_EVENTS is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-    L.check(L.lib().spk_conv3x3_fwd(C.byref(d), L.stream_ptr()), "spk_conv3x3_fwd")
+    L.check(L.lib().spk_conv2d_fwd(C.byref(d), L.stream_ptr()), "spk_conv2d_fwd")
     if CONV_EVENTS is not None:
         e1.record()
         CONV_EVENTS.append((e0, e1))
     return out
+
+
+# 3x3 stride-1 spellings used by the decoder
+def conv3x3_pick_config(B, Cin, Cout, H, W) -> int:
+    return conv2d_pick_config(3, 1, B, Cin, Cout, H, W)
+
+
+def conv3x3_config_fits(config, B, Cin, Cout, H, W) -> bool:
+    return conv2d_config_fits(config, 3, 1, B, Cin, Cout, H, W)
+
+
+conv3x3_config_info = conv2d_config_info
+pack_conv3x3_weight = pack_conv_weight
+
+
+def conv3x3_fused(x, w_packed, Cout, **kw):
+    return conv2d_fused(x, w_packed, Cout, 3, 1, **kw)
 
 
 def _style_ptr(style):
@@ -199,4 +238,48 @@ def upsample2x_bilinear(x):
     out = torch.empty((B, Cc, 2 * H, 2 * W), device=x.device, dtype=torch.float32)
     L.check(L.lib().spk_upsample2x_bilinear_fwd(L.dptr(x, "x"), L.dptr(out), B * Cc, H, W, L.stream_ptr()),
             "spk_upsample2x_bilinear_fwd")
+    return out
+
+
+# ---- BatchNorm / pooling pieces of the ResNet-50 trunk ----------------------------------------------
+def bn_finalize(stats, count, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, save=False):
+    """Batch sums (fp64 [2C], from a conv epilogue) -> the per-channel affine (scale, shift) its consumer
+    applies; updates running statistics when momentum > 0.  ``stats=None``: eval mode (running statistics).
+    With ``save`` also returns (mean, invstd) for the backward pass."""
+    Cc = gamma.numel()
+    dev = gamma.device
+    scale = torch.empty(Cc, device=dev, dtype=torch.float32)
+    shift = torch.empty(Cc, device=dev, dtype=torch.float32)
+    mean = torch.empty(Cc, device=dev, dtype=torch.float32) if save else None
+    invstd = torch.empty(Cc, device=dev, dtype=torch.float32) if save else None
+    L.check(L.lib().spk_bn_finalize(stats.data_ptr() if stats is not None else None, int(count), L.dptr(gamma, "gamma"),
+                                    L.dptr(beta, "beta"), L.dptr(running_mean, "running_mean"),
+                                    L.dptr(running_var, "running_var"), float(momentum), float(eps), L.dptr(scale),
+                                    L.dptr(shift), L.dptr(mean), L.dptr(invstd), Cc, L.stream_ptr()), "spk_bn_finalize")
+    return (scale, shift, mean, invstd) if save else (scale, shift)
+
+
+def bn_add_relu(a, sa, ba, b=None, sb=None, bb=None, relu=True):
+    """y = [relu](a*sa[c] + ba[c] + (b*sb[c] + bb[c])) -- BatchNorm apply + residual add + ReLU, one pass."""
+    B, Cc, H, W = a.shape
+    out = torch.empty_like(a)
+    L.check(L.lib().spk_bn_add_relu_fwd(L.dptr(a, "a"), L.dptr(sa, "sa"), L.dptr(ba, "ba"), L.dptr(b, "b"),
+                                        L.dptr(sb, "sb"), L.dptr(bb, "bb"), L.dptr(out), B, Cc, H * W,
+                                        1 if relu else 0, L.stream_ptr()), "spk_bn_add_relu_fwd")
+    return out
+
+
+def maxpool3x3s2(x, in_scale=None, in_shift=None):
+    B, Cc, H, W = x.shape
+    out = torch.empty((B, Cc, (H - 1) // 2 + 1, (W - 1) // 2 + 1), device=x.device, dtype=torch.float32)
+    L.check(L.lib().spk_maxpool3x3s2_fwd(L.dptr(x, "x"), L.dptr(in_scale, "in_scale"), L.dptr(in_shift, "in_shift"),
+                                         L.dptr(out), B, Cc, H, W, L.stream_ptr()), "spk_maxpool3x3s2_fwd")
+    return out
+
+
+def global_avgpool(x):
+    B, Cc, H, W = x.shape
+    out = torch.empty((B, Cc, 1, 1), device=x.device, dtype=torch.float32)
+    L.check(L.lib().spk_global_avgpool_fwd(L.dptr(x, "x"), L.dptr(out), B * Cc, H * W, L.stream_ptr()),
+            "spk_global_avgpool_fwd")
     return out

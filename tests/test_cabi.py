@@ -37,16 +37,16 @@ def test_library_exports_every_declared_symbol(pkg):
 
 def test_host_side_queries_and_argument_errors(pkg):
     lib = pkg._lib.lib()
-    n = lib.spk_conv3x3_num_configs()
+    n = lib.spk_conv2d_num_configs()
     assert n >= 4
     for cfg in range(n):
         co, ci, px = pkg.ops.conv3x3_config_info(cfg)
         assert co % 32 == 0 and px % 32 == 0 and ci % 2 == 0
         # packed image is zero-padded up to whole tiles
-        assert lib.spk_conv3x3_packed_floats(cfg, 3, 5) == -(-5 // co) * -(-3 // ci) * 9 * ci * co
-    assert lib.spk_conv3x3_packed_floats(99, 3, 5) < 0
+        assert lib.spk_conv2d_packed_floats(cfg, 3, 3, 3, 5) == -(-5 // co) * -(-3 // ci) * 9 * ci * co
+    assert lib.spk_conv2d_packed_floats(99, 3, 3, 3, 5) < 0
     # error behaviour: negative code + message, never an exception/abort from C
-    assert lib.spk_conv3x3_fwd(None, None) < 0
+    assert lib.spk_conv2d_fwd(None, None) < 0
     assert b"null" in lib.spk_last_error()
     assert lib.spk_fc_fwd(None, 0, None, None, None, 0, 1, 1, 1, 1.0, 1.0, 1.0, None) < 0
 

@@ -1,0 +1,166 @@
+"""GPU parity of the ResNet-50 trunk path: generic conv (1x1 / 3x3 / 7x7,
+stride 1/2, folded BatchNorm+ReLU input, BatchNorm statistics in the epilogue), BN finalize, the
+residual pass, pools, and the whole trunk in eval and train mode against the CPU oracle.
+Tolerances: 2e-5 rel-L2 per op, 2e-4 through the 53-conv trunk (exact fp32 arithmetic; only the
+summation order and the folded-BN rounding differ)."""
+import importlib
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2
+from oracle import resnet_ref as RR
+from oracle.weights_recipe import recipe_input, recipe_tensor, resnet_trunk_state_dict
+
+pytestmark = pytest.mark.gpu
+TOL_OP = 2e-5
+TOL_TRUNK = 2e-4
+
+
+@pytest.fixture(scope="module")
+def pkg():
+    assert torch.cuda.is_available()
+    p = importlib.import_module("speak-hack_amd")
+    p._lib.lib()
+    return p
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("k,stride,B,Cin,Cout,H,W", [
+    (1, 1, 2, 64, 256, 16, 16), (1, 1, 3, 40, 72, 9, 13), (1, 1, 1, 256, 64, 64, 64), (1, 1, 2, 2048, 512, 8, 8),
+    (1, 2, 2, 256, 512, 16, 16), (1, 2, 1, 24, 40, 15, 11),
+    (3, 2, 2, 128, 128, 32, 32), (3, 2, 3, 20, 36, 13, 10), (3, 2, 1, 512, 512, 16, 16),
+    (7, 2, 2, 3, 64, 64, 64), (7, 2, 1, 3, 64, 37, 51),
+])
+def test_conv2d_kernels_strides(pkg, dev, k, stride, B, Cin, Cout, H, W):
+    tag = f"c2.{k}.{stride}.{B}.{Cin}.{Cout}.{H}.{W}"
+    x = recipe_input(tag + ".x", (B, Cin, H, W))
+    w = recipe_tensor(tag + ".weight", (Cout, Cin, k, k))
+    ref = F.conv2d(x, w, stride=stride, padding=(k - 1) // 2)
+    Ho, Wo = ref.shape[-2:]
+    n = pkg._lib.lib().spk_conv2d_num_configs()
+    ran = 0
+    for cfg in [-1] + list(range(n)):
+        c = cfg if cfg >= 0 else pkg.ops.conv2d_pick_config(k, stride, B, Cin, Cout, Ho, Wo)
+        if not pkg.ops.conv2d_config_fits(c, k, stride, B, Cin, Cout, Ho, Wo):
+            continue
+        wp = pkg.ops.pack_conv_weight(w.to(dev), c)
+        for ksplit in (1, 0):
+            y = pkg.ops.conv2d_fused(x.to(dev), wp, Cout, k, stride, config=c, ksplit=ksplit)
+            assert rel_l2(y, ref) < TOL_OP, (c, ksplit)
+        ran += 1
+    assert ran >= 2
+
+
+@pytest.mark.parametrize("k,stride", [(1, 1), (3, 1), (3, 2), (1, 2)])
+def test_conv2d_folded_bn_relu_input_and_statistics(pkg, dev, k, stride):
+    """x' = relu(x*a+b) applied while staging; sum / sum-of-squares of y from the epilogue."""
+    B, Cin, Cout, H = 3, 44, 72, 14
+    tag = f"c2aff.{k}.{stride}"
+    x = recipe_input(tag + ".x", (B, Cin, H, H))
+    a = 1.0 + recipe_tensor(tag + ".a", (Cin,), 0.3)
+    b = recipe_tensor(tag + ".b", (Cin,), 0.3)
+    w = recipe_tensor(tag + ".weight", (Cout, Cin, k, k))
+    xin = F.relu(x * a.view(1, -1, 1, 1) + b.view(1, -1, 1, 1))
+    ref = F.conv2d(xin, w, stride=stride, padding=(k - 1) // 2)
+    cfg = pkg.ops.conv2d_pick_config(k, stride, B, Cin, Cout, ref.shape[-2], ref.shape[-1])
+    wp = pkg.ops.pack_conv_weight(w.to(dev), cfg)
+    for ksplit in (1, 2):
+        stats = torch.zeros(2 * Cout, device=dev, dtype=torch.float64)
+        y = pkg.ops.conv2d_fused(x.to(dev), wp, Cout, k, stride, in_affine=(a.to(dev), b.to(dev)), stats=stats,
+                                 config=cfg, ksplit=ksplit)
+        assert rel_l2(y, ref) < TOL_OP
+        assert rel_l2(stats[:Cout], ref.double().sum((0, 2, 3))) < 1e-6
+        assert rel_l2(stats[Cout:], (ref.double() ** 2).sum((0, 2, 3))) < 1e-6
+
+
+def test_bn_finalize_train_and_eval(pkg, dev):
+    C, B, H = 37, 4, 9
+    y = recipe_input("bnf.y", (B, C, H, H)) * 2.0 + 0.7
+    g, be = 1.0 + recipe_tensor("bnf.g", (C,), 0.2), recipe_tensor("bnf.b", (C,), 0.2)
+    rm, rv = recipe_tensor("bnf.rm", (C,), 0.3), recipe_tensor("bnf.rv", (C,), 1.0).abs() + 0.5
+    rm_ref, rv_ref = rm.clone(), rv.clone()
+    ref = F.batch_norm(y, rm_ref, rv_ref, g, be, True, 0.1, 1e-5)
+    stats = torch.cat([y.double().sum((0, 2, 3)), (y.double() ** 2).sum((0, 2, 3))]).to(dev)
+    rm_d, rv_d = rm.to(dev), rv.to(dev)
+    sc, sh, mean, invstd = pkg.ops.bn_finalize(stats, B * H * H, g.to(dev), be.to(dev), rm_d, rv_d, 0.1, 1e-5, save=True)
+    out = y.to(dev) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)
+    assert rel_l2(out, ref) < TOL_OP
+    assert rel_l2(rm_d, rm_ref) < 1e-6 and rel_l2(rv_d, rv_ref) < 1e-6
+    assert rel_l2(mean, y.mean((0, 2, 3))) < 1e-6
+    assert rel_l2(invstd, 1.0 / torch.sqrt(y.var((0, 2, 3), unbiased=False) + 1e-5)) < 1e-5
+    # eval: running statistics, nothing updated
+    ref_e = F.batch_norm(y, rm_ref, rv_ref, g, be, False, 0.1, 1e-5)
+    sc, sh = pkg.ops.bn_finalize(None, 1, g.to(dev), be.to(dev), rm_d, rv_d, 0.0, 1e-5)
+    assert rel_l2(y.to(dev) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1), ref_e) < TOL_OP
+    assert rel_l2(rm_d, rm_ref) < 1e-6
+
+
+def test_residual_pass_and_pools(pkg, dev):
+    B, C, H, W = 2, 19, 11, 14
+    a, b = recipe_input("rp.a", (B, C, H, W)), recipe_input("rp.b", (B, C, H, W))
+    sa, ba, sb, bb = (recipe_tensor(f"rp.{n}", (C,), 0.5) for n in ("sa", "ba", "sb", "bb"))
+    v = lambda t: t.view(1, -1, 1, 1)
+    ref = F.relu(a * v(sa) + v(ba) + b * v(sb) + v(bb))
+    out = pkg.ops.bn_add_relu(a.to(dev), sa.to(dev), ba.to(dev), b.to(dev), sb.to(dev), bb.to(dev))
+    assert rel_l2(out, ref) < 1e-6
+    ref = F.relu(a * v(sa) + v(ba) + b)
+    assert rel_l2(pkg.ops.bn_add_relu(a.to(dev), sa.to(dev), ba.to(dev), b.to(dev)), ref) < 1e-6
+    x4 = recipe_input("rp.x4", (2, 8, 16, 20))       # HW % 4 == 0: vector path
+    assert rel_l2(pkg.ops.bn_add_relu(x4.to(dev), None, None, x4.to(dev), relu=False), 2 * x4) < 1e-6
+    # max pool 3x3 s2 p1, plain and with folded affine+relu; odd sizes
+    for shape in [(2, 5, 9, 12), (1, 3, 16, 16), (1, 2, 1, 1)]:
+        x = recipe_input(f"rp.mp.{shape}", shape)
+        assert rel_l2(pkg.ops.maxpool3x3s2(x.to(dev)), F.max_pool2d(x, 3, 2, 1)) < 1e-7
+        s, o = 1.0 + recipe_tensor("rp.mp.s", (shape[1],), 0.3), recipe_tensor("rp.mp.o", (shape[1],), 0.3)
+        ref = F.max_pool2d(F.relu(x * v(s) + v(o)), 3, 2, 1)
+        assert rel_l2(pkg.ops.maxpool3x3s2(x.to(dev), s.to(dev), o.to(dev)), ref) < 1e-6
+    x = recipe_input("rp.ap", (3, 7, 5, 9))
+    assert rel_l2(pkg.ops.global_avgpool(x.to(dev)), F.adaptive_avg_pool2d(x, 1)) < 1e-6
+
+
+def _trunk(pkg, dev, prefix):
+    enc = importlib.import_module("speak-hack_amd.encoder")
+    m = enc.ResNet50Trunk()
+    sd = resnet_trunk_state_dict(prefix)
+    m.load_state_dict(sd)
+    return m.to(dev), sd
+
+
+def test_trunk_state_dict_keys(pkg, dev):
+    enc = importlib.import_module("speak-hack_amd.encoder")
+    m = enc.ResNet50Trunk()
+    assert {k: tuple(v.shape) for k, v in m.state_dict().items()} == RR.trunk_param_shapes()
+    assert sum(p.numel() for p in m.parameters()) == 23508032
+
+
+@pytest.mark.parametrize("B,H", [(2, 96), (2, 256), (1, 64)])
+def test_trunk_eval_vs_oracle(pkg, dev, B, H):
+    m, sd = _trunk(pkg, dev, "Ei.")
+    m.eval()
+    x = recipe_input(f"trunk.x.{B}.{H}", (B, 3, H, H), "uniform")
+    with torch.no_grad():
+        y = m(x.to(dev))
+        ref = RR.resnet50_trunk(x, sd)
+    assert y.shape == (B, 2048, 1, 1)
+    assert rel_l2(y, ref) < TOL_TRUNK
+
+
+def test_trunk_train_mode_batch_statistics_and_running_update(pkg, dev):
+    m, sd = _trunk(pkg, dev, "Ee.")
+    m.train()
+    x = recipe_input("trunk.train.x", (4, 3, 128, 128), "uniform")
+    with torch.no_grad():
+        y = m(x.to(dev))
+        ref = RR.resnet50_trunk(x, sd, training=True, update_running_stats=True)
+    assert rel_l2(y, ref) < TOL_TRUNK
+    got = m.state_dict()
+    for k in ("1.running_mean", "1.running_var", "4.0.bn2.running_var", "5.0.downsample.1.running_mean",
+              "7.2.bn3.running_var", "7.2.bn3.running_mean"):
+        assert rel_l2(got[k], sd[k]) < 1e-4, k
+    assert int(got["6.3.bn1.num_batches_tracked"]) == 1

@@ -34,7 +34,7 @@ def main():
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     B = args.batch
-    ncfg = pkg._lib.lib().spk_conv3x3_num_configs()
+    ncfg = pkg._lib.lib().spk_conv2d_num_configs()
     for cin, cout, r, ups in layers(args.res):
         hs = r // 2 if ups else r
         x = torch.randn(B, cin, hs, hs, device=dev)
