@@ -70,6 +70,8 @@ typedef struct spk_conv2d_desc {
     const float* in_shift;   /* [Cin] */
     double*      stats;      /* [2*Cout] (SPK_EPI_STATS) or NULL; caller zeroes it */
     float*       y;          /* [B,Cout,H,W] */
+    float*       y_pre;      /* [B,Cout,H,W] or NULL: the value before the style stage (after LeakyReLU), kept
+                              * for the backward pass (sign = LeakyReLU mask, value = d style / d s0) */
     int32_t B, Cin, Cout;
     int32_t H, W;            /* OUTPUT spatial size */
     int32_t Hin, Win;        /* input spatial size (H = 2*Hin with SPK_CONV_UPSAMPLE2X, else (Hin+2p-k)/s+1) */
@@ -104,6 +106,55 @@ int64_t spk_conv2d_workspace_bytes(int config, int ksplit, int kh, int kw, int s
 int spk_conv2d_pack_weights(const float* w, float* w_packed, int kh, int kw, int Cin, int Cout, int config,
                             int transpose_flip, void* stream);
 int spk_conv2d_fwd(const spk_conv2d_desc* desc, void* stream);
+
+/* ---- backward of the convolution ---------------------------------------------------------------------
+ * Data gradient: spk_conv2d_fwd itself on the output gradient with weights packed transpose_flip = 1
+ * (stride 1).  Weight gradient (any supported kernel / stride), on the f32 MFMA pipe with the pixel axis
+ * as the contraction:
+ *   dw[co,ci,ky,kx] (+)= scale * sum_{b,h,w} g[b,co,h,w] * xin[b,ci,h*s+ky-p,w*s+kx-p]
+ * xin is formed exactly as the forward pass formed it (flags SPK_CONV_UPSAMPLE2X / SPK_CONV_IN_AFFINE_RELU).
+ * Partial sums go to `workspace` and are reduced in a fixed order: bitwise reproducible, no float atomics.
+ * replaces: the aten::convolution_backward weight path under loss.backward() (train.py:205) for
+ *           styleganv1.py:625,630 and the trunk convs. */
+typedef struct spk_wgrad_desc {
+    const float* g;          /* [B,Cout,H,W] gradient w.r.t. the conv output */
+    const float* x;          /* [B,Cin,Hin,Win] forward input */
+    const float* in_scale;   /* [Cin] / NULL, as in the forward call */
+    const float* in_shift;
+    float*       dw;         /* [Cout,Cin,kh,kw] */
+    int32_t B, Cin, Cout, H, W, Hin, Win, kh, kw, stride;
+    uint32_t flags;          /* SPK_CONV_UPSAMPLE2X | SPK_CONV_IN_AFFINE_RELU */
+    float scale;
+    int32_t accumulate;      /* dw += instead of dw = */
+    int32_t splits;          /* pixel-range splits; 0 = auto */
+    void*   workspace;
+    int64_t workspace_bytes; /* >= spk_conv2d_wgrad_workspace_bytes(...) */
+} spk_wgrad_desc;
+int64_t spk_conv2d_wgrad_workspace_bytes(int kh, int kw, int stride, int splits, int B, int Cin, int Cout, int H, int W);
+int spk_conv2d_wgrad(const spk_wgrad_desc* desc, void* stream);
+
+/* Adjoint of the fused epilogue of spk_conv2d_fwd, one pass.  With y = a*(s0+1)+s1, a = lrelu(t),
+ * t = conv + bias + noise_w*noise and dy = dL/dy:
+ *   dt[b,c,p] = dy * (s0[b,c]+1) * (a > 0 ? 1 : slope)          (feeds the data / weight gradient)
+ *   sums[b,c,:] = { sum_p dy, sum_p dy*a, sum_p dt, sum_p dt*noise[b,p] }
+ * so d s1 = sums[..,0], d s0 = sums[..,1], d bias = sum_b sums[..,2], d noise_w = sum_b sums[..,3].
+ * a / noise / style may be NULL (stage absent).  dt may alias dy.
+ * replaces: autograd's backward of styleganv1.py:626-628 / :631-633 (noise, leaky_relu, style_mod). */
+int spk_epilogue_bwd(const float* dy, const float* a, const float* noise, const float* style, int64_t style_stride,
+                     float slope, float* dt, float* sums, int B, int C, int64_t HW, void* stream);
+/* adjoint of spk_upsample2x_bilinear_fwd: dy [planes,2Hin,2Win] -> dx [planes,Hin,Win] */
+int spk_upsample2x_bilinear_bwd(const float* dy, float* dx, int64_t planes, int Hin, int Win, void* stream);
+/* toRGB backward: dx (may be NULL) and per-workgroup partial sums partial[blocks][O*C + O]
+ * (d w then d bias; sum over the first axis, blocks = spk_conv1x1_small_bwd_blocks(B, HW)). */
+int spk_conv1x1_small_bwd_blocks(int B, int64_t HW);
+int spk_conv1x1_small_bwd(const float* x, const float* w, const float* dy, float* dx, float* partial, int B, int C, int O,
+                          int64_t HW, float in_scale, void* stream);
+/* FC backward: dz = dout * (out > 0 ? 1 : slope); dx = wmul * dz @ w (NULL to skip);
+ * dw = wmul * dz^T @ x, db = bmul * sum_b dz (dw NULL to skip both).
+ * replaces: autograd's backward of FC.forward (styleganv1.py:489-495). */
+int spk_fc_bwd(const float* dout, const float* out, const float* x, int64_t x_stride, const float* w, float* dx,
+               int64_t dx_stride, float* dw, float* db, int B, int I, int O, float wmul, float bmul, float slope,
+               void* stream);
 
 /* ---- fully connected + LeakyReLU ---------------------------------------------------------------
  * out[b,o] = act( wmul * sum_i x[b*x_stride + i] * w[o*I + i] + bmul * bias[o] ),

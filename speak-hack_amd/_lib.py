@@ -25,7 +25,7 @@ class Conv2dDesc(C.Structure):
     """Mirror of spk_conv2d_desc (include/spk.h)."""
     _fields_ = [("x", C.c_void_p), ("w_packed", C.c_void_p), ("bias", C.c_void_p), ("noise_w", C.c_void_p),
                 ("noise", C.c_void_p), ("style", C.c_void_p), ("in_scale", C.c_void_p), ("in_shift", C.c_void_p),
-                ("stats", C.c_void_p), ("y", C.c_void_p),
+                ("stats", C.c_void_p), ("y", C.c_void_p), ("y_pre", C.c_void_p),
                 ("B", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
                 ("Hin", C.c_int32), ("Win", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32),
                 ("style_stride", C.c_int32), ("flags", C.c_uint32), ("lrelu_slope", C.c_float),
@@ -33,7 +33,26 @@ class Conv2dDesc(C.Structure):
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
 
 
+class WgradDesc(C.Structure):
+    """Mirror of spk_wgrad_desc (include/spk.h)."""
+    _fields_ = [("g", C.c_void_p), ("x", C.c_void_p), ("in_scale", C.c_void_p), ("in_shift", C.c_void_p),
+                ("dw", C.c_void_p),
+                ("B", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("Hin", C.c_int32), ("Win", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32),
+                ("flags", C.c_uint32), ("scale", C.c_float), ("accumulate", C.c_int32), ("splits", C.c_int32),
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
+
+
 _PROTOTYPES = {
+    "spk_conv2d_wgrad_workspace_bytes": (C.c_int64, [C.c_int] * 9),
+    "spk_conv2d_wgrad": (C.c_int, [C.POINTER(WgradDesc), C.c_void_p]),
+    "spk_epilogue_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p,
+                                   C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p]),
+    "spk_upsample2x_bilinear_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
+    "spk_conv1x1_small_bwd_blocks": (C.c_int, [C.c_int, C.c_int64]),
+    "spk_conv1x1_small_bwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_float, C.c_void_p]),
+    "spk_fc_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
+                             C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "spk_version": (C.c_char_p, []),
     "spk_last_error": (C.c_char_p, []),
     "spk_conv2d_num_configs": (C.c_int, []),

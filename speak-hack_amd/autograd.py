@@ -1,0 +1,147 @@
+"""``torch.autograd.Function`` wrappers: forward and backward of every decoder op run on the HIP
+kernels (include/spk.h); autograd only sequences them.  No torch math on activations -- the only
+torch arithmetic in a backward is on per-(batch,channel) scalars the kernels already reduced
+(e.g. summing ``[B,C]`` partials over ``B``).
+"""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+
+def _needs(ctx, grad_mode):
+    """Whether to keep tensors for backward.  Grad mode is always off *inside* Function.forward and
+    ``needs_input_grad`` ignores ``torch.no_grad()``, so the caller samples the mode and passes it in."""
+    return bool(grad_mode) and any(ctx.needs_input_grad)
+
+
+class FusedConvFn(torch.autograd.Function):
+    """y = style(lrelu(conv3x3(up?(x)) + bias + noise_w*noise)) -- styleganv1.py:624-628 / :630-633.
+
+    Backward: one epilogue-adjoint pass (dt + the four per-plane sums that give d style, d bias,
+    d noise_w), the data gradient as the same MFMA conv on transpose-flipped weights (+ the bilinear
+    adjoint), the weight gradient on the MFMA wgrad kernel (upsampling re-formed on the fly)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, noise_w, noise, style, upsample, slope, packed, grad_mode):
+        B, Cin, Hs, Ws = x.shape
+        Cout = weight.shape[0]
+        H, W = (2 * Hs, 2 * Ws) if upsample else (Hs, Ws)
+        cfg = ops.conv2d_pick_config(3, 1, B, Cin, Cout, H, W)
+        keep = _needs(ctx, grad_mode)
+        a = torch.empty((B, Cout, H, W), device=x.device, dtype=torch.float32) if keep else None
+        y = ops.conv2d_fused(x, packed.get(weight, cfg), Cout, 3, 1, bias=bias, noise_w=noise_w, noise=noise,
+                             style=style, upsample=upsample, lrelu_slope=slope, config=cfg, out_pre=a)
+        if keep:
+            ctx.save_for_backward(x, weight, a, noise, style)
+            ctx.conf = (upsample, slope, packed, bias is not None, noise_w is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, a, noise, style = ctx.saved_tensors
+        upsample, slope, packed, has_bias, has_noise = ctx.conf
+        B, Cin = x.shape[:2]
+        Cout, H, W = a.shape[1:]
+        dt, sums = ops.epilogue_bwd(dy.contiguous(), a, noise if has_noise else None, style,
+                                    slope if slope is not None else 1.0)
+        dstyle = torch.cat([sums[..., 1], sums[..., 0]], dim=1) if style is not None else None   # [ds0 | ds1]
+        dbias = sums[..., 2].sum(0) if has_bias else None
+        dnw = sums[..., 3].sum(0) if has_noise else None
+        dx = dw = None
+        if ctx.needs_input_grad[0]:
+            cfg = ops.conv2d_pick_config(3, 1, B, Cout, Cin, H, W)
+            dx = ops.conv2d_fused(dt, packed.get(weight, cfg, transpose_flip=True), Cin, 3, 1, config=cfg)
+            if upsample:
+                dx = ops.upsample2x_bilinear_bwd(dx)
+        if ctx.needs_input_grad[1]:
+            dw = ops.conv2d_wgrad(dt, x, Cout, Cin, 3, 1, upsample=upsample)
+        return dx, dw, dbias, dnw, None, dstyle, None, None, None, None
+
+
+class FCFn(torch.autograd.Function):
+    """out = lrelu_slope(wmul * x @ W^T + bmul * bias) -- FC.forward, styleganv1.py:489-495."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, wmul, bmul, slope, grad_mode):
+        out = ops.fc(x, weight, bias, wmul, bmul, slope)
+        if _needs(ctx, grad_mode):
+            ctx.save_for_backward(x, weight, out)
+            ctx.conf = (wmul, bmul, slope, bias is not None)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        x, weight, out = ctx.saved_tensors
+        wmul, bmul, slope, has_bias = ctx.conf
+        dx, dw, db = ops.fc_bwd(dout.contiguous(), out, x, weight, wmul, bmul, slope,
+                                need_dx=ctx.needs_input_grad[0], need_dw=ctx.needs_input_grad[1] or
+                                (has_bias and ctx.needs_input_grad[2]), has_bias=has_bias)
+        return dx, dw, db, None, None, None, None
+
+
+class ToRGBFn(torch.autograd.Function):
+    """1x1 conv to <= 4 channels -- styleganv1.py:607."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, grad_mode):
+        y = ops.conv1x1_small(x, weight, bias)
+        if _needs(ctx, grad_mode):
+            ctx.save_for_backward(x, weight)
+            ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dx, dw, db = ops.conv1x1_small_bwd(x, weight, dy.contiguous(), need_dx=ctx.needs_input_grad[0])
+        return dx, dw, (db if ctx.has_bias else None), None
+
+
+class BiasNoiseStyleFn(torch.autograd.Function):
+    """y = (x + bias + noise_w*noise) * (s0+1) + s1 -- the decoder prologue (styleganv1.py:596-599) and the
+    stand-alone ApplyNoise / ApplyStyle.  ``x`` may be a [1,C,H,W] constant broadcast over the batch."""
+
+    @staticmethod
+    def forward(ctx, x, bias, noise_w, noise, style, B, grad_mode):
+        y = ops.bias_noise_style(x, B, bias, noise_w, noise, style)
+        if _needs(ctx, grad_mode):
+            # value before the style stage: needed for d s0 = sum dy * pre
+            pre = None
+            if style is not None:
+                pre = ops.bias_noise_style(x, B, bias, noise_w, noise, None) if (bias is not None or noise is not None
+                                                                                   or x.size(0) != B) else x
+            ctx.save_for_backward(pre, noise, style)
+            ctx.conf = (x.size(0) == 1 and B > 1, bias is not None, noise_w is not None and noise is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        pre, noise, style = ctx.saved_tensors
+        broadcast, has_bias, has_noise = ctx.conf
+        dt, sums = ops.epilogue_bwd(dy.contiguous(), pre, noise if has_noise else None, style, 1.0)
+        dstyle = torch.cat([sums[..., 1], sums[..., 0]], dim=1) if style is not None else None
+        dbias = sums[..., 2].sum(0) if has_bias else None
+        dnw = sums[..., 3].sum(0) if has_noise else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = dt.sum(0, keepdim=True) if broadcast else dt      # [1,C,4,4] constant: B tiny planes
+        return dx, dbias, dnw, None, dstyle, None, None
+
+
+# call-site spellings: sample the grad mode where it is still visible
+def fused_conv(x, weight, bias, noise_w, noise, style, upsample, slope, packed):
+    return FusedConvFn.apply(x, weight, bias, noise_w, noise, style, upsample, slope, packed, torch.is_grad_enabled())
+
+
+def fc(x, weight, bias, wmul, bmul, slope):
+    return FCFn.apply(x, weight, bias, wmul, bmul, slope, torch.is_grad_enabled())
+
+
+def to_rgb(x, weight, bias):
+    return ToRGBFn.apply(x, weight, bias, torch.is_grad_enabled())
+
+
+def bias_noise_style(x, bias, noise_w, noise, style, B):
+    return BiasNoiseStyleFn.apply(x, bias, noise_w, noise, style, B, torch.is_grad_enabled())

@@ -30,6 +30,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const ConvArgs p, 
             if (f_bias) v += p.bias[co];
             if (f_noise) v += p.noise_w[co] * p.noise[(size_t)b * HW + pix];
             if (f_lrelu) v = v > 0.f ? v : v * p.slope;
+            if (p.y_pre) p.y_pre[idx] = v;
             if (f_style) {
                 const float* st = p.style + (size_t)b * p.style_stride;
                 v = v * (st[co] + 1.f) + st[p.Cout + co];

@@ -55,6 +55,7 @@ struct ConvArgs {
     const float* in_shift;
     double* stats;           // [2*Cout] sum / sum of squares of y (SPK_EPI_STATS)
     float* y;                // output, or the split-K workspace [ksplit][B][Cout][H][W]
+    float* y_pre;            // optional: value before the style stage (kept for backward)
     int B, Cin, Cout, H, W;  // output spatial size
     int Hs, Ws;              // source tensor spatial size
     int lgTW, lgTH, lgTB;    // log2 of the pixel-tile geometry
@@ -367,6 +368,7 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
                     float v = acc[m][n][r] * p.out_scale + bb;
                     if (f_noise) v += nwc * nz[n];
                     if (f_lrelu) v = v > 0.f ? v : v * p.slope;
+                    if (p.y_pre) p.y_pre[poff[n] + (size_t)co * HW] = v;
                     if (f_style) v = v * (st[n][co] + 1.f) + st[n][p.Cout + co];
                     if (f_accum) v += *dst;
                     *dst = v;
@@ -444,7 +446,7 @@ template <class C, int KH, int KW, int S, int MODE>
 int run(const spk_conv2d_desc* d, hipStream_t stream) {
     ConvArgs a;
     a.x = d->x; a.wp = d->w_packed; a.bias = d->bias; a.noise_w = d->noise_w; a.noise = d->noise;
-    a.style = d->style; a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.stats = d->stats; a.y = d->y;
+    a.style = d->style; a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.stats = d->stats; a.y = d->y; a.y_pre = d->y_pre;
     a.B = d->B; a.Cin = d->Cin; a.Cout = d->Cout; a.H = d->H; a.W = d->W; a.Hs = d->Hin; a.Ws = d->Win;
     const Geometry g = geometry<C, KH, KW, S>(d->B, d->Cin, d->Cout, d->H, d->W);
     SPK_REQUIRE(g.ok, "conv2d: config %d does not fit this shape (%dx%d, B=%d)", d->config, d->H, d->W, d->B);

@@ -1,0 +1,279 @@
+// Weight gradient of the 2-D convolution on the gfx950 f32 MFMA pipe:
+//     dW[co][ci][ky][kx] = sum_{b,y,x} g[b,co,y,x] * xin[b,ci,y*S+ky-P,x*S+kx-P]
+// as the GEMM  D[co][(tap,ci)] = sum_pix G[co][pix] * X[ci][pix (+) tap]  with the pixel axis as K.
+//   A fragment (v_mfma_f32_32x32x2_f32): lane l holds G[co = l&31][pix = l>>5]   (LDS row pitch odd)
+//   B fragment, one per tap:             lane l holds X[ci = l&31][pix (+) tap]   (LDS row pitch odd)
+//   D: col = lane&31 = ci, row = output channel; one 32x32 accumulator tile PER TAP per wave, so
+//   the A fragment is read once per k-step and reused by all taps.
+// A workgroup owns a 64co x CI_T block of dW and walks a strided share of the pixel tiles
+// (64 pixels each, with halo, xin formed exactly as the forward pass forms it: plain, bilinear x2
+// upsampled, or BatchNorm-affine+ReLU).  Partial blocks go to a slab per (pixel split, wave pixel
+// half) in a ci-contiguous layout (coalesced stores); wgrad_reduce_kernel sums the slabs in a fixed
+// order (bitwise reproducible, no float atomics) and transposes to [Cout][Cin][kh][kw].
+//
+// replaces: the weight-gradient half of F.conv2d's backward for every conv on the path
+// (styleganv1.py:625,630 conv1/conv2; the torchvision trunk convs of model.py:60-62).
+#include "spk_common.hpp"
+
+#include <algorithm>
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+namespace {
+
+enum { WG_PLAIN = 0, WG_UPSAMPLE = 1, WG_AFFINE_RELU = 2 };
+
+struct WgradArgs {
+    const float* g;        // [B,Cout,H,W]   output-side gradient
+    const float* x;        // [B,Cin,Hs,Ws]  forward input
+    const float* in_scale; // WG_AFFINE_RELU
+    const float* in_shift;
+    float* slabs;          // [n_slabs][Cout][TAPS][Cin]
+    int B, Cin, Cout, H, W, Hs, Ws;
+    int lgTW, lgTH, lgTB;
+    int tiles_x, tiles_y, n_tiles;
+};
+
+template <int KH, int KW, int S>
+struct WShape {
+    static constexpr int TAPS = KH * KW;
+    static constexpr bool ROWPASS = TAPS > 9;               // 7x7: one tap row per workgroup
+    static constexpr int TP = ROWPASS ? KW : TAPS;          // taps per pass (accumulator tiles per wave)
+    static constexpr int CI_T = (S == 2 || KH == 7) ? 32 : 64;
+    static constexpr int WCI = CI_T / 32, WPX = 2 / WCI;    // 4 waves = 2 (co) x WCI x WPX
+    static constexpr int CO_T = 64, PIX_T = 64, PAD = (KH - 1) / 2;
+};
+
+template <int KH, int KW, int S, int MODE>
+__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
+    using SH = WShape<KH, KW, S>;
+    constexpr int TAPS = SH::TAPS, TP = SH::TP, CI_T = SH::CI_T, CO_T = SH::CO_T, PIX_T = SH::PIX_T, PAD = SH::PAD;
+    constexpr bool UPS = MODE == WG_UPSAMPLE, AFF = MODE == WG_AFFINE_RELU;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l32 = lane & 31;
+    const int wco = wave & 1, wci = (wave >> 1) % SH::WCI, wpx = (wave >> 1) / SH::WCI;
+
+    const int TW = 1 << p.lgTW, TH = 1 << p.lgTH, TB = 1 << p.lgTB;
+    const int PW = (TW - 1) * S + KW, PH = (TH - 1) * S + KH, PLANE = PH * PW;
+    const int GPITCH = PIX_T + 1, XPITCH = (TB * PLANE) | 1;
+    float* const g_s = smem;
+    float* const x_s = smem + CO_T * GPITCH;
+
+    const int co0 = blockIdx.x * CO_T;
+    const int ci_blocks = (p.Cin + CI_T - 1) / CI_T;
+    const int ci0 = (blockIdx.y % ci_blocks) * CI_T;
+    const int pass = blockIdx.y / ci_blocks;            // tap row for ROWPASS kernels, else 0
+    const int tap0 = SH::ROWPASS ? pass * KW : 0;
+    const int Hv = UPS ? 2 * p.Hs : p.Hs, Wv = UPS ? 2 * p.Ws : p.Ws;
+    const size_t HW = (size_t)p.H * p.W, src_plane = (size_t)p.Hs * p.Ws;
+
+    f32x16 acc[TP];
+#pragma unroll
+    for (int t = 0; t < TP; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    for (int tile = blockIdx.z; tile < p.n_tiles; tile += gridDim.z) {
+        int bx = tile;
+        const int tx = bx % p.tiles_x; bx /= p.tiles_x;
+        const int ty = bx % p.tiles_y;
+        const int b0 = (bx / p.tiles_y) << p.lgTB, y0 = ty << p.lgTH, x0 = tx << p.lgTW;
+        __syncthreads();  // previous tile fully consumed
+        // ---- stage G tile: [co][pix], pixels of a row contiguous -> coalesced ----
+#pragma unroll 4
+        for (int e = tid; e < CO_T * PIX_T; e += 256) {
+            const int co = e / PIX_T, pix = e % PIX_T;
+            const int px = pix & (TW - 1), py = (pix >> p.lgTW) & (TH - 1), tb = pix >> (p.lgTW + p.lgTH);
+            const int b = b0 + tb, yy = y0 + py, xx = x0 + px;
+            float v = 0.f;
+            if (tb < TB && b < p.B && yy < p.H && xx < p.W && co0 + co < p.Cout)
+                v = p.g[((size_t)b * p.Cout + co0 + co) * HW + (size_t)yy * p.W + xx];
+            g_s[co * GPITCH + pix] = v;
+        }
+        // ---- stage X tile: [ci][tb][PH][PW] with halo, formed as the forward pass forms its input ----
+        {
+            const int per_ci = TB * PLANE, total = CI_T * per_ci;
+            for (int e = tid; e < total; e += 256) {
+                const int ci = e / per_ci, rem = e - ci * per_ci;
+                const int tb = rem / PLANE, pidx = rem - tb * PLANE;
+                const int r = pidx / PW, c = pidx - r * PW;
+                const int uy = y0 * S + r - PAD, ux = x0 * S + c - PAD, b = b0 + tb, cig = ci0 + ci;
+                float v = 0.f;
+                if (uy >= 0 && uy < Hv && ux >= 0 && ux < Wv && b < p.B && cig < p.Cin) {
+                    const float* src = p.x + ((size_t)b * p.Cin + cig) * src_plane;
+                    if (!UPS) {
+                        v = src[(size_t)uy * p.Ws + ux];
+                        if (AFF) v = fmaxf(v * p.in_scale[cig] + p.in_shift[cig], 0.f);
+                    } else {
+                        const int iy0 = uy == 0 ? 0 : (uy - 1) >> 1, ix0 = ux == 0 ? 0 : (ux - 1) >> 1;
+                        const float ly1 = uy == 0 ? 0.f : ((uy & 1) ? 0.25f : 0.75f);
+                        const float lx1 = ux == 0 ? 0.f : ((ux & 1) ? 0.25f : 0.75f);
+                        const int iy1 = min(iy0 + 1, p.Hs - 1), ix1 = min(ix0 + 1, p.Ws - 1);
+                        const float v00 = src[iy0 * p.Ws + ix0], v01 = src[iy0 * p.Ws + ix1];
+                        const float v10 = src[iy1 * p.Ws + ix0], v11 = src[iy1 * p.Ws + ix1];
+                        v = (1.f - ly1) * ((1.f - lx1) * v00 + lx1 * v01) + ly1 * ((1.f - lx1) * v10 + lx1 * v11);
+                    }
+                }
+                x_s[ci * XPITCH + rem] = v;
+            }
+        }
+        __syncthreads();
+        // ---- k-steps over this wave's pixel range: A read once per step, reused by every tap ----
+        const float* ga = g_s + (wco * 32 + l32) * GPITCH;
+        const float* xb = x_s + (wci * 32 + l32) * XPITCH;
+        constexpr int STEPS = PIX_T / 2 / SH::WPX;
+#pragma unroll 4
+        for (int st = 0; st < STEPS; ++st) {
+            const int pix = wpx * (PIX_T / SH::WPX) + 2 * st + half;
+            const int px = pix & (TW - 1), py = (pix >> p.lgTW) & (TH - 1);
+            const int tb = min(pix >> (p.lgTW + p.lgTH), TB - 1);   // idle pixel groups hold zeros in g_s
+            const float a = ga[pix];
+            const float* xp = xb + tb * PLANE + (py * S) * PW + px * S;
+#pragma unroll
+            for (int t = 0; t < TP; ++t) {
+                const int tap = tap0 + t;                         // tap0 is 0 unless ROWPASS
+                const int ky = SH::ROWPASS ? pass : tap / KW, kx = SH::ROWPASS ? t : tap % KW;
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xp[ky * PW + kx], acc[t], 0, 0, 0);
+            }
+        }
+    }
+
+    // ---- partial block -> slab [slab][co][tap][ci] (ci contiguous: 128-B stores per half wave) ----
+    const int slab = blockIdx.z * SH::WPX + wpx;
+    float* out = p.slabs + (size_t)slab * p.Cout * TAPS * p.Cin;
+    const int ci = ci0 + wci * 32 + l32;
+#pragma unroll
+    for (int t = 0; t < TP; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (co < p.Cout && ci < p.Cin) out[((size_t)co * TAPS + tap0 + t) * p.Cin + ci] = acc[t][r];
+        }
+}
+
+// dW[co][ci][tap] (+)= scale * sum_slab slabs[slab][co][tap][ci]   (fixed order)
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw,
+                                                          int n_slabs, int Cout, int Cin, int taps, float scale,
+                                                          int accumulate) {
+    const size_t total = (size_t)Cout * Cin * taps;
+    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
+        const int tap = (int)(idx % taps);
+        const int ci = (int)((idx / taps) % Cin);
+        const int co = (int)(idx / ((size_t)taps * Cin));
+        const size_t src = ((size_t)co * taps + tap) * Cin + ci;
+        float v = 0.f;
+        for (int s = 0; s < n_slabs; ++s) v += slabs[(size_t)s * total + src];
+        v *= scale;
+        dw[idx] = accumulate ? dw[idx] + v : v;
+    }
+}
+
+struct WGeom {
+    int TW, TH, TB, tiles_x, tiles_y, n_tiles, splits, n_slabs;
+    size_t lds_bytes;
+};
+
+template <int KH, int KW, int S>
+WGeom wgeom(int B, int Cin, int Cout, int H, int W, int want_splits) {
+    using SH = WShape<KH, KW, S>;
+    WGeom g;
+    g.TW = std::min(32, spk::pow2_ceil(W));
+    g.TH = std::min(SH::PIX_T / g.TW, spk::pow2_ceil(H));
+    g.TB = SH::PIX_T / (g.TW * g.TH);
+    // keep the staged input tile within LDS: shrink the image group first, then the rows
+    auto lds = [&]() {
+        const size_t plane = (size_t)((g.TH - 1) * S + KH) * ((g.TW - 1) * S + KW);
+        return (SH::CO_T * (SH::PIX_T + 1) + SH::CI_T * ((g.TB * plane) | 1)) * sizeof(float);
+    };
+    while (lds() > 100 * 1024 && g.TB > 1) g.TB >>= 1;
+    g.lds_bytes = lds();
+    g.tiles_x = spk::ceil_div(W, g.TW);
+    g.tiles_y = spk::ceil_div(H, g.TH);
+    g.n_tiles = g.tiles_x * g.tiles_y * spk::ceil_div(B, g.TB);
+    const int blocks = spk::ceil_div(Cout, SH::CO_T) * spk::ceil_div(Cin, SH::CI_T) * (SH::ROWPASS ? KH : 1);
+    int sp = want_splits > 0 ? want_splits : std::max(1, 768 / blocks);     // ~3 workgroups per CU
+    g.splits = std::max(1, std::min(sp, g.n_tiles));
+    g.n_slabs = g.splits * SH::WPX;
+    return g;
+}
+
+template <int KH, int KW, int S, int MODE>
+int run_wgrad(const spk_wgrad_desc* d, hipStream_t stream) {
+    using SH = WShape<KH, KW, S>;
+    const WGeom g = wgeom<KH, KW, S>(d->B, d->Cin, d->Cout, d->H, d->W, d->splits);
+    SPK_REQUIRE(g.lds_bytes <= 160 * 1024, "wgrad: input tile does not fit LDS");
+    const size_t slab_floats = (size_t)d->Cout * d->Cin * SH::TAPS;
+    SPK_REQUIRE(d->workspace && (size_t)d->workspace_bytes >= g.n_slabs * slab_floats * sizeof(float),
+                "wgrad: needs a %zu-byte workspace (see spk_conv2d_wgrad_workspace_bytes)", g.n_slabs * slab_floats * sizeof(float));
+    WgradArgs a;
+    a.g = d->g; a.x = d->x; a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.slabs = static_cast<float*>(d->workspace);
+    a.B = d->B; a.Cin = d->Cin; a.Cout = d->Cout; a.H = d->H; a.W = d->W; a.Hs = d->Hin; a.Ws = d->Win;
+    a.lgTW = spk::ilog2(g.TW); a.lgTH = spk::ilog2(g.TH); a.lgTB = spk::ilog2(g.TB);
+    a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y; a.n_tiles = g.n_tiles;
+    auto kern = &wgrad_kernel<KH, KW, S, MODE>;
+    if (g.lds_bytes > 64 * 1024) {
+        static bool raised = false;
+        if (!raised) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return spk::fail(SPK_ELAUNCH, "hipFuncSetAttribute(LDS): %s", hipGetErrorString(e));
+            raised = true;
+        }
+    }
+    dim3 grid((unsigned)spk::ceil_div(d->Cout, SH::CO_T),
+              (unsigned)(spk::ceil_div(d->Cin, SH::CI_T) * (SH::ROWPASS ? KH : 1)), (unsigned)g.splits);
+    hipLaunchKernelGGL(kern, grid, dim3(256), g.lds_bytes, stream, a);
+    int rc = spk::check_launch("wgrad_kernel");
+    if (rc != SPK_OK) return rc;
+    const unsigned blocks = (unsigned)std::min<size_t>((slab_floats + 255) / 256, 2048);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, a.slabs, d->dw, g.n_slabs, d->Cout,
+                       d->Cin, SH::TAPS, d->scale, d->accumulate ? 1 : 0);
+    return spk::check_launch("wgrad_reduce_kernel");
+}
+
+template <int KH, int KW, int S>
+int by_mode(int mode, const spk_wgrad_desc* d, hipStream_t s) {
+    if (mode == WG_AFFINE_RELU) return run_wgrad<KH, KW, S, WG_AFFINE_RELU>(d, s);
+    return run_wgrad<KH, KW, S, WG_PLAIN>(d, s);
+}
+
+bool wg_supported(int kh, int kw, int stride) {
+    return kh == kw && (kh == 1 || kh == 3 || kh == 7) && (stride == 1 || stride == 2) && !(kh == 7 && stride == 1);
+}
+
+}  // namespace
+
+extern "C" {
+
+int64_t spk_conv2d_wgrad_workspace_bytes(int kh, int kw, int stride, int splits, int B, int Cin, int Cout, int H, int W) {
+    if (!wg_supported(kh, kw, stride) || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return -1;
+    WGeom g;
+    if (kh == 1) g = stride == 1 ? wgeom<1, 1, 1>(B, Cin, Cout, H, W, splits) : wgeom<1, 1, 2>(B, Cin, Cout, H, W, splits);
+    else if (kh == 3) g = stride == 1 ? wgeom<3, 3, 1>(B, Cin, Cout, H, W, splits) : wgeom<3, 3, 2>(B, Cin, Cout, H, W, splits);
+    else g = wgeom<7, 7, 2>(B, Cin, Cout, H, W, splits);
+    return (int64_t)g.n_slabs * Cout * Cin * kh * kw * (int64_t)sizeof(float);
+}
+
+int spk_conv2d_wgrad(const spk_wgrad_desc* d, void* stream) {
+    SPK_REQUIRE(d && d->g && d->x && d->dw, "wgrad: null pointer");
+    SPK_REQUIRE(d->B > 0 && d->Cin > 0 && d->Cout > 0 && d->H > 0 && d->W > 0 && d->Hin > 0 && d->Win > 0, "wgrad: bad shape");
+    SPK_REQUIRE(wg_supported(d->kh, d->kw, d->stride), "wgrad: unsupported kernel %dx%d stride %d", d->kh, d->kw, d->stride);
+    const bool ups = d->flags & SPK_CONV_UPSAMPLE2X, aff = d->flags & SPK_CONV_IN_AFFINE_RELU;
+    SPK_REQUIRE(!(ups && aff), "wgrad: UPSAMPLE2X and IN_AFFINE_RELU are exclusive");
+    SPK_REQUIRE(!ups || (d->kh == 3 && d->stride == 1), "wgrad: UPSAMPLE2X needs a 3x3 stride-1 kernel");
+    SPK_REQUIRE(!aff || (d->in_scale && d->in_shift), "wgrad: IN_AFFINE_RELU without in_scale/in_shift");
+    const int pad = (d->kh - 1) / 2;
+    if (ups) SPK_REQUIRE(d->H == 2 * d->Hin && d->W == 2 * d->Win, "wgrad: upsampled size mismatch");
+    else SPK_REQUIRE(d->H == (d->Hin + 2 * pad - d->kh) / d->stride + 1 && d->W == (d->Win + 2 * pad - d->kw) / d->stride + 1,
+                     "wgrad: output size %dx%d does not match input %dx%d", d->H, d->W, d->Hin, d->Win);
+    hipStream_t s = (hipStream_t)stream;
+    const int mode = aff ? WG_AFFINE_RELU : WG_PLAIN;
+    if (ups) return run_wgrad<3, 3, 1, WG_UPSAMPLE>(d, s);
+    if (d->kh == 1) return d->stride == 1 ? by_mode<1, 1, 1>(mode, d, s) : by_mode<1, 1, 2>(mode, d, s);
+    if (d->kh == 3) return d->stride == 1 ? by_mode<3, 3, 1>(mode, d, s) : by_mode<3, 3, 2>(mode, d, s);
+    return by_mode<7, 7, 2>(mode, d, s);
+}
+
+}  // extern "C"

@@ -23,6 +23,7 @@ import torch
 import torch.nn as nn
 
 from . import ops
+from . import autograd as AG
 
 LRELU = 0.2
 
@@ -47,7 +48,8 @@ class FC(nn.Module):
 
     def forward(self, x):
         lead = x.shape[:-1]
-        y = ops.fc(x.reshape(-1, x.shape[-1]), self.weight, self.bias, self.w_lrmul, self.b_lrmul, LRELU)
+        x2 = x if x.dim() == 2 else x.reshape(-1, x.shape[-1])
+        y = AG.fc(x2, self.weight, self.bias, self.w_lrmul, self.b_lrmul, LRELU)
         return y.view(*lead, -1)
 
 
@@ -62,8 +64,7 @@ class ApplyNoise(nn.Module):
     def forward(self, x, noise):
         if noise is None:
             noise = torch.randn(x.size(0), 1, x.size(2), x.size(3), device=x.device, dtype=x.dtype)
-        return ops.bias_noise_style(x.contiguous(), x.size(0), noise_w=self.weight,
-                                    noise=noise.to(x.device).contiguous())
+        return AG.bias_noise_style(x.contiguous(), None, self.weight, noise.to(x.device).contiguous(), None, x.size(0))
 
 
 class ApplyStyle(nn.Module):
@@ -77,7 +78,7 @@ class ApplyStyle(nn.Module):
         return self.linear(latent)
 
     def forward(self, x, latent):
-        return ops.bias_noise_style(x.contiguous(), x.size(0), style=self.style(latent))
+        return AG.bias_noise_style(x.contiguous(), None, None, None, self.style(latent), x.size(0))
 
 
 class SynthesisBlock(nn.Module):
@@ -100,10 +101,7 @@ class SynthesisBlock(nn.Module):
         H, W = (2 * Hs, 2 * Ws) if upsample else (Hs, Ws)
         if noise is None:
             noise = torch.randn(B, 1, H, W, device=x.device, dtype=torch.float32)
-        cfg = ops.conv3x3_pick_config(B, Cin, self.out_channels, H, W)
-        return ops.conv3x3_fused(x, pk.get(conv.weight, cfg), self.out_channels, bias=conv.bias,
-                                 noise_w=noise_mod.weight, noise=noise, style=style, upsample=upsample,
-                                 lrelu_slope=LRELU, config=cfg)
+        return AG.fused_conv(x, conv.weight, conv.bias, noise_mod.weight, noise, style, upsample, LRELU, pk)
 
     def forward(self, x, w, noise1=None, noise2=None, styles=None):
         """``w`` is [B,2,512].  ``styles`` (optional) = precomputed ([B,2C],[B,2C]) affine outputs."""
@@ -150,11 +148,11 @@ class SynthesisNetwork(nn.Module):
             noises = [torch.randn(s, device=w.device, dtype=torch.float32) for s in self.noise_shapes(B)]
         elif len(noises) != 2 * len(self.layers) + 1:
             raise ValueError(f"expected {2 * len(self.layers) + 1} noise tensors, got {len(noises)}")
-        x = ops.const_prologue(self.const_input, self.bias, self.noise_input1.weight, noises[0],
-                               self.style_mod.style(w[:, 0]), B)
+        x = AG.bias_noise_style(self.const_input, self.bias, self.noise_input1.weight, noises[0],
+                                   self.style_mod.style(w[:, 0]), B)
         for i, layer in enumerate(self.layers):
             x = layer(x, w[:, 2 * i + 1:2 * i + 3], noises[1 + 2 * i], noises[2 + 2 * i])
-        return ops.conv1x1_small(x, self.to_rgb.weight, self.to_rgb.bias)
+        return AG.to_rgb(x, self.to_rgb.weight, self.to_rgb.bias)
 
 
 class StyleGenerator(nn.Module):
@@ -175,18 +173,23 @@ class StyleGenerator(nn.Module):
         self.bn = None
         self.logger = logging.getLogger(__name__)
 
-    def forward(self, features, noises=None):
+    def forward(self, features, noises=None, style_mix=None):
+        """``style_mix`` (optional, tests): ``(mix_features, mix_layer)`` replacing the three RNG draws of the
+        train-mode mixing branch, or ``False`` to skip the branch."""
         L = self.synthesis.num_layers
         w = self.mapping(features).unsqueeze(1).repeat(1, L, 1)
         if self.truncation_psi and self.truncation_cutoff:
             coefs = torch.ones_like(w)
             coefs[:, :self.truncation_cutoff] *= self.truncation_psi
             w = coefs * w
-        if self.training and self.style_mixing_prob > 0:
-            # host RNG draws in the reference's order: rand(1), randn_like(features), randint
-            if torch.rand(1) < self.style_mixing_prob:
+        if self.training and self.style_mixing_prob > 0 and style_mix is not False:
+            # RNG draws in the reference's order: rand(1), randn_like(features), randint (styleganv1.py:548-552)
+            if style_mix is not None or torch.rand(1) < self.style_mixing_prob:
                 with torch.no_grad():
-                    w2 = self.mapping(torch.randn_like(features)).unsqueeze(1).repeat(1, L, 1)
-                    mix_layer = torch.randint(1, w.size(1), (1,)).item()
+                    z2 = style_mix[0] if style_mix is not None else torch.randn_like(features)
+                    w2 = self.mapping(z2).unsqueeze(1).repeat(1, L, 1)
+                    mix_layer = style_mix[1] if style_mix is not None else torch.randint(1, w.size(1), (1,)).item()
+                    # in place and under no_grad, as the reference: autograd never sees the overwrite, so the
+                    # gradient of the mixed rows still flows into the first mapping pass (a reference quirk)
                     w[:, mix_layer:] = w2[:, mix_layer:]
         return self.synthesis(w, noises)

@@ -88,7 +88,7 @@ def conv_out_size(n, k, stride):
 
 def conv2d_fused(x, w_packed, Cout: int, k: int = 3, stride: int = 1, *, bias=None, noise_w=None, noise=None,
                  style=None, style_stride=None, upsample=False, lrelu_slope=None, out_scale=1.0, in_affine=None,
-                 stats=None, config=-1, ksplit=0, out=None, accumulate=False):
+                 stats=None, config=-1, ksplit=0, out=None, accumulate=False, out_pre=None):
     """y = style(lrelu(conv_kxk(in(x)) * out_scale + bias + noise_w*noise)) -- one launch.
 
     ``in``: identity; or bilinear x2 (``upsample``; x is [B,Cin,H/2,W/2]); or ``max(x*a+b, 0)`` per
@@ -138,7 +138,7 @@ def conv2d_fused(x, w_packed, Cout: int, k: int = 3, stride: int = 1, *, bias=No
                      in_scale=L.dptr(in_affine[0], "in_scale") if in_affine is not None else None,
                      in_shift=L.dptr(in_affine[1], "in_shift") if in_affine is not None else None,
                      stats=stats.data_ptr() if stats is not None else None, y=L.dptr(out, "out"),
-                     B=B, Cin=Cin, Cout=Cout, H=H, W=W, Hin=Hs, Win=Ws, kh=k, kw=k, stride=stride,
+                     y_pre=L.dptr(out_pre, "out_pre"), B=B, Cin=Cin, Cout=Cout, H=H, W=W, Hin=Hs, Win=Ws, kh=k, kw=k, stride=stride,
                      style_stride=int(style_stride or 0), flags=flags,
                      lrelu_slope=float(lrelu_slope if lrelu_slope is not None else 1.0), out_scale=float(out_scale),
                      config=int(config), ksplit=int(ksplit), workspace=ws.data_ptr() if ws is not None else None,
@@ -239,6 +239,77 @@ def upsample2x_bilinear(x):
     L.check(L.lib().spk_upsample2x_bilinear_fwd(L.dptr(x, "x"), L.dptr(out), B * Cc, H, W, L.stream_ptr()),
             "spk_upsample2x_bilinear_fwd")
     return out
+
+
+# ---- backward launchers ------------------------------------------------------------------------------
+def conv2d_wgrad(g, x, Cout, Cin, k=3, stride=1, *, upsample=False, in_affine=None, scale=1.0, out=None,
+                 accumulate=False, splits=0):
+    """dW[Cout,Cin,k,k] = scale * sum_{b,h,w} g[b,co,h,w] * in(x)[b,ci,h*s+ky-p,w*s+kx-p]."""
+    B, _, H, W = g.shape
+    Hs, Ws = x.shape[-2:]
+    if out is None:
+        out = torch.empty((Cout, Cin, k, k), device=g.device, dtype=torch.float32)
+    ws_bytes = L.lib().spk_conv2d_wgrad_workspace_bytes(k, k, stride, int(splits), B, Cin, Cout, H, W)
+    if ws_bytes < 0:
+        raise L.SpkError("conv2d_wgrad: unsupported problem")
+    ws = _workspace(g.device, ws_bytes)
+    flags = (L.CONV_UPSAMPLE2X if upsample else 0) | (L.CONV_IN_AFFINE_RELU if in_affine is not None else 0)
+    d = L.WgradDesc(g=L.dptr(g, "g"), x=L.dptr(x, "x"),
+                    in_scale=L.dptr(in_affine[0], "in_scale") if in_affine is not None else None,
+                    in_shift=L.dptr(in_affine[1], "in_shift") if in_affine is not None else None,
+                    dw=L.dptr(out, "dw"), B=B, Cin=Cin, Cout=Cout, H=H, W=W, Hin=Hs, Win=Ws, kh=k, kw=k, stride=stride,
+                    flags=flags, scale=float(scale), accumulate=1 if accumulate else 0, splits=int(splits),
+                    workspace=ws.data_ptr(), workspace_bytes=ws.numel() * 4)
+    L.check(L.lib().spk_conv2d_wgrad(C.byref(d), L.stream_ptr()), "spk_conv2d_wgrad")
+    return out
+
+
+def epilogue_bwd(dy, a=None, noise=None, style=None, slope=1.0, inplace=False):
+    """Adjoint of the fused conv epilogue: returns (dt, sums[B,C,4]) with
+    sums = {sum dy, sum dy*a, sum dt, sum dt*noise} per (b,c) plane."""
+    B, Cc, H, W = dy.shape
+    dt = dy if inplace else torch.empty_like(dy)
+    sums = torch.empty((B, Cc, 4), device=dy.device, dtype=torch.float32)
+    L.check(L.lib().spk_epilogue_bwd(L.dptr(dy, "dy"), L.dptr(a, "a"), L.dptr(noise, "noise"), _style_ptr(style),
+                                     style.stride(0) if style is not None else 0, float(slope), L.dptr(dt), L.dptr(sums),
+                                     B, Cc, H * W, L.stream_ptr()), "spk_epilogue_bwd")
+    return dt, sums
+
+
+def upsample2x_bilinear_bwd(dy):
+    B, Cc, H2, W2 = dy.shape
+    dx = torch.empty((B, Cc, H2 // 2, W2 // 2), device=dy.device, dtype=torch.float32)
+    L.check(L.lib().spk_upsample2x_bilinear_bwd(L.dptr(dy, "dy"), L.dptr(dx), B * Cc, H2 // 2, W2 // 2, L.stream_ptr()),
+            "spk_upsample2x_bilinear_bwd")
+    return dx
+
+
+def conv1x1_small_bwd(x, weight, dy, need_dx=True, in_scale=1.0):
+    """toRGB backward -> (dx | None, dw[O,C,1,1], db[O])."""
+    B, Cc, H, W = x.shape
+    O = weight.shape[0]
+    nblk = L.lib().spk_conv1x1_small_bwd_blocks(B, H * W)
+    partial = torch.empty((nblk, O * Cc + O), device=x.device, dtype=torch.float32)
+    dx = torch.empty_like(x) if need_dx else None
+    L.check(L.lib().spk_conv1x1_small_bwd(L.dptr(x, "x"), L.dptr(weight.reshape(O, Cc), "weight"), L.dptr(dy, "dy"),
+                                          L.dptr(dx), L.dptr(partial), B, Cc, O, H * W, float(in_scale), L.stream_ptr()),
+            "spk_conv1x1_small_bwd")
+    tot = partial.sum(0)                      # [O*C + O]: a few hundred numbers
+    return dx, tot[:O * Cc].view(O, Cc, 1, 1), tot[O * Cc:]
+
+
+def fc_bwd(dout, out, x, weight, wmul=1.0, bmul=1.0, slope=1.0, need_dx=True, need_dw=True, has_bias=True):
+    """FC backward -> (dx | None, dw | None, db | None); ``out`` is the saved forward output."""
+    B, I = x.shape
+    O = weight.shape[0]
+    dev = x.device
+    dx = torch.empty((B, I), device=dev, dtype=torch.float32) if need_dx else None
+    dw = torch.empty((O, I), device=dev, dtype=torch.float32) if need_dw else None
+    db = torch.empty(O, device=dev, dtype=torch.float32) if (need_dw and has_bias) else None
+    L.check(L.lib().spk_fc_bwd(L.dptr(dout, "dout"), L.dptr(out, "out"), x.data_ptr(), x.stride(0), L.dptr(weight, "weight"),
+                               L.dptr(dx), I, L.dptr(dw), L.dptr(db), B, I, O, float(wmul), float(bmul), float(slope),
+                               L.stream_ptr()), "spk_fc_bwd")
+    return dx, dw, db
 
 
 # ---- BatchNorm / pooling pieces of the ResNet-50 trunk ----------------------------------------------
