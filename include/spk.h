@@ -112,7 +112,8 @@ int spk_conv2d_fwd(const spk_conv2d_desc* desc, void* stream);
  * (stride 1).  Weight gradient (any supported kernel / stride), on the f32 MFMA pipe with the pixel axis
  * as the contraction:
  *   dw[co,ci,ky,kx] (+)= scale * sum_{b,h,w} g[b,co,h,w] * xin[b,ci,h*s+ky-p,w*s+kx-p]
- * xin is formed exactly as the forward pass formed it (flags SPK_CONV_UPSAMPLE2X / SPK_CONV_IN_AFFINE_RELU).
+ * xin is x, or max(x*a+b, 0) per input channel (SPK_CONV_IN_AFFINE_RELU), as the forward pass formed it; for a
+ * forward that used SPK_CONV_UPSAMPLE2X pass the x2 image itself (spk_upsample2x_bilinear_fwd).
  * Partial sums go to `workspace` and are reduced in a fixed order: bitwise reproducible, no float atomics.
  * replaces: the aten::convolution_backward weight path under loss.backward() (train.py:205) for
  *           styleganv1.py:625,630 and the trunk convs. */
@@ -123,7 +124,7 @@ typedef struct spk_wgrad_desc {
     const float* in_shift;
     float*       dw;         /* [Cout,Cin,kh,kw] */
     int32_t B, Cin, Cout, H, W, Hin, Win, kh, kw, stride;
-    uint32_t flags;          /* SPK_CONV_UPSAMPLE2X | SPK_CONV_IN_AFFINE_RELU */
+    uint32_t flags;          /* 0 or SPK_CONV_IN_AFFINE_RELU */
     float scale;
     int32_t accumulate;      /* dw += instead of dw = */
     int32_t splits;          /* pixel-range splits; 0 = auto */

@@ -33,15 +33,36 @@ __global__ __launch_bounds__(256) void epilogue_bwd_kernel(const float* __restri
     const float* np = noise ? noise + b * HW : nullptr;
     float* dtp = dt + plane * HW;
     float s_dy = 0.f, s_dya = 0.f, s_dt = 0.f, s_dtn = 0.f;
-    for (long long i = threadIdx.x; i < HW; i += 256) {
-        const float d = dyp[i];
-        const float av = ap ? ap[i] : 0.f;
-        const float t = d * g * ((!ap || av > 0.f) ? 1.f : slope);
-        dtp[i] = t;
-        s_dy += d;
-        s_dya += d * av;
-        s_dt += t;
-        if (np) s_dtn += t * np[i];
+    const bool vec = (HW % 4 == 0) && (((uintptr_t)dy | (uintptr_t)dt | (uintptr_t)(a ? a : dy) | (uintptr_t)(noise ? noise : dy)) % 16 == 0);
+    if (vec) {
+        const long long n4 = HW / 4;
+#pragma unroll 2
+        for (long long i = threadIdx.x; i < n4; i += 256) {
+            const float4 d = reinterpret_cast<const float4*>(dyp)[i];
+            const float4 av = ap ? reinterpret_cast<const float4*>(ap)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            const float4 nv = np ? reinterpret_cast<const float4*>(np)[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+            float4 t;
+            t.x = d.x * g * ((!ap || av.x > 0.f) ? 1.f : slope);
+            t.y = d.y * g * ((!ap || av.y > 0.f) ? 1.f : slope);
+            t.z = d.z * g * ((!ap || av.z > 0.f) ? 1.f : slope);
+            t.w = d.w * g * ((!ap || av.w > 0.f) ? 1.f : slope);
+            reinterpret_cast<float4*>(dtp)[i] = t;
+            s_dy += (d.x + d.y) + (d.z + d.w);
+            s_dya += (d.x * av.x + d.y * av.y) + (d.z * av.z + d.w * av.w);
+            s_dt += (t.x + t.y) + (t.z + t.w);
+            s_dtn += (t.x * nv.x + t.y * nv.y) + (t.z * nv.z + t.w * nv.w);
+        }
+    } else {
+        for (long long i = threadIdx.x; i < HW; i += 256) {
+            const float d = dyp[i];
+            const float av = ap ? ap[i] : 0.f;
+            const float t = d * g * ((!ap || av > 0.f) ? 1.f : slope);
+            dtp[i] = t;
+            s_dy += d;
+            s_dya += d * av;
+            s_dt += t;
+            if (np) s_dtn += t * np[i];
+        }
     }
     s_dy = block_sum(s_dy, red);
     s_dya = block_sum(s_dya, red);
@@ -63,82 +84,188 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __rest
         const int ix = (int)(idx % Win), iy = (int)((idx / Win) % Hin);
         const long long pl = idx / ((long long)Win * Hin);
         const float* g = dy + pl * Ho * Wo;
-        float acc = 0.f;
-        for (int uy = max(2 * iy - 2, 0); uy <= min(2 * iy + 2, Ho - 1); ++uy) {
-            const int y0 = uy == 0 ? 0 : (uy - 1) >> 1, y1 = min(y0 + 1, Hin - 1);
-            const float ly1 = uy == 0 ? 0.f : ((uy & 1) ? 0.25f : 0.75f);
-            const float wy = (y0 == iy ? 1.f - ly1 : 0.f) + (y1 == iy ? ly1 : 0.f);
-            if (wy == 0.f) continue;
-            for (int ux = max(2 * ix - 2, 0); ux <= min(2 * ix + 2, Wo - 1); ++ux) {
-                const int x0 = ux == 0 ? 0 : (ux - 1) >> 1, x1 = min(x0 + 1, Win - 1);
-                const float lx1 = ux == 0 ? 0.f : ((ux & 1) ? 0.25f : 0.75f);
-                const float wx = (x0 == ix ? 1.f - lx1 : 0.f) + (x1 == ix ? lx1 : 0.f);
-                if (wx != 0.f) acc += wy * wx * g[(size_t)uy * Wo + ux];
+        // rows 2iy-1 .. 2iy+2 (cols likewise) are the only ones whose forward stencil can touch (iy, ix)
+        float wy[4], wx[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int uy = 2 * iy - 1 + k, ux = 2 * ix - 1 + k;
+            wy[k] = 0.f; wx[k] = 0.f;
+            if (uy >= 0 && uy < Ho) {
+                const int y0 = uy == 0 ? 0 : (uy - 1) >> 1, y1 = min(y0 + 1, Hin - 1);
+                const float l1 = uy == 0 ? 0.f : ((uy & 1) ? 0.25f : 0.75f);
+                wy[k] = (y0 == iy ? 1.f - l1 : 0.f) + (y1 == iy ? l1 : 0.f);
             }
+            if (ux >= 0 && ux < Wo) {
+                const int x0 = ux == 0 ? 0 : (ux - 1) >> 1, x1 = min(x0 + 1, Win - 1);
+                const float l1 = ux == 0 ? 0.f : ((ux & 1) ? 0.25f : 0.75f);
+                wx[k] = (x0 == ix ? 1.f - l1 : 0.f) + (x1 == ix ? l1 : 0.f);
+            }
+        }
+        float acc = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < 4; ++ky) {
+            if (wy[ky] == 0.f) continue;
+            const float* row = g + (size_t)(2 * iy - 1 + ky) * Wo + (2 * ix - 1);
+            float r = 0.f;
+#pragma unroll
+            for (int kx = 0; kx < 4; ++kx)
+                if (wx[kx] != 0.f) r += wx[kx] * row[kx];
+            acc += wy[ky] * r;
         }
         dx[idx] = acc;
     }
 }
 
-// toRGB backward.  Each workgroup owns a pixel range of one image:
-//   dx[b,c,p] = in_scale * sum_o w[o,c] * dy[b,o,p]                      (written)
-//   partial[blk][o*C + c] = in_scale * sum_p dy[b,o,p] * x[b,c,p];  partial[blk][O*C + o] = sum_p dy[b,o,p]
-__global__ __launch_bounds__(256) void conv1x1_small_bwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                               const float* __restrict__ dy, float* __restrict__ dx,
-                                                               float* __restrict__ partial, int C, int O, long long HW,
-                                                               long long px_per_block, float in_scale) {
-    __shared__ float red[4];
+// toRGB backward, data half: dx[b,c,p] = in_scale * sum_o w[o,c] * dy[b,o,p]   (one streaming pass, 16-B accesses)
+template <bool VEC>
+__global__ __launch_bounds__(256) void conv1x1_small_bwd_data_kernel(const float* __restrict__ w, const float* __restrict__ dy,
+                                                                    float* __restrict__ dx, int C, int O, long long HW,
+                                                                    float in_scale) {
+    extern __shared__ float w_s[];  // [O][C]
+    for (int i = threadIdx.x; i < O * C; i += blockDim.x) w_s[i] = w[i] * in_scale;
+    __syncthreads();
     const int b = blockIdx.y;
-    const long long p_begin = (long long)blockIdx.x * px_per_block, p_end = min(HW, p_begin + px_per_block);
-    const float* xb = x + (size_t)b * C * HW;
     const float* dyb = dy + (size_t)b * O * HW;
-    float* dxb = dx ? dx + (size_t)b * C * HW : nullptr;
-    float* part = partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (O * C + O);
-    for (int c = 0; c < C; ++c) {
-        float wc[4], s[4] = {0.f, 0.f, 0.f, 0.f};
+    float* dxb = dx + (size_t)b * C * HW;
+    if (VEC) {
+        const long long n4 = HW / 4;
+        for (long long p4 = (long long)blockIdx.x * blockDim.x + threadIdx.x; p4 < n4; p4 += (long long)gridDim.x * blockDim.x) {
+            float4 g[4];
 #pragma unroll
-        for (int o = 0; o < 4; ++o) wc[o] = o < O ? w[o * C + c] * in_scale : 0.f;
-        for (long long pp = p_begin + threadIdx.x; pp < p_end; pp += 256) {
-            const float xv = xb[(size_t)c * HW + pp];
-            float d = 0.f;
+            for (int o = 0; o < 4; ++o) g[o] = o < O ? reinterpret_cast<const float4*>(dyb + (size_t)o * HW)[p4] : make_float4(0, 0, 0, 0);
+            for (int c = 0; c < C; ++c) {
+                float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-            for (int o = 0; o < 4; ++o)
-                if (o < O) {
-                    const float g = dyb[(size_t)o * HW + pp];
-                    d += wc[o] * g;
-                    s[o] += g * xv;
-                }
-            if (dxb) dxb[(size_t)c * HW + pp] = d;
-        }
-#pragma unroll
-        for (int o = 0; o < 4; ++o)
-            if (o < O) {
-                const float t = block_sum(s[o], red);
-                if (threadIdx.x == 0) part[o * C + c] = t * in_scale;
+                for (int o = 0; o < 4; ++o)
+                    if (o < O) {
+                        const float wv = w_s[o * C + c];
+                        v.x += wv * g[o].x; v.y += wv * g[o].y; v.z += wv * g[o].z; v.w += wv * g[o].w;
+                    }
+                reinterpret_cast<float4*>(dxb + (size_t)c * HW)[p4] = v;
             }
-    }
-    for (int o = 0; o < O; ++o) {
-        float s = 0.f;
-        for (long long pp = p_begin + threadIdx.x; pp < p_end; pp += 256) s += dyb[(size_t)o * HW + pp];
-        s = block_sum(s, red);
-        if (threadIdx.x == 0) part[O * C + o] = s;
+        }
+    } else {
+        for (long long pp = (long long)blockIdx.x * blockDim.x + threadIdx.x; pp < HW; pp += (long long)gridDim.x * blockDim.x) {
+            float g[4];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) g[o] = o < O ? dyb[(size_t)o * HW + pp] : 0.f;
+            for (int c = 0; c < C; ++c) {
+                float v = 0.f;
+#pragma unroll
+                for (int o = 0; o < 4; ++o)
+                    if (o < O) v += w_s[o * C + c] * g[o];
+                dxb[(size_t)c * HW + pp] = v;
+            }
+        }
     }
 }
 
-// dx[b,i] = wmul * sum_o dz[b,o] * w[o,i],  dz = dout * (out > 0 ? 1 : slope).  Lanes run along i.
+// toRGB backward, weight half.  A workgroup walks a pixel range of one image in 128-pixel tiles; per 64-channel
+// group the x tile is staged through LDS (coalesced HBM reads, odd row pitch) and thread (c, q) accumulates
+// sum_p dy[o,p]*x[c,p] over its quarter of the tile.  partial[blk][o*C + c], partial[blk][O*C + o] (d bias).
+__global__ __launch_bounds__(256) void conv1x1_small_bwd_weight_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                      float* __restrict__ partial, int C, int O, long long HW,
+                                                                      long long px_per_block, float in_scale) {
+    __shared__ float x_s[64 * 129];
+    __shared__ float dy_s[4 * 128];
+    __shared__ float red[4];
+    const int b = blockIdx.y, tid = threadIdx.x, c_l = tid & 63, q = tid >> 6;
+    const long long p_begin = (long long)blockIdx.x * px_per_block, p_end = min(HW, p_begin + px_per_block);
+    const float* xb = x + (size_t)b * C * HW;
+    const float* dyb = dy + (size_t)b * O * HW;
+    float* part = partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (O * C + O);
+    float dbacc[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int cg = 0; cg < C; cg += 64) {
+        float acc[4] = {0.f, 0.f, 0.f, 0.f};
+        for (long long p0 = p_begin; p0 < p_end; p0 += 128) {
+            __syncthreads();
+            for (int e = tid; e < 64 * 128; e += 256) {
+                const int c = e >> 7, pp = e & 127;
+                x_s[c * 129 + pp] = (cg + c < C && p0 + pp < p_end) ? xb[(size_t)(cg + c) * HW + p0 + pp] : 0.f;
+            }
+            for (int o = 0; o < O; ++o) {
+                const float g = (tid < 128 && p0 + tid < p_end) ? dyb[(size_t)o * HW + p0 + tid] : 0.f;
+                if (tid < 128) dy_s[o * 128 + tid] = g;
+                if (cg == 0) dbacc[o] += g;
+            }
+            __syncthreads();
+            const float* xr = x_s + c_l * 129 + q * 32;
+#pragma unroll 8
+            for (int pp = 0; pp < 32; ++pp) {
+                const float xv = xr[pp];
+#pragma unroll
+                for (int o = 0; o < 4; ++o)
+                    if (o < O) acc[o] += dy_s[o * 128 + q * 32 + pp] * xv;
+            }
+        }
+        // reduce the four pixel quarters (waves) of each channel through LDS
+        __syncthreads();
+        for (int o = 0; o < O; ++o) x_s[(o * 4 + q) * 64 + c_l] = acc[o];
+        __syncthreads();
+        if (q == 0 && cg + c_l < C)
+            for (int o = 0; o < O; ++o)
+                part[o * C + cg + c_l] = (x_s[(o * 4 + 0) * 64 + c_l] + x_s[(o * 4 + 1) * 64 + c_l] + x_s[(o * 4 + 2) * 64 + c_l] +
+                                          x_s[(o * 4 + 3) * 64 + c_l]) * in_scale;
+    }
+    for (int o = 0; o < O; ++o) {
+        const float t = block_sum(dbacc[o], red);
+        if (tid == 0) part[O * C + o] = t;
+    }
+}
+
+// dx[b,i] = wmul * sum_o dz[b,o] * w[o,i],  dz = dout * (out > 0 ? 1 : slope).  A workgroup owns 64 consecutive i
+// (one per lane); its 4 waves split the o range; dz for a tile of 8 batch rows sits in LDS (broadcast reads), so
+// every weight element is read once per batch tile.
+constexpr int FCB_BT = 8;
 __global__ __launch_bounds__(256) void fc_bwd_input_kernel(const float* __restrict__ dout, const float* __restrict__ out,
                                                           const float* __restrict__ w, float* __restrict__ dx,
                                                           long long dx_stride, int B, int I, int O, float wmul, float slope) {
-    const int i = blockIdx.x * 256 + threadIdx.x;
-    const int b = blockIdx.y;
-    if (i >= I) return;
-    float acc = 0.f;
-    for (int o = 0; o < O; ++o) {
-        const float ov = out[(size_t)b * O + o];
-        const float dz = dout[(size_t)b * O + o] * (ov > 0.f ? 1.f : slope);
-        acc += dz * w[(size_t)o * I + i];
+    extern __shared__ float dz_s[];            // [FCB_BT][O]
+    __shared__ float red[4][FCB_BT][64];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = blockIdx.x * 64 + lane;
+    for (int b0 = 0; b0 < B; b0 += FCB_BT) {
+        __syncthreads();
+        for (int e = tid; e < FCB_BT * O; e += 256) {
+            const int b = e / O, o = e - b * O;
+            float v = 0.f;
+            if (b0 + b < B) {
+                const size_t idx = (size_t)(b0 + b) * O + o;
+                v = dout[idx] * (out[idx] > 0.f ? 1.f : slope);
+            }
+            dz_s[e] = v;
+        }
+        __syncthreads();
+        float acc[FCB_BT];
+#pragma unroll
+        for (int b = 0; b < FCB_BT; ++b) acc[b] = 0.f;
+        if (i < I) {
+            int o = wave;
+            for (; o + 28 < O; o += 32) {            // 8 independent row loads in flight
+                float wv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) wv[u] = w[(size_t)(o + 4 * u) * I + i];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+#pragma unroll
+                    for (int b = 0; b < FCB_BT; ++b) acc[b] += dz_s[b * O + o + 4 * u] * wv[u];
+            }
+            for (; o < O; o += 4) {
+                const float wv = w[(size_t)o * I + i];
+#pragma unroll
+                for (int b = 0; b < FCB_BT; ++b) acc[b] += dz_s[b * O + o] * wv;
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < FCB_BT; ++b) red[wave][b][lane] = acc[b];
+        __syncthreads();
+        if (wave == 0 && i < I) {
+#pragma unroll
+            for (int b = 0; b < FCB_BT; ++b)
+                if (b0 + b < B)
+                    dx[(size_t)(b0 + b) * dx_stride + i] = (red[0][b][lane] + red[1][b][lane] + red[2][b][lane] + red[3][b][lane]) * wmul;
+        }
     }
-    dx[(size_t)b * dx_stride + i] = acc * wmul;
 }
 
 // dw[o,i] = wmul * sum_b dz[b,o] * x[b,i];  db[o] = bmul * sum_b dz[b,o]
@@ -187,7 +314,7 @@ int spk_upsample2x_bilinear_bwd(const float* dy, float* dx, int64_t planes, int 
 }
 
 int spk_conv1x1_small_bwd_blocks(int B, int64_t HW) {
-    const long long per_img = std::max(1ll, std::min((long long)(HW + 4095) / 4096, 64ll));
+    const long long per_img = std::max(1ll, std::min((long long)(HW + 1023) / 1024, 128ll));
     return (int)(per_img * B);
 }
 
@@ -195,11 +322,23 @@ int spk_conv1x1_small_bwd(const float* x, const float* w, const float* dy, float
                           int64_t HW, float in_scale, void* stream) {
     SPK_REQUIRE(x && w && dy && partial, "conv1x1_small_bwd: null pointer");
     SPK_REQUIRE(B > 0 && C > 0 && O > 0 && O <= 4 && HW > 0, "conv1x1_small_bwd: bad shape (O must be <= 4)");
+    SPK_REQUIRE((size_t)O * C * sizeof(float) <= 48 * 1024, "conv1x1_small_bwd: weight too large for LDS");
+    hipStream_t s = (hipStream_t)stream;
+    if (dx) {
+        const bool vec = (HW % 4 == 0) && ((uintptr_t)dy % 16 == 0) && ((uintptr_t)dx % 16 == 0);
+        const long long work = vec ? HW / 4 : HW;
+        dim3 grid((unsigned)std::max(1ll, std::min((work + 255) / 256, 256ll)), (unsigned)B);
+        const size_t lds = (size_t)O * C * sizeof(float);
+        if (vec) hipLaunchKernelGGL(conv1x1_small_bwd_data_kernel<true>, grid, dim3(256), lds, s, w, dy, dx, C, O, (long long)HW, in_scale);
+        else     hipLaunchKernelGGL(conv1x1_small_bwd_data_kernel<false>, grid, dim3(256), lds, s, w, dy, dx, C, O, (long long)HW, in_scale);
+        int rc = spk::check_launch("conv1x1_small_bwd_data_kernel");
+        if (rc != SPK_OK) return rc;
+    }
     const int per_img = spk_conv1x1_small_bwd_blocks(B, HW) / B;
-    const long long px_per_block = (HW + per_img - 1) / per_img;
-    hipLaunchKernelGGL(conv1x1_small_bwd_kernel, dim3((unsigned)per_img, (unsigned)B), dim3(256), 0, (hipStream_t)stream, x, w,
-                       dy, dx, partial, C, O, (long long)HW, px_per_block, in_scale);
-    return spk::check_launch("conv1x1_small_bwd_kernel");
+    const long long px_per_block = ((HW + per_img - 1) / per_img + 127) / 128 * 128;
+    hipLaunchKernelGGL(conv1x1_small_bwd_weight_kernel, dim3((unsigned)per_img, (unsigned)B), dim3(256), 0, s, x, dy, partial, C,
+                       O, (long long)HW, px_per_block, in_scale);
+    return spk::check_launch("conv1x1_small_bwd_weight_kernel");
 }
 
 int spk_fc_bwd(const float* dout, const float* out, const float* x, int64_t x_stride, const float* w, float* dx,
@@ -209,8 +348,9 @@ int spk_fc_bwd(const float* dout, const float* out, const float* x, int64_t x_st
     SPK_REQUIRE(B > 0 && I > 0 && O > 0, "fc_bwd: bad shape");
     hipStream_t s = (hipStream_t)stream;
     if (dx) {
-        hipLaunchKernelGGL(fc_bwd_input_kernel, dim3((unsigned)spk::ceil_div(I, 256), (unsigned)B), dim3(256), 0, s, dout, out,
-                           w, dx, (long long)dx_stride, B, I, O, wmul, slope);
+        SPK_REQUIRE((size_t)FCB_BT * O * sizeof(float) <= 60 * 1024, "fc_bwd: O too large for the LDS tile");
+        hipLaunchKernelGGL(fc_bwd_input_kernel, dim3((unsigned)spk::ceil_div(I, 64)), dim3(256), (size_t)FCB_BT * O * sizeof(float),
+                           s, dout, out, w, dx, (long long)dx_stride, B, I, O, wmul, slope);
         int rc = spk::check_launch("fc_bwd_input_kernel");
         if (rc != SPK_OK) return rc;
     }

@@ -85,23 +85,38 @@ __global__ __launch_bounds__(256) void conv1x1_small_kernel(const float* __restr
     }
 }
 
-// bilinear x2, align_corners=False (torch area_pixel_compute_source_index with scale 0.5)
+// bilinear x2, align_corners=False (torch area_pixel_compute_source_index with scale 0.5).
+// One thread makes 4 consecutive outputs of a row (Wo % 4 == 0 always: Wo = 2*Win, handled per pair otherwise).
 __global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                         long long planes, int Hin, int Win) {
     const int Ho = 2 * Hin, Wo = 2 * Win;
-    const long long total = planes * Ho * Wo;
+    const int Wq = (Wo + 3) / 4;
+    const long long total = planes * Ho * Wq;
     for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
          idx += (long long)gridDim.x * blockDim.x) {
-        const int ux = (int)(idx % Wo);
-        const int uy = (int)((idx / Wo) % Ho);
-        const long long pl = idx / ((long long)Wo * Ho);
-        const float sy = fmaxf(0.5f * (uy + 0.5f) - 0.5f, 0.f), sx = fmaxf(0.5f * (ux + 0.5f) - 0.5f, 0.f);
-        const int iy0 = (int)sy, ix0 = (int)sx;
-        const int iy1 = min(iy0 + 1, Hin - 1), ix1 = min(ix0 + 1, Win - 1);
-        const float ly1 = sy - iy0, lx1 = sx - ix0, ly0 = 1.f - ly1, lx0 = 1.f - lx1;
-        const float* s = x + (size_t)pl * Hin * Win;
-        y[idx] = ly0 * (lx0 * s[iy0 * Win + ix0] + lx1 * s[iy0 * Win + ix1]) +
-                 ly1 * (lx0 * s[iy1 * Win + ix0] + lx1 * s[iy1 * Win + ix1]);
+        const int q = (int)(idx % Wq);
+        const int uy = (int)((idx / Wq) % Ho);
+        const long long pl = idx / ((long long)Wq * Ho);
+        const float sy = fmaxf(0.5f * (uy + 0.5f) - 0.5f, 0.f);
+        const int iy0 = (int)sy, iy1 = min(iy0 + 1, Hin - 1);
+        const float ly1 = sy - iy0, ly0 = 1.f - ly1;
+        const float* r0 = x + (size_t)pl * Hin * Win + (size_t)iy0 * Win;
+        const float* r1 = x + (size_t)pl * Hin * Win + (size_t)iy1 * Win;
+        float out[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const int ux = min(4 * q + k, Wo - 1);
+            const float sx = fmaxf(0.5f * (ux + 0.5f) - 0.5f, 0.f);
+            const int ix0 = (int)sx, ix1 = min(ix0 + 1, Win - 1);
+            const float lx1 = sx - ix0, lx0 = 1.f - lx1;
+            out[k] = ly0 * (lx0 * r0[ix0] + lx1 * r0[ix1]) + ly1 * (lx0 * r1[ix0] + lx1 * r1[ix1]);
+        }
+        float* dst = y + (size_t)pl * Ho * Wo + (size_t)uy * Wo + 4 * q;
+        if (Wo % 4 == 0) {
+            *reinterpret_cast<float4*>(dst) = make_float4(out[0], out[1], out[2], out[3]);
+        } else {
+            for (int k = 0; k < 4 && 4 * q + k < Wo; ++k) dst[k] = out[k];
+        }
     }
 }
 
@@ -148,7 +163,7 @@ int spk_conv1x1_small_fwd(const float* x, const float* w, const float* bias, flo
 int spk_upsample2x_bilinear_fwd(const float* x, float* y, int64_t planes, int Hin, int Win, void* stream) {
     SPK_REQUIRE(x && y, "upsample2x: null pointer");
     SPK_REQUIRE(planes > 0 && Hin > 0 && Win > 0, "upsample2x: bad shape");
-    hipLaunchKernelGGL(upsample2x_kernel, dim3(stream_grid(planes * 4ll * Hin * Win, 256)), dim3(256), 0,
+    hipLaunchKernelGGL(upsample2x_kernel, dim3(stream_grid(planes * 2ll * Hin * ((2 * Win + 3) / 4), 256)), dim3(256), 0,
                        (hipStream_t)stream, x, y, (long long)planes, Hin, Win);
     return spk::check_launch("upsample2x_kernel");
 }

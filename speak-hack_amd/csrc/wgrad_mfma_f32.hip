@@ -42,13 +42,15 @@ struct WShape {
     static constexpr int CI_T = (S == 2 || KH == 7) ? 32 : 64;
     static constexpr int WCI = CI_T / 32, WPX = 2 / WCI;    // 4 waves = 2 (co) x WCI x WPX
     static constexpr int CO_T = 64, PIX_T = 64, PAD = (KH - 1) / 2;
+    static constexpr int KX = KH == 7 ? 3 : (S == 2 ? 2 : 1);   // plane positions (x256) a thread stages
 };
 
 template <int KH, int KW, int S, int MODE>
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     using SH = WShape<KH, KW, S>;
     constexpr int TAPS = SH::TAPS, TP = SH::TP, CI_T = SH::CI_T, CO_T = SH::CO_T, PIX_T = SH::PIX_T, PAD = SH::PAD;
-    constexpr bool UPS = MODE == WG_UPSAMPLE, AFF = MODE == WG_AFFINE_RELU;
+    constexpr bool AFF = MODE == WG_AFFINE_RELU;
+    constexpr int KX = SH::KX, NG = CO_T * PIX_T / 256;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -67,7 +69,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     const int ci0 = (blockIdx.y % ci_blocks) * CI_T;
     const int pass = blockIdx.y / ci_blocks;            // tap row for ROWPASS kernels, else 0
     const int tap0 = SH::ROWPASS ? pass * KW : 0;
-    const int Hv = UPS ? 2 * p.Hs : p.Hs, Wv = UPS ? 2 * p.Ws : p.Ws;
+    const int nci = min(CI_T, p.Cin - ci0);
     const size_t HW = (size_t)p.H * p.W, src_plane = (size_t)p.Hs * p.Ws;
 
     f32x16 acc[TP];
@@ -76,51 +78,79 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
-    for (int tile = blockIdx.z; tile < p.n_tiles; tile += gridDim.z) {
-        int bx = tile;
-        const int tx = bx % p.tiles_x; bx /= p.tiles_x;
-        const int ty = bx % p.tiles_y;
-        const int b0 = (bx / p.tiles_y) << p.lgTB, y0 = ty << p.lgTH, x0 = tx << p.lgTW;
-        __syncthreads();  // previous tile fully consumed
-        // ---- stage G tile: [co][pix], pixels of a row contiguous -> coalesced ----
-#pragma unroll 4
-        for (int e = tid; e < CO_T * PIX_T; e += 256) {
-            const int co = e / PIX_T, pix = e % PIX_T;
-            const int px = pix & (TW - 1), py = (pix >> p.lgTW) & (TH - 1), tb = pix >> (p.lgTW + p.lgTH);
-            const int b = b0 + tb, yy = y0 + py, xx = x0 + px;
-            float v = 0.f;
-            if (tb < TB && b < p.B && yy < p.H && xx < p.W && co0 + co < p.Cout)
-                v = p.g[((size_t)b * p.Cout + co0 + co) * HW + (size_t)yy * p.W + xx];
-            g_s[co * GPITCH + pix] = v;
+    // plane positions this thread stages for every channel of every tile (relative to the tile origin)
+    int xs_rem[KX], xs_r[KX], xs_c[KX], xs_tb[KX];
+#pragma unroll
+    for (int k = 0; k < KX; ++k) {
+        const int e = tid + 256 * k;
+        xs_rem[k] = -1; xs_r[k] = 0; xs_c[k] = 0; xs_tb[k] = 0;
+        if (e < TB * PLANE) {
+            const int tb = e / PLANE, pidx = e - tb * PLANE;
+            xs_rem[k] = e; xs_tb[k] = tb; xs_r[k] = pidx / PW; xs_c[k] = pidx - (pidx / PW) * PW;
         }
-        // ---- stage X tile: [ci][tb][PH][PW] with halo, formed as the forward pass forms its input ----
-        {
-            const int per_ci = TB * PLANE, total = CI_T * per_ci;
-            for (int e = tid; e < total; e += 256) {
-                const int ci = e / per_ci, rem = e - ci * per_ci;
-                const int tb = rem / PLANE, pidx = rem - tb * PLANE;
-                const int r = pidx / PW, c = pidx - r * PW;
-                const int uy = y0 * S + r - PAD, ux = x0 * S + c - PAD, b = b0 + tb, cig = ci0 + ci;
-                float v = 0.f;
-                if (uy >= 0 && uy < Hv && ux >= 0 && ux < Wv && b < p.B && cig < p.Cin) {
-                    const float* src = p.x + ((size_t)b * p.Cin + cig) * src_plane;
-                    if (!UPS) {
-                        v = src[(size_t)uy * p.Ws + ux];
-                        if (AFF) v = fmaxf(v * p.in_scale[cig] + p.in_shift[cig], 0.f);
-                    } else {
-                        const int iy0 = uy == 0 ? 0 : (uy - 1) >> 1, ix0 = ux == 0 ? 0 : (ux - 1) >> 1;
-                        const float ly1 = uy == 0 ? 0.f : ((uy & 1) ? 0.25f : 0.75f);
-                        const float lx1 = ux == 0 ? 0.f : ((ux & 1) ? 0.25f : 0.75f);
-                        const int iy1 = min(iy0 + 1, p.Hs - 1), ix1 = min(ix0 + 1, p.Ws - 1);
-                        const float v00 = src[iy0 * p.Ws + ix0], v01 = src[iy0 * p.Ws + ix1];
-                        const float v10 = src[iy1 * p.Ws + ix0], v11 = src[iy1 * p.Ws + ix1];
-                        v = (1.f - ly1) * ((1.f - lx1) * v00 + lx1 * v01) + ly1 * ((1.f - lx1) * v10 + lx1 * v11);
-                    }
-                }
-                x_s[ci * XPITCH + rem] = v;
-            }
-        }
+    }
+
+    // prefetch registers: the next tile's global loads are in flight during the current tile's MFMAs
+    float xg[KX * CI_T], gg[NG];
+    unsigned xok = 0;   // bit k: plane position k of the prefetched tile is inside the image
+    unsigned gok = 0;   // bit i: gradient element i of the prefetched tile is inside the tensor
+
+#define SPK_WG_PREFETCH(tile_)                                                                              \
+    {                                                                                                       \
+        int bx_ = (tile_);                                                                                  \
+        const int tx_ = bx_ % p.tiles_x; bx_ /= p.tiles_x;                                                  \
+        const int ty_ = bx_ % p.tiles_y;                                                                    \
+        const int b0_ = (bx_ / p.tiles_y) << p.lgTB, y0_ = ty_ << p.lgTH, x0_ = tx_ << p.lgTW;              \
+        gok = 0;                                                                                            \
+        _Pragma("unroll") for (int i = 0; i < NG; ++i) {                                                    \
+            const int e = tid + 256 * i;                                                                    \
+            const int co = e / PIX_T, pix = e % PIX_T;                                                      \
+            const int px = pix & (TW - 1), py = (pix >> p.lgTW) & (TH - 1), tb = pix >> (p.lgTW + p.lgTH);  \
+            const int b = b0_ + tb, yy = y0_ + py, xx = x0_ + px;                                           \
+            const bool ok = tb < TB && b < p.B && yy < p.H && xx < p.W && co0 + co < p.Cout;                \
+            const size_t off = ok ? ((size_t)b * p.Cout + co0 + co) * HW + (size_t)yy * p.W + xx : 0;       \
+            gg[i] = p.g[off];          /* masked at store time: no wait on the load here */                \
+            if (ok) gok |= 1u << i;                                                                         \
+        }                                                                                                   \
+        xok = 0;                                                                                            \
+        _Pragma("unroll") for (int k = 0; k < KX; ++k) {                                                    \
+            const int uy = y0_ * S + xs_r[k] - PAD, ux = x0_ * S + xs_c[k] - PAD, b = b0_ + xs_tb[k];       \
+            const bool ok = xs_rem[k] >= 0 && uy >= 0 && uy < p.Hs && ux >= 0 && ux < p.Ws && b < p.B;      \
+            if (ok) xok |= 1u << k;                                                                         \
+            const float* src = p.x + ((size_t)(ok ? b : 0) * p.Cin + ci0) * src_plane +                     \
+                               (ok ? (size_t)uy * p.Ws + ux : 0);                                           \
+            _Pragma("unroll") for (int ci = 0; ci < CI_T; ++ci)                                             \
+                xg[k * CI_T + ci] = src[(size_t)(ci < nci ? ci : 0) * src_plane];                           \
+        }                                                                                                   \
+    }
+
+#define SPK_WG_STORE()                                                                                      \
+    {                                                                                                       \
+        _Pragma("unroll") for (int i = 0; i < NG; ++i) {                                                    \
+            const int e = tid + 256 * i;                                                                    \
+            g_s[(e / PIX_T) * GPITCH + (e % PIX_T)] = ((gok >> i) & 1u) ? gg[i] : 0.f;                      \
+        }                                                                                                   \
+        _Pragma("unroll") for (int k = 0; k < KX; ++k) {                                                    \
+            if (xs_rem[k] >= 0) {                                                                           \
+                const bool ok = (xok >> k) & 1u;                                                            \
+                float* dst = x_s + xs_rem[k];                                                               \
+                _Pragma("unroll") for (int ci = 0; ci < CI_T; ++ci) {                                       \
+                    float v = xg[k * CI_T + ci];                                                            \
+                    if (AFF) v = fmaxf(v * p.in_scale[ci0 + (ci < nci ? ci : 0)] +                          \
+                                       p.in_shift[ci0 + (ci < nci ? ci : 0)], 0.f);                         \
+                    dst[ci * XPITCH] = (ok && ci < nci) ? v : 0.f;                                          \
+                }                                                                                           \
+            }                                                                                               \
+        }                                                                                                   \
+    }
+
+    int tile = blockIdx.z;
+    if (tile < p.n_tiles) SPK_WG_PREFETCH(tile);
+    for (; tile < p.n_tiles; tile += gridDim.z) {
+        __syncthreads();          // previous tile fully consumed
+        SPK_WG_STORE();
         __syncthreads();
+        if (tile + (int)gridDim.z < p.n_tiles) SPK_WG_PREFETCH(tile + (int)gridDim.z);
         // ---- k-steps over this wave's pixel range: A read once per step, reused by every tap ----
         const float* ga = g_s + (wco * 32 + l32) * GPITCH;
         const float* xb = x_s + (wci * 32 + l32) * XPITCH;
@@ -140,6 +170,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
             }
         }
     }
+#undef SPK_WG_PREFETCH
+#undef SPK_WG_STORE
 
     // ---- partial block -> slab [slab][co][tap][ci] (ci contiguous: 128-B stores per half wave) ----
     const int slab = blockIdx.z * SH::WPX + wpx;
@@ -159,14 +191,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
                                                           int n_slabs, int Cout, int Cin, int taps, float scale,
                                                           int accumulate) {
     const size_t total = (size_t)Cout * Cin * taps;
-    for (size_t idx = (size_t)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (size_t)gridDim.x * blockDim.x) {
-        const int tap = (int)(idx % taps);
-        const int ci = (int)((idx / taps) % Cin);
-        const int co = (int)(idx / ((size_t)taps * Cin));
-        const size_t src = ((size_t)co * taps + tap) * Cin + ci;
+    // walk the slabs in THEIR order ([co][tap][ci]: coalesced reads of n_slabs x total floats) and scatter the
+    // (n_slabs times smaller) result into [co][ci][tap]
+    for (size_t src = (size_t)blockIdx.x * blockDim.x + threadIdx.x; src < total; src += (size_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(src % Cin);
+        const int tap = (int)((src / Cin) % taps);
+        const int co = (int)(src / ((size_t)Cin * taps));
         float v = 0.f;
         for (int s = 0; s < n_slabs; ++s) v += slabs[(size_t)s * total + src];
         v *= scale;
+        const size_t idx = ((size_t)co * Cin + ci) * taps + tap;
         dw[idx] = accumulate ? dw[idx] + v : v;
     }
 }
@@ -188,13 +222,15 @@ WGeom wgeom(int B, int Cin, int Cout, int H, int W, int want_splits) {
         const size_t plane = (size_t)((g.TH - 1) * S + KH) * ((g.TW - 1) * S + KW);
         return (SH::CO_T * (SH::PIX_T + 1) + SH::CI_T * ((g.TB * plane) | 1)) * sizeof(float);
     };
-    while (lds() > 100 * 1024 && g.TB > 1) g.TB >>= 1;
+    auto plane_elems = [&]() { return g.TB * ((g.TH - 1) * S + KH) * ((g.TW - 1) * S + KW); };
+    while ((lds() > 100 * 1024 || plane_elems() > 256 * SH::KX) && g.TB > 1) g.TB >>= 1;   // idle pixel groups
+    while (plane_elems() > 256 * SH::KX && g.TH > 1) g.TH >>= 1;
     g.lds_bytes = lds();
     g.tiles_x = spk::ceil_div(W, g.TW);
     g.tiles_y = spk::ceil_div(H, g.TH);
     g.n_tiles = g.tiles_x * g.tiles_y * spk::ceil_div(B, g.TB);
     const int blocks = spk::ceil_div(Cout, SH::CO_T) * spk::ceil_div(Cin, SH::CI_T) * (SH::ROWPASS ? KH : 1);
-    int sp = want_splits > 0 ? want_splits : std::max(1, 768 / blocks);     // ~3 workgroups per CU
+    int sp = want_splits > 0 ? want_splits : std::max(1, 512 / blocks);     // 2 rounds of one workgroup per CU
     g.splits = std::max(1, std::min(sp, g.n_tiles));
     g.n_slabs = g.splits * SH::WPX;
     return g;
@@ -270,7 +306,9 @@ int spk_conv2d_wgrad(const spk_wgrad_desc* d, void* stream) {
                      "wgrad: output size %dx%d does not match input %dx%d", d->H, d->W, d->Hin, d->Win);
     hipStream_t s = (hipStream_t)stream;
     const int mode = aff ? WG_AFFINE_RELU : WG_PLAIN;
-    if (ups) return run_wgrad<3, 3, 1, WG_UPSAMPLE>(d, s);
+    // the bilinear-folded variant lost to "materialise the x2 image once, then plain wgrad" by 2x (4 gathers per
+    // element cannot be prefetched in registers); callers upsample with spk_upsample2x_bilinear_fwd first
+    if (ups) return spk::fail(SPK_EUNSUPPORTED, "wgrad: pass the upsampled input (spk_upsample2x_bilinear_fwd) instead of SPK_CONV_UPSAMPLE2X");
     if (d->kh == 1) return d->stride == 1 ? by_mode<1, 1, 1>(mode, d, s) : by_mode<1, 1, 2>(mode, d, s);
     if (d->kh == 3) return d->stride == 1 ? by_mode<3, 3, 1>(mode, d, s) : by_mode<3, 3, 2>(mode, d, s);
     return by_mode<7, 7, 2>(mode, d, s);
