@@ -205,6 +205,25 @@ int spk_bn_add_relu_fwd(const float* a, const float* sa, const float* ba, const 
  * fly (stem bn1+relu folded).  replaces: resnet50.maxpool (children()[3], model.py:62). */
 int spk_maxpool3x3s2_fwd(const float* x, const float* in_scale, const float* in_shift, float* y, int B, int C,
                          int Hin, int Win, void* stream);
+/* BatchNorm2d backward (training mode), in the same split form as the forward.  z = r*scale[c]+shift[c] is the BN
+ * output of the raw conv output r; g is the gradient w.r.t. relu(z) (mask_mode 1: mask recomputed from r), w.r.t.
+ * relu(z + identity) (mask_mode 2: mask = mask_src > 0, mask_src = the block output) or w.r.t. z (mask_mode 0).
+ * g_per_plane != 0: g holds one value per (b,c) plane (the global-average-pool gradient), scaled by g_scale.
+ *   spk_bn_bwd_reduce: sums[b,c,:] = { sum dz, sum dz*rhat }   (d beta = sum_b sums[..,0], d gamma = sum_b sums[..,1])
+ *   spk_bn_bwd_apply : dr = gamma*invstd*(dz - csum[c,0]/count - rhat*csum[c,1]/count); dz_out (may be NULL) = dz
+ * replaces: autograd's native_batch_norm_backward + threshold_backward for every BatchNorm2d/ReLU of the trunk. */
+int spk_bn_bwd_reduce(const float* g, const float* r, const float* mask_src, int mask_mode, const float* scale,
+                      const float* shift, const float* mean, const float* invstd, float g_scale, int g_per_plane,
+                      float* sums, int B, int C, int64_t HW, void* stream);
+int spk_bn_bwd_apply(const float* g, const float* r, const float* mask_src, int mask_mode, const float* scale,
+                     const float* shift, const float* mean, const float* invstd, const float* csum, int64_t count,
+                     float g_scale, int g_per_plane, float* dr, float* dz_out, int B, int C, int64_t HW, void* stream);
+/* zero-insertion x2 ([planes,H,W] -> [planes,Ho,Wo], Ho in {2H-1,2H}): the data gradient of a stride-2 conv is the
+ * stride-1 transpose_flip conv of the dilated output gradient. */
+int spk_dilate2x(const float* x, float* y, int64_t planes, int H, int W, int Ho, int Wo, void* stream);
+/* adjoint of spk_maxpool3x3s2_fwd (same optional folded affine+relu on x; torch's first-maximum tie rule) */
+int spk_maxpool3x3s2_bwd(const float* x, const float* in_scale, const float* in_shift, const float* dy, float* dx, int B,
+                         int C, int Hin, int Win, void* stream);
 /* y[b,c] = mean_hw x[b,c,:,:].  replaces: resnet50.avgpool = AdaptiveAvgPool2d(1) (children()[8]). */
 int spk_global_avgpool_fwd(const float* x, float* y, int64_t planes, int64_t HW, void* stream);
 

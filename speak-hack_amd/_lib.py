@@ -44,6 +44,12 @@ class WgradDesc(C.Structure):
 
 
 _PROTOTYPES = {
+    "spk_bn_bwd_reduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 4 +
+                          [C.c_float, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p]),
+    "spk_bn_bwd_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 5 +
+                         [C.c_int64, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p]),
+    "spk_dilate2x": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "spk_maxpool3x3s2_bwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p]),
     "spk_conv2d_wgrad_workspace_bytes": (C.c_int64, [C.c_int] * 9),
     "spk_conv2d_wgrad": (C.c_int, [C.POINTER(WgradDesc), C.c_void_p]),
     "spk_epilogue_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p,

@@ -48,7 +48,7 @@ __global__ __launch_bounds__(256) void bn_add_relu_kernel(const float* __restric
                                                          const float* __restrict__ ba, const float* __restrict__ b,
                                                          const float* __restrict__ sb, const float* __restrict__ bb,
                                                          float* __restrict__ y, int C, long long HW, int relu) {
-    const long long plane = blockIdx.y;
+    const long long plane = blockIdx.x;
     const int c = (int)(plane % C);
     const float s1 = sa ? sa[c] : 1.f, o1 = ba ? ba[c] : 0.f;
     const float s2 = sb ? sb[c] : 1.f, o2 = bb ? bb[c] : 0.f;
@@ -57,7 +57,7 @@ __global__ __launch_bounds__(256) void bn_add_relu_kernel(const float* __restric
     float* yp = y + plane * HW;
     if (VEC) {
         const long long n4 = HW / 4;
-        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+        for (long long i = (long long)blockIdx.y * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.y * blockDim.x) {
             float4 v = reinterpret_cast<const float4*>(ap)[i];
             v.x = v.x * s1 + o1; v.y = v.y * s1 + o1; v.z = v.z * s1 + o1; v.w = v.w * s1 + o1;
             if (bp) {
@@ -68,7 +68,7 @@ __global__ __launch_bounds__(256) void bn_add_relu_kernel(const float* __restric
             reinterpret_cast<float4*>(yp)[i] = v;
         }
     } else {
-        for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < HW; i += (long long)gridDim.x * blockDim.x) {
+        for (long long i = (long long)blockIdx.y * blockDim.x + threadIdx.x; i < HW; i += (long long)gridDim.y * blockDim.x) {
             float v = ap[i] * s1 + o1;
             if (bp) v += bp[i] * s2 + o2;
             if (relu) v = fmaxf(v, 0.f);
@@ -120,6 +120,129 @@ __global__ __launch_bounds__(256) void global_avgpool_kernel(const float* __rest
     if (lane == 0) y[plane] = s / (float)HW;
 }
 
+
+// ---- BatchNorm backward (training mode), split like the forward --------------------------------------
+// z = r*scale[c] + shift[c] is the BN output of raw conv output r.  The incoming gradient g is w.r.t.
+//   MASK_RECOMPUTE: relu(z)            -> dz = g * (z > 0)          (conv -> bn -> relu chains)
+//   MASK_TENSOR   : relu(z + identity) -> dz = g * (mask_src > 0)   (block end; mask_src = the block output)
+//   MASK_NONE     : z                  -> dz = g                    (downsample branch; g already masked)
+// pass 1 (one workgroup per (b,c) plane): sums[b,c,:] = { sum dz, sum dz * rhat },  rhat = (r - mean)*invstd
+// pass 2: dr = gamma*invstd * (dz - c1[c] - rhat*c2[c]),  c1 = sum_bhw dz / N, c2 = sum_bhw dz*rhat / N;
+//         optionally also writes dz (the identity branch's gradient at a block end).
+enum { MASK_NONE = 0, MASK_RECOMPUTE = 1, MASK_TENSOR = 2 };
+
+__device__ __forceinline__ float bn_block_sum(float v, float* red) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) v += __shfl_xor(v, off);
+    __syncthreads();
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return red[0] + red[1] + red[2] + red[3];
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restrict__ g, const float* __restrict__ r,
+                                                           const float* __restrict__ mask_src, int mask_mode,
+                                                           const float* __restrict__ scale, const float* __restrict__ shift,
+                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                           float g_scale, long long g_plane_stride, float* __restrict__ sums,
+                                                           int C, long long HW) {
+    __shared__ float red[4];
+    const long long plane = blockIdx.x;
+    const int c = (int)(plane % C);
+    const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
+    // g_plane_stride == 0: g holds ONE value per plane (the global-average-pool gradient, broadcast)
+    const float* gp = g + (g_plane_stride ? plane * g_plane_stride : plane);
+    const float* rp = r + plane * HW;
+    const float* mp = mask_src ? mask_src + plane * HW : nullptr;
+    float s0 = 0.f, s1 = 0.f;
+    for (long long i = threadIdx.x; i < HW; i += 256) {
+        const float rv = rp[i];
+        float d = (g_plane_stride ? gp[i] : gp[0]) * g_scale;
+        if (mask_mode == MASK_RECOMPUTE) d = (rv * sc + sh > 0.f) ? d : 0.f;
+        else if (mask_mode == MASK_TENSOR) d = (mp[i] > 0.f) ? d : 0.f;
+        s0 += d;
+        s1 += d * (rv - mu) * is;
+    }
+    s0 = bn_block_sum(s0, red);
+    s1 = bn_block_sum(s1, red);
+    if (threadIdx.x == 0) { sums[plane * 2] = s0; sums[plane * 2 + 1] = s1; }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ r,
+                                                          const float* __restrict__ mask_src, int mask_mode,
+                                                          const float* __restrict__ scale, const float* __restrict__ shift,
+                                                          const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                          const float* __restrict__ csum, float inv_count, float g_scale,
+                                                          long long g_plane_stride, float* __restrict__ dr, float* __restrict__ dz_out,
+                                                          int C, long long HW) {
+    const long long plane = blockIdx.x;
+    const int c = (int)(plane % C);
+    const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
+    const float c1 = csum[2 * c] * inv_count, c2 = csum[2 * c + 1] * inv_count;   // csum: sums reduced over the batch
+    const float* gp = g + (g_plane_stride ? plane * g_plane_stride : plane);
+    const float* rp = r + plane * HW;
+    const float* mp = mask_src ? mask_src + plane * HW : nullptr;
+    for (long long i = (long long)blockIdx.y * blockDim.x + threadIdx.x; i < HW; i += (long long)gridDim.y * blockDim.x) {
+        const float rv = rp[i];
+        float d = (g_plane_stride ? gp[i] : gp[0]) * g_scale;
+        if (mask_mode == MASK_RECOMPUTE) d = (rv * sc + sh > 0.f) ? d : 0.f;
+        else if (mask_mode == MASK_TENSOR) d = (mp[i] > 0.f) ? d : 0.f;
+        if (dz_out) dz_out[plane * HW + i] = d;
+        dr[plane * HW + i] = sc * (d - c1 - (rv - mu) * is * c2);     // sc = gamma * invstd
+    }
+}
+
+// y[2h, 2w] = x[h, w], zeros elsewhere ([planes,H,W] -> [planes,Ho,Wo], Ho in {2H-1, 2H}): turns the data gradient
+// of a stride-2 conv into a stride-1 conv with flipped weights.
+__global__ __launch_bounds__(256) void dilate2x_kernel(const float* __restrict__ x, float* __restrict__ y, long long planes,
+                                                      int H, int W, int Ho, int Wo) {
+    const long long total = planes * Ho * Wo;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int ox = (int)(idx % Wo), oy = (int)((idx / Wo) % Ho);
+        const long long pl = idx / ((long long)Wo * Ho);
+        float v = 0.f;
+        if (!(ox & 1) && !(oy & 1) && (oy >> 1) < H && (ox >> 1) < W) v = x[(pl * H + (oy >> 1)) * W + (ox >> 1)];
+        y[idx] = v;
+    }
+}
+
+// adjoint of maxpool3x3s2 (input optionally max(x*s+b,0) on the fly): every input pixel collects dy from the
+// <= 4 windows in which it is the (first, row-major) maximum -- torch's tie rule.
+__global__ __launch_bounds__(256) void maxpool3x3s2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ sc,
+                                                              const float* __restrict__ sh, const float* __restrict__ dy,
+                                                              float* __restrict__ dx, int C, int Hin, int Win, int Ho, int Wo,
+                                                              long long total) {
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int ix = (int)(idx % Win), iy = (int)((idx / Win) % Hin);
+        const long long plane = idx / ((long long)Win * Hin);
+        const int c = (int)(plane % C);
+        const float s = sc ? sc[c] : 1.f, o = sc ? sh[c] : 0.f;
+        const float* xp = x + plane * Hin * Win;
+        const float* gp = dy + plane * Ho * Wo;
+        float acc = 0.f;
+        for (int oy = max((iy - 1 + 1) / 2, 0); oy <= min((iy + 1) / 2, Ho - 1); ++oy) {
+            for (int ox = max((ix - 1 + 1) / 2, 0); ox <= min((ix + 1) / 2, Wo - 1); ++ox) {
+                // argmax of window (oy, ox), first maximum in row-major order
+                float m = -INFINITY;
+                int my = -1, mx = -1;
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int yy = oy * 2 + ky - 1;
+                    if (yy < 0 || yy >= Hin) continue;
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int xx = ox * 2 + kx - 1;
+                        if (xx < 0 || xx >= Win) continue;
+                        float v = xp[yy * Win + xx];
+                        if (sc) v = fmaxf(v * s + o, 0.f);
+                        if (v > m) { m = v; my = yy; mx = xx; }
+                    }
+                }
+                if (my == iy && mx == ix) acc += gp[oy * Wo + ox];
+            }
+        }
+        dx[idx] = acc;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -142,7 +265,7 @@ int spk_bn_add_relu_fwd(const float* a, const float* sa, const float* ba, const 
     SPK_REQUIRE((long long)B * C < (1ll << 31), "bn_add_relu: too many planes");
     const bool vec = HW % 4 == 0 && (uintptr_t)a % 16 == 0 && (uintptr_t)y % 16 == 0 && (!b || (uintptr_t)b % 16 == 0);
     const long long work = vec ? HW / 4 : HW;
-    dim3 grid((unsigned)std::max(1ll, std::min((work + 255) / 256, 64ll)), (unsigned)(B * C));
+    dim3 grid((unsigned)(B * C), (unsigned)std::max(1ll, std::min((work + 255) / 256, 64ll)));   // planes on x (no 65535 limit)
     if (vec) hipLaunchKernelGGL(bn_add_relu_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, a, sa, ba, b, sb, bb, y, C, (long long)HW, relu);
     else     hipLaunchKernelGGL(bn_add_relu_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, a, sa, ba, b, sb, bb, y, C, (long long)HW, relu);
     return spk::check_launch("bn_add_relu_kernel");
@@ -164,6 +287,48 @@ int spk_global_avgpool_fwd(const float* x, float* y, int64_t planes, int64_t HW,
     hipLaunchKernelGGL(global_avgpool_kernel, dim3((unsigned)((planes + 3) / 4)), dim3(256), 0, (hipStream_t)stream, x, y,
                        (long long)planes, (long long)HW);
     return spk::check_launch("global_avgpool_kernel");
+}
+
+int spk_bn_bwd_reduce(const float* g, const float* r, const float* mask_src, int mask_mode, const float* scale,
+                      const float* shift, const float* mean, const float* invstd, float g_scale, int g_per_plane,
+                      float* sums, int B, int C, int64_t HW, void* stream) {
+    SPK_REQUIRE(g && r && scale && shift && mean && invstd && sums && B > 0 && C > 0 && HW > 0, "bn_bwd_reduce: bad arguments");
+    SPK_REQUIRE(mask_mode != MASK_TENSOR || mask_src, "bn_bwd_reduce: MASK_TENSOR without mask tensor");
+    hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)(B * C)), dim3(256), 0, (hipStream_t)stream, g, r, mask_src, mask_mode,
+                       scale, shift, mean, invstd, g_scale, (long long)(g_per_plane ? 0 : HW), sums, C, (long long)HW);
+    return spk::check_launch("bn_bwd_reduce_kernel");
+}
+
+int spk_bn_bwd_apply(const float* g, const float* r, const float* mask_src, int mask_mode, const float* scale,
+                     const float* shift, const float* mean, const float* invstd, const float* csum, int64_t count,
+                     float g_scale, int g_per_plane, float* dr, float* dz_out, int B, int C, int64_t HW, void* stream) {
+    SPK_REQUIRE(g && r && scale && shift && mean && invstd && csum && dr && B > 0 && C > 0 && HW > 0 && count > 0,
+                "bn_bwd_apply: bad arguments");
+    SPK_REQUIRE(mask_mode != MASK_TENSOR || mask_src, "bn_bwd_apply: MASK_TENSOR without mask tensor");
+    dim3 grid((unsigned)(B * C), (unsigned)std::max(1ll, std::min(((long long)HW + 255) / 256, 64ll)));
+    hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(256), 0, (hipStream_t)stream, g, r, mask_src, mask_mode, scale, shift, mean,
+                       invstd, csum, 1.0f / (float)count, g_scale, (long long)(g_per_plane ? 0 : HW), dr, dz_out, C, (long long)HW);
+    return spk::check_launch("bn_bwd_apply_kernel");
+}
+
+int spk_dilate2x(const float* x, float* y, int64_t planes, int H, int W, int Ho, int Wo, void* stream) {
+    SPK_REQUIRE(x && y && planes > 0 && H > 0 && W > 0, "dilate2x: bad arguments");
+    SPK_REQUIRE((Ho == 2 * H || Ho == 2 * H - 1) && (Wo == 2 * W || Wo == 2 * W - 1), "dilate2x: output must be 2H or 2H-1");
+    const long long total = planes * Ho * Wo;
+    hipLaunchKernelGGL(dilate2x_kernel, dim3((unsigned)std::min((total + 255) / 256, 256ll * 16)), dim3(256), 0,
+                       (hipStream_t)stream, x, y, (long long)planes, H, W, Ho, Wo);
+    return spk::check_launch("dilate2x_kernel");
+}
+
+int spk_maxpool3x3s2_bwd(const float* x, const float* in_scale, const float* in_shift, const float* dy, float* dx, int B,
+                         int C, int Hin, int Win, void* stream) {
+    SPK_REQUIRE(x && dy && dx && B > 0 && C > 0 && Hin > 0 && Win > 0, "maxpool_bwd: bad arguments");
+    SPK_REQUIRE(!in_scale == !in_shift, "maxpool_bwd: in_scale and in_shift go together");
+    const int Ho = (Hin - 1) / 2 + 1, Wo = (Win - 1) / 2 + 1;
+    const long long total = (long long)B * C * Hin * Win;
+    hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, dim3((unsigned)std::min((total + 255) / 256, 256ll * 16)), dim3(256), 0,
+                       (hipStream_t)stream, x, in_scale, in_shift, dy, dx, C, Hin, Win, Ho, Wo, total);
+    return spk::check_launch("maxpool3x3s2_bwd_kernel");
 }
 
 }  // extern "C"

@@ -1,5 +1,5 @@
 """ResNet-50 trunk encoder -- the module ``IRFD._create_encoder`` builds at ``model.py:60-62``
-(``nn.Sequential(*list(resnet50().children())[:-1])``), on the HIP kernels.
+(``nn.Sequential(*list(resnet50().children())[:-1])``), on the HIP kernels, forward and backward.
 
 ``ResNet50Trunk`` IS an ``nn.Sequential`` whose children sit at torchvision's indices (0 conv1,
 1 bn1, 2 relu, 3 maxpool, 4-7 layer1..4, 8 avgpool), so its ``state_dict`` keys are the reference's
@@ -13,8 +13,13 @@ children only hold parameters/buffers; ``forward`` runs the whole trunk MI355X-s
   that the *consumer* conv (or the max-pool) applies while staging its input;
 * only each block's output (bn3 + identity + ReLU) is written, by one HBM-bound pass.
 
-A bottleneck is 3-4 conv launches + 3-4 tiny finalize launches + 1 elementwise pass, against the
-reference's 10-13 ATen kernels with a full HBM round trip each.
+Backward (``TrunkFn``) has the reference's ``torch.utils.checkpoint`` semantics (model.py:84-90): the
+forward keeps only the input image; backward re-runs the forward (which, exactly as the reference's
+re-entrant checkpoint does, updates the BatchNorm running statistics a second time), then walks the
+blocks in reverse: BatchNorm(+ReLU) backward as a two-pass reduce/apply pair on the raw conv output,
+data gradients on the forward MFMA kernel with transpose-flipped weights (stride 2: zero-dilated
+gradient), weight gradients on the MFMA wgrad kernel with the BatchNorm+ReLU of the input re-formed
+in its staging.  The residual sum is folded into the data-gradient epilogue (accumulate flag).
 """
 from __future__ import annotations
 
@@ -48,15 +53,15 @@ class Bottleneck(nn.Module):
 
 
 class _ConvBN:
-    """One conv + its BatchNorm: launches the conv (statistics in the epilogue when training) and
-    returns (raw output, (scale, shift)) -- the affine the consumer folds into its staging."""
+    """One conv + its BatchNorm in the folded form."""
 
     def __init__(self, conv: nn.Conv2d, bn: nn.BatchNorm2d):
         self.conv, self.bn = conv, bn
         self.k, self.stride = conv.kernel_size[0], conv.stride[0]
         self.packed = ops.PackedConvWeight()
 
-    def __call__(self, x, in_affine, training, stats_pool):
+    def fwd(self, x, in_affine, training, stats_pool, keep):
+        """-> record {y: raw conv output, affine: (scale, shift) its consumer applies, ...}."""
         conv, bn = self.conv, self.bn
         B, Cin, H, W = x.shape
         Cout = conv.out_channels
@@ -69,11 +74,33 @@ class _ConvBN:
             if bn.num_batches_tracked is not None:
                 bn.num_batches_tracked += 1
             momentum = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
-            affine = ops.bn_finalize(stats, B * Ho * Wo, bn.weight, bn.bias, bn.running_mean, bn.running_var,
-                                     momentum, bn.eps)
+            fin = ops.bn_finalize(stats, B * Ho * Wo, bn.weight, bn.bias, bn.running_mean, bn.running_var, momentum,
+                                  bn.eps, save=keep)
         else:
-            affine = ops.bn_finalize(None, 1, bn.weight, bn.bias, bn.running_mean, bn.running_var, 0.0, bn.eps)
-        return y, affine
+            fin = ops.bn_finalize(None, 1, bn.weight, bn.bias, bn.running_mean, bn.running_var, 0.0, bn.eps, save=keep)
+        rec = {"y": y, "affine": (fin[0], fin[1])}
+        if keep:
+            rec.update(x=x, in_affine=in_affine, mean=fin[2], invstd=fin[3], training=training)
+        return rec
+
+    def bn_bwd(self, rec, g, mask_mode, mask_src=None, want_dz=False, **kw):
+        """Gradient w.r.t. the raw conv output + BatchNorm parameter gradients (into ``grads``)."""
+        out = ops.bn_backward(g, rec["y"], rec["affine"], rec["mean"], rec["invstd"], mask_mode, mask_src,
+                              want_dz=want_dz, batch_stats=rec["training"], **kw)
+        return out
+
+    def conv_bwd(self, rec, dr, grads, need_dx, dx_out=None, accumulate=False):
+        """Weight gradient (into ``grads``) and, if asked, the gradient w.r.t. the conv's (staged) input."""
+        conv = self.conv
+        Cout, Cin = conv.out_channels, conv.in_channels
+        x = rec["x"]
+        B, _, H, W = x.shape
+        grads[conv.weight] = ops.conv2d_wgrad(dr, x, Cout, Cin, self.k, self.stride, in_affine=rec["in_affine"])
+        if not need_dx:
+            return None
+        cfg = ops.conv2d_pick_config(self.k, 1, B, Cout, Cin, H, W)
+        return ops.conv2d_dgrad(dr, self.packed.get(conv.weight, cfg, transpose_flip=True), Cin, self.k, self.stride,
+                                (H, W), cfg, out=dx_out, accumulate=accumulate)
 
 
 class _StatsPool:
@@ -87,6 +114,31 @@ class _StatsPool:
         out = self.buf[self.pos:self.pos + n]
         self.pos += n
         return out
+
+
+class TrunkFn(torch.autograd.Function):
+    """Checkpointed trunk: forward keeps the input only; backward recomputes, then back-propagates."""
+
+    @staticmethod
+    def forward(ctx, x, trunk, grad_mode, *params):
+        y = trunk._run(x, keep=False)[0]
+        if grad_mode and any(ctx.needs_input_grad):
+            ctx.trunk, ctx.training = trunk, trunk.training
+            ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dfeat):
+        (x,) = ctx.saved_tensors
+        trunk = ctx.trunk
+        was_training = trunk.training
+        trunk.train(ctx.training)
+        try:
+            _, recs = trunk._run(x, keep=True)          # the checkpoint recomputation
+        finally:
+            trunk.train(was_training)
+        grads = trunk._backward(recs, dfeat.contiguous())
+        return (None, None, None) + tuple(grads.get(p) for p in trunk.parameters())
 
 
 class ResNet50Trunk(nn.Sequential):
@@ -119,21 +171,65 @@ class ResNet50Trunk(nn.Sequential):
         self._plan = (stem, blocks)
 
     def forward(self, x):
+        return TrunkFn.apply(x, self, torch.is_grad_enabled(), *self.parameters())
+
+    def _run(self, x, keep):
+        """Forward; with ``keep`` also returns what backward needs (raw conv outputs, block outputs, statistics)."""
         if self._plan is None:
             self._build_plan()
         stem, blocks = self._plan
         training = self.training
         x = x.contiguous()
         pool = _StatsPool(x.device, self._stats_total) if training else None
-        y, aff = stem(x, None, training, pool)
-        cur = ops.maxpool3x3s2(y, aff[0], aff[1])                    # bn1 + relu folded into the pool's loads
+        s = stem.fwd(x, None, training, pool, keep)
+        cur = ops.maxpool3x3s2(s["y"], s["affine"][0], s["affine"][1])      # bn1 + relu folded into the pool's loads
+        recs = {"stem": s, "blocks": []} if keep else None
         for c1, c2, c3, down in blocks:
-            r1, a1 = c1(cur, None, training, pool)                    # block input is materialised (post-ReLU)
-            r2, a2 = c2(r1, a1, training, pool)
-            r3, a3 = c3(r2, a2, training, pool)
-            if down is not None:
-                rd, ad = down(cur, None, training, pool)
-                cur = ops.bn_add_relu(r3, a3[0], a3[1], rd, ad[0], ad[1], relu=True)
+            r1 = c1.fwd(cur, None, training, pool, keep)                      # block input is materialised (post-ReLU)
+            r2 = c2.fwd(r1["y"], r1["affine"], training, pool, keep)
+            r3 = c3.fwd(r2["y"], r2["affine"], training, pool, keep)
+            rd = down.fwd(cur, None, training, pool, keep) if down is not None else None
+            a3 = r3["affine"]
+            if rd is not None:
+                out = ops.bn_add_relu(r3["y"], a3[0], a3[1], rd["y"], rd["affine"][0], rd["affine"][1], relu=True)
             else:
-                cur = ops.bn_add_relu(r3, a3[0], a3[1], cur, None, None, relu=True)
-        return ops.global_avgpool(cur)
+                out = ops.bn_add_relu(r3["y"], a3[0], a3[1], cur, None, None, relu=True)
+            if keep:
+                recs["blocks"].append((r1, r2, r3, rd, out))
+            cur = out
+        return ops.global_avgpool(cur), recs
+
+    def _backward(self, recs, dfeat):
+        """dfeat [B,2048,1,1] -> {parameter: gradient}."""
+        stem, blocks = self._plan
+        grads = {}
+        g, per_plane, g_scale = dfeat.view(dfeat.size(0), -1).contiguous(), True, None
+        for (c1, c2, c3, down), (r1, r2, r3, rd, out) in zip(reversed(blocks), reversed(recs["blocks"])):
+            if per_plane:                      # last block: gradient of the global average pool, one value per plane
+                g_scale = 1.0 / (out.shape[2] * out.shape[3])
+            # out = relu(bn3(r3) + identity): mask from the block output; dz also feeds the identity branch
+            dr3, dg, db, dz = c3.bn_bwd(r3, g, ops.MASK_TENSOR, mask_src=out, want_dz=True,
+                                        g_scale=g_scale if per_plane else 1.0, g_per_plane=per_plane)
+            grads[c3.bn.weight], grads[c3.bn.bias] = dg, db
+            dv2 = c3.conv_bwd(r3, dr3, grads, need_dx=True)
+            dr2, dg, db = c2.bn_bwd(r2, dv2, ops.MASK_RECOMPUTE)
+            grads[c2.bn.weight], grads[c2.bn.bias] = dg, db
+            dv1 = c2.conv_bwd(r2, dr2, grads, need_dx=True)
+            dr1, dg, db = c1.bn_bwd(r1, dv1, ops.MASK_RECOMPUTE)
+            grads[c1.bn.weight], grads[c1.bn.bias] = dg, db
+            if down is None:
+                # d(block input) = dz (identity) + conv1's data gradient, summed in the conv epilogue
+                g = c1.conv_bwd(r1, dr1, grads, need_dx=True, dx_out=dz, accumulate=True)
+            else:
+                drd, dg, db = down.bn_bwd(rd, dz, ops.MASK_NONE)
+                grads[down.bn.weight], grads[down.bn.bias] = dg, db
+                g = down.conv_bwd(rd, drd, grads, need_dx=True)
+                g = c1.conv_bwd(r1, dr1, grads, need_dx=True, dx_out=g, accumulate=True)
+            per_plane = False
+        # stem: max-pool adjoint (bn1+relu re-formed on the fly), BatchNorm backward, 7x7 weight gradient
+        s = recs["stem"]
+        dv0 = ops.maxpool3x3s2_bwd(s["y"], g, s["affine"][0], s["affine"][1])
+        dr0, dg, db = stem.bn_bwd(s, dv0, ops.MASK_RECOMPUTE)
+        grads[stem.bn.weight], grads[stem.bn.bias] = dg, db
+        stem.conv_bwd(s, dr0, grads, need_dx=False)       # the image itself takes no gradient
+        return grads

@@ -21,7 +21,7 @@ import logging
 import torch
 import torch.nn as nn
 
-from . import ops
+from . import autograd as AG
 from .decoder import StyleGenerator
 from .discriminator import StyleDiscriminator
 from .encoder import ResNet50Trunk
@@ -64,7 +64,7 @@ class IRFD(nn.Module):
                               tensor.std().item(), tensor.min().item(), tensor.max().item())
 
     def _emotion(self, fe):
-        logits = ops.fc(fe.view(fe.size(0), -1), self.Cm.weight, self.Cm.bias)
+        logits = AG.fc(fe.view(fe.size(0), -1), self.Cm.weight, self.Cm.bias, 1.0, 1.0, 1.0)
         return torch.softmax(logits, dim=1)
 
     def forward(self, x_s, x_t, swap_type=None, noises_s=None, noises_t=None):

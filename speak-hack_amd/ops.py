@@ -316,6 +316,59 @@ def fc_bwd(dout, out, x, weight, wmul=1.0, bmul=1.0, slope=1.0, need_dx=True, ne
     return dx, dw, db
 
 
+MASK_NONE, MASK_RECOMPUTE, MASK_TENSOR = 0, 1, 2
+
+
+def bn_backward(g, r, affine, mean, invstd, mask_mode, mask_src=None, g_scale=1.0, g_per_plane=False, want_dz=False,
+                batch_stats=True):
+    """Training-mode BatchNorm (+ReLU) backward in the folded form: returns (dr, dgamma, dbeta[, dz]).
+
+    ``r`` raw conv output, ``affine`` = (scale, shift) of its BatchNorm, ``g`` the gradient w.r.t. what the
+    forward consumer saw (see spk_bn_bwd_reduce in include/spk.h for ``mask_mode``).  ``g_per_plane``: g is
+    [B,C] (one value per plane, e.g. the global-average-pool gradient)."""
+    B, Cc, H, W = r.shape
+    HW = H * W
+    sums = torch.empty((B, Cc, 2), device=r.device, dtype=torch.float32)
+    args = (L.dptr(g, "g"), L.dptr(r, "r"), L.dptr(mask_src, "mask_src"), int(mask_mode), L.dptr(affine[0], "scale"),
+            L.dptr(affine[1], "shift"), L.dptr(mean, "mean"), L.dptr(invstd, "invstd"))
+    L.check(L.lib().spk_bn_bwd_reduce(*args, float(g_scale), 1 if g_per_plane else 0, L.dptr(sums), B, Cc, HW,
+                                      L.stream_ptr()), "spk_bn_bwd_reduce")
+    csum = sums.sum(0).contiguous()                 # [C,2]: the kernel reduced over pixels, this over the batch
+    dr = torch.empty_like(r)
+    dz = torch.empty_like(r) if want_dz else None
+    # eval-mode BatchNorm is a fixed affine: no mean / variance terms in the input gradient
+    capply = csum if batch_stats else torch.zeros_like(csum)
+    L.check(L.lib().spk_bn_bwd_apply(*args, L.dptr(capply), B * HW, float(g_scale), 1 if g_per_plane else 0, L.dptr(dr),
+                                     L.dptr(dz), B, Cc, HW, L.stream_ptr()), "spk_bn_bwd_apply")
+    out = (dr, csum[:, 1].contiguous(), csum[:, 0].contiguous())
+    return out + (dz,) if want_dz else out
+
+
+def dilate2x(x, Ho, Wo):
+    B, Cc, H, W = x.shape
+    y = torch.empty((B, Cc, Ho, Wo), device=x.device, dtype=torch.float32)
+    L.check(L.lib().spk_dilate2x(L.dptr(x, "x"), L.dptr(y), B * Cc, H, W, Ho, Wo, L.stream_ptr()), "spk_dilate2x")
+    return y
+
+
+def maxpool3x3s2_bwd(x, dy, in_scale=None, in_shift=None):
+    B, Cc, H, W = x.shape
+    dx = torch.empty_like(x)
+    L.check(L.lib().spk_maxpool3x3s2_bwd(L.dptr(x, "x"), L.dptr(in_scale, "in_scale"), L.dptr(in_shift, "in_shift"),
+                                         L.dptr(dy, "dy"), L.dptr(dx), B, Cc, H, W, L.stream_ptr()), "spk_maxpool3x3s2_bwd")
+    return dx
+
+
+def conv2d_dgrad(g, weight_packed_tf, Cin, k, stride, in_hw, config, out=None, accumulate=False):
+    """Data gradient of a k x k conv: the forward MFMA kernel on ``g`` with transpose-flipped weights
+    (stride 2: on the zero-dilated ``g``).  ``in_hw`` = (H, W) of the conv's input."""
+    if stride == 2:
+        # dx[i] = sum_k gd[i + k' - p] * w[k-1-k'] with gd[2o] = g[o], zeros elsewhere, extended to the input size
+        # (an even-sized input has a last row/column no window's stride lattice reaches: it stays zero)
+        g = dilate2x(g, in_hw[0], in_hw[1])
+    return conv2d_fused(g, weight_packed_tf, Cin, k, 1, config=config, out=out, accumulate=accumulate)
+
+
 # ---- BatchNorm / pooling pieces of the ResNet-50 trunk ----------------------------------------------
 def bn_finalize(stats, count, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, save=False):
     """Batch sums (fp64 [2C], from a conv epilogue) -> the per-channel affine (scale, shift) its consumer

@@ -95,6 +95,42 @@ def test_irfd_forward_train_mode_host_rng_and_running_stats(irfd_and_sd, dev):
     m.load_state_dict({k: v for k, v in sd.items()}, strict=False)      # restore for other tests
 
 
+def test_irfd_generator_step_gradients_vs_oracle(irfd_and_sd, dev):
+    """A10: IRFD.forward with grad + backward of the reconstruction loss, through the decoder AND the three
+    checkpointed encoders (eval-mode BatchNorm here so that the comparison is not dominated by batch-statistics
+    noise at B=1; train-mode BatchNorm backward is covered by test_encoder_backward_gpu.py)."""
+    m, sd = irfd_and_sd
+    m.load_state_dict({k: v for k, v in sd.items()}, strict=False)
+    m.eval()
+    for p in m.D.parameters():
+        p.requires_grad_(False)
+    m.zero_grad(set_to_none=True)
+    B = 1
+    x_s = recipe_input("irfd.g.x_s", (B, 3, 256, 256), "uniform")
+    x_t = recipe_input("irfd.g.x_t", (B, 3, 256, 256), "uniform")
+    ns, nt = recipe_noises("irfd.g.s", B, 256), recipe_noises("irfd.g.t", B, 256)
+    sd_ref = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone())
+              for k, v in sd.items()}
+    ref = IR.irfd_forward(x_s, x_t, sd_ref, 1, ns, nt)
+    # recipe weights make the frames huge; a constant rescale keeps the squared error inside fp32 range
+    sc = 1.0 / max(float(ref[0].detach().abs().max()), float(ref[1].detach().abs().max()))
+    loss_ref = ((ref[0] * sc - x_s) ** 2).mean() + ((ref[1] * sc - x_t) ** 2).mean()
+    loss_ref.backward()
+    out = m(x_s.to(dev), x_t.to(dev), swap_type=1, noises_s=[n.to(dev) for n in ns], noises_t=[n.to(dev) for n in nt])
+    loss = ((out[0] * sc - x_s.to(dev)) ** 2).mean() + ((out[1] * sc - x_t.to(dev)) ** 2).mean()
+    loss.backward()
+    assert abs(loss.item() / loss_ref.item() - 1) < 1e-3
+    got = dict(m.named_parameters())
+    missing = [k for k, p in got.items() if p.requires_grad and p.grad is None and not k.startswith("Cm.")]
+    assert not missing, missing[:5]            # every encoder and decoder parameter received a gradient
+    for k in ("Gd.synthesis.to_rgb.weight", "Gd.synthesis.layers.5.conv2.weight", "Gd.synthesis.layers.0.conv1.weight",
+              "Gd.mapping.0.weight", "Ei.7.2.conv3.weight", "Ee.7.2.bn3.weight", "Ep.7.0.downsample.0.weight",
+              "Ei.4.0.conv1.weight", "Ee.0.weight"):
+        assert rel_l2(got[k].grad, sd_ref[k].grad) < 2e-2, k      # deep ReLU nets: mask-flip noise (see backward tests)
+    for p in m.D.parameters():
+        p.requires_grad_(True)
+
+
 def test_discriminator_forward_vs_torch_reference(dev):
     """F2 forward: spectral-norm convs (3x3 s1, 3x3 s2, 1x1) with fused bias + LeakyReLU, pool, dense."""
     disc = importlib.import_module("speak-hack_amd.discriminator")

@@ -1,0 +1,102 @@
+#!/usr/bin/env python3
+"""BASELINE configs 3 / 4: the IRFD generator step -- 3 ResNet-50 encoders (train-mode BatchNorm,
+checkpoint recompute) x 2 images + StyleGAN decoder x 2, forward + backward of
+mean((x_s_recon-x_s)^2) + mean((x_t_recon-x_t)^2), global-norm clip over all parameters
+(train.py:207-208) and Adam on Gd (train.py:346,210) -- per GPU batch B, data parallel over ranks with
+the bucketed gradient all-reduce of speak-hack_amd/dp.py.
+
+    python tools/train_step_bench.py --batch 8 --steps 5                       # 1 GPU
+    python -m torch.distributed.run --nproc-per-node N --master-addr 127.0.0.1 tools/train_step_bench.py --batch 8
+
+Prints one JSON line from rank 0: pairs/s (a pair = source+target image), ms/step, algorithmic TFLOP/s
+(593.5 GFLOP per pair) and the gradient bytes exchanged per step.
+"""
+import argparse
+import importlib
+import json
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--decoder-only", action="store_true")
+    args = ap.parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+    import model as M
+    dp = importlib.import_module("speak-hack_amd.dp")
+    torch.manual_seed(0)                       # identical initial weights on every rank
+    net = M.IRFD().to(dev).train()
+    for p in net.D.parameters():               # D has its own step (train.py:156-183); not part of the G step here
+        p.requires_grad_(False)
+    params = [p for p in net.parameters() if p.requires_grad]
+    red = dp.GradBucketReducer(params)
+    opt = torch.optim.Adam(net.Gd.parameters(), lr=1e-4, betas=(0.5, 0.999))
+    torch.manual_seed(10 + rank)               # per-rank data and per-rank host RNG
+    B = args.batch
+    x_s = torch.rand(B, 3, 256, 256, device=dev) * 2 - 1
+    x_t = torch.rand(B, 3, 256, 256, device=dev) * 2 - 1
+
+    def step():
+        red.zero_grad()
+        if args.decoder_only:
+            f = torch.randn(B, 6144, device=dev)
+            loss = ((net.Gd(f) - x_s) ** 2).mean() + ((net.Gd(f) - x_t) ** 2).mean()
+        else:
+            out = net(x_s, x_t)
+            loss = ((out[0] - x_s) ** 2).mean() + ((out[1] - x_t) ** 2).mean()
+        loss.backward()
+        red.finish()
+        red.clip_(1.0)
+        opt.step()
+        return loss
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+        torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        loss = step()
+    torch.cuda.synchronize()
+    if dist is not None:
+        dist.barrier()
+        torch.cuda.synchronize()
+    el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+    if rank == 0:
+        gflop_pair = (2 * 3 * 56.214) if args.decoder_only else 593.5
+        pairs = world * B * args.steps / el
+        print(json.dumps({"metric": "IRFD generator-step pairs/s (fwd+bwd+clip+Adam)", "value": round(pairs, 2),
+                          "unit": "pairs/s", "n_gpus": world, "batch_per_gpu": B, "ms_per_step": round(el / args.steps * 1e3, 2),
+                          "algorithmic_tflops": round(pairs * gflop_pair / 1e3, 1), "dtype": "f32", "scaling": "weak",
+                          "grad_bytes_per_step": red.bytes_per_step(), "buckets": len(red.buckets),
+                          "loss": round(float(loss), 5), "decoder_only": args.decoder_only}), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
