@@ -227,6 +227,23 @@ int spk_maxpool3x3s2_bwd(const float* x, const float* in_scale, const float* in_
 /* y[b,c] = mean_hw x[b,c,:,:].  replaces: resnet50.avgpool = AdaptiveAvgPool2d(1) (children()[8]). */
 int spk_global_avgpool_fwd(const float* x, float* y, int64_t planes, int64_t HW, void* stream);
 
+/* ---- stand-alone StyleGAN1 / ProGAN ops (the reference's only definitions of the PixelNorm / FIR-blur family) ----
+ * spk_pixelnorm_fwd: y = x * rsqrt(mean_c x^2 + eps) over dim 1 of [B,C,HW] (HW = 1 for latents).
+ *   replaces: styleganv1.py:132-136 (PixelNorm, sqrt_form = 0); stylegan.py:28-29 (x / sqrt(...), sqrt_form = 1).
+ * spk_instance_norm_affine_fwd: per (b,c) plane y = (x-mean)*rsqrt(var_biased+eps) * scale[b*sb_stride+c] + bias[...]
+ *   (scale / bias NULL = 1 / 0).  replaces: styleganv1.py:148-152 (InstanceNorm, eps 1e-8);
+ *   stylegan.py:91-95 (AdaIN = nn.InstanceNorm2d (eps 1e-5) then style_scale * x + style_bias).
+ * spk_blur2d_fwd: depthwise k x k FIR (filter given on the HOST, k <= 7), zero pad (k-1)/2, stride 1 or 2.
+ *   replaces: styleganv1.py:52-63 (Blur2d.forward: F.conv2d with groups = C).
+ * spk_upscale2d_nearest_fwd: y[h,w] = gain * x[h/f, w/f].  replaces: styleganv1.py:113-120 (Upscale2d).
+ * spk_fade_in_tanh_fwd: y = tanh(alpha*a + (1-alpha)*b).  replaces: stylegan.py:155-157 (Generator.fade_in). */
+int spk_pixelnorm_fwd(const float* x, float* y, int B, int C, int64_t HW, float eps, int sqrt_form, void* stream);
+int spk_instance_norm_affine_fwd(const float* x, float* y, const float* scale, const float* bias, int64_t sb_stride, int B, int C,
+                                 int64_t HW, float eps, void* stream);
+int spk_blur2d_fwd(const float* x, float* y, const float* filter_host, int k, int64_t planes, int H, int W, int stride, void* stream);
+int spk_upscale2d_nearest_fwd(const float* x, float* y, int64_t planes, int H, int W, int factor, float gain, void* stream);
+int spk_fade_in_tanh_fwd(const float* a, const float* b, float* y, float alpha, int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -44,6 +44,13 @@ class WgradDesc(C.Structure):
 
 
 _PROTOTYPES = {
+    "spk_pixelnorm_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_float, C.c_int, C.c_void_p]),
+    "spk_instance_norm_affine_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
+                                               C.c_int64, C.c_float, C.c_void_p]),
+    "spk_blur2d_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int,
+                                 C.c_void_p]),
+    "spk_upscale2d_nearest_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "spk_fade_in_tanh_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_void_p]),
     "spk_bn_bwd_reduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 4 +
                           [C.c_float, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p]),
     "spk_bn_bwd_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 5 +

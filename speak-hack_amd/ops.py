@@ -316,6 +316,57 @@ def fc_bwd(dout, out, x, weight, wmul=1.0, bmul=1.0, slope=1.0, need_dx=True, ne
     return dx, dw, db
 
 
+# ---- stand-alone StyleGAN1 / ProGAN ops ------------------------------------------------------------------
+def pixelnorm(x, eps=1e-8, sqrt_form=False):
+    """x * rsqrt(mean over dim 1 of x^2 + eps); x is [B,C] or [B,C,H,W]."""
+    B, Cc = x.shape[:2]
+    HW = x.numel() // (B * Cc)
+    y = torch.empty_like(x)
+    L.check(L.lib().spk_pixelnorm_fwd(L.dptr(x, "x"), L.dptr(y), B, Cc, HW, float(eps), 1 if sqrt_form else 0, L.stream_ptr()),
+            "spk_pixelnorm_fwd")
+    return y
+
+
+def instance_norm_affine(x, scale=None, bias=None, eps=1e-5):
+    """Per-(b,c)-plane normalisation then y*scale[b,c] + bias[b,c] (AdaIN); scale/bias are [B,C] (row-strided ok)."""
+    B, Cc, H, W = x.shape
+    y = torch.empty_like(x)
+    stride = scale.stride(0) if scale is not None else (bias.stride(0) if bias is not None else 0)
+    if scale is not None and bias is not None and scale.stride(0) != bias.stride(0):
+        raise L.SpkError("instance_norm_affine: scale and bias must share their row stride")
+    L.check(L.lib().spk_instance_norm_affine_fwd(L.dptr(x, "x"), L.dptr(y), _style_ptr(scale), _style_ptr(bias), stride, B, Cc,
+                                                 H * W, float(eps), L.stream_ptr()), "spk_instance_norm_affine_fwd")
+    return y
+
+
+def blur2d(x, filt2d, stride=1):
+    """Depthwise FIR with the k x k filter ``filt2d`` (a CPU tensor / nested list), zero pad (k-1)/2."""
+    B, Cc, H, W = x.shape
+    f = torch.as_tensor(filt2d, dtype=torch.float32).contiguous().cpu()
+    k = f.shape[0]
+    pad = (k - 1) // 2
+    Ho, Wo = (H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1
+    y = torch.empty((B, Cc, Ho, Wo), device=x.device, dtype=torch.float32)
+    arr = (C.c_float * (k * k))(*f.flatten().tolist())
+    L.check(L.lib().spk_blur2d_fwd(L.dptr(x, "x"), L.dptr(y), arr, k, B * Cc, H, W, int(stride), L.stream_ptr()), "spk_blur2d_fwd")
+    return y
+
+
+def upscale2d_nearest(x, factor=2, gain=1.0):
+    B, Cc, H, W = x.shape
+    y = torch.empty((B, Cc, H * factor, W * factor), device=x.device, dtype=torch.float32)
+    L.check(L.lib().spk_upscale2d_nearest_fwd(L.dptr(x, "x"), L.dptr(y), B * Cc, H, W, int(factor), float(gain), L.stream_ptr()),
+            "spk_upscale2d_nearest_fwd")
+    return y
+
+
+def fade_in_tanh(a, b, alpha):
+    y = torch.empty_like(a)
+    L.check(L.lib().spk_fade_in_tanh_fwd(L.dptr(a, "a"), L.dptr(b, "b"), L.dptr(y), float(alpha), a.numel(), L.stream_ptr()),
+            "spk_fade_in_tanh_fwd")
+    return y
+
+
 MASK_NONE, MASK_RECOMPUTE, MASK_TENSOR = 0, 1, 2
 
 
