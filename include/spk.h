@@ -40,6 +40,7 @@ extern "C" {
 #define SPK_EPI_ACCUM  32u           /* y += result */
 #define SPK_EPI_STATS  64u           /* stats[0:Cout] += sum_bhw y, stats[Cout:2Cout] += sum_bhw y^2 (fp64) */
 #define SPK_CONV_IN_AFFINE_RELU 128u /* x' = max(x*in_scale[ci] + in_shift[ci], 0) applied while staging */
+#define SPK_CONV_IN_BATCH_SCALE 256u /* x' = x * in_scale[b*Cin + ci] applied while staging (weight modulation) */
 
 const char* spk_version(void);
 const char* spk_last_error(void);
@@ -84,6 +85,12 @@ typedef struct spk_conv2d_desc {
     int32_t ksplit;          /* slices of the input-channel range (split-K); 0 = auto, 1 = none */
     void*   workspace;       /* device scratch for split-K partial sums (may be NULL if not needed) */
     int64_t workspace_bytes; /* its size; see spk_conv2d_workspace_bytes */
+    /* StyleGAN2-style modulated convolution (build-defined variant): with
+     * SPK_CONV_IN_BATCH_SCALE, in_scale is the modulation s[B,Cin]; out_scale_bc[B,Cout] (or NULL) multiplies the
+     * contraction before bias/noise (the demodulation d[b,co] = rsqrt(sum (w*s)^2 + eps), spk_modconv_demod);
+     * act_gain (0 = 1) multiplies the LeakyReLU output (sqrt 2 of FusedLeakyReLU). */
+    const float* out_scale_bc;
+    float act_gain;
 } spk_conv2d_desc;
 
 int spk_conv2d_num_configs(void);
@@ -226,6 +233,21 @@ int spk_maxpool3x3s2_bwd(const float* x, const float* in_scale, const float* in_
                          int C, int Hin, int Win, void* stream);
 /* y[b,c] = mean_hw x[b,c,:,:].  replaces: resnet50.avgpool = AdaptiveAvgPool2d(1) (children()[8]). */
 int spk_global_avgpool_fwd(const float* x, float* y, int64_t planes, int64_t HW, void* stream);
+
+/* ---- StyleGAN2 pieces (build-defined variant; the reference only describes them in prose,
+ *      reference/styleganv2.txt:1835,1912 -- parity unpinned by the reference) --------------------------------
+ * spk_modconv_demod: d[b,co] = rsqrt( scale^2 * sum_{ci,k} (w[co,ci,k] * s[b,ci])^2 + eps )
+ * spk_upfirdn2d_fwd: zero-insert upsample by `up`, pad (pad0 before / pad1 after, negative = crop), correlate
+ *   with the FLIPPED k x k filter (given on the host), keep every `down`-th sample -- upfirdn2d of the StyleGAN2
+ *   reference implementation; out size = (H*up + pad0 + pad1 - k)/down + 1.
+ * spk_conv1x1_small_mod_fwd: y[b,o,p] = sum_c w[o,c]*mod[b,c]*x[b,c,p]*in_scale + bias[o] (toRGB: modulated, no
+ *   demodulation), O <= 4. */
+int spk_modconv_demod(const float* w, const float* s, float* d, int B, int Cin, int Cout, int taps, float scale, float eps,
+                      void* stream);
+int spk_upfirdn2d_fwd(const float* x, float* y, const float* filter_host, int k, int64_t planes, int H, int W, int up, int down,
+                      int pad0, int pad1, float gain, void* stream);
+int spk_conv1x1_small_mod_fwd(const float* x, const float* w, const float* mod, const float* bias, float* y, int B, int C, int O,
+                              int64_t HW, float in_scale, void* stream);
 
 /* ---- stand-alone StyleGAN1 / ProGAN ops (the reference's only definitions of the PixelNorm / FIR-blur family) ----
  * spk_pixelnorm_fwd: y = x * rsqrt(mean_c x^2 + eps) over dim 1 of [B,C,HW] (HW = 1 for latents).

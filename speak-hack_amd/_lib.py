@@ -30,7 +30,11 @@ class Conv2dDesc(C.Structure):
                 ("Hin", C.c_int32), ("Win", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32),
                 ("style_stride", C.c_int32), ("flags", C.c_uint32), ("lrelu_slope", C.c_float),
                 ("out_scale", C.c_float), ("config", C.c_int32), ("ksplit", C.c_int32),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64)]
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
+                ("out_scale_bc", C.c_void_p), ("act_gain", C.c_float)]
+
+
+CONV_IN_BATCH_SCALE = 256
 
 
 class WgradDesc(C.Structure):
@@ -44,6 +48,11 @@ class WgradDesc(C.Structure):
 
 
 _PROTOTYPES = {
+    "spk_modconv_demod": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
+                                    C.c_void_p]),
+    "spk_upfirdn2d_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int,
+                                    C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
+    "spk_conv1x1_small_mod_fwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_float, C.c_void_p]),
     "spk_pixelnorm_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_float, C.c_int, C.c_void_p]),
     "spk_instance_norm_affine_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
                                                C.c_int64, C.c_float, C.c_void_p]),

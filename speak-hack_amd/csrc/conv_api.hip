@@ -27,9 +27,10 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const ConvArgs p, 
             co = (int)((idx / HW) % p.Cout);
             const int b = (int)(idx / (HW * p.Cout));
             v *= p.out_scale;
+            if (p.out_scale_bc) v *= p.out_scale_bc[(size_t)b * p.Cout + co];
             if (f_bias) v += p.bias[co];
             if (f_noise) v += p.noise_w[co] * p.noise[(size_t)b * HW + pix];
-            if (f_lrelu) v = v > 0.f ? v : v * p.slope;
+            if (f_lrelu) v = (v > 0.f ? v : v * p.slope) * p.act_gain;
             if (p.y_pre) p.y_pre[idx] = v;
             if (f_style) {
                 const float* st = p.style + (size_t)b * p.style_stride;
@@ -211,7 +212,9 @@ int spk_conv2d_fwd(const spk_conv2d_desc* d, void* stream) {
     SPK_REQUIRE(d->B > 0 && d->Cin > 0 && d->Cout > 0 && d->H > 0 && d->W > 0 && d->Hin > 0 && d->Win > 0, "conv2d: bad shape");
     SPK_REQUIRE(supported_kernel(d->kh, d->kw, d->stride), "conv2d: unsupported kernel %dx%d stride %d", d->kh, d->kw, d->stride);
     const bool ups = d->flags & SPK_CONV_UPSAMPLE2X, aff = d->flags & SPK_CONV_IN_AFFINE_RELU;
-    SPK_REQUIRE(!(ups && aff), "conv2d: UPSAMPLE2X and IN_AFFINE_RELU are exclusive");
+    const bool bsc = d->flags & SPK_CONV_IN_BATCH_SCALE;
+    SPK_REQUIRE((int)ups + (int)aff + (int)bsc <= 1, "conv2d: UPSAMPLE2X, IN_AFFINE_RELU and IN_BATCH_SCALE are exclusive");
+    SPK_REQUIRE(!bsc || (d->in_scale && d->kh == 3 && d->stride == 1), "conv2d: IN_BATCH_SCALE needs in_scale[B,Cin] and a 3x3 stride-1 kernel");
     SPK_REQUIRE(!ups || (d->kh == 3 && d->stride == 1), "conv2d: UPSAMPLE2X needs a 3x3 stride-1 kernel");
     const int pad = (d->kh - 1) / 2;
     if (ups) SPK_REQUIRE(d->H == 2 * d->Hin && d->W == 2 * d->Win, "conv2d: upsampled output must be 2x the input (%dx%d vs %dx%d)", d->H, d->W, d->Hin, d->Win);
@@ -225,10 +228,11 @@ int spk_conv2d_fwd(const spk_conv2d_desc* d, void* stream) {
     SPK_REQUIRE((long long)d->B * d->Cout * d->H * d->W < (1ll << 40), "conv2d: tensor too large");
     int cfg = d->config;
     if (cfg < 0) cfg = pick_config(d->kh, d->stride, d->B, d->Cin, d->Cout, d->H, d->W);
+    SPK_REQUIRE(!bsc || cfg >= 4, "conv2d: IN_BATCH_SCALE is built for the half-depth configs (4-7)");
     SPK_REQUIRE(config_valid(cfg, d->kh, d->kw, d->stride), "conv2d: config %d is not built for %dx%d stride %d", cfg, d->kh, d->kw, d->stride);
     spk_conv2d_desc dd = *d;
     dd.config = cfg;
-    const int mode = ups ? MODE_UPSAMPLE : (aff ? MODE_AFFINE_RELU : MODE_PLAIN);
+    const int mode = ups ? MODE_UPSAMPLE : (aff ? MODE_AFFINE_RELU : (bsc ? MODE_BATCH_SCALE : MODE_PLAIN));
     hipStream_t s = (hipStream_t)stream;
     if (d->kh == 1) return run_1x1(d->stride, cfg, mode, &dd, s);
     if (d->kh == 3 && d->stride == 1) return cfg <= 3 ? run_3x3s1_a(cfg, mode, &dd, s) : run_3x3s1_b(cfg, mode, &dd, s);

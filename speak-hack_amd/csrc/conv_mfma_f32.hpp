@@ -34,7 +34,7 @@ namespace spkconv {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-enum Mode { MODE_PLAIN = 0, MODE_UPSAMPLE = 1, MODE_AFFINE_RELU = 2 };
+enum Mode { MODE_PLAIN = 0, MODE_UPSAMPLE = 1, MODE_AFFINE_RELU = 2, MODE_BATCH_SCALE = 3 };
 
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -51,7 +51,8 @@ struct ConvArgs {
     const float* noise_w;
     const float* noise;
     const float* style;
-    const float* in_scale;   // MODE_AFFINE_RELU: per input channel
+    const float* in_scale;   // MODE_AFFINE_RELU: per input channel; MODE_BATCH_SCALE: [B,Cin] modulation
+    const float* out_scale_bc;  // optional [B,Cout] factor applied right after the contraction (demodulation)
     const float* in_shift;
     double* stats;           // [2*Cout] sum / sum of squares of y (SPK_EPI_STATS)
     float* y;                // output, or the split-K workspace [ksplit][B][Cout][H][W]
@@ -64,7 +65,7 @@ struct ConvArgs {
     int chunks_per_split;
     int style_stride;
     unsigned flags;
-    float slope, out_scale;
+    float slope, out_scale, act_gain;
 };
 
 template <int WM_, int WN_, int MT_, int NT_, int CIT_>
@@ -96,13 +97,14 @@ constexpr unsigned D_DX = 1u << 7;      // bilinear: second tap is one column to
 constexpr unsigned D_DY = 1u << 8;      // bilinear: second row is one source row below
 constexpr unsigned D_LX_SHIFT = 9;      // 2 bits: lambda code (0: 0, 1: 0.25, 2: 0.75)
 constexpr unsigned D_LY_SHIFT = 11;
+constexpr unsigned D_TB_SHIFT = 13;     // 7 bits: image within the tile's image group (MODE_BATCH_SCALE)
 
 __device__ __forceinline__ float lambda_of(unsigned code) { return code == 0 ? 0.f : (code == 1 ? 0.25f : 0.75f); }
 
 template <class C, int KH, int KW, int S, int MODE>
 __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
     using SH = Shape<C, KH, KW, S>;
-    constexpr bool UPS = MODE == MODE_UPSAMPLE, AFF = MODE == MODE_AFFINE_RELU;
+    constexpr bool UPS = MODE == MODE_UPSAMPLE, AFF = MODE == MODE_AFFINE_RELU, BSC = MODE == MODE_BATCH_SCALE;
     constexpr int NSLOT = SH::NSLOT, W_FLOATS = SH::W_FLOATS, WV = SH::WV, PAD = SH::PAD;
     static_assert(!UPS || S == 1, "upsample folding needs stride 1");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -146,7 +148,7 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
             const int ci = q >> p.lgTB, tb = q & (TB - 1);
             const int r = pidx / PW, c = pidx - r * PW;
             const int uy = y0 * S + r - PAD, ux = x0 * S + c - PAD;
-            unsigned d = (unsigned)ci << D_CI_SHIFT;
+            unsigned d = ((unsigned)ci << D_CI_SHIFT) | ((unsigned)tb << D_TB_SHIFT);
             if (uy >= 0 && uy < Hv && ux >= 0 && ux < Wv && b0 + tb < p.B) {
                 d |= D_VALID;
                 int goff;
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
     // prefetch registers
     f32x4 wreg[WV];
     float xin[UPS ? 4 * NSLOT : NSLOT];
-    float xsc[AFF ? NSLOT : 1], xsh[AFF ? NSLOT : 1];
+    float xsc[(AFF || BSC) ? NSLOT : 1], xsh[AFF ? NSLOT : 1];
 
     // staging is written as macros (not lambdas / functions) so that the prefetch arrays stay in
     // registers: every index is a compile-time constant after unrolling.
@@ -226,6 +228,10 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
                 xin[4 * s + 1] = s0[dx];                                                                      \
                 xin[4 * s + 2] = s0[dy];                                                                      \
                 xin[4 * s + 3] = s0[dy + dx];                                                                 \
+            }                                                                                                 \
+            if (BSC) { /* modulation s[b,ci]: the per-sample input scale of a modulated convolution */        \
+                const int b_ = min(b0 + (int)((d >> D_TB_SHIFT) & 127u), p.B - 1);                            \
+                xsc[s] = p.in_scale[(size_t)b_ * p.Cin + (chunk_) * C::CI_T + (past_ ? 0 : ci_)];             \
             }                                                                                                 \
             if (AFF) {                                                                                        \
                 const int cg_ = (chunk_) * C::CI_T + (past_ ? 0 : ci_);                                       \
@@ -260,6 +266,7 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
                         ly1 * (lx0 * xin[4 * s + 2] + lx1 * xin[4 * s + 3]);                                  \
                 }                                                                                             \
                 if (AFF) v = fmaxf(v * xsc[s] + xsh[s], 0.f);                                                 \
+                if (BSC) v *= xsc[s];                                                                         \
                 dst[e] = ok ? v : 0.f;                                                                        \
             }                                                                                                 \
         }                                                                                                     \
@@ -334,6 +341,7 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
     // per pixel group: validity, output offset, noise value, style row
     bool pv[C::NT];
     size_t poff[C::NT];
+    int pb[C::NT];
     float nz[C::NT];
     const float* st[C::NT];
 #pragma unroll
@@ -344,6 +352,7 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
         pv[n] = tb < TB && b < p.B && yy < p.H && xx < p.W;
         const size_t pix = (size_t)yy * p.W + xx;
         poff[n] = pv[n] ? (size_t)b * p.Cout * HW + pix : 0;
+        pb[n] = pv[n] ? b : 0;
         nz[n] = (f_noise && pv[n] && !split) ? p.noise[(size_t)b * HW + pix] : 0.f;
         st[n] = (f_style && pv[n]) ? p.style + (size_t)b * p.style_stride : nullptr;
     }
@@ -365,9 +374,11 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
                         *dst = acc[m][n][r];
                         continue;
                     }
-                    float v = acc[m][n][r] * p.out_scale + bb;
+                    float v = acc[m][n][r] * p.out_scale;
+                    if (p.out_scale_bc) v *= p.out_scale_bc[(size_t)pb[n] * p.Cout + co];   // demodulation d[b,co]
+                    v += bb;
                     if (f_noise) v += nwc * nz[n];
-                    if (f_lrelu) v = v > 0.f ? v : v * p.slope;
+                    if (f_lrelu) v = (v > 0.f ? v : v * p.slope) * p.act_gain;
                     if (p.y_pre) p.y_pre[poff[n] + (size_t)co * HW] = v;
                     if (f_style) v = v * (st[n][co] + 1.f) + st[n][p.Cout + co];
                     if (f_accum) v += *dst;
@@ -446,7 +457,7 @@ template <class C, int KH, int KW, int S, int MODE>
 int run(const spk_conv2d_desc* d, hipStream_t stream) {
     ConvArgs a;
     a.x = d->x; a.wp = d->w_packed; a.bias = d->bias; a.noise_w = d->noise_w; a.noise = d->noise;
-    a.style = d->style; a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.stats = d->stats; a.y = d->y; a.y_pre = d->y_pre;
+    a.style = d->style; a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.stats = d->stats; a.y = d->y; a.y_pre = d->y_pre; a.out_scale_bc = d->out_scale_bc;
     a.B = d->B; a.Cin = d->Cin; a.Cout = d->Cout; a.H = d->H; a.W = d->W; a.Hs = d->Hin; a.Ws = d->Win;
     const Geometry g = geometry<C, KH, KW, S>(d->B, d->Cin, d->Cout, d->H, d->W);
     SPK_REQUIRE(g.ok, "conv2d: config %d does not fit this shape (%dx%d, B=%d)", d->config, d->H, d->W, d->B);
@@ -454,7 +465,7 @@ int run(const spk_conv2d_desc* d, hipStream_t stream) {
     a.lgTW = spk::ilog2(g.TW); a.lgTH = spk::ilog2(g.TH); a.lgTB = spk::ilog2(g.TB);
     a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y;
     a.n_chunks = g.n_chunks;
-    a.style_stride = d->style_stride; a.flags = d->flags; a.slope = d->lrelu_slope; a.out_scale = d->out_scale;
+    a.style_stride = d->style_stride; a.flags = d->flags; a.slope = d->lrelu_slope; a.out_scale = d->out_scale; a.act_gain = d->act_gain != 0.f ? d->act_gain : 1.f;
     const int ksplit = resolve_ksplit(g, d->ksplit, &a.chunks_per_split);
     const size_t out_floats = (size_t)d->B * d->Cout * d->H * d->W;
     if (ksplit > 1) {

@@ -1,0 +1,128 @@
+// StyleGAN2-specific pieces of the build-defined decoder variant: the demodulation
+// coefficients of a modulated convolution, upfirdn2d, and the modulated 1x1 toRGB.  The modulated 3x3 conv
+// itself is the MFMA conv kernel with the modulation applied to the *input* in staging and the demodulation
+// to the *output* in the epilogue, so the weights stay shared across the batch (no per-sample weight tensor).
+#include "spk_common.hpp"
+
+#include <algorithm>
+
+namespace {
+
+// d[b,co] = rsqrt(scale^2 * sum_ci s[b,ci]^2 * (sum_k w[co,ci,k]^2) + eps): one wave per output channel,
+// lanes over ci (weight row read once), batch looped in registers.
+__global__ __launch_bounds__(256) void demod_kernel(const float* __restrict__ w, const float* __restrict__ s, float* __restrict__ d,
+                                                   int B, int Cin, int Cout, int taps, float scale2, float eps) {
+    const int co = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (co >= Cout) return;
+    const float* wr = w + (size_t)co * Cin * taps;
+    for (int b0 = 0; b0 < B; b0 += 8) {
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int ci = lane; ci < Cin; ci += 64) {
+            float wsq = 0.f;
+            for (int k = 0; k < taps; ++k) { const float v = wr[(size_t)ci * taps + k]; wsq += v * v; }
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+                if (b0 + b < B) { const float sv = s[(size_t)(b0 + b) * Cin + ci]; acc[b] += sv * sv * wsq; }
+        }
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) acc[b] += __shfl_xor(acc[b], off);
+            if (lane == 0 && b0 + b < B) d[(size_t)(b0 + b) * Cout + co] = rsqrtf(acc[b] * scale2 + eps);
+        }
+    }
+}
+
+struct Fir2 { float f[49]; int k; };
+
+// out[oy,ox] = gain * sum_{ky,kx} f[k-1-ky][k-1-kx] * xu[oy*down + ky - pad0][ox*down + kx - pad0],
+// xu = x with (up-1) zeros inserted after every sample (size H*up), zero outside.
+__global__ __launch_bounds__(256) void upfirdn2d_kernel(const float* __restrict__ x, float* __restrict__ y, Fir2 fir, long long planes,
+                                                       int H, int W, int Ho, int Wo, int up, int down, int pad0, float gain) {
+    const int k = fir.k;
+    const long long total = planes * Ho * Wo;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int ox = (int)(idx % Wo), oy = (int)((idx / Wo) % Ho);
+        const long long pl = idx / ((long long)Wo * Ho);
+        const float* xp = x + pl * H * W;
+        float acc = 0.f;
+        for (int ky = 0; ky < k; ++ky) {
+            const int uy = oy * down + ky - pad0;
+            if (uy < 0 || uy >= H * up || uy % up) continue;
+            for (int kx = 0; kx < k; ++kx) {
+                const int ux = ox * down + kx - pad0;
+                if (ux < 0 || ux >= W * up || ux % up) continue;
+                acc += fir.f[(k - 1 - ky) * k + (k - 1 - kx)] * xp[(size_t)(uy / up) * W + ux / up];
+            }
+        }
+        y[idx] = acc * gain;
+    }
+}
+
+// 1x1 conv with O <= 4 outputs and per-(b,c) modulation of the weight
+__global__ __launch_bounds__(256) void conv1x1_small_mod_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                               const float* __restrict__ mod, const float* __restrict__ bias,
+                                                               float* __restrict__ y, int C, int O, long long HW, float in_scale) {
+    extern __shared__ float w_s[];  // [O][C], already modulated for this image
+    const int b = blockIdx.y;
+    for (int i = threadIdx.x; i < O * C; i += blockDim.x) w_s[i] = w[i] * in_scale * mod[(size_t)b * C + (i % C)];
+    __syncthreads();
+    const float* xb = x + (size_t)b * C * HW;
+    float* yb = y + (size_t)b * O * HW;
+    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += (long long)gridDim.x * blockDim.x) {
+        float acc[4];
+#pragma unroll
+        for (int o = 0; o < 4; ++o) acc[o] = (bias && o < O) ? bias[o] : 0.f;
+#pragma unroll 8
+        for (int c = 0; c < C; ++c) {
+            const float xv = xb[(size_t)c * HW + p];
+#pragma unroll
+            for (int o = 0; o < 4; ++o)
+                if (o < O) acc[o] += w_s[o * C + c] * xv;
+        }
+#pragma unroll
+        for (int o = 0; o < 4; ++o)
+            if (o < O) yb[(size_t)o * HW + p] = acc[o];
+    }
+}
+
+inline unsigned sgrid2(long long n) { return (unsigned)std::max(1ll, std::min((n + 255) / 256, 256ll * 16)); }
+
+}  // namespace
+
+extern "C" {
+
+int spk_modconv_demod(const float* w, const float* s, float* d, int B, int Cin, int Cout, int taps, float scale, float eps,
+                      void* stream) {
+    SPK_REQUIRE(w && s && d && B > 0 && Cin > 0 && Cout > 0 && taps > 0, "modconv_demod: bad arguments");
+    hipLaunchKernelGGL(demod_kernel, dim3((unsigned)spk::ceil_div(Cout, 4)), dim3(256), 0, (hipStream_t)stream, w, s, d, B, Cin, Cout,
+                       taps, scale * scale, eps);
+    return spk::check_launch("demod_kernel");
+}
+
+int spk_upfirdn2d_fwd(const float* x, float* y, const float* filter_host, int k, int64_t planes, int H, int W, int up, int down,
+                      int pad0, int pad1, float gain, void* stream) {
+    SPK_REQUIRE(x && y && filter_host && k >= 1 && k <= 7 && planes > 0 && H > 0 && W > 0 && up >= 1 && down >= 1,
+                "upfirdn2d: bad arguments (k <= 7)");
+    const int Ho = (H * up + pad0 + pad1 - k) / down + 1, Wo = (W * up + pad0 + pad1 - k) / down + 1;
+    SPK_REQUIRE(Ho > 0 && Wo > 0, "upfirdn2d: empty output");
+    Fir2 fir;
+    fir.k = k;
+    for (int i = 0; i < k * k; ++i) fir.f[i] = filter_host[i];
+    hipLaunchKernelGGL(upfirdn2d_kernel, dim3(sgrid2((long long)planes * Ho * Wo)), dim3(256), 0, (hipStream_t)stream, x, y, fir,
+                       (long long)planes, H, W, Ho, Wo, up, down, pad0, gain);
+    return spk::check_launch("upfirdn2d_kernel");
+}
+
+int spk_conv1x1_small_mod_fwd(const float* x, const float* w, const float* mod, const float* bias, float* y, int B, int C, int O,
+                              int64_t HW, float in_scale, void* stream) {
+    SPK_REQUIRE(x && w && mod && y, "conv1x1_small_mod: null pointer");
+    SPK_REQUIRE(B > 0 && C > 0 && O > 0 && O <= 4 && HW > 0, "conv1x1_small_mod: bad shape (O must be <= 4)");
+    SPK_REQUIRE((size_t)O * C * sizeof(float) <= 48 * 1024, "conv1x1_small_mod: weight too large for LDS");
+    dim3 grid(sgrid2(HW) > 64 ? 64 : sgrid2(HW), (unsigned)B);
+    hipLaunchKernelGGL(conv1x1_small_mod_kernel, grid, dim3(256), (size_t)O * C * sizeof(float), (hipStream_t)stream, x, w, mod, bias,
+                       y, C, O, (long long)HW, in_scale);
+    return spk::check_launch("conv1x1_small_mod_kernel");
+}
+
+}  // extern "C"

@@ -88,7 +88,8 @@ def conv_out_size(n, k, stride):
 
 def conv2d_fused(x, w_packed, Cout: int, k: int = 3, stride: int = 1, *, bias=None, noise_w=None, noise=None,
                  style=None, style_stride=None, upsample=False, lrelu_slope=None, out_scale=1.0, in_affine=None,
-                 stats=None, config=-1, ksplit=0, out=None, accumulate=False, out_pre=None):
+                 stats=None, config=-1, ksplit=0, out=None, accumulate=False, out_pre=None, batch_scale=None, demod=None,
+                 act_gain=1.0):
     """y = style(lrelu(conv_kxk(in(x)) * out_scale + bias + noise_w*noise)) -- one launch.
 
     ``in``: identity; or bilinear x2 (``upsample``; x is [B,Cin,H/2,W/2]); or ``max(x*a+b, 0)`` per
@@ -122,12 +123,20 @@ def conv2d_fused(x, w_packed, Cout: int, k: int = 3, stride: int = 1, *, bias=No
         flags |= L.EPI_ACCUM
     if in_affine is not None:
         flags |= L.CONV_IN_AFFINE_RELU
+    if batch_scale is not None:          # modulated convolution: s[B,Cin] applied to the input while staging
+        if tuple(batch_scale.shape) != (B, Cin) or in_affine is not None or upsample:
+            raise L.SpkError("conv2d_fused: batch_scale must be [B,Cin] and excludes in_affine / upsample")
+        flags |= L.CONV_IN_BATCH_SCALE
+    if demod is not None and tuple(demod.shape) != (B, Cout):
+        raise L.SpkError("conv2d_fused: demod must be [B,Cout]")
     if stats is not None:
         if stats.dtype != torch.float64 or stats.numel() != 2 * Cout or not stats.is_cuda:
             raise L.SpkError("conv2d_fused: stats must be a float64 HIP tensor of 2*Cout elements")
         flags |= L.EPI_STATS
     if config < 0:
         config = conv2d_pick_config(k, stride, B, Cin, Cout, H, W)
+        if batch_scale is not None and config < 4:
+            config += 4                  # the modulated variant is built for the half-depth-chunk configs
     ws_bytes = L.lib().spk_conv2d_workspace_bytes(int(config), int(ksplit), k, k, stride, B, Cin, Cout, H, W)
     if ws_bytes < 0:
         raise L.SpkError(f"conv2d_fused: config {config} cannot host k={k} s={stride} shape {(B, Cin, Cout, H, W)}")
@@ -135,8 +144,10 @@ def conv2d_fused(x, w_packed, Cout: int, k: int = 3, stride: int = 1, *, bias=No
     d = L.Conv2dDesc(x=L.dptr(x, "x"), w_packed=L.dptr(w_packed, "w_packed"), bias=L.dptr(bias, "bias"),
                      noise_w=L.dptr(noise_w, "noise_w") if noise is not None else None,
                      noise=L.dptr(noise, "noise"), style=_style_ptr(style),
-                     in_scale=L.dptr(in_affine[0], "in_scale") if in_affine is not None else None,
+                     in_scale=(L.dptr(in_affine[0], "in_scale") if in_affine is not None
+                               else L.dptr(batch_scale, "batch_scale")),
                      in_shift=L.dptr(in_affine[1], "in_shift") if in_affine is not None else None,
+                     out_scale_bc=L.dptr(demod, "demod"), act_gain=float(act_gain),
                      stats=stats.data_ptr() if stats is not None else None, y=L.dptr(out, "out"),
                      y_pre=L.dptr(out_pre, "out_pre"), B=B, Cin=Cin, Cout=Cout, H=H, W=W, Hin=Hs, Win=Ws, kh=k, kw=k, stride=stride,
                      style_stride=int(style_stride or 0), flags=flags,
@@ -314,6 +325,41 @@ def fc_bwd(dout, out, x, weight, wmul=1.0, bmul=1.0, slope=1.0, need_dx=True, ne
                                L.dptr(dx), I, L.dptr(dw), L.dptr(db), B, I, O, float(wmul), float(bmul), float(slope),
                                L.stream_ptr()), "spk_fc_bwd")
     return dx, dw, db
+
+
+# ---- StyleGAN2 pieces (build-defined variant) ---------------------------------------------------------------
+def modconv_demod(weight, s, scale, eps=1e-8):
+    """d[b,co] = rsqrt(scale^2 * sum_{ci,k} (w[co,ci,k]*s[b,ci])^2 + eps)."""
+    Cout, Cin, kh, kw = weight.shape
+    B = s.shape[0]
+    d = torch.empty((B, Cout), device=s.device, dtype=torch.float32)
+    L.check(L.lib().spk_modconv_demod(L.dptr(weight, "weight"), L.dptr(s, "s"), L.dptr(d), B, Cin, Cout, kh * kw, float(scale),
+                                      float(eps), L.stream_ptr()), "spk_modconv_demod")
+    return d
+
+
+def upfirdn2d(x, filt2d, up=1, down=1, pad=(0, 0), gain=1.0):
+    """upfirdn2d of the StyleGAN2 reference implementation (zero-insert, pad/crop, flipped-FIR, decimate)."""
+    B, Cc, H, W = x.shape
+    f = torch.as_tensor(filt2d, dtype=torch.float32).contiguous().cpu()
+    k = f.shape[0]
+    Ho, Wo = (H * up + pad[0] + pad[1] - k) // down + 1, (W * up + pad[0] + pad[1] - k) // down + 1
+    y = torch.empty((B, Cc, Ho, Wo), device=x.device, dtype=torch.float32)
+    arr = (C.c_float * (k * k))(*f.flatten().tolist())
+    L.check(L.lib().spk_upfirdn2d_fwd(L.dptr(x, "x"), L.dptr(y), arr, k, B * Cc, H, W, int(up), int(down), int(pad[0]), int(pad[1]),
+                                      float(gain), L.stream_ptr()), "spk_upfirdn2d_fwd")
+    return y
+
+
+def conv1x1_small_mod(x, weight, mod, bias=None, in_scale=1.0):
+    """Modulated (not demodulated) 1x1 conv to <= 4 channels: the StyleGAN2 toRGB."""
+    B, Cc, H, W = x.shape
+    O = weight.shape[0]
+    y = torch.empty((B, O, H, W), device=x.device, dtype=torch.float32)
+    L.check(L.lib().spk_conv1x1_small_mod_fwd(L.dptr(x, "x"), L.dptr(weight.reshape(O, Cc), "weight"), L.dptr(mod, "mod"),
+                                              L.dptr(bias, "bias"), L.dptr(y), B, Cc, O, H * W, float(in_scale), L.stream_ptr()),
+            "spk_conv1x1_small_mod_fwd")
+    return y
 
 
 # ---- stand-alone StyleGAN1 / ProGAN ops ------------------------------------------------------------------

@@ -1,0 +1,168 @@
+"""Build-defined StyleGAN2 decoder variant -- the north-star's named kernels
+(modulated 3x3 conv + demodulation, upfirdn2d, noise injection, FusedLeakyReLU, PixelNorm) on the HIP path.
+The reference has no StyleGAN2 code; module layout and formulas follow the published
+StyleGAN2 / the common stylegan2-pytorch naming, with the reference decoder's channel schedule and I/O
+signature ([B,6144] latent -> [B,3,256,256]) so it can stand in for ``IRFD.Gd``.  Forward only.
+
+How the modulated conv maps to the MI355X kernel: StyleGAN2's per-sample weight
+``w'' = w * s[b,ci] * d[b,co]`` is never formed.  ``s`` multiplies the *input* while it is staged into LDS
+(SPK_CONV_IN_BATCH_SCALE), the demodulation ``d = rsqrt(sum (w*s)^2 + eps)`` (a tiny [B,Cout] kernel)
+multiplies the *output* in the epilogue together with noise, bias, LeakyReLU and the sqrt(2) gain -- so the
+packed weights are shared by the whole batch and the conv is the same implicit GEMM as everywhere else.
+"""
+from __future__ import annotations
+
+import math
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+SQRT2 = math.sqrt(2.0)
+
+
+def make_kernel(k=(1, 3, 3, 1)):
+    k = torch.tensor(k, dtype=torch.float32)
+    k = k[None, :] * k[:, None]
+    return k / k.sum()
+
+
+class EqualLinear(nn.Module):
+    def __init__(self, in_dim, out_dim, bias_init=0.0, lr_mul=1.0, activation=False):
+        super().__init__()
+        self.weight = nn.Parameter(torch.randn(out_dim, in_dim).div_(lr_mul))
+        self.bias = nn.Parameter(torch.zeros(out_dim).fill_(bias_init))
+        self.scale = (1 / math.sqrt(in_dim)) * lr_mul
+        self.lr_mul, self.activation = lr_mul, activation
+
+    def forward(self, x):
+        if self.activation:     # sqrt2 * lrelu(v) == lrelu(sqrt2 * v): fold the gain into the FC's multipliers
+            return ops.fc(x.contiguous(), self.weight, self.bias, self.scale * SQRT2, self.lr_mul * SQRT2, 0.2)
+        return ops.fc(x.contiguous(), self.weight, self.bias, self.scale, self.lr_mul, 1.0)
+
+
+class Upsample(nn.Module):
+    def __init__(self, kernel=(1, 3, 3, 1), factor=2):
+        super().__init__()
+        self.factor = factor
+        self.register_buffer("kernel", make_kernel(kernel) * (factor ** 2))
+        p = self.kernel.shape[0] - factor
+        self.pad = ((p + 1) // 2 + factor - 1, p // 2)
+
+    def forward(self, x):
+        return ops.upfirdn2d(x.contiguous(), self.kernel.cpu(), up=self.factor, down=1, pad=self.pad)
+
+
+class ModulatedConv2d(nn.Module):
+    def __init__(self, in_channel, out_channel, kernel_size, style_dim, demodulate=True):
+        super().__init__()
+        self.in_channel, self.out_channel, self.kernel_size, self.demodulate = in_channel, out_channel, kernel_size, demodulate
+        self.scale = 1 / math.sqrt(in_channel * kernel_size ** 2)
+        self.weight = nn.Parameter(torch.randn(out_channel, in_channel, kernel_size, kernel_size))
+        self.modulation = EqualLinear(style_dim, in_channel, bias_init=1.0)
+        self._pk = ops.PackedConvWeight()
+
+    def forward(self, x, style, bias=None, noise_w=None, noise=None, lrelu=None, act_gain=1.0):
+        s = self.modulation(style)
+        if self.kernel_size == 1 and self.out_channel <= 4 and not self.demodulate:
+            return ops.conv1x1_small_mod(x.contiguous(), self.weight, s, bias, in_scale=self.scale)
+        if self.kernel_size != 3:
+            raise NotImplementedError("ModulatedConv2d: 3x3 (styled convs) and 1x1 toRGB are on the HIP path")
+        d = ops.modconv_demod(self.weight, s, self.scale) if self.demodulate else None
+        B, Cin, H, W = x.shape
+        cfg = ops.conv2d_pick_config(3, 1, B, Cin, self.out_channel, H, W)
+        return ops.conv2d_fused(x.contiguous(), self._pk.get(self.weight, cfg), self.out_channel, 3, 1, bias=bias, noise_w=noise_w,
+                                noise=noise, lrelu_slope=lrelu, out_scale=self.scale, batch_scale=s, demod=d, act_gain=act_gain,
+                                config=cfg)
+
+
+class NoiseInjection(nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.weight = nn.Parameter(torch.zeros(1))
+
+
+class FusedLeakyReLU(nn.Module):
+    def __init__(self, channel):
+        super().__init__()
+        self.bias = nn.Parameter(torch.zeros(channel))
+
+
+class StyledConv(nn.Module):
+    def __init__(self, in_channel, out_channel, kernel_size, style_dim, upsample=False):
+        super().__init__()
+        self.up = Upsample() if upsample else None
+        self.conv = ModulatedConv2d(in_channel, out_channel, kernel_size, style_dim)
+        self.noise = NoiseInjection()
+        self.activate = FusedLeakyReLU(out_channel)
+
+    def forward(self, x, style, noise=None):
+        if self.up is not None:
+            x = self.up(x)
+        B, _, H, W = x.shape
+        if noise is None:
+            noise = torch.randn(B, 1, H, W, device=x.device)
+        nw = self.noise.weight.expand(self.conv.out_channel).contiguous()
+        # conv*demod + noise_w*noise + bias -> lrelu(0.2) * sqrt2: one launch
+        return self.conv(x, style, bias=self.activate.bias, noise_w=nw, noise=noise.contiguous(), lrelu=0.2, act_gain=SQRT2)
+
+
+class ToRGB(nn.Module):
+    def __init__(self, in_channel, style_dim, upsample=True):
+        super().__init__()
+        self.upsample = Upsample() if upsample else None
+        self.conv = ModulatedConv2d(in_channel, 3, 1, style_dim, demodulate=False)
+        self.bias = nn.Parameter(torch.zeros(1, 3, 1, 1))
+
+    def forward(self, x, style, skip=None):
+        out = self.conv(x, style, bias=self.bias.view(-1))
+        if skip is not None:
+            out = out + self.upsample(skip)         # 3-channel skip sum
+        return out
+
+
+class ConstantInput(nn.Module):
+    def __init__(self, channel, size=4):
+        super().__init__()
+        self.input = nn.Parameter(torch.randn(1, channel, size, size))
+
+
+class StyleGAN2Generator(nn.Module):
+    """[B,input_dim] -> [B,3,resolution,resolution]; same constructor-level knobs as ``StyleGenerator``."""
+
+    def __init__(self, input_dim=6144, style_dim=512, n_mlp=8, resolution=256, fmap_base=8192, fmap_max=512):
+        super().__init__()
+        self.input_dim, self.style_dim, self.resolution = input_dim, style_dim, resolution
+        nf = lambda stage: min(int(fmap_base / (2.0 ** stage)), fmap_max)
+        self.style = nn.ModuleList(EqualLinear(input_dim if i == 0 else style_dim, style_dim, lr_mul=0.01, activation=True)
+                                   for i in range(n_mlp))
+        self.input = ConstantInput(nf(1))
+        self.conv1 = StyledConv(nf(1), nf(1), 3, style_dim)
+        self.to_rgb1 = ToRGB(nf(1), style_dim, upsample=False)
+        self.convs, self.to_rgbs = nn.ModuleList(), nn.ModuleList()
+        cin = nf(1)
+        for r in range(3, int(math.log2(resolution)) + 1):
+            cout = nf(r - 1)
+            self.convs.append(StyledConv(cin, cout, 3, style_dim, upsample=True))
+            self.convs.append(StyledConv(cout, cout, 3, style_dim))
+            self.to_rgbs.append(ToRGB(cout, style_dim))
+            cin = cout
+
+    def forward(self, features, noises=None):
+        if torch.is_grad_enabled():
+            raise NotImplementedError("StyleGAN2Generator: forward only (call under torch.no_grad())")
+        w = ops.pixelnorm(features.contiguous(), 1e-8, sqrt_form=False)
+        for layer in self.style:
+            w = layer(w)
+        B = w.size(0)
+        nz = iter(noises) if noises is not None else None
+        nxt = (lambda: next(nz)) if nz is not None else (lambda: None)
+        out = self.input.input.expand(B, -1, -1, -1).contiguous()
+        out = self.conv1(out, w, nxt())
+        skip = self.to_rgb1(out, w)
+        for i, rgb in enumerate(self.to_rgbs):
+            out = self.convs[2 * i](out, w, nxt())
+            out = self.convs[2 * i + 1](out, w, nxt())
+            skip = rgb(out, w, skip)
+        return skip

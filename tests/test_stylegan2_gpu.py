@@ -1,0 +1,114 @@
+"""GPU parity of the build-defined StyleGAN2 variant (parity unpinned by the reference,
+which has no StyleGAN2 code): modulated conv with the modulation folded into the input staging and the
+demodulation into the epilogue, upfirdn2d, modulated toRGB, and the whole variant decoder, against the CPU
+restatement of the published formulas (oracle/modconv_ref.py).  Tolerance 2e-5 per op, 2e-4 end to end."""
+import importlib
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2
+from oracle import modconv_ref as M
+from oracle.weights_recipe import recipe_input, recipe_tensor
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def sg2():
+    assert torch.cuda.is_available()
+    return importlib.import_module("speak-hack_amd.stylegan2")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    return importlib.import_module("speak-hack_amd.ops")
+
+
+@pytest.fixture(scope="module")
+def dev():
+    return torch.device("cuda:0")
+
+
+@pytest.mark.parametrize("up,down,pad,k1d,shape", [
+    (2, 1, (2, 1), (1, 3, 3, 1), (2, 5, 8, 8)),       # Upsample
+    (1, 2, (1, 1), (1, 3, 3, 1), (1, 3, 12, 10)),     # Downsample
+    (1, 1, (1, 1), (1, 2, 1), (2, 4, 7, 9)),          # Blur, 3-tap
+    (1, 1, (2, 1), (1, 3, 3, 1), (1, 2, 6, 6)),       # Blur after a transposed conv
+    (2, 2, (3, 2), (1, 3, 3, 1), (1, 2, 9, 5)),       # both, odd sizes
+    (1, 1, (-1, 0), (1, 3, 3, 1), (1, 1, 8, 8)),      # negative padding = crop
+])
+def test_upfirdn2d(ops, dev, up, down, pad, k1d, shape):
+    x = recipe_input(f"ufd.{up}.{down}.{pad}.{shape}", shape)
+    k = M.make_kernel(k1d) * (up ** 2)
+    ref = M.upfirdn2d(x, k, up, down, pad)
+    y = ops.upfirdn2d(x.to(dev), k, up, down, pad)
+    assert y.shape == ref.shape
+    assert rel_l2(y, ref) < 2e-6
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H", [(2, 16, 24, 8), (3, 64, 64, 16), (1, 512, 512, 4), (8, 128, 64, 32), (2, 20, 40, 11)])
+@pytest.mark.parametrize("demodulate", [True, False])
+def test_modulated_conv3x3(sg2, dev, B, Cin, Cout, H, demodulate):
+    m = sg2.ModulatedConv2d(Cin, Cout, 3, 32, demodulate=demodulate)
+    with torch.no_grad():
+        m.weight.copy_(recipe_tensor(f"mc.{Cin}.{Cout}.weight", m.weight.shape, 1.0))
+        m.modulation.weight.copy_(recipe_tensor(f"mc.{Cin}.mod.weight", m.modulation.weight.shape, 1.0))
+        m.modulation.bias.copy_(1.0 + recipe_tensor(f"mc.{Cin}.mod.bias", m.modulation.bias.shape, 0.2))
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x = recipe_input(f"mc.x.{B}.{Cin}.{H}", (B, Cin, H, H))
+    st = recipe_input(f"mc.st.{B}", (B, 32))
+    ref = M.modulated_conv2d(x, sd["weight"], M.equal_linear(st, sd["modulation.weight"], sd["modulation.bias"]), demodulate)
+    with torch.no_grad():
+        y = m.to(dev)(x.to(dev), st.to(dev))
+    assert rel_l2(y, ref) < 2e-5
+
+
+def test_styled_conv_and_to_rgb(sg2, dev):
+    B, Cin, Cout, H = 2, 32, 24, 8
+    for upsample in (False, True):
+        m = sg2.StyledConv(Cin, Cout, 3, 32, upsample=upsample)
+        with torch.no_grad():
+            m.noise.weight.fill_(0.37)
+            m.activate.bias.copy_(recipe_tensor("sc.act.bias", (Cout,), 0.3))
+        sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+        x, st = recipe_input("sc.x", (B, Cin, H, H)), recipe_input("sc.st", (B, 32))
+        Ho = 2 * H if upsample else H
+        nz = recipe_input(f"sc.nz.{Ho}", (B, 1, Ho, Ho))
+        ref = M.styled_conv(x, st, sd, "", nz, upsample)
+        with torch.no_grad():
+            y = m.to(dev)(x.to(dev), st.to(dev), nz.to(dev))
+        assert rel_l2(y, ref) < 2e-5, upsample
+    rgb = sg2.ToRGB(Cin, 32)
+    with torch.no_grad():
+        rgb.bias.copy_(recipe_tensor("rgb.bias", (1, 3, 1, 1), 0.3))
+    sd = {k: v.detach().clone() for k, v in rgb.state_dict().items()}
+    x, st, skip = recipe_input("rgb.x", (B, Cin, 16, 16)), recipe_input("rgb.st", (B, 32)), recipe_input("rgb.skip", (B, 3, 8, 8))
+    ref = M.to_rgb(x, st, sd, "", skip)
+    with torch.no_grad():
+        y = rgb.to(dev)(x.to(dev), st.to(dev), skip.to(dev))
+    assert rel_l2(y, ref) < 2e-5
+
+
+@pytest.mark.parametrize("B,res", [(2, 256), (1, 64)])
+def test_variant_generator_vs_oracle(sg2, dev, B, res):
+    torch.manual_seed(5)
+    g = sg2.StyleGAN2Generator(6144, resolution=res).eval()
+    with torch.no_grad():
+        for n, p in g.named_parameters():
+            if n.endswith("noise.weight"):
+                p.fill_(0.1)
+            elif n.endswith("activate.bias") or (n.endswith("bias") and "to_rgb" in n and "modulation" not in n):
+                p.normal_(0, 0.1)
+    sd = {k: v.detach().clone() for k, v in g.state_dict().items()}
+    feats = recipe_input(f"sg2.f.{B}", (B, 6144))
+    noises = [recipe_input(f"sg2.n{i}.{B}.{res}", s) for i, s in enumerate(M.noise_shapes(B, res))]
+    with torch.no_grad():
+        ref = M.generator(feats, sd, noises, resolution=res)
+        y = g.to(dev)(feats.to(dev), [n.to(dev) for n in noises])
+        y2 = g(feats.to(dev))                       # device-drawn noise path
+    assert y.shape == (B, 3, res, res) and torch.isfinite(y2).all()
+    assert rel_l2(y, ref) < 2e-4
+    with pytest.raises(NotImplementedError):
+        g(feats.to(dev))                            # grad mode
