@@ -147,6 +147,23 @@ def main():
         n_launch = len(pkg.ops.CONV_EVENTS) // prof_steps
         pkg.ops.CONV_EVENTS = None
 
+        # ---- the build-defined StyleGAN2 variant (modulated conv + upfirdn2d, A11) on the same workload ----
+        sg2 = importlib.import_module("speak-hack_amd.stylegan2")
+        gen2 = sg2.StyleGAN2Generator(6144).eval().to(dev)
+        for n, p in gen2.named_parameters():
+            if n.endswith("noise.weight"):
+                p.fill_(0.1)
+        for _ in range(max(2, args.warmup // 2)):
+            gen2(feats)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        sg2_steps = max(5, args.steps // 2)
+        for _ in range(sg2_steps):
+            gen2(feats)
+        torch.cuda.synchronize()
+        sg2_ms = (time.perf_counter() - t1) / sg2_steps * 1e3
+        del gen2
+
     if rank == 0:
         traffic = None
         try:   # HBM bytes per conv launch from the committed PMC pass of this same command
@@ -176,6 +193,9 @@ def main():
                          "conv_share_of_step": round(conv_ms / ms_per_step, 3),
                          "algorithmic_gflop_per_step": round(flops / 1e9, 2)},
         }
+        line["stylegan2_variant"] = {"what": "speak-hack_amd.stylegan2.StyleGAN2Generator (modulated 3x3 conv + demod, upfirdn2d "
+                                             "[1,3,3,1], skip toRGB; same channel schedule; parity unpinned by the reference)",
+                                     "frames_per_s_per_gpu": round(BATCH / sg2_ms * 1e3, 2), "ms_per_step": round(sg2_ms, 4)}
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(host_cores())
         print(json.dumps(line), flush=True)

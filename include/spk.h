@@ -40,7 +40,10 @@ extern "C" {
 #define SPK_EPI_ACCUM  32u           /* y += result */
 #define SPK_EPI_STATS  64u           /* stats[0:Cout] += sum_bhw y, stats[Cout:2Cout] += sum_bhw y^2 (fp64) */
 #define SPK_CONV_IN_AFFINE_RELU 128u /* x' = max(x*in_scale[ci] + in_shift[ci], 0) applied while staging */
-#define SPK_CONV_IN_BATCH_SCALE 256u /* x' = x * in_scale[b*Cin + ci] applied while staging (weight modulation) */
+#define SPK_CONV_IN_BATCH_SCALE 256u /* x' = x * in_scale[b*Cin + ci] applied while staging (weight modulation); may be
+                                      * combined with SPK_CONV_UPSAMPLE2X (configs 4-7) */
+#define SPK_CONV_UP_FIR1331 512u     /* with UPSAMPLE2X: the x2 interpolation is upfirdn2d(up=2, FIR [1,3,3,1], pad (2,1)) --
+                                      * the same (.75,.25) taps as bilinear, but neighbours outside the image are zero */
 
 const char* spk_version(void);
 const char* spk_last_error(void);

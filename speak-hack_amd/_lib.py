@@ -35,6 +35,7 @@ class Conv2dDesc(C.Structure):
 
 
 CONV_IN_BATCH_SCALE = 256
+CONV_UP_FIR1331 = 512
 
 
 class WgradDesc(C.Structure):

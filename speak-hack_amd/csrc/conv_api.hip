@@ -213,7 +213,8 @@ int spk_conv2d_fwd(const spk_conv2d_desc* d, void* stream) {
     SPK_REQUIRE(supported_kernel(d->kh, d->kw, d->stride), "conv2d: unsupported kernel %dx%d stride %d", d->kh, d->kw, d->stride);
     const bool ups = d->flags & SPK_CONV_UPSAMPLE2X, aff = d->flags & SPK_CONV_IN_AFFINE_RELU;
     const bool bsc = d->flags & SPK_CONV_IN_BATCH_SCALE;
-    SPK_REQUIRE((int)ups + (int)aff + (int)bsc <= 1, "conv2d: UPSAMPLE2X, IN_AFFINE_RELU and IN_BATCH_SCALE are exclusive");
+    SPK_REQUIRE(!aff || (!ups && !bsc), "conv2d: IN_AFFINE_RELU excludes UPSAMPLE2X and IN_BATCH_SCALE");
+    SPK_REQUIRE(!(d->flags & SPK_CONV_UP_FIR1331) || ups, "conv2d: UP_FIR1331 qualifies UPSAMPLE2X");
     SPK_REQUIRE(!bsc || (d->in_scale && d->kh == 3 && d->stride == 1), "conv2d: IN_BATCH_SCALE needs in_scale[B,Cin] and a 3x3 stride-1 kernel");
     SPK_REQUIRE(!ups || (d->kh == 3 && d->stride == 1), "conv2d: UPSAMPLE2X needs a 3x3 stride-1 kernel");
     const int pad = (d->kh - 1) / 2;
@@ -232,7 +233,7 @@ int spk_conv2d_fwd(const spk_conv2d_desc* d, void* stream) {
     SPK_REQUIRE(config_valid(cfg, d->kh, d->kw, d->stride), "conv2d: config %d is not built for %dx%d stride %d", cfg, d->kh, d->kw, d->stride);
     spk_conv2d_desc dd = *d;
     dd.config = cfg;
-    const int mode = ups ? MODE_UPSAMPLE : (aff ? MODE_AFFINE_RELU : (bsc ? MODE_BATCH_SCALE : MODE_PLAIN));
+    const int mode = ups ? (bsc ? MODE_UPSAMPLE_BATCH_SCALE : MODE_UPSAMPLE) : (aff ? MODE_AFFINE_RELU : (bsc ? MODE_BATCH_SCALE : MODE_PLAIN));
     hipStream_t s = (hipStream_t)stream;
     if (d->kh == 1) return run_1x1(d->stride, cfg, mode, &dd, s);
     if (d->kh == 3 && d->stride == 1) return cfg <= 3 ? run_3x3s1_a(cfg, mode, &dd, s) : run_3x3s1_b(cfg, mode, &dd, s);

@@ -9,6 +9,7 @@ static int by_mode(int mode, const spk_conv2d_desc* d, hipStream_t s) {
         case MODE_PLAIN: return run<C, 3, 3, 1, MODE_PLAIN>(d, s);
         case MODE_UPSAMPLE: return run<C, 3, 3, 1, MODE_UPSAMPLE>(d, s);
         case MODE_BATCH_SCALE: return run<C, 3, 3, 1, MODE_BATCH_SCALE>(d, s);
+        case MODE_UPSAMPLE_BATCH_SCALE: return run<C, 3, 3, 1, MODE_UPSAMPLE_BATCH_SCALE>(d, s);
         default: return run<C, 3, 3, 1, MODE_AFFINE_RELU>(d, s);
     }
 }

@@ -34,7 +34,7 @@ namespace spkconv {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-enum Mode { MODE_PLAIN = 0, MODE_UPSAMPLE = 1, MODE_AFFINE_RELU = 2, MODE_BATCH_SCALE = 3 };
+enum Mode { MODE_PLAIN = 0, MODE_UPSAMPLE = 1, MODE_AFFINE_RELU = 2, MODE_BATCH_SCALE = 3, MODE_UPSAMPLE_BATCH_SCALE = 4 };
 
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -95,16 +95,18 @@ constexpr unsigned D_VALID = 1u;        // element is inside the image (else: ze
 constexpr unsigned D_CI_SHIFT = 1;      // 6 bits: ci within the chunk
 constexpr unsigned D_DX = 1u << 7;      // bilinear: second tap is one column to the right
 constexpr unsigned D_DY = 1u << 8;      // bilinear: second row is one source row below
-constexpr unsigned D_LX_SHIFT = 9;      // 2 bits: lambda code (0: 0, 1: 0.25, 2: 0.75)
+constexpr unsigned D_LX_SHIFT = 9;      // 2 bits: tap-weight code (w0,w1): 0 (1,0); 1 (.75,.25); 2 (.25,.75); 3 (.75,0)
 constexpr unsigned D_LY_SHIFT = 11;
 constexpr unsigned D_TB_SHIFT = 13;     // 7 bits: image within the tile's image group (MODE_BATCH_SCALE)
 
-__device__ __forceinline__ float lambda_of(unsigned code) { return code == 0 ? 0.f : (code == 1 ? 0.25f : 0.75f); }
+__device__ __forceinline__ float w1_of(unsigned code) { return code == 1 ? 0.25f : (code == 2 ? 0.75f : 0.f); }
+__device__ __forceinline__ float w0_of(unsigned code) { return code == 0 ? 1.f : (code == 2 ? 0.25f : 0.75f); }
 
 template <class C, int KH, int KW, int S, int MODE>
 __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
     using SH = Shape<C, KH, KW, S>;
-    constexpr bool UPS = MODE == MODE_UPSAMPLE, AFF = MODE == MODE_AFFINE_RELU, BSC = MODE == MODE_BATCH_SCALE;
+    constexpr bool UPS = MODE == MODE_UPSAMPLE || MODE == MODE_UPSAMPLE_BATCH_SCALE, AFF = MODE == MODE_AFFINE_RELU;
+    constexpr bool BSC = MODE == MODE_BATCH_SCALE || MODE == MODE_UPSAMPLE_BATCH_SCALE;
     constexpr int NSLOT = SH::NSLOT, W_FLOATS = SH::W_FLOATS, WV = SH::WV, PAD = SH::PAD;
     static_assert(!UPS || S == 1, "upsample folding needs stride 1");
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -157,11 +159,14 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
                 } else {
                     // torch area_pixel_compute_source_index(scale=0.5, align_corners=False):
                     // src = max(0.5*(dst+0.5)-0.5, 0); lambdas are exactly 0, 0.25 or 0.75
+                    // SPK_CONV_UP_FIR1331: the same two taps, but a neighbour outside the image counts as zero
+                    // (upfirdn2d, up = 2, FIR [1,3,3,1], pad (2,1)) instead of being clamped.
+                    const bool zb = p.flags & SPK_CONV_UP_FIR1331;
                     const int iy0 = uy == 0 ? 0 : (uy - 1) >> 1, ix0 = ux == 0 ? 0 : (ux - 1) >> 1;
-                    const unsigned ly = uy == 0 ? 0u : ((uy & 1) ? 1u : 2u);
-                    const unsigned lx = ux == 0 ? 0u : ((ux & 1) ? 1u : 2u);
-                    if (iy0 + 1 < p.Hs) d |= D_DY;
-                    if (ix0 + 1 < p.Ws) d |= D_DX;
+                    unsigned ly = uy == 0 ? (zb ? 3u : 0u) : ((uy & 1) ? 1u : 2u);
+                    unsigned lx = ux == 0 ? (zb ? 3u : 0u) : ((ux & 1) ? 1u : 2u);
+                    if (iy0 + 1 < p.Hs) d |= D_DY; else if (zb) ly = 3u;
+                    if (ix0 + 1 < p.Ws) d |= D_DX; else if (zb) lx = 3u;
                     d |= (lx << D_LX_SHIFT) | (ly << D_LY_SHIFT);
                     goff = iy0 * p.Ws + ix0;
                 }
@@ -260,8 +265,8 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
                 if (!UPS) {                                                                                   \
                     v = xin[s];                                                                               \
                 } else {                                                                                      \
-                    const float lx1 = lambda_of((d >> D_LX_SHIFT) & 3u), ly1 = lambda_of((d >> D_LY_SHIFT) & 3u); \
-                    const float lx0 = 1.f - lx1, ly0 = 1.f - ly1;                                             \
+                    const float lx1 = w1_of((d >> D_LX_SHIFT) & 3u), ly1 = w1_of((d >> D_LY_SHIFT) & 3u);     \
+                    const float lx0 = w0_of((d >> D_LX_SHIFT) & 3u), ly0 = w0_of((d >> D_LY_SHIFT) & 3u);     \
                     v = ly0 * (lx0 * xin[4 * s] + lx1 * xin[4 * s + 1]) +                                     \
                         ly1 * (lx0 * xin[4 * s + 2] + lx1 * xin[4 * s + 3]);                                  \
                 }                                                                                             \

@@ -31,6 +31,20 @@ __device__ __forceinline__ float lg_block_sum(float v, float* red) {
     return red[0] + red[1] + red[2] + red[3];
 }
 
+// few pixels, many channels (the mapping network's [B,6144] latent): one workgroup per pixel, channels across the lanes
+__global__ __launch_bounds__(256) void pixelnorm_wide_kernel(const float* __restrict__ x, float* __restrict__ y, int C, long long HW,
+                                                            float eps, int mode) {
+    __shared__ float red[4];
+    const long long b = blockIdx.x / HW, p = blockIdx.x % HW;
+    const float* xp = x + b * C * HW + p;
+    float* yp = y + b * C * HW + p;
+    float s = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) { const float v = xp[(size_t)c * HW]; s += v * v; }
+    const float m = lg_block_sum(s, red) / (float)C + eps;
+    const float f = mode == 0 ? rsqrtf(m) : 1.f / sqrtf(m);
+    for (int c = threadIdx.x; c < C; c += 256) yp[(size_t)c * HW] = xp[(size_t)c * HW] * f;
+}
+
 // one workgroup per (b,c) plane: mean, biased variance (two-pass), y = (x-mean)*rsqrt(var+eps)*scale[b,c] + bias[b,c]
 __global__ __launch_bounds__(256) void instance_norm_affine_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                                   const float* __restrict__ scale, const float* __restrict__ bias,
@@ -100,6 +114,11 @@ extern "C" {
 
 int spk_pixelnorm_fwd(const float* x, float* y, int B, int C, int64_t HW, float eps, int sqrt_form, void* stream) {
     SPK_REQUIRE(x && y && B > 0 && C > 0 && HW > 0, "pixelnorm: bad arguments");
+    if ((long long)B * HW <= 4096 && C >= 256) {
+        hipLaunchKernelGGL(pixelnorm_wide_kernel, dim3((unsigned)(B * HW)), dim3(256), 0, (hipStream_t)stream, x, y, C, (long long)HW,
+                           eps, sqrt_form ? 1 : 0);
+        return spk::check_launch("pixelnorm_wide_kernel");
+    }
     hipLaunchKernelGGL(pixelnorm_kernel, dim3(sgrid((long long)B * HW)), dim3(256), 0, (hipStream_t)stream, x, y, C, (long long)HW,
                        (long long)B * HW, eps, sqrt_form ? 1 : 0);
     return spk::check_launch("pixelnorm_kernel");

@@ -34,11 +34,12 @@ __global__ __launch_bounds__(256) void bias_noise_style_kernel(const float* __re
 template <bool VEC>
 __global__ __launch_bounds__(256) void conv1x1_small_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ bias, float* __restrict__ y, int C,
-                                                           int O, long long HW, float in_scale) {
-    extern __shared__ float w_s[];  // [O][C]
-    for (int i = threadIdx.x; i < O * C; i += blockDim.x) w_s[i] = w[i] * in_scale;
-    __syncthreads();
+                                                           int O, long long HW, float in_scale,
+                                                           const float* __restrict__ mod) {
+    extern __shared__ float w_s[];  // [O][C]; with ``mod`` [B,C] the weight is modulated per image (StyleGAN2 toRGB)
     const int b = blockIdx.y;
+    for (int i = threadIdx.x; i < O * C; i += blockDim.x) w_s[i] = w[i] * in_scale * (mod ? mod[(size_t)b * C + (i % C)] : 1.f);
+    __syncthreads();
     const float* xb = x + (size_t)b * C * HW;
     float* yb = y + (size_t)b * O * HW;
     if (VEC) {
@@ -141,8 +142,8 @@ int spk_bias_noise_style_fwd(const float* x, int64_t x_batch_stride, const float
     return spk::check_launch("bias_noise_style_kernel");
 }
 
-int spk_conv1x1_small_fwd(const float* x, const float* w, const float* bias, float* y, int B, int C, int O, int64_t HW,
-                          float in_scale, void* stream) {
+static int conv1x1_small_launch(const float* x, const float* w, const float* mod, const float* bias, float* y, int B, int C, int O,
+                                int64_t HW, float in_scale, void* stream) {
     SPK_REQUIRE(x && w && y, "conv1x1_small: null pointer");
     SPK_REQUIRE(B > 0 && C > 0 && O > 0 && O <= 4 && HW > 0, "conv1x1_small: bad shape (O must be <= 4)");
     SPK_REQUIRE((size_t)O * C * sizeof(float) <= 48 * 1024, "conv1x1_small: weight too large for LDS");
@@ -151,13 +152,24 @@ int spk_conv1x1_small_fwd(const float* x, const float* w, const float* bias, flo
     if (vec) {
         dim3 grid(stream_grid(HW / 4, 256), (unsigned)B);
         hipLaunchKernelGGL(conv1x1_small_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, x, w, bias, y, C, O,
-                           (long long)HW, in_scale);
+                           (long long)HW, in_scale, mod);
     } else {
         dim3 grid(stream_grid(HW, 256), (unsigned)B);
         hipLaunchKernelGGL(conv1x1_small_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, x, w, bias, y, C, O,
-                           (long long)HW, in_scale);
+                           (long long)HW, in_scale, mod);
     }
     return spk::check_launch("conv1x1_small_kernel");
+}
+
+int spk_conv1x1_small_fwd(const float* x, const float* w, const float* bias, float* y, int B, int C, int O, int64_t HW,
+                          float in_scale, void* stream) {
+    return conv1x1_small_launch(x, w, nullptr, bias, y, B, C, O, HW, in_scale, stream);
+}
+
+int spk_conv1x1_small_mod_fwd(const float* x, const float* w, const float* mod, const float* bias, float* y, int B, int C, int O,
+                              int64_t HW, float in_scale, void* stream) {
+    SPK_REQUIRE(mod, "conv1x1_small_mod: null modulation");
+    return conv1x1_small_launch(x, w, mod, bias, y, B, C, O, HW, in_scale, stream);
 }
 
 int spk_upsample2x_bilinear_fwd(const float* x, float* y, int64_t planes, int Hin, int Win, void* stream) {

@@ -59,33 +59,6 @@ __global__ __launch_bounds__(256) void upfirdn2d_kernel(const float* __restrict_
     }
 }
 
-// 1x1 conv with O <= 4 outputs and per-(b,c) modulation of the weight
-__global__ __launch_bounds__(256) void conv1x1_small_mod_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                               const float* __restrict__ mod, const float* __restrict__ bias,
-                                                               float* __restrict__ y, int C, int O, long long HW, float in_scale) {
-    extern __shared__ float w_s[];  // [O][C], already modulated for this image
-    const int b = blockIdx.y;
-    for (int i = threadIdx.x; i < O * C; i += blockDim.x) w_s[i] = w[i] * in_scale * mod[(size_t)b * C + (i % C)];
-    __syncthreads();
-    const float* xb = x + (size_t)b * C * HW;
-    float* yb = y + (size_t)b * O * HW;
-    for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < HW; p += (long long)gridDim.x * blockDim.x) {
-        float acc[4];
-#pragma unroll
-        for (int o = 0; o < 4; ++o) acc[o] = (bias && o < O) ? bias[o] : 0.f;
-#pragma unroll 8
-        for (int c = 0; c < C; ++c) {
-            const float xv = xb[(size_t)c * HW + p];
-#pragma unroll
-            for (int o = 0; o < 4; ++o)
-                if (o < O) acc[o] += w_s[o * C + c] * xv;
-        }
-#pragma unroll
-        for (int o = 0; o < 4; ++o)
-            if (o < O) yb[(size_t)o * HW + p] = acc[o];
-    }
-}
-
 inline unsigned sgrid2(long long n) { return (unsigned)std::max(1ll, std::min((n + 255) / 256, 256ll * 16)); }
 
 }  // namespace
@@ -112,17 +85,6 @@ int spk_upfirdn2d_fwd(const float* x, float* y, const float* filter_host, int k,
     hipLaunchKernelGGL(upfirdn2d_kernel, dim3(sgrid2((long long)planes * Ho * Wo)), dim3(256), 0, (hipStream_t)stream, x, y, fir,
                        (long long)planes, H, W, Ho, Wo, up, down, pad0, gain);
     return spk::check_launch("upfirdn2d_kernel");
-}
-
-int spk_conv1x1_small_mod_fwd(const float* x, const float* w, const float* mod, const float* bias, float* y, int B, int C, int O,
-                              int64_t HW, float in_scale, void* stream) {
-    SPK_REQUIRE(x && w && mod && y, "conv1x1_small_mod: null pointer");
-    SPK_REQUIRE(B > 0 && C > 0 && O > 0 && O <= 4 && HW > 0, "conv1x1_small_mod: bad shape (O must be <= 4)");
-    SPK_REQUIRE((size_t)O * C * sizeof(float) <= 48 * 1024, "conv1x1_small_mod: weight too large for LDS");
-    dim3 grid(sgrid2(HW) > 64 ? 64 : sgrid2(HW), (unsigned)B);
-    hipLaunchKernelGGL(conv1x1_small_mod_kernel, grid, dim3(256), (size_t)O * C * sizeof(float), (hipStream_t)stream, x, w, mod, bias,
-                       y, C, O, (long long)HW, in_scale);
-    return spk::check_launch("conv1x1_small_mod_kernel");
 }
 
 }  // extern "C"

@@ -89,7 +89,7 @@ def conv_out_size(n, k, stride):
 def conv2d_fused(x, w_packed, Cout: int, k: int = 3, stride: int = 1, *, bias=None, noise_w=None, noise=None,
                  style=None, style_stride=None, upsample=False, lrelu_slope=None, out_scale=1.0, in_affine=None,
                  stats=None, config=-1, ksplit=0, out=None, accumulate=False, out_pre=None, batch_scale=None, demod=None,
-                 act_gain=1.0):
+                 act_gain=1.0, up_fir=False):
     """y = style(lrelu(conv_kxk(in(x)) * out_scale + bias + noise_w*noise)) -- one launch.
 
     ``in``: identity; or bilinear x2 (``upsample``; x is [B,Cin,H/2,W/2]); or ``max(x*a+b, 0)`` per
@@ -118,14 +118,14 @@ def conv2d_fused(x, w_packed, Cout: int, k: int = 3, stride: int = 1, *, bias=No
             style_stride = style.stride(0) if style.dim() == 2 else 2 * Cout
         flags |= L.EPI_STYLE
     if upsample:
-        flags |= L.CONV_UPSAMPLE2X
+        flags |= L.CONV_UPSAMPLE2X | (L.CONV_UP_FIR1331 if up_fir else 0)
     if accumulate:
         flags |= L.EPI_ACCUM
     if in_affine is not None:
         flags |= L.CONV_IN_AFFINE_RELU
     if batch_scale is not None:          # modulated convolution: s[B,Cin] applied to the input while staging
-        if tuple(batch_scale.shape) != (B, Cin) or in_affine is not None or upsample:
-            raise L.SpkError("conv2d_fused: batch_scale must be [B,Cin] and excludes in_affine / upsample")
+        if tuple(batch_scale.shape) != (B, Cin) or in_affine is not None:
+            raise L.SpkError("conv2d_fused: batch_scale must be [B,Cin] and excludes in_affine")
         flags |= L.CONV_IN_BATCH_SCALE
     if demod is not None and tuple(demod.shape) != (B, Cout):
         raise L.SpkError("conv2d_fused: demod must be [B,Cout]")

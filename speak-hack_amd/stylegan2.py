@@ -63,7 +63,7 @@ class ModulatedConv2d(nn.Module):
         self.modulation = EqualLinear(style_dim, in_channel, bias_init=1.0)
         self._pk = ops.PackedConvWeight()
 
-    def forward(self, x, style, bias=None, noise_w=None, noise=None, lrelu=None, act_gain=1.0):
+    def forward(self, x, style, bias=None, noise_w=None, noise=None, lrelu=None, act_gain=1.0, upsample=False):
         s = self.modulation(style)
         if self.kernel_size == 1 and self.out_channel <= 4 and not self.demodulate:
             return ops.conv1x1_small_mod(x.contiguous(), self.weight, s, bias, in_scale=self.scale)
@@ -71,10 +71,13 @@ class ModulatedConv2d(nn.Module):
             raise NotImplementedError("ModulatedConv2d: 3x3 (styled convs) and 1x1 toRGB are on the HIP path")
         d = ops.modconv_demod(self.weight, s, self.scale) if self.demodulate else None
         B, Cin, H, W = x.shape
+        if upsample:            # upfirdn2d(up=2, [1,3,3,1]) folded into the conv's input staging: no 4x tensor in HBM
+            H, W = 2 * H, 2 * W
         cfg = ops.conv2d_pick_config(3, 1, B, Cin, self.out_channel, H, W)
+        cfg = cfg + 4 if cfg < 4 else cfg
         return ops.conv2d_fused(x.contiguous(), self._pk.get(self.weight, cfg), self.out_channel, 3, 1, bias=bias, noise_w=noise_w,
                                 noise=noise, lrelu_slope=lrelu, out_scale=self.scale, batch_scale=s, demod=d, act_gain=act_gain,
-                                config=cfg)
+                                config=cfg, upsample=upsample, up_fir=True)
 
 
 class NoiseInjection(nn.Module):
@@ -92,20 +95,21 @@ class FusedLeakyReLU(nn.Module):
 class StyledConv(nn.Module):
     def __init__(self, in_channel, out_channel, kernel_size, style_dim, upsample=False):
         super().__init__()
-        self.up = Upsample() if upsample else None
+        self.upsample = upsample
         self.conv = ModulatedConv2d(in_channel, out_channel, kernel_size, style_dim)
         self.noise = NoiseInjection()
         self.activate = FusedLeakyReLU(out_channel)
 
     def forward(self, x, style, noise=None):
-        if self.up is not None:
-            x = self.up(x)
         B, _, H, W = x.shape
+        if self.upsample:
+            H, W = 2 * H, 2 * W
         if noise is None:
             noise = torch.randn(B, 1, H, W, device=x.device)
         nw = self.noise.weight.expand(self.conv.out_channel).contiguous()
         # conv*demod + noise_w*noise + bias -> lrelu(0.2) * sqrt2: one launch
-        return self.conv(x, style, bias=self.activate.bias, noise_w=nw, noise=noise.contiguous(), lrelu=0.2, act_gain=SQRT2)
+        return self.conv(x, style, bias=self.activate.bias, noise_w=nw, noise=noise.contiguous(), lrelu=0.2, act_gain=SQRT2,
+                         upsample=self.upsample)
 
 
 class ToRGB(nn.Module):

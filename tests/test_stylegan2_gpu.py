@@ -65,6 +65,26 @@ def test_modulated_conv3x3(sg2, dev, B, Cin, Cout, H, demodulate):
     assert rel_l2(y, ref) < 2e-5
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 16, 24, 8, 8), (1, 6, 10, 5, 7), (3, 64, 32, 16, 16), (9, 12, 8, 3, 4), (8, 128, 64, 32, 32)])
+def test_modulated_conv_fused_upfirdn(sg2, dev, B, Cin, Cout, H, W):
+    """upfirdn2d(up=2, [1,3,3,1]) folded into the modulated conv's input staging (SPK_CONV_UP_FIR1331) vs
+    the oracle's materialised Upsample -> modulated conv; ragged channels, odd / non-square sizes."""
+    m = sg2.ModulatedConv2d(Cin, Cout, 3, 32)
+    with torch.no_grad():
+        m.weight.copy_(recipe_tensor(f"mcu.{Cin}.{Cout}.weight", m.weight.shape, 1.0))
+        m.modulation.weight.copy_(recipe_tensor(f"mcu.{Cin}.mod.weight", m.modulation.weight.shape, 1.0))
+        m.modulation.bias.copy_(1.0 + recipe_tensor(f"mcu.{Cin}.mod.bias", m.modulation.bias.shape, 0.2))
+    sd = {k: v.detach().clone() for k, v in m.state_dict().items()}
+    x = recipe_input(f"mcu.x.{B}.{Cin}.{H}.{W}", (B, Cin, H, W))
+    st = recipe_input(f"mcu.st.{B}", (B, 32))
+    s = M.equal_linear(st, sd["modulation.weight"], sd["modulation.bias"])
+    ref = M.modulated_conv2d(M.upsample2x(x), sd["weight"], s, True)
+    with torch.no_grad():
+        y = m.to(dev)(x.to(dev), st.to(dev), upsample=True)
+    assert y.shape == ref.shape == (B, Cout, 2 * H, 2 * W)
+    assert rel_l2(y, ref) < 2e-5
+
+
 def test_styled_conv_and_to_rgb(sg2, dev):
     B, Cin, Cout, H = 2, 32, 24, 8
     for upsample in (False, True):

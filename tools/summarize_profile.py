@@ -32,7 +32,8 @@ def kernel_stats(path, out):
 
 def kernel_trace(path, out, n_conv=12):
     rows = list(csv.DictReader(open(path)))
-    convs = [r for r in rows if "conv3x3" in r["Kernel_Name"] and "pack" not in r["Kernel_Name"]]
+    convs = [r for r in rows if ("conv_kernel<" in r["Kernel_Name"] or "conv3x3" in r["Kernel_Name"])
+             and "pack" not in r["Kernel_Name"]]
     if not convs:
         return
     out.append(f"## last {n_conv} conv dispatches ({os.path.basename(path)})")
