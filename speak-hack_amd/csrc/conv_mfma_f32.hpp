@@ -29,6 +29,14 @@
 #include <algorithm>
 #include <type_traits>
 
+// lab switches (tools/conv_lab.hip): re-read the same chunk so that every load hits the vector L1
+#ifndef SPK_LAB_WFIX
+#define SPK_LAB_WFIX 0
+#endif
+#ifndef SPK_LAB_XFIX
+#define SPK_LAB_XFIX 0
+#endif
+
 namespace spkconv {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -74,7 +82,7 @@ struct Cfg {
     static constexpr int NW = WM * WN, NTHREADS = NW * 64;
     static constexpr int CO_T = WM * MT * 32, PIX_T = WN * NT * 32;
     // fragment prefetch distance in k-steps: about 256 MFMA cycles of cover for the ds_read latency
-    static constexpr int PD = MT * NT >= 4 ? 1 : (MT * NT >= 2 ? 2 : 4);
+    static constexpr int PD = MT * NT >= 4 ? 2 : 4;   // wanted distance; the kernel rounds it up so that PD + 1 divides the step count
 };
 
 // compile-time shape of one (config, kernel size, stride) instantiation
@@ -99,6 +107,13 @@ constexpr unsigned D_LX_SHIFT = 9;      // 2 bits: tap-weight code (w0,w1): 0 (1
 constexpr unsigned D_LY_SHIFT = 11;
 constexpr unsigned D_TB_SHIFT = 13;     // 7 bits: image within the tile's image group (MODE_BATCH_SCALE)
 
+// smallest prefetch distance >= want whose ring size divides the number of k-steps of a chunk
+constexpr int pick_pd(int want, int steps) {
+    for (int pd = want; pd < steps; ++pd)
+        if (steps % (pd + 1) == 0) return pd;
+    return steps - 1;
+}
+
 __device__ __forceinline__ float w1_of(unsigned code) { return code == 1 ? 0.25f : (code == 2 ? 0.75f : 0.f); }
 __device__ __forceinline__ float w0_of(unsigned code) { return code == 0 ? 1.f : (code == 2 ? 0.25f : 0.75f); }
 
@@ -120,7 +135,7 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
     const int TW = 1 << p.lgTW, TH = 1 << p.lgTH, TB = 1 << p.lgTB;
     const int PW = (TW - 1) * S + KW, PLANE = ((TH - 1) * S + KH) * PW;
     const int IN_FLOATS = C::CI_T * TB * PLANE;
-    const int BUF_FLOATS = W_FLOATS + ((IN_FLOATS + 3) & ~3);
+    const int BUF_FLOATS = W_FLOATS + ((IN_FLOATS + 3) & ~3) + 4;  // +4: dump slot for lanes without an element
     int bx = blockIdx.x;
     const int tx = bx % p.tiles_x;
     bx /= p.tiles_x;
@@ -201,140 +216,219 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
 
     const f32x4* wsrc = reinterpret_cast<const f32x4*>(p.wp) + ((size_t)blockIdx.y * p.n_chunks + c_begin) * (W_FLOATS / 4);
 
-    // prefetch registers
+    // prefetch registers: the global loads of one chunk (weights: WV 16-B vectors; input: NSLOT gather slots)
     f32x4 wreg[WV];
     float xin[UPS ? 4 * NSLOT : NSLOT];
     float xsc[(AFF || BSC) ? NSLOT : 1], xsh[AFF ? NSLOT : 1];
 
-    // staging is written as macros (not lambdas / functions) so that the prefetch arrays stay in
-    // registers: every index is a compile-time constant after unrolling.
-#define SPK_ISSUE_LOADS(chunk_)                                                                               \
+    // Staging is written as macros over compile-time piece indices (not lambdas / functions over arrays) so that the
+    // prefetch arrays stay in registers.  Every piece is branch-free: surplus weight lanes re-load / re-store the
+    // last vector, lanes without an input element read a valid address and write the buffer's dump slot.  The chunk
+    // loop body is therefore a single basic block and the pieces can be placed between individual MFMAs.
+#define SPK_LOAD_W(chunk_, i_)                                                                                \
     {                                                                                                         \
-        _Pragma("unroll") for (int i = 0; i < WV; ++i) {                                                      \
-            const int idx = tid + i * C::NTHREADS;                                                            \
-            if (W_FLOATS / 4 % C::NTHREADS == 0 || idx < W_FLOATS / 4) wreg[i] = wsrc[idx];                   \
-        }                                                                                                     \
-        wsrc += W_FLOATS / 4;                                                                                 \
-        const float* xc = xblk + (size_t)(chunk_) * C::CI_T * src_plane;                                      \
+        const int idx = tid + (i_) * C::NTHREADS;                                                             \
+        wreg[i_] = (wsrc + (size_t)(SPK_LAB_WFIX ? 0 : (chunk_) - c_begin) * (W_FLOATS / 4))                  \
+            [W_FLOATS / 4 % C::NTHREADS == 0 ? idx : min(idx, W_FLOATS / 4 - 1)];                             \
+    }
+#define SPK_LOAD_X(chunk_, s_)                                                                                \
+    {                                                                                                         \
+        /* loads from always-valid addresses; masking happens at LDS-store time.  Channels past Cin            \
+           (zero-padded last chunk) are folded onto channel 0 of the chunk. */                                \
+        const float* xc = xblk + (size_t)(SPK_LAB_XFIX ? 0 : (chunk_)) * C::CI_T * src_plane;                 \
         const int ci_left_ = p.Cin - (chunk_) * C::CI_T;                                                      \
-        _Pragma("unroll") for (int s = 0; s < NSLOT; ++s) {                                                   \
-            /* unconditional loads from always-valid addresses; masking happens at LDS-store time.            \
-               Channels past Cin (zero-padded last chunk) are folded onto channel 0 of the chunk. */          \
-            const unsigned d = s_desc[s];                                                                     \
-            const int ci_ = (int)((d >> D_CI_SHIFT) & 63u);                                                   \
-            const bool past_ = ci_ >= ci_left_;                                                               \
-            const int off_ = s_off[s] - (past_ ? ci_ * (int)src_plane : 0);                                   \
-            if (!UPS) {                                                                                       \
-                xin[s] = xc[off_];                                                                            \
-            } else {                                                                                          \
-                const float* s0 = xc + off_;                                                                  \
-                const int dx = (d & D_DX) ? 1 : 0, dy = (d & D_DY) ? p.Ws : 0;                                \
-                xin[4 * s + 0] = s0[0];                                                                       \
-                xin[4 * s + 1] = s0[dx];                                                                      \
-                xin[4 * s + 2] = s0[dy];                                                                      \
-                xin[4 * s + 3] = s0[dy + dx];                                                                 \
-            }                                                                                                 \
-            if (BSC) { /* modulation s[b,ci]: the per-sample input scale of a modulated convolution */        \
-                const int b_ = min(b0 + (int)((d >> D_TB_SHIFT) & 127u), p.B - 1);                            \
-                xsc[s] = p.in_scale[(size_t)b_ * p.Cin + (chunk_) * C::CI_T + (past_ ? 0 : ci_)];             \
-            }                                                                                                 \
-            if (AFF) {                                                                                        \
-                const int cg_ = (chunk_) * C::CI_T + (past_ ? 0 : ci_);                                       \
-                xsc[s] = p.in_scale[cg_];                                                                     \
-                xsh[s] = p.in_shift[cg_];                                                                     \
-            }                                                                                                 \
+        const unsigned d = s_desc[s_];                                                                        \
+        const int ci_ = (int)((d >> D_CI_SHIFT) & 63u);                                                       \
+        const bool past_ = ci_ >= ci_left_;                                                                   \
+        const int off_ = s_off[s_] - (past_ ? ci_ * (int)src_plane : 0);                                      \
+        if (!UPS) {                                                                                           \
+            xin[s_] = xc[off_];                                                                               \
+        } else {                                                                                              \
+            const float* s0 = xc + off_;                                                                      \
+            const int dx = (d & D_DX) ? 1 : 0, dy = (d & D_DY) ? p.Ws : 0;                                    \
+            xin[4 * (s_) + 0] = s0[0];                                                                        \
+            xin[4 * (s_) + 1] = s0[dx];                                                                       \
+            xin[4 * (s_) + 2] = s0[dy];                                                                       \
+            xin[4 * (s_) + 3] = s0[dy + dx];                                                                  \
+        }                                                                                                     \
+        if (BSC) { /* modulation s[b,ci]: the per-sample input scale of a modulated convolution */            \
+            const int b_ = min(b0 + (int)((d >> D_TB_SHIFT) & 127u), p.B - 1);                                \
+            xsc[s_] = p.in_scale[(size_t)b_ * p.Cin + (chunk_) * C::CI_T + (past_ ? 0 : ci_)];                \
+        }                                                                                                     \
+        if (AFF) {                                                                                            \
+            const int cg_ = (chunk_) * C::CI_T + (past_ ? 0 : ci_);                                           \
+            xsc[s_] = p.in_scale[cg_];                                                                        \
+            xsh[s_] = p.in_shift[cg_];                                                                        \
         }                                                                                                     \
     }
-
-#define SPK_STORE_LDS(buf_, chunk_)                                                                           \
+#define SPK_STORE_W(buf_, i_)                                                                                 \
     {                                                                                                         \
-        float* const sbuf = (buf_);                                                                           \
-        const int ci_left = p.Cin - (chunk_) * C::CI_T; /* channels of this chunk that exist */               \
-        _Pragma("unroll") for (int i = 0; i < WV; ++i) {                                                      \
-            const int idx = tid + i * C::NTHREADS;                                                            \
-            if (W_FLOATS / 4 % C::NTHREADS == 0 || idx < W_FLOATS / 4)                                        \
-                reinterpret_cast<f32x4*>(sbuf)[idx] = wreg[i];                                                \
-        }                                                                                                     \
-        float* dst = sbuf + W_FLOATS + wave * wave_elems;                                                     \
-        _Pragma("unroll") for (int s = 0; s < NSLOT; ++s) {                                                   \
-            const int e = s * 64 + lane;                                                                      \
-            if (e < wave_elems) {                                                                             \
-                float v;                                                                                      \
-                const unsigned d = s_desc[s];                                                                 \
-                const bool ok = (d & D_VALID) && (int)((d >> D_CI_SHIFT) & 63u) < ci_left;                    \
-                if (!UPS) {                                                                                   \
-                    v = xin[s];                                                                               \
-                } else {                                                                                      \
-                    const float lx1 = w1_of((d >> D_LX_SHIFT) & 3u), ly1 = w1_of((d >> D_LY_SHIFT) & 3u);     \
-                    const float lx0 = w0_of((d >> D_LX_SHIFT) & 3u), ly0 = w0_of((d >> D_LY_SHIFT) & 3u);     \
-                    v = ly0 * (lx0 * xin[4 * s] + lx1 * xin[4 * s + 1]) +                                     \
-                        ly1 * (lx0 * xin[4 * s + 2] + lx1 * xin[4 * s + 3]);                                  \
-                }                                                                                             \
-                if (AFF) v = fmaxf(v * xsc[s] + xsh[s], 0.f);                                                 \
-                if (BSC) v *= xsc[s];                                                                         \
-                dst[e] = ok ? v : 0.f;                                                                        \
-            }                                                                                                 \
-        }                                                                                                     \
+        const int idx = tid + (i_) * C::NTHREADS;                                                             \
+        reinterpret_cast<f32x4*>(buf_)[W_FLOATS / 4 % C::NTHREADS == 0 ? idx : min(idx, W_FLOATS / 4 - 1)] = wreg[i_]; \
     }
+#define SPK_STORE_X(buf_, ci_left_, s_)                                                                       \
+    {                                                                                                         \
+        const int e = (s_) * 64 + lane;                                                                       \
+        float v;                                                                                              \
+        const unsigned d = s_desc[s_];                                                                        \
+        const bool ok = (d & D_VALID) && (int)((d >> D_CI_SHIFT) & 63u) < (ci_left_);                         \
+        if (!UPS) {                                                                                           \
+            v = xin[s_];                                                                                      \
+        } else {                                                                                              \
+            const float lx1 = w1_of((d >> D_LX_SHIFT) & 3u), ly1 = w1_of((d >> D_LY_SHIFT) & 3u);             \
+            const float lx0 = w0_of((d >> D_LX_SHIFT) & 3u), ly0 = w0_of((d >> D_LY_SHIFT) & 3u);             \
+            v = ly0 * (lx0 * xin[4 * (s_)] + lx1 * xin[4 * (s_) + 1]) +                                       \
+                ly1 * (lx0 * xin[4 * (s_) + 2] + lx1 * xin[4 * (s_) + 3]);                                    \
+        }                                                                                                     \
+        if (AFF) v = fmaxf(v * xsc[s_] + xsh[s_], 0.f);                                                       \
+        if (BSC) v *= xsc[s_];                                                                                \
+        (buf_)[e < wave_elems ? W_FLOATS + wave * wave_elems + e : BUF_FLOATS - 1] = ok ? v : 0.f;            \
+    }
+    // piece j of a chunk's staging: j < WV -> weight vector j, else gather slot j - WV
+#define SPK_LOAD_PIECE(chunk_, j_)                                                                            \
+    {                                                                                                         \
+        if constexpr ((j_) < WV) { SPK_LOAD_W(chunk_, ((j_) < WV ? (j_) : 0)); }                              \
+        else { SPK_LOAD_X(chunk_, ((j_) < WV ? 0 : (j_) - WV)); }                                             \
+    }
+#define SPK_STORE_PIECE(buf_, ci_left_, j_)                                                                   \
+    {                                                                                                         \
+        if constexpr ((j_) < WV) { SPK_STORE_W(buf_, ((j_) < WV ? (j_) : 0)); }                               \
+        else { SPK_STORE_X(buf_, ci_left_, ((j_) < WV ? 0 : (j_) - WV)); }                                    \
+    }
+    constexpr int PIECES = WV + NSLOT;
+    // VMEM instructions of one load piece (for the scheduling groups)
+    constexpr int X_LOADS = (UPS ? 4 : 1) + (BSC ? 1 : 0) + (AFF ? 2 : 0);
 
-    if (c_begin < c_end) {
-        SPK_ISSUE_LOADS(c_begin);
-        SPK_STORE_LDS(smem, c_begin);
+    // ---- prologue: chunk c_begin -> ring slot 0; chunk c_begin+1 -> registers ----
+    const int n_my = c_end - c_begin;
+    float* ring0 = smem;
+    float* ring1 = smem + BUF_FLOATS;
+    float* ring2 = smem + 2 * BUF_FLOATS;
+    if (n_my > 0) {
+        static_for<0, PIECES>([&](auto j) { SPK_LOAD_PIECE(c_begin, decltype(j)::value); });
+        const int cl0 = p.Cin - c_begin * C::CI_T;
+        static_for<0, PIECES>([&](auto j) { SPK_STORE_PIECE(ring0, cl0, decltype(j)::value); });
+        const int c1 = min(c_begin + 1, c_end - 1);
+        static_for<0, PIECES>([&](auto j) { SPK_LOAD_PIECE(c1, decltype(j)::value); });
     }
     __syncthreads();
 
-    for (int chunk = c_begin; chunk < c_end; ++chunk) {
-        const float* buf = smem + ((chunk - c_begin) & 1) * BUF_FLOATS;
-        const bool more = chunk + 1 < c_end;
-        if (more) SPK_ISSUE_LOADS(chunk + 1);
+    // ---- main loop -------------------------------------------------------------------------------------------
+    // Invariant at the top of chunk i: ring slot i%3 holds chunk i (complete, visible); the prefetch registers hold
+    // chunk i+1; ring slot (i+1)%3 was last read during chunk i-2.  During chunk i, between its MFMAs:
+    //   steps [0, SB)      the registers are stored to slot (i+1)%3                      (ds_write pieces)
+    //   step  SB           s_waitcnt lgkmcnt(0) + s_barrier: slot (i+1)%3 becomes readable; every wave is past chunk i-1
+    //   steps (SB, STEPS)  the global loads of chunk i+2 are issued into the registers   (VMEM pieces)
+    //   last PD steps      the fragment ring already reads chunk i+1 from slot (i+1)%3
+    // so a wave issues MFMAs without interruption from the first chunk to the last: there is no barrier, no load
+    // burst and no LDS-latency bubble at the chunk boundary.  Three slots are what allows the single barrier to sit
+    // in the middle of a chunk.
+    constexpr bool ROWLOOP = KH * KW > 9;
+    constexpr int ROWS = ROWLOOP ? KH : 1;
+    constexpr int STEPS = SH::STEPS / ROWS;
+    constexpr int PD = pick_pd(C::PD, STEPS);          // (PD + 1) divides STEPS: ring indices line up across chunks
+    constexpr int HALF = (STEPS - 1) / 2;              // steps available to each of the store / load phases
+    constexpr int PER = (PIECES + HALF - 1) / HALF;    // pieces per step
+    constexpr int NST = (PIECES + PER - 1) / PER;      // steps that carry pieces
+    constexpr int SB = NST;                            // barrier step (its MFMAs cover the wait)
+    static_assert(ROWLOOP || (SB + NST < STEPS && SB <= STEPS - PD - 1), "staging pieces do not fit the k-steps");
+    float fa[PD + 1][C::MT], fb[PD + 1][C::NT];
 
-        // k-steps: step = (tap, kk).  Fragments are read PD steps ahead of the MFMAs that use them
-        // (register ring, all indices static after unrolling) so LDS latency hides under the MFMAs;
-        // sched_group_barrier pins the ds_read / MFMA interleave the source states.
-        // Large kernels (7x7) keep the tap-row loop rolled: ROWS runtime iterations of KW*CI_T/2 static steps.
-        {
-            constexpr bool ROWLOOP = KH * KW > 9;
-            constexpr int ROWS = ROWLOOP ? KH : 1;
-            constexpr int STEPS = SH::STEPS / ROWS;
-            constexpr int PD = C::PD < STEPS ? C::PD : STEPS - 1;
-            float fa[PD + 1][C::MT], fb[PD + 1][C::NT];
-#pragma unroll 1
-            for (int row = 0; row < ROWS; ++row) {
-                const float* abuf = buf + row * (KW * C::CI_T * C::CO_T);
-                const float* bbuf = buf + row * PW;
-#define SPK_LOAD_FRAG(step_)                                                                                  \
+#define SPK_LOAD_FRAG(abuf_, bbuf_, step_, slot_)                                                             \
     {                                                                                                         \
         constexpr int tap_ = (step_) / (C::CI_T / 2), kk_ = (step_) % (C::CI_T / 2);                          \
         const int tapoff_ = (tap_ / KW) * PW + (tap_ % KW);                                                   \
         _Pragma("unroll") for (int m = 0; m < C::MT; ++m)                                                     \
-            fa[(step_) % (PD + 1)][m] = abuf[a_off + (tap_ * C::CI_T + 2 * kk_) * C::CO_T + m * 32];          \
+            fa[slot_][m] = (abuf_)[a_off + (tap_ * C::CI_T + 2 * kk_) * C::CO_T + m * 32];                    \
         _Pragma("unroll") for (int n = 0; n < C::NT; ++n)                                                     \
-            fb[(step_) % (PD + 1)][n] = bbuf[b_off[n] + kk_ * ci_stride2 + tapoff_];                          \
+            fb[slot_][n] = (bbuf_)[b_off[n] + kk_ * ci_stride2 + tapoff_];                                    \
     }
-                static_for<0, PD>([&](auto i) { SPK_LOAD_FRAG(decltype(i)::value); });
-                static_for<0, STEPS>([&](auto i) {
-                    constexpr int st = decltype(i)::value;
+#define SPK_MFMA_STEP(slot_)                                                                                  \
+    _Pragma("unroll") for (int m = 0; m < C::MT; ++m)                                                         \
+        _Pragma("unroll") for (int n = 0; n < C::NT; ++n)                                                     \
+            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[slot_][m], fb[slot_][n], acc[m][n], 0, 0, 0);
+
+    if constexpr (!ROWLOOP) {
+        if (n_my > 0) static_for<0, PD>([&](auto i) { SPK_LOAD_FRAG(ring0, ring0, decltype(i)::value, decltype(i)::value); });
+    }
+    float *cur = ring0, *nxt = ring1, *oth = ring2;
+#ifdef SPK_LAB_STEPTIME
+    unsigned long long lab_ts[STEPS > 1 ? STEPS : 1];
+#pragma unroll
+    for (int k = 0; k < STEPS; ++k) lab_ts[k] = 0;
+#endif
+    for (int i = 0; i < n_my; ++i) {
+        const int chunk = c_begin + i;
+        const int chunk2 = min(chunk + 2, c_end - 1);
+        const int cl1 = p.Cin - min(chunk + 1, c_end - 1) * C::CI_T;   // channels that exist in the chunk held in registers
+        if constexpr (ROWLOOP) {
+            // large kernels (7x7): the tap rows stay a runtime loop of KW*CI_T/2 static steps; staging is not interleaved
+            static_for<0, PIECES>([&](auto j) { SPK_STORE_PIECE(nxt, cl1, decltype(j)::value); });
+            __syncthreads();
+            static_for<0, PIECES>([&](auto j) { SPK_LOAD_PIECE(chunk2, decltype(j)::value); });
+#pragma unroll 1
+            for (int row = 0; row < ROWS; ++row) {
+                const float* abuf = cur + row * (KW * C::CI_T * C::CO_T);
+                const float* bbuf = cur + row * PW;
+                static_for<0, PD>([&](auto s) { SPK_LOAD_FRAG(abuf, bbuf, decltype(s)::value, decltype(s)::value % (PD + 1)); });
+                static_for<0, STEPS>([&](auto s) {
+                    constexpr int st = decltype(s)::value;
                     if constexpr (st + PD < STEPS) {
-                        SPK_LOAD_FRAG(st + PD);
+                        SPK_LOAD_FRAG(abuf, bbuf, st + PD, (st + PD) % (PD + 1));
                         __builtin_amdgcn_sched_group_barrier(0x100, C::MT + C::NT, 0);
                     }
-#pragma unroll
-                    for (int m = 0; m < C::MT; ++m)
-#pragma unroll
-                        for (int n = 0; n < C::NT; ++n)
-                            acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[st % (PD + 1)][m], fb[st % (PD + 1)][n],
-                                                                            acc[m][n], 0, 0, 0);
+                    SPK_MFMA_STEP(st % (PD + 1));
                     __builtin_amdgcn_sched_group_barrier(0x8, C::MT * C::NT, 0);
                 });
-#undef SPK_LOAD_FRAG
             }
+        } else {
+            static_for<0, STEPS>([&](auto s) {
+                constexpr int st = decltype(s)::value;
+                // fragments PD steps ahead; the last PD steps read the next chunk's slot (readable since step SB)
+                if constexpr (st + PD < STEPS) { SPK_LOAD_FRAG(cur, cur, st + PD, (st + PD) % (PD + 1)); }
+                else { SPK_LOAD_FRAG(nxt, nxt, st + PD - STEPS, (st + PD) % (PD + 1)); }
+                SPK_MFMA_STEP(st % (PD + 1));
+                constexpr int sj = st * PER, lj = (st - SB - 1) * PER;
+                if constexpr (st < NST) {
+                    static_for<sj, (sj + PER < PIECES ? sj + PER : PIECES)>([&](auto j) { SPK_STORE_PIECE(nxt, cl1, decltype(j)::value); });
+                }
+                if constexpr (st > SB && st <= SB + NST) {
+                    static_for<lj, (lj + PER < PIECES ? lj + PER : PIECES)>([&](auto j) { SPK_LOAD_PIECE(chunk2, decltype(j)::value); });
+                }
+                // pin the interleave: one LDS fragment read behind each of the first MFMAs, the staging piece behind the last
+                static_for<0, C::MT * C::NT>([&](auto q) {
+                    __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+                    if constexpr (decltype(q)::value < C::MT + C::NT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                });
+                if constexpr (C::MT * C::NT < C::MT + C::NT) __builtin_amdgcn_sched_group_barrier(0x100, C::MT + C::NT - C::MT * C::NT, 0);
+                if constexpr (st < NST) __builtin_amdgcn_sched_group_barrier(0x200, (sj + PER < PIECES ? PER : PIECES - sj), 0);
+                if constexpr (st > SB && st <= SB + NST) {
+                    constexpr int np = (lj + PER < PIECES ? PER : PIECES - lj);
+                    __builtin_amdgcn_sched_group_barrier(0x20, np * (X_LOADS > 1 ? X_LOADS : 1), 0);
+                }
+                if constexpr (st == SB) __syncthreads();
+#ifdef SPK_LAB_STEPTIME
+                if (i == 10) lab_ts[st] = __builtin_readcyclecounter();
+#endif
+            });
         }
-
-        if (more) SPK_STORE_LDS(smem + (((chunk - c_begin) & 1) ^ 1) * BUF_FLOATS, chunk + 1);
-        __syncthreads();
+        float* t = cur; cur = nxt; nxt = oth; oth = t;
     }
-#undef SPK_ISSUE_LOADS
-#undef SPK_STORE_LDS
+    if constexpr (ROWLOOP) __syncthreads();
+#ifdef SPK_LAB_STEPTIME
+    if (p.stats && lane == 0 && blockIdx.x == 8 && blockIdx.y == 0) {
+#pragma unroll
+        for (int k = 0; k < STEPS; ++k) reinterpret_cast<unsigned long long*>(p.stats)[wave * 64 + k] = lab_ts[k];
+    }
+#endif
+#undef SPK_MFMA_STEP
+#undef SPK_LOAD_FRAG
+#undef SPK_STORE_PIECE
+#undef SPK_LOAD_PIECE
+#undef SPK_STORE_X
+#undef SPK_STORE_W
+#undef SPK_LOAD_X
+#undef SPK_LOAD_W
 
     // ---- epilogue ----
     const bool split = gridDim.z > 1;
@@ -434,7 +528,7 @@ Geometry geometry(int B, int Cin, int Cout, int H, int W) {
     g.n_chunks = spk::ceil_div(Cin, C::CI_T);
     g.co_tiles = spk::ceil_div(Cout, C::CO_T);
     const size_t in_floats = ((size_t)C::CI_T * g.TB * g.PLANE + 3) & ~(size_t)3;
-    g.lds_bytes = 2 * (SH::W_FLOATS + in_floats) * sizeof(float);
+    g.lds_bytes = 3 * (SH::W_FLOATS + in_floats + 4) * sizeof(float);   // three-slot ring
     if (g.lds_bytes > 160 * 1024) g.ok = false;
     return g;
 }

@@ -16,10 +16,13 @@ __global__ __launch_bounds__(256) void mfma_loop(float* out, int iters, float a0
 #pragma unroll
         for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
     float a = a0 + threadIdx.x * 1e-6f, b = b0;
+    const unsigned long long t0 = __builtin_readcyclecounter();
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int i = 0; i < NACC; ++i) acc[i] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[i], 0, 0, 0);
     }
+    const unsigned long long t1 = __builtin_readcyclecounter();
+    if (blockIdx.x == 0 && threadIdx.x == 0) reinterpret_cast<unsigned long long*>(out)[1] = t1 - t0;   // s_memtime ticks of the loop
     float s = 0.f;
 #pragma unroll
     for (int i = 0; i < NACC; ++i)
@@ -46,6 +49,9 @@ static int run(const char* name, int wgs_per_cu, int iters, float* d) {
         if (ms < best) best = ms;
         sum += ms;
     }
+    unsigned long long ticks = 0; CK(hipMemcpy(&ticks, d + 2, 8, hipMemcpyDeviceToHost));
+    printf("   s_memtime: %llu ticks for %d x %d MFMAs of one wave (x%d waves/SIMD) = %.2f ticks/MFMA; tick rate %.0f MHz\n", ticks, iters, NACC,
+           wgs_per_cu, double(ticks) / (double(iters) * NACC), ticks / (sum / reps) / 1e3);
     double flop = double(grid) * 4 /*waves*/ * iters * NACC * (2.0 * 32 * 32 * 2);
     printf("%-28s grid=%5d iters=%7d  best %.3f ms = %7.2f TFLOP/s   mean %.3f ms = %7.2f TFLOP/s  (implied clock %.0f MHz)\n", name, grid,
            iters, best, flop / best / 1e9, sum / reps, flop / (sum / reps) / 1e9,
