@@ -29,14 +29,6 @@
 #include <algorithm>
 #include <type_traits>
 
-// lab switches (tools/conv_lab.hip): re-read the same chunk so that every load hits the vector L1
-#ifndef SPK_LAB_WFIX
-#define SPK_LAB_WFIX 0
-#endif
-#ifndef SPK_LAB_XFIX
-#define SPK_LAB_XFIX 0
-#endif
-
 namespace spkconv {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -93,19 +85,12 @@ struct Shape {
     static constexpr int WV = (W_FLOATS / 4 + C::NTHREADS - 1) / C::NTHREADS;  // 16-B loads per thread per chunk
     static constexpr int STEPS = TAPS * (C::CI_T / 2);
     // largest input plane of a tile (TW = 32): register slots (64 elements each) a wave prefetches
-    static constexpr int PH_MAX = (C::PIX_T / 32 - 1) * S + KH, PW_MAX = 31 * S + KW;
+    // stride of the staged tile in LDS: a 1x1 kernel stages only the pixels it samples, so its tile is dense
+    static constexpr int SL = KH * KW == 1 ? 1 : S;
+    static constexpr int PH_MAX = (C::PIX_T / 32 - 1) * SL + KH, PW_MAX = 31 * SL + KW;
     static constexpr int PPW = C::CI_T / C::NW > 0 ? C::CI_T / C::NW : 1;
     static constexpr int NSLOT = (PPW * PH_MAX * PW_MAX + 63) / 64;
 };
-
-// slot descriptor bits
-constexpr unsigned D_VALID = 1u;        // element is inside the image (else: zero padding)
-constexpr unsigned D_CI_SHIFT = 1;      // 6 bits: ci within the chunk
-constexpr unsigned D_DX = 1u << 7;      // bilinear: second tap is one column to the right
-constexpr unsigned D_DY = 1u << 8;      // bilinear: second row is one source row below
-constexpr unsigned D_LX_SHIFT = 9;      // 2 bits: tap-weight code (w0,w1): 0 (1,0); 1 (.75,.25); 2 (.25,.75); 3 (.75,0)
-constexpr unsigned D_LY_SHIFT = 11;
-constexpr unsigned D_TB_SHIFT = 13;     // 7 bits: image within the tile's image group (MODE_BATCH_SCALE)
 
 // smallest prefetch distance >= want whose ring size divides the number of k-steps of a chunk
 constexpr int pick_pd(int want, int steps) {
@@ -133,7 +118,8 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
     const int wm = wave / C::WN, wn = wave % C::WN;
 
     const int TW = 1 << p.lgTW, TH = 1 << p.lgTH, TB = 1 << p.lgTB;
-    const int PW = (TW - 1) * S + KW, PLANE = ((TH - 1) * S + KH) * PW;
+    constexpr int SL = SH::SL;
+    const int PW = (TW - 1) * SL + KW, PLANE = ((TH - 1) * SL + KH) * PW;
     const int IN_FLOATS = C::CI_T * TB * PLANE;
     const int BUF_FLOATS = W_FLOATS + ((IN_FLOATS + 3) & ~3) + 4;  // +4: dump slot for lanes without an element
     int bx = blockIdx.x;
@@ -148,26 +134,41 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
     // extent of the (virtual) input image the taps index: the x2-upsampled image in MODE_UPSAMPLE
     const int Hv = UPS ? 2 * p.Hs : p.Hs, Wv = UPS ? 2 * p.Ws : p.Ws;
 
-    // ---- per-lane gather slots: wave w owns planes [w*ppw, (w+1)*ppw), contiguous in LDS ----
+    // ---- per-lane gather slots: wave w owns planes [w*ppw, (w+1)*ppw), contiguous in LDS.  Everything a chunk's
+    // staging needs per slot is tabulated once, so that a staging piece is one or two instructions in the main loop:
+    //   s_xoff / s_xoffl  byte offset of the element from the chunk's first input plane (always inside the tensor); the
+    //                     *l variant serves the zero-padded last chunk, whose missing channels fold onto its channel 0
+    //   s_vc              2: element exists in every chunk, 1: in every chunk but a ragged last one, 0: zero padding
+    //   s_dst             byte offset of the element in an LDS ring slot (the dump float for lanes without an element)
+    //   s_dxb/s_dyb, s_l* (MODE_UPSAMPLE) byte steps to the second column / row tap and the four tap weights
+    //   s_sc / s_scl      (AFFINE_RELU, BATCH_SCALE) byte offset of the element's scale in in_scale (+ in_shift)
     const int ppw = (C::CI_T * TB) / C::NW;
     const int wave_elems = ppw * PLANE;
     const size_t src_plane = (size_t)p.Hs * p.Ws;
-    int s_off[NSLOT];
-    unsigned s_desc[NSLOT];
+    const int ci_left_last = p.Cin - (p.n_chunks - 1) * C::CI_T;
+    unsigned s_xoff[NSLOT], s_xoffl[NSLOT], s_dst[NSLOT], s_vc[NSLOT];
+    unsigned s_dxb[UPS ? NSLOT : 1], s_dyb[UPS ? NSLOT : 1];
+    float s_lx0[UPS ? NSLOT : 1], s_lx1[UPS ? NSLOT : 1], s_ly0[UPS ? NSLOT : 1], s_ly1[UPS ? NSLOT : 1];
+    unsigned s_sc[(AFF || BSC) ? NSLOT : 1], s_scl[(AFF || BSC) ? NSLOT : 1];
 #pragma unroll
     for (int s = 0; s < NSLOT; ++s) {
-        s_off[s] = 0;
-        s_desc[s] = 0;
+        s_xoff[s] = s_xoffl[s] = 0;
+        s_vc[s] = 0;
+        s_dst[s] = (unsigned)(BUF_FLOATS - 1) * 4u;
+        if (UPS) { s_dxb[s] = s_dyb[s] = 0; s_lx0[s] = s_ly0[s] = 1.f; s_lx1[s] = s_ly1[s] = 0.f; }
+        if (AFF || BSC) s_sc[s] = s_scl[s] = 0;
         const int e = s * 64 + lane;
         if (e < wave_elems) {
             const int pl = e / PLANE, pidx = e - pl * PLANE;
             const int q = wave * ppw + pl;
             const int ci = q >> p.lgTB, tb = q & (TB - 1);
             const int r = pidx / PW, c = pidx - r * PW;
-            const int uy = y0 * S + r - PAD, ux = x0 * S + c - PAD;
-            unsigned d = ((unsigned)ci << D_CI_SHIFT) | ((unsigned)tb << D_TB_SHIFT);
+            const int uy = (y0 * SL + r) * (S / SL) - PAD, ux = (x0 * SL + c) * (S / SL) - PAD;
+            const bool past = ci >= ci_left_last;
+            s_dst[s] = (unsigned)(W_FLOATS + wave * wave_elems + e) * 4u;
+            unsigned off = (unsigned)ci * (unsigned)src_plane;  // padding elements read any address inside the tensor
             if (uy >= 0 && uy < Hv && ux >= 0 && ux < Wv && b0 + tb < p.B) {
-                d |= D_VALID;
+                s_vc[s] = past ? 1u : 2u;
                 int goff;
                 if (!UPS) {
                     goff = uy * p.Ws + ux;
@@ -180,18 +181,27 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
                     const int iy0 = uy == 0 ? 0 : (uy - 1) >> 1, ix0 = ux == 0 ? 0 : (ux - 1) >> 1;
                     unsigned ly = uy == 0 ? (zb ? 3u : 0u) : ((uy & 1) ? 1u : 2u);
                     unsigned lx = ux == 0 ? (zb ? 3u : 0u) : ((ux & 1) ? 1u : 2u);
-                    if (iy0 + 1 < p.Hs) d |= D_DY; else if (zb) ly = 3u;
-                    if (ix0 + 1 < p.Ws) d |= D_DX; else if (zb) lx = 3u;
-                    d |= (lx << D_LX_SHIFT) | (ly << D_LY_SHIFT);
+                    if (iy0 + 1 < p.Hs) s_dyb[s] = (unsigned)p.Ws * 4u; else if (zb) ly = 3u;
+                    if (ix0 + 1 < p.Ws) s_dxb[s] = 4u; else if (zb) lx = 3u;
+                    s_lx0[s] = w0_of(lx); s_lx1[s] = w1_of(lx);
+                    s_ly0[s] = w0_of(ly); s_ly1[s] = w1_of(ly);
                     goff = iy0 * p.Ws + ix0;
                 }
-                s_off[s] = (int)((size_t)(tb * p.Cin + ci) * src_plane) + goff;
-            } else {
-                s_off[s] = ci * (int)src_plane;  // masked at store time; any address inside the tensor will do
+                off = (unsigned)((size_t)(tb * p.Cin + ci) * src_plane) + (unsigned)goff;
             }
-            s_desc[s] = d;
+            s_xoff[s] = off * 4u;
+            s_xoffl[s] = (off - (past ? (unsigned)ci * (unsigned)src_plane : 0u)) * 4u;
+            if (BSC) {   // modulation s[b,ci]: the per-sample input scale of a modulated convolution
+                const unsigned b_ = (unsigned)min(b0 + tb, p.B - 1);
+                s_sc[s] = (b_ * (unsigned)p.Cin + (unsigned)ci) * 4u;
+                s_scl[s] = (b_ * (unsigned)p.Cin + (past ? 0u : (unsigned)ci)) * 4u;
+            }
+            if (AFF) { s_sc[s] = (unsigned)ci * 4u; s_scl[s] = past ? 0u : (unsigned)ci * 4u; }
         }
     }
+    // weight vectors: lane offsets inside a chunk's packed block; the ragged last vector is clamped
+    const unsigned w_tid16 = (unsigned)tid * 16u;
+    const unsigned w_last16 = (unsigned)(min(tid + (WV - 1) * C::NTHREADS, W_FLOATS / 4 - 1) - (WV - 1) * C::NTHREADS) * 16u;
     const float* xblk = p.x + (size_t)b0 * p.Cin * src_plane;
 
     // ---- per-lane fragment addresses ----
@@ -201,7 +211,7 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
         const int pt = (wn * C::NT + n) * 32 + l32;
         const int px = pt & (TW - 1), py = (pt >> p.lgTW) & (TH - 1);
         const int tb = min(pt >> (p.lgTW + p.lgTH), TB - 1);  // pixel groups beyond the tile idle (results dropped)
-        b_off[n] = W_FLOATS + half * TB * PLANE + tb * PLANE + py * S * PW + px * S;
+        b_off[n] = W_FLOATS + half * TB * PLANE + tb * PLANE + py * SL * PW + px * SL;
     }
     const int a_off = half * C::CO_T + wm * C::MT * 32 + l32;
     const int ci_stride2 = 2 * TB * PLANE;
@@ -225,75 +235,60 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
     // prefetch arrays stay in registers.  Every piece is branch-free: surplus weight lanes re-load / re-store the
     // last vector, lanes without an input element read a valid address and write the buffer's dump slot.  The chunk
     // loop body is therefore a single basic block and the pieces can be placed between individual MFMAs.
+#define SPK_BYTES(ptr_, off_) (reinterpret_cast<const char*>(ptr_) + (off_))
 #define SPK_LOAD_W(chunk_, i_)                                                                                \
     {                                                                                                         \
-        const int idx = tid + (i_) * C::NTHREADS;                                                             \
-        wreg[i_] = (wsrc + (size_t)(SPK_LAB_WFIX ? 0 : (chunk_) - c_begin) * (W_FLOATS / 4))                  \
-            [W_FLOATS / 4 % C::NTHREADS == 0 ? idx : min(idx, W_FLOATS / 4 - 1)];                             \
+        const f32x4* wc_ = wsrc + (size_t)((chunk_) - c_begin) * (W_FLOATS / 4) + (i_) * C::NTHREADS; /* uniform */ \
+        wreg[i_] = *reinterpret_cast<const f32x4*>(SPK_BYTES(wc_, (i_) == WV - 1 ? w_last16 : w_tid16));      \
     }
 #define SPK_LOAD_X(chunk_, s_)                                                                                \
     {                                                                                                         \
-        /* loads from always-valid addresses; masking happens at LDS-store time.  Channels past Cin            \
-           (zero-padded last chunk) are folded onto channel 0 of the chunk. */                                \
-        const float* xc = xblk + (size_t)(SPK_LAB_XFIX ? 0 : (chunk_)) * C::CI_T * src_plane;                 \
-        const int ci_left_ = p.Cin - (chunk_) * C::CI_T;                                                      \
-        const unsigned d = s_desc[s_];                                                                        \
-        const int ci_ = (int)((d >> D_CI_SHIFT) & 63u);                                                       \
-        const bool past_ = ci_ >= ci_left_;                                                                   \
-        const int off_ = s_off[s_] - (past_ ? ci_ * (int)src_plane : 0);                                      \
+        /* loads from always-valid addresses; masking happens at LDS-store time */                            \
+        const float* xc = xblk + (size_t)(chunk_) * C::CI_T * src_plane; /* uniform */                        \
+        const bool lastc_ = (chunk_) == p.n_chunks - 1;                                                       \
+        const unsigned vo_ = lastc_ ? s_xoffl[s_] : s_xoff[s_];                                               \
         if (!UPS) {                                                                                           \
-            xin[s_] = xc[off_];                                                                               \
+            xin[s_] = *reinterpret_cast<const float*>(SPK_BYTES(xc, vo_));                                    \
         } else {                                                                                              \
-            const float* s0 = xc + off_;                                                                      \
-            const int dx = (d & D_DX) ? 1 : 0, dy = (d & D_DY) ? p.Ws : 0;                                    \
-            xin[4 * (s_) + 0] = s0[0];                                                                        \
-            xin[4 * (s_) + 1] = s0[dx];                                                                       \
-            xin[4 * (s_) + 2] = s0[dy];                                                                       \
-            xin[4 * (s_) + 3] = s0[dy + dx];                                                                  \
+            xin[4 * (s_) + 0] = *reinterpret_cast<const float*>(SPK_BYTES(xc, vo_));                          \
+            xin[4 * (s_) + 1] = *reinterpret_cast<const float*>(SPK_BYTES(xc, vo_ + s_dxb[s_]));              \
+            xin[4 * (s_) + 2] = *reinterpret_cast<const float*>(SPK_BYTES(xc, vo_ + s_dyb[s_]));              \
+            xin[4 * (s_) + 3] = *reinterpret_cast<const float*>(SPK_BYTES(xc, vo_ + s_dyb[s_] + s_dxb[s_]));  \
         }                                                                                                     \
-        if (BSC) { /* modulation s[b,ci]: the per-sample input scale of a modulated convolution */            \
-            const int b_ = min(b0 + (int)((d >> D_TB_SHIFT) & 127u), p.B - 1);                                \
-            xsc[s_] = p.in_scale[(size_t)b_ * p.Cin + (chunk_) * C::CI_T + (past_ ? 0 : ci_)];                \
-        }                                                                                                     \
-        if (AFF) {                                                                                            \
-            const int cg_ = (chunk_) * C::CI_T + (past_ ? 0 : ci_);                                           \
-            xsc[s_] = p.in_scale[cg_];                                                                        \
-            xsh[s_] = p.in_shift[cg_];                                                                        \
+        if (BSC || AFF) {                                                                                     \
+            const unsigned so_ = lastc_ ? s_scl[s_] : s_sc[s_];                                               \
+            xsc[s_] = *reinterpret_cast<const float*>(SPK_BYTES(p.in_scale + (size_t)(chunk_) * C::CI_T, so_)); \
+            if (AFF) xsh[s_] = *reinterpret_cast<const float*>(SPK_BYTES(p.in_shift + (size_t)(chunk_) * C::CI_T, so_)); \
         }                                                                                                     \
     }
 #define SPK_STORE_W(buf_, i_)                                                                                 \
     {                                                                                                         \
-        const int idx = tid + (i_) * C::NTHREADS;                                                             \
-        reinterpret_cast<f32x4*>(buf_)[W_FLOATS / 4 % C::NTHREADS == 0 ? idx : min(idx, W_FLOATS / 4 - 1)] = wreg[i_]; \
+        *reinterpret_cast<f32x4*>(reinterpret_cast<char*>(buf_) + (i_) * C::NTHREADS * 16 +                   \
+                                  ((i_) == WV - 1 ? w_last16 : w_tid16)) = wreg[i_];                          \
     }
-#define SPK_STORE_X(buf_, ci_left_, s_)                                                                       \
+#define SPK_STORE_X(buf_, lastc_, s_)                                                                         \
     {                                                                                                         \
-        const int e = (s_) * 64 + lane;                                                                       \
         float v;                                                                                              \
-        const unsigned d = s_desc[s_];                                                                        \
-        const bool ok = (d & D_VALID) && (int)((d >> D_CI_SHIFT) & 63u) < (ci_left_);                         \
         if (!UPS) {                                                                                           \
             v = xin[s_];                                                                                      \
         } else {                                                                                              \
-            const float lx1 = w1_of((d >> D_LX_SHIFT) & 3u), ly1 = w1_of((d >> D_LY_SHIFT) & 3u);             \
-            const float lx0 = w0_of((d >> D_LX_SHIFT) & 3u), ly0 = w0_of((d >> D_LY_SHIFT) & 3u);             \
-            v = ly0 * (lx0 * xin[4 * (s_)] + lx1 * xin[4 * (s_) + 1]) +                                       \
-                ly1 * (lx0 * xin[4 * (s_) + 2] + lx1 * xin[4 * (s_) + 3]);                                    \
+            v = s_ly0[s_] * (s_lx0[s_] * xin[4 * (s_)] + s_lx1[s_] * xin[4 * (s_) + 1]) +                     \
+                s_ly1[s_] * (s_lx0[s_] * xin[4 * (s_) + 2] + s_lx1[s_] * xin[4 * (s_) + 3]);                  \
         }                                                                                                     \
         if (AFF) v = fmaxf(v * xsc[s_] + xsh[s_], 0.f);                                                       \
         if (BSC) v *= xsc[s_];                                                                                \
-        (buf_)[e < wave_elems ? W_FLOATS + wave * wave_elems + e : BUF_FLOATS - 1] = ok ? v : 0.f;            \
+        *reinterpret_cast<float*>(reinterpret_cast<char*>(buf_) + s_dst[s_]) = s_vc[s_] > ((lastc_) ? 1u : 0u) ? v : 0.f; \
     }
-    // piece j of a chunk's staging: j < WV -> weight vector j, else gather slot j - WV
-#define SPK_LOAD_PIECE(chunk_, j_)                                                                            \
+    // piece j of a chunk's staging (store order: weight vectors, then gather slots)
+#define SPK_LOAD_PIECE(chunk_, j_) /* load order: gather slots, then weight vectors */                       \
     {                                                                                                         \
-        if constexpr ((j_) < WV) { SPK_LOAD_W(chunk_, ((j_) < WV ? (j_) : 0)); }                              \
-        else { SPK_LOAD_X(chunk_, ((j_) < WV ? 0 : (j_) - WV)); }                                             \
+        if constexpr ((j_) < NSLOT) { SPK_LOAD_X(chunk_, ((j_) < NSLOT ? (j_) : 0)); }                        \
+        else { SPK_LOAD_W(chunk_, ((j_) < NSLOT ? 0 : (j_) - NSLOT)); }                                       \
     }
-#define SPK_STORE_PIECE(buf_, ci_left_, j_)                                                                   \
+#define SPK_STORE_PIECE(buf_, lastc_, j_)                                                                   \
     {                                                                                                         \
         if constexpr ((j_) < WV) { SPK_STORE_W(buf_, ((j_) < WV ? (j_) : 0)); }                               \
-        else { SPK_STORE_X(buf_, ci_left_, ((j_) < WV ? 0 : (j_) - WV)); }                                    \
+        else { SPK_STORE_X(buf_, lastc_, ((j_) < WV ? 0 : (j_) - WV)); }                                    \
     }
     constexpr int PIECES = WV + NSLOT;
     // VMEM instructions of one load piece (for the scheduling groups)
@@ -306,8 +301,8 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
     float* ring2 = smem + 2 * BUF_FLOATS;
     if (n_my > 0) {
         static_for<0, PIECES>([&](auto j) { SPK_LOAD_PIECE(c_begin, decltype(j)::value); });
-        const int cl0 = p.Cin - c_begin * C::CI_T;
-        static_for<0, PIECES>([&](auto j) { SPK_STORE_PIECE(ring0, cl0, decltype(j)::value); });
+        const bool l0 = c_begin == p.n_chunks - 1;
+        static_for<0, PIECES>([&](auto j) { SPK_STORE_PIECE(ring0, l0, decltype(j)::value); });
         const int c1 = min(c_begin + 1, c_end - 1);
         static_for<0, PIECES>([&](auto j) { SPK_LOAD_PIECE(c1, decltype(j)::value); });
     }
@@ -316,9 +311,10 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
     // ---- main loop -------------------------------------------------------------------------------------------
     // Invariant at the top of chunk i: ring slot i%3 holds chunk i (complete, visible); the prefetch registers hold
     // chunk i+1; ring slot (i+1)%3 was last read during chunk i-2.  During chunk i, between its MFMAs:
-    //   steps [0, SB)      the registers are stored to slot (i+1)%3                      (ds_write pieces)
-    //   step  SB           s_waitcnt lgkmcnt(0) + s_barrier: slot (i+1)%3 becomes readable; every wave is past chunk i-1
-    //   steps (SB, STEPS)  the global loads of chunk i+2 are issued into the registers   (VMEM pieces)
+    //   steps [0, NST)     the registers are stored to slot (i+1)%3 (ds_write pieces: weights first, gathers last)
+    //   end of step SB     s_waitcnt lgkmcnt(0) + s_barrier: slot (i+1)%3 becomes readable; every wave is past chunk i-1
+    //   steps (SB, ...)    the global loads of chunk i+2 are issued into the registers (VMEM pieces: gathers first --
+    //                      they are the ones that miss L2 -- so that they get the longest flight time)
     //   last PD steps      the fragment ring already reads chunk i+1 from slot (i+1)%3
     // so a wave issues MFMAs without interruption from the first chunk to the last: there is no barrier, no load
     // burst and no LDS-latency bubble at the chunk boundary.  Three slots are what allows the single barrier to sit
@@ -327,11 +323,11 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
     constexpr int ROWS = ROWLOOP ? KH : 1;
     constexpr int STEPS = SH::STEPS / ROWS;
     constexpr int PD = pick_pd(C::PD, STEPS);          // (PD + 1) divides STEPS: ring indices line up across chunks
-    constexpr int HALF = (STEPS - 1) / 2;              // steps available to each of the store / load phases
+    constexpr int HALF = STEPS / 2;                    // steps available to each of the store / load phases
     constexpr int PER = (PIECES + HALF - 1) / HALF;    // pieces per step
     constexpr int NST = (PIECES + PER - 1) / PER;      // steps that carry pieces
-    constexpr int SB = NST;                            // barrier step (its MFMAs cover the wait)
-    static_assert(ROWLOOP || (SB + NST < STEPS && SB <= STEPS - PD - 1), "staging pieces do not fit the k-steps");
+    constexpr int SB = NST - 1;                        // the barrier closes the last store step
+    static_assert(ROWLOOP || (2 * NST <= STEPS && SB <= STEPS - PD - 1), "staging pieces do not fit the k-steps");
     float fa[PD + 1][C::MT], fb[PD + 1][C::NT];
 
 #define SPK_LOAD_FRAG(abuf_, bbuf_, step_, slot_)                                                             \
@@ -360,10 +356,10 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
     for (int i = 0; i < n_my; ++i) {
         const int chunk = c_begin + i;
         const int chunk2 = min(chunk + 2, c_end - 1);
-        const int cl1 = p.Cin - min(chunk + 1, c_end - 1) * C::CI_T;   // channels that exist in the chunk held in registers
+        const bool l1 = min(chunk + 1, c_end - 1) == p.n_chunks - 1;   // the chunk held in registers is the ragged last one
         if constexpr (ROWLOOP) {
             // large kernels (7x7): the tap rows stay a runtime loop of KW*CI_T/2 static steps; staging is not interleaved
-            static_for<0, PIECES>([&](auto j) { SPK_STORE_PIECE(nxt, cl1, decltype(j)::value); });
+            static_for<0, PIECES>([&](auto j) { SPK_STORE_PIECE(nxt, l1, decltype(j)::value); });
             __syncthreads();
             static_for<0, PIECES>([&](auto j) { SPK_LOAD_PIECE(chunk2, decltype(j)::value); });
 #pragma unroll 1
@@ -388,11 +384,11 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
                 if constexpr (st + PD < STEPS) { SPK_LOAD_FRAG(cur, cur, st + PD, (st + PD) % (PD + 1)); }
                 else { SPK_LOAD_FRAG(nxt, nxt, st + PD - STEPS, (st + PD) % (PD + 1)); }
                 SPK_MFMA_STEP(st % (PD + 1));
-                constexpr int sj = st * PER, lj = (st - SB - 1) * PER;
+                constexpr int sj = st * PER, lj = (st - NST) * PER;
                 if constexpr (st < NST) {
-                    static_for<sj, (sj + PER < PIECES ? sj + PER : PIECES)>([&](auto j) { SPK_STORE_PIECE(nxt, cl1, decltype(j)::value); });
+                    static_for<sj, (sj + PER < PIECES ? sj + PER : PIECES)>([&](auto j) { SPK_STORE_PIECE(nxt, l1, decltype(j)::value); });
                 }
-                if constexpr (st > SB && st <= SB + NST) {
+                if constexpr (st >= NST && st < 2 * NST) {
                     static_for<lj, (lj + PER < PIECES ? lj + PER : PIECES)>([&](auto j) { SPK_LOAD_PIECE(chunk2, decltype(j)::value); });
                 }
                 // pin the interleave: one LDS fragment read behind each of the first MFMAs, the staging piece behind the last
@@ -402,7 +398,7 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
                 });
                 if constexpr (C::MT * C::NT < C::MT + C::NT) __builtin_amdgcn_sched_group_barrier(0x100, C::MT + C::NT - C::MT * C::NT, 0);
                 if constexpr (st < NST) __builtin_amdgcn_sched_group_barrier(0x200, (sj + PER < PIECES ? PER : PIECES - sj), 0);
-                if constexpr (st > SB && st <= SB + NST) {
+                if constexpr (st >= NST && st < 2 * NST) {
                     constexpr int np = (lj + PER < PIECES ? PER : PIECES - lj);
                     __builtin_amdgcn_sched_group_barrier(0x20, np * (X_LOADS > 1 ? X_LOADS : 1), 0);
                 }
@@ -426,6 +422,7 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
 #undef SPK_STORE_PIECE
 #undef SPK_LOAD_PIECE
 #undef SPK_STORE_X
+#undef SPK_BYTES
 #undef SPK_STORE_W
 #undef SPK_LOAD_X
 #undef SPK_LOAD_W
@@ -515,7 +512,7 @@ Geometry geometry(int B, int Cin, int Cout, int H, int W) {
     g.TW = std::min(32, spk::pow2_ceil(W));
     g.TH = std::min(C::PIX_T / g.TW, spk::pow2_ceil(H));
     g.TB = C::PIX_T / (g.TW * g.TH);
-    auto plane = [&]() { return ((g.TH - 1) * S + KH) * ((g.TW - 1) * S + KW); };
+    auto plane = [&]() { return ((g.TH - 1) * SH::SL + KH) * ((g.TW - 1) * SH::SL + KW); };
     // the wave's share of the input tile must fit its prefetch slots
     auto slots = [&]() { return spk::ceil_div(C::CI_T * g.TB / C::NW * plane(), 64); };
     while (slots() > SH::NSLOT && g.TB > 1 && (C::CI_T * (g.TB / 2)) % C::NW == 0) g.TB >>= 1;  // idle pixel groups
