@@ -75,6 +75,12 @@ class FCFn(torch.autograd.Function):
     def backward(ctx, dout):
         x, weight, out = ctx.saved_tensors
         wmul, bmul, slope, has_bias = ctx.conf
+        if torch.is_grad_enabled():        # double backward (R1): [B, <=512] matrices -- differentiable torch algebra
+            dz = dout * torch.where(out > 0, 1.0, float(slope)) if slope != 1.0 else dout
+            dx = (dz @ weight) * wmul if ctx.needs_input_grad[0] else None
+            dw = (dz.t() @ x) * wmul if ctx.needs_input_grad[1] else None
+            db = dz.sum(0) * bmul if (has_bias and ctx.needs_input_grad[2]) else None
+            return dx, dw, db, None, None, None, None
         dx, dw, db = ops.fc_bwd(dout.contiguous(), out, x, weight, wmul, bmul, slope,
                                 need_dx=ctx.needs_input_grad[0], need_dw=ctx.needs_input_grad[1] or
                                 (has_bias and ctx.needs_input_grad[2]), has_bias=has_bias)
@@ -130,6 +136,120 @@ class BiasNoiseStyleFn(torch.autograd.Function):
         return dx, dbias, dnw, None, dstyle, None, None
 
 
+class _LReluMaskFn(torch.autograd.Function):
+    """dt = dy * lrelu'(y) (y = the saved activation: same sign as the pre-activation).  Linear in dy and its own
+    adjoint, so it is differentiable to any order -- the first-order backward of a conv+LeakyReLU layer is built from
+    this and ``ConvDgradFn`` when a double backward is requested (R1, train.py:246-255)."""
+
+    @staticmethod
+    def forward(ctx, dy, y, slope):
+        ctx.save_for_backward(y)
+        ctx.slope = slope
+        return ops.epilogue_bwd(dy.contiguous(), y, None, None, slope)[0]
+
+    @staticmethod
+    def backward(ctx, g):
+        (y,) = ctx.saved_tensors
+        return _LReluMaskFn.apply(g, y, ctx.slope), None, None
+
+
+def _conv_plain(x, weight, k, stride):
+    B, Cin, H, W = x.shape
+    Cout = weight.shape[0]
+    Ho, Wo = ops.conv_out_size(H, k, stride), ops.conv_out_size(W, k, stride)
+    cfg = ops.conv2d_pick_config(k, stride, B, Cin, Cout, Ho, Wo)
+    return ops.conv2d_fused(x, ops.pack_conv_weight(weight, cfg), Cout, k, stride, config=cfg)
+
+
+def _conv_dgrad(dt, weight, k, stride, in_hw):
+    B, Cout = dt.shape[:2]
+    Cin = weight.shape[1]
+    cfg = ops.conv2d_pick_config(k, 1, B, Cout, Cin, in_hw[0], in_hw[1])
+    return ops.conv2d_dgrad(dt, ops.pack_conv_weight(weight, cfg, transpose_flip=True), Cin, k, stride, in_hw, cfg)
+
+
+class ConvDgradFn(torch.autograd.Function):
+    """dx = conv_transpose(dt, w) as a differentiable function of (dt, w): its adjoints are the forward conv
+    (w.r.t. dt) and the weight-gradient kernel (w.r.t. w) -- the same MFMA kernels, so the R1 double backward of the
+    discriminator (d/dw of |dD/dx|^2) never leaves the HIP path."""
+
+    @staticmethod
+    def forward(ctx, dt, weight, k, stride, in_hw):
+        ctx.save_for_backward(dt, weight)
+        ctx.conf = (k, stride)
+        return _conv_dgrad(dt, weight, k, stride, in_hw)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        dt, weight = ctx.saved_tensors
+        k, stride = ctx.conf
+        g = g.contiguous()
+        ddt = _conv_plain(g, weight, k, stride) if ctx.needs_input_grad[0] else None
+        dw = ops.conv2d_wgrad(dt, g, weight.shape[0], weight.shape[1], k, stride) if ctx.needs_input_grad[1] else None
+        return ddt, dw, None, None, None
+
+
+class ConvBiasLReLUFn(torch.autograd.Function):
+    """y = lrelu_slope(conv_kxk(x, w, stride) + bias) -- the discriminator's layers (styleganv1.py:662-695): one fused
+    launch forward; backward on the epilogue-adjoint / dgrad / wgrad kernels.  When the backward itself is recorded
+    (``create_graph=True``) the data path is rebuilt from ``_LReluMaskFn`` and ``ConvDgradFn`` so that it can be
+    differentiated once more; the parameter gradients of that pass are plain (non-differentiable) kernel outputs."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, k, stride, slope, grad_mode):
+        B, Cin, H, W = x.shape
+        Cout = weight.shape[0]
+        Ho, Wo = ops.conv_out_size(H, k, stride), ops.conv_out_size(W, k, stride)
+        cfg = ops.conv2d_pick_config(k, stride, B, Cin, Cout, Ho, Wo)
+        y = ops.conv2d_fused(x, ops.pack_conv_weight(weight, cfg), Cout, k, stride, bias=bias, lrelu_slope=slope, config=cfg)
+        if _needs(ctx, grad_mode):
+            ctx.save_for_backward(x, weight, y)
+            ctx.conf = (k, stride, slope, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, y = ctx.saved_tensors
+        k, stride, slope, has_bias = ctx.conf
+        Cout, Cin = weight.shape[:2]
+        dx = dw = db = None
+        if torch.is_grad_enabled():        # double backward requested: differentiable data path
+            dt = _LReluMaskFn.apply(dy, y, slope) if slope is not None else dy.contiguous()
+            if ctx.needs_input_grad[0]:
+                dx = ConvDgradFn.apply(dt, weight, k, stride, tuple(x.shape[-2:]))
+            with torch.no_grad():
+                dtd = dt.detach()
+                if ctx.needs_input_grad[1]:
+                    dw = ops.conv2d_wgrad(dtd, x, Cout, Cin, k, stride)
+                if has_bias and ctx.needs_input_grad[2]:
+                    db = dtd.sum((0, 2, 3))
+            return dx, dw, db, None, None, None, None
+        dt, sums = ops.epilogue_bwd(dy.contiguous(), y, None, None, slope if slope is not None else 1.0)
+        if ctx.needs_input_grad[0]:
+            dx = _conv_dgrad(dt, weight, k, stride, tuple(x.shape[-2:]))
+        if ctx.needs_input_grad[1]:
+            dw = ops.conv2d_wgrad(dt, x, Cout, Cin, k, stride)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = sums[..., 2].sum(0)
+        return dx, dw, db, None, None, None, None
+
+
+class GlobalAvgPoolFn(torch.autograd.Function):
+    """AdaptiveAvgPool2d((1,1)) -- styleganv1.py:676.  The adjoint is a broadcast, written with differentiable torch
+    views so that a double backward passes through it."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.shape = tuple(x.shape)
+        return ops.global_avgpool(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        B, C, H, W = ctx.shape
+        return (dy / float(H * W)).expand(B, C, H, W)
+
+
 # call-site spellings: sample the grad mode where it is still visible
 def fused_conv(x, weight, bias, noise_w, noise, style, upsample, slope, packed):
     return FusedConvFn.apply(x, weight, bias, noise_w, noise, style, upsample, slope, packed, torch.is_grad_enabled())
@@ -145,3 +265,11 @@ def to_rgb(x, weight, bias):
 
 def bias_noise_style(x, bias, noise_w, noise, style, B):
     return BiasNoiseStyleFn.apply(x, bias, noise_w, noise, style, B, torch.is_grad_enabled())
+
+
+def conv_bias_lrelu(x, weight, bias, k, stride, slope):
+    return ConvBiasLReLUFn.apply(x, weight, bias, k, stride, slope, torch.is_grad_enabled())
+
+
+def global_avgpool(x):
+    return GlobalAvgPoolFn.apply(x)

@@ -600,10 +600,10 @@ typedef Cfg<2, 2, 2, 2, 4> Cfg4;   //  128   128   3x3 s1/s2, 7x7 s2   (half-dep
 typedef Cfg<1, 4, 2, 2, 4> Cfg5;   //   64   256   3x3 s1/s2, 7x7 s2
 typedef Cfg<2, 2, 1, 1, 4> Cfg6;   //   64    64   3x3 s1/s2, 7x7 s2
 typedef Cfg<1, 4, 1, 1, 4> Cfg7;   //   32   128   3x3 s1/s2, 7x7 s2
-typedef Cfg<2, 2, 2, 2, 32> Cfg8;  //  128   128   1x1 s1/s2
+typedef Cfg<2, 2, 2, 2, 16> Cfg8;  //  128   128   1x1 s1/s2   (16-channel chunks keep the three-slot ring under 64 KB)
 typedef Cfg<1, 4, 2, 2, 16> Cfg9;  //   64   256   1x1 s1/s2
-typedef Cfg<2, 2, 1, 1, 32> Cfg10; //   64    64   1x1 s1/s2
-typedef Cfg<1, 4, 1, 1, 32> Cfg11; //   32   128   1x1 s1/s2
+typedef Cfg<2, 2, 1, 1, 16> Cfg10; //   64    64   1x1 s1/s2
+typedef Cfg<1, 4, 1, 1, 16> Cfg11; //   32   128   1x1 s1/s2
 constexpr int kNumConfigs = 12;
 
 // per-family dispatchers, one translation unit each (parallel compilation)

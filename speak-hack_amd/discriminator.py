@@ -4,8 +4,11 @@ Same constructor, attribute names and ``state_dict`` layout as the reference (sp
 convs / linears: ``*.weight_orig``, ``*.weight_u``, ``*.weight_v``, ``*.bias``).  Forward runs on the HIP
 conv / FC kernels (3x3 s1 and 3x3 s2 with fused bias + LeakyReLU); the spectral normalisation itself
 (one power iteration on a [Cout, Cin*k*k] matrix in training mode, torch.nn.utils.spectral_norm's
-own hook) is a few tiny matrix-vector products and stays on torch.  Backward (incl. the R1
-double-backward of train.py:246-255) is not built yet.
+own hook) is a few tiny matrix-vector products and stays on torch: the hook's ``weight = weight_orig / sigma``
+is an ordinary autograd node, so parameter gradients reach ``weight_orig`` through it.  Backward runs on the HIP
+epilogue-adjoint / dgrad / wgrad kernels (``autograd.ConvBiasLReLUFn``); the R1 penalty's double backward
+(train.py:246-255: ``autograd.grad(D(x).sum(), x, create_graph=True)``) runs on ``autograd.ConvDgradFn``, whose
+adjoints are again the forward-conv and wgrad kernels.
 """
 from __future__ import annotations
 
@@ -16,6 +19,7 @@ import torch
 import torch.nn as nn
 from torch.nn.utils import spectral_norm
 
+from . import autograd as A
 from . import ops
 
 LRELU = 0.2
@@ -30,14 +34,8 @@ def _sn_weight(m: nn.Module) -> torch.Tensor:
 
 
 def _conv_lrelu(conv: nn.Conv2d, x, lrelu=True):
-    w = _sn_weight(conv).detach().contiguous()
-    k, stride = conv.kernel_size[0], conv.stride[0]
-    B, Cin, H, W = x.shape
-    Cout = conv.out_channels
-    Ho, Wo = ops.conv_out_size(H, k, stride), ops.conv_out_size(W, k, stride)
-    cfg = ops.conv2d_pick_config(k, stride, B, Cin, Cout, Ho, Wo)
-    return ops.conv2d_fused(x, ops.pack_conv_weight(w, cfg), Cout, k, stride, bias=conv.bias,
-                            lrelu_slope=LRELU if lrelu else None, config=cfg)
+    return A.conv_bias_lrelu(x, _sn_weight(conv).contiguous(), conv.bias, conv.kernel_size[0], conv.stride[0],
+                             LRELU if lrelu else None)
 
 
 class DiscriminatorBlock(nn.Module):
@@ -65,13 +63,10 @@ class StyleDiscriminator(nn.Module):
         self.logger = logging.getLogger(__name__)
 
     def forward(self, x):
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
-            raise NotImplementedError("StyleDiscriminator backward is not built yet (SURVEY.md 8f F2); "
-                                      "call it under torch.no_grad()")
         x = _conv_lrelu(self.fromrgb, x.contiguous())
         for block in self.blocks:
             x = block(x)
         x = _conv_lrelu(self.final_conv, x)
-        x = ops.global_avgpool(x).view(x.size(0), -1)
-        x = ops.fc(x, _sn_weight(self.dense0).detach().contiguous(), self.dense0.bias, slope=LRELU)
-        return ops.fc(x, _sn_weight(self.dense1).detach().contiguous(), self.dense1.bias)
+        x = A.global_avgpool(x).view(x.size(0), -1)
+        x = A.fc(x, _sn_weight(self.dense0).contiguous(), self.dense0.bias, 1.0, 1.0, LRELU)
+        return A.fc(x, _sn_weight(self.dense1).contiguous(), self.dense1.bias, 1.0, 1.0, 1.0)
