@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--decoder-only", action="store_true")
+    ap.add_argument("--d-step", action="store_true", help="the discriminator step of train.py:155-183 instead "
+                    "(4 D passes with BCE + 2 R1 penalties, backward, Adam on D); fakes are synthetic images")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -44,17 +46,45 @@ def main():
     dp = importlib.import_module("speak-hack_amd.dp")
     torch.manual_seed(0)                       # identical initial weights on every rank
     net = M.IRFD().to(dev).train()
-    for p in net.D.parameters():               # D has its own step (train.py:156-183); not part of the G step here
-        p.requires_grad_(False)
+    if args.d_step:
+        for n, p in net.named_parameters():
+            p.requires_grad_(n.startswith("D."))
+    else:
+        for p in net.D.parameters():           # D has its own step (train.py:156-183); not part of the G step
+            p.requires_grad_(False)
     params = [p for p in net.parameters() if p.requires_grad]
     red = dp.GradBucketReducer(params)
-    opt = torch.optim.Adam(net.Gd.parameters(), lr=1e-4, betas=(0.5, 0.999))
+    opt = torch.optim.Adam(net.D.parameters() if args.d_step else net.Gd.parameters(), lr=1e-4, betas=(0.5, 0.999))
     torch.manual_seed(10 + rank)               # per-rank data and per-rank host RNG
     B = args.batch
     x_s = torch.rand(B, 3, 256, 256, device=dev) * 2 - 1
     x_t = torch.rand(B, 3, 256, 256, device=dev) * 2 - 1
 
+    import torch.nn.functional as F
+    fake_s = torch.rand(B, 3, 256, 256, device=dev) * 2 - 1
+    fake_t = torch.rand(B, 3, 256, 256, device=dev) * 2 - 1
+
+    def r1(x):                                 # train.py:246-255
+        x = x.detach().requires_grad_(True)
+        (g,) = torch.autograd.grad(outputs=net.D(x).sum(), inputs=x, create_graph=True)
+        return g.pow(2).reshape(g.shape[0], -1).sum(1).mean()
+
+    def bce(pred, label):
+        return F.binary_cross_entropy_with_logits(pred, torch.full_like(pred, label))
+
+    def d_step():
+        red.zero_grad()
+        noise = lambda t: t + 0.05 * torch.randn_like(t)
+        loss = (bce(net.D(noise(x_s)), 0.9) + bce(net.D(noise(x_t)), 0.9)) / 2 \
+            + (bce(net.D(noise(fake_s)), 0.1) + bce(net.D(noise(fake_t)), 0.1)) / 2 + 10.0 * (r1(x_s) + r1(x_t)) / 2
+        loss.backward()
+        red.finish()
+        opt.step()
+        return loss
+
     def step():
+        if args.d_step:
+            return d_step()
         red.zero_grad()
         if args.decoder_only:
             f = torch.randn(B, 6144, device=dev)
@@ -89,9 +119,10 @@ def main():
     if rank == 0:
         gflop_pair = (2 * 3 * 56.214) if args.decoder_only else 593.5
         pairs = world * B * args.steps / el
-        print(json.dumps({"metric": "IRFD generator-step pairs/s (fwd+bwd+clip+Adam)", "value": round(pairs, 2),
+        print(json.dumps({"metric": "discriminator-step pairs/s (4 D fwd+bwd + 2 R1 double backward + Adam)" if args.d_step
+                          else "IRFD generator-step pairs/s (fwd+bwd+clip+Adam)", "value": round(pairs, 2),
                           "unit": "pairs/s", "n_gpus": world, "batch_per_gpu": B, "ms_per_step": round(el / args.steps * 1e3, 2),
-                          "algorithmic_tflops": round(pairs * gflop_pair / 1e3, 1), "dtype": "f32", "scaling": "weak",
+                          "algorithmic_tflops": None if args.d_step else round(pairs * gflop_pair / 1e3, 1), "dtype": "f32", "scaling": "weak",
                           "grad_bytes_per_step": red.bytes_per_step(), "buckets": len(red.buckets),
                           "loss": round(float(loss), 5), "decoder_only": args.decoder_only}), flush=True)
     if dist is not None:
