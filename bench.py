@@ -12,7 +12,7 @@ an independent replica on its own batch (the forward path has no exchange step -
 barrier + synchronize on both sides of the timed region, MAX over ranks, rank 0 prints ONE JSON line.
 
 Extra objects in the line:
-  roofline     -- the dominant kernel (conv3x3_kernel, MFMA-bound): algorithmic conv FLOPs per
+  roofline     -- the dominant kernel (spkconv::conv_kernel, MFMA-bound): algorithmic conv FLOPs per
                   step / conv kernel time per step, timed live with HIP events on the launch stream.
   cpu_baseline -- the CPU oracle (a port of the reference's algorithm, parity-pinned to it) timed
                   on this box's host cores on the same B=8 workload (rank 0, N=1 only).
@@ -186,7 +186,7 @@ def main():
                                    "fp32, random-init weights, synthetic [8,6144] latents, device-drawn noise",
                        "global_batch": BATCH * world, "resolution": RES,
                        "parallelism": f"replicas x{world} (no data-path collective)"},
-            "roofline": {"bound": "mfma", "kernel": "conv3x3_kernel (f32 MFMA implicit GEMM, fused epilogue)",
+            "roofline": {"bound": "mfma", "kernel": "spkconv::conv_kernel<Cfg,3,3,1,MODE> (f32 MFMA implicit GEMM, fused upsample + epilogue)",
                          "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
                          "launches_per_step": n_launch, "conv_ms_per_step": round(conv_ms, 4),

@@ -13,13 +13,13 @@
 //        stores), row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) = output channel.
 // One workgroup = WM x WN waves; each wave owns MT x NT accumulator tiles of 32co x 32pix.
 //
-// Pipeline: LDS is double buffered.  While the waves run the KH*KW*CI_T/2 MFMA k-steps of chunk c out
-// of buffer c&1, the global loads of chunk c+1 (weights: 16-B loads of one contiguous packed block;
-// input: per-lane gathers whose addresses, validity and bilinear codes were computed once at kernel
-// start) are in flight into registers; they are written to buffer (c+1)&1 after the k-steps, followed
-// by the only barrier of the chunk.  Fragments are read PD k-steps ahead of the MFMAs that use them.
-// The f32 MFMA is 64 cycles/SIMD per instruction (an exact fmaf chain), so staging issue fits in its
-// shadow; 2-3 workgroups per CU cover each other's barriers and epilogues.
+// Pipeline: a three-slot LDS ring.  During chunk i a wave -- between its KH*KW*CI_T/2 MFMA k-steps out of slot i%3 --
+// stores the prefetch registers (chunk i+1) to slot (i+1)%3, passes the chunk's single barrier, issues the global
+// loads of chunk i+2 (weights: 16-B loads of one contiguous packed block; input: per-lane gathers whose offsets,
+// validity and interpolation weights were tabulated once at kernel start) and already reads chunk i+1's first
+// fragments.  Nothing serial happens at a chunk boundary, so a wave's MFMA stream is continuous from the first chunk
+// to the last; the f32 MFMA is 64 cycles/SIMD per instruction (an exact fmaf chain) and every staging piece is 1-3
+// branch-free instructions pinned behind one of them (see the main loop for the protocol and its hazards).
 //
 // Split-K: gridDim.z slices the ci-chunk range; slices write raw partial sums to a workspace and
 // splitk_epilogue_kernel reduces them in a fixed order and applies the epilogue.
@@ -92,11 +92,15 @@ struct Shape {
     static constexpr int NSLOT = (PPW * PH_MAX * PW_MAX + 63) / 64;
 };
 
-// smallest prefetch distance >= want whose ring size divides the number of k-steps of a chunk
+// fragment prefetch distance: the ring size PD + 1 must divide the number of k-steps of a chunk (so that ring indices
+// line up across chunks) and leave room for the barrier before the cross-chunk reads; prefer the smallest such
+// distance >= want, else the largest one below it
 constexpr int pick_pd(int want, int steps) {
-    for (int pd = want; pd < steps; ++pd)
+    for (int pd = want; pd + 1 <= steps / 2; ++pd)
         if (steps % (pd + 1) == 0) return pd;
-    return steps - 1;
+    for (int pd = want - 1; pd >= 1; --pd)
+        if (steps % (pd + 1) == 0) return pd;
+    return 1;
 }
 
 __device__ __forceinline__ float w1_of(unsigned code) { return code == 1 ? 0.25f : (code == 2 ? 0.75f : 0.f); }
