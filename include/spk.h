@@ -176,6 +176,24 @@ int spk_fc_bwd(const float* dout, const float* out, const float* x, int64_t x_st
 int spk_fc_fwd(const float* x, int64_t x_stride, const float* w, const float* bias, float* out,
                int64_t out_stride, int B, int I, int O, float wmul, float bmul, float slope, void* stream);
 
+/* Several independent FCs in one launch -- the 13 ApplyStyle affines of a decoder step (styleganv1.py:466, called
+ * from :599,:628,:633) all depend only on the dlatents, so they need not be 13 launches.  `groups` is a HOST array of
+ * n_groups <= SPK_FC_MAX_GROUPS descriptors (copied into the kernel arguments); every group computes
+ * out[b,o] = lrelu_slope(wmul * <x[b], w[o]> + bmul * bias[o]) for b < B.  Rows must be 16-byte aligned, I % 4 == 0. */
+#define SPK_FC_MAX_GROUPS 16
+typedef struct spk_fc_group {
+    const float* x;      /* [B, I], row stride x_stride */
+    int64_t x_stride;
+    const float* w;      /* [O, I] */
+    const float* bias;   /* [O] or NULL */
+    float* out;          /* [B, O], row stride out_stride */
+    int64_t out_stride;
+    int32_t I, O;
+    float wmul, bmul, slope;
+    int32_t reserved;
+} spk_fc_group;
+int spk_fc_grouped_fwd(const spk_fc_group* groups, int n_groups, int B, void* stream);
+
 /* ---- bias + noise + style (decoder prologue; stand-alone ApplyNoise / ApplyStyle) ------------------
  * y[b,c,p] = (x[b*x_batch_stride + c*HW + p] + bias[c] + noise_w[c]*noise[b,p]) * (s0[b,c]+1) + s1[b,c]
  * x_batch_stride = 0 broadcasts one [C,HW] constant over the batch; bias / noise / style may be NULL.

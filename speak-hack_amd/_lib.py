@@ -38,6 +38,16 @@ CONV_IN_BATCH_SCALE = 256
 CONV_UP_FIR1331 = 512
 
 
+FC_MAX_GROUPS = 16
+
+
+class FcGroup(C.Structure):
+    """``spk_fc_group`` (include/spk.h)."""
+    _fields_ = [("x", C.c_void_p), ("x_stride", C.c_int64), ("w", C.c_void_p), ("bias", C.c_void_p), ("out", C.c_void_p),
+                ("out_stride", C.c_int64), ("I", C.c_int32), ("O", C.c_int32), ("wmul", C.c_float), ("bmul", C.c_float),
+                ("slope", C.c_float), ("reserved", C.c_int32)]
+
+
 class WgradDesc(C.Structure):
     """Mirror of spk_wgrad_desc (include/spk.h)."""
     _fields_ = [("g", C.c_void_p), ("x", C.c_void_p), ("in_scale", C.c_void_p), ("in_shift", C.c_void_p),
@@ -94,6 +104,7 @@ _PROTOTYPES = {
     "spk_global_avgpool_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),
     "spk_fc_fwd": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
                              C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    "spk_fc_grouped_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "spk_bias_noise_style_fwd": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "spk_conv1x1_small_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,

@@ -145,13 +145,27 @@ class SynthesisNetwork(nn.Module):
         B = w.size(0)
         w = w.contiguous()
         if noises is None:
-            noises = [torch.randn(s, device=w.device, dtype=torch.float32) for s in self.noise_shapes(B)]
+            # one device draw for the whole step, cut into the 13 per-layer tensors (the reference draws them one by
+            # one inside ApplyNoise.forward, styleganv1.py:455; device RNG streams are not comparable across
+            # implementations anyway -- parity tests pass explicit noise)
+            shapes = self.noise_shapes(B)
+            sizes = [s[0] * s[2] * s[3] for s in shapes]
+            flat = torch.randn(sum(sizes), device=w.device, dtype=torch.float32)
+            noises = [t.view(s) for t, s in zip(flat.split(sizes), shapes)]
         elif len(noises) != 2 * len(self.layers) + 1:
             raise ValueError(f"expected {2 * len(self.layers) + 1} noise tensors, got {len(noises)}")
+        styles = None
+        if not (torch.is_grad_enabled() and (w.requires_grad or any(p.requires_grad for p in self.parameters()))):
+            # inference: the 13 style affines depend only on w -> one grouped launch instead of 13
+            mods = [self.style_mod] + [m for layer in self.layers for m in (layer.style_mod1, layer.style_mod2)]
+            if len(mods) <= ops.L.FC_MAX_GROUPS and w.size(1) >= len(mods):
+                styles = ops.fc_grouped((w[:, j], m.linear.weight, m.linear.bias, m.linear.w_lrmul, m.linear.b_lrmul, LRELU)
+                                        for j, m in enumerate(mods))
         x = AG.bias_noise_style(self.const_input, self.bias, self.noise_input1.weight, noises[0],
-                                   self.style_mod.style(w[:, 0]), B)
+                                   styles[0] if styles is not None else self.style_mod.style(w[:, 0]), B)
         for i, layer in enumerate(self.layers):
-            x = layer(x, w[:, 2 * i + 1:2 * i + 3], noises[1 + 2 * i], noises[2 + 2 * i])
+            x = layer(x, w[:, 2 * i + 1:2 * i + 3], noises[1 + 2 * i], noises[2 + 2 * i],
+                      styles=(styles[1 + 2 * i], styles[2 + 2 * i]) if styles is not None else None)
         return AG.to_rgb(x, self.to_rgb.weight, self.to_rgb.bias)
 
 

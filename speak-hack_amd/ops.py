@@ -210,6 +210,25 @@ def fc(x, weight, bias=None, wmul=1.0, bmul=1.0, slope=1.0, out=None):
     return out
 
 
+def fc_grouped(items):
+    """One launch for up to 16 independent FCs.  ``items``: iterable of (x [B,I] row-strided view, weight [O,I], bias | None,
+    wmul, bmul, slope); returns the list of outputs [B,O].  All x share the batch size."""
+    items = list(items)
+    outs, groups = [], (L.FcGroup * len(items))()
+    B = items[0][0].shape[0]
+    for g, (x, weight, bias, wmul, bmul, slope) in zip(groups, items):
+        if x.dim() != 2 or x.stride(1) != 1 or x.shape[0] != B or not x.is_cuda or x.dtype != torch.float32:
+            raise L.SpkError("fc_grouped: every x must be a float32 HIP [B,I] view with unit inner stride")
+        O, I = weight.shape
+        out = torch.empty((B, O), device=x.device, dtype=torch.float32)
+        outs.append(out)
+        g.x, g.x_stride, g.w, g.bias = x.data_ptr(), x.stride(0), L.dptr(weight, "weight"), L.dptr(bias, "bias")
+        g.out, g.out_stride, g.I, g.O = out.data_ptr(), O, I, O
+        g.wmul, g.bmul, g.slope = float(wmul), float(bmul), float(slope)
+    L.check(L.lib().spk_fc_grouped_fwd(C.cast(groups, C.c_void_p), len(items), B, L.stream_ptr()), "spk_fc_grouped_fwd")
+    return outs
+
+
 def bias_noise_style(x, B: int, bias=None, noise_w=None, noise=None, style=None):
     """y = (x + bias + noise_w*noise) * (s0+1) + s1 -> [B,C,H,W]; x is [B,C,H,W] or a [1,C,H,W]
     constant broadcast over the batch.  Any of bias / noise / style may be None."""

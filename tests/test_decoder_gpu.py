@@ -209,3 +209,32 @@ def test_noise_default_draw_and_errors(pkg, dev):
     assert torch.isfinite(y).all()
     with pytest.raises(RuntimeError):
         pkg.ops.fc(torch.zeros(2, 8), torch.zeros(4, 8))
+
+
+@pytest.mark.parametrize("B,I,O", [(8, 6144, 512), (3, 2048, 40), (1, 4100, 7), (9, 6144, 64)])
+def test_fc_long_rows(pkg, dev, B, I, O):
+    """Rows >= 2048 floats take the workgroup-per-row kernel (the 6144 -> 512 first mapping layer)."""
+    x, w, b = recipe_input(f"fcw.x.{B}.{I}", (B, I)), recipe_tensor(f"fcw.w.{I}.{O}", (O, I), 1.0), recipe_tensor(f"fcw.b.{O}", (O,), 0.5)
+    ref = F.leaky_relu(F.linear(x.double(), w.double() * 0.013, b.double() * 0.7), 0.2)
+    y = pkg.ops.fc(x.to(dev), w.to(dev), b.to(dev), 0.013, 0.7, 0.2)
+    assert rel_l2(y, ref) < TOL_OP
+
+
+def test_fc_grouped_equals_separate_launches(pkg, dev):
+    """spk_fc_grouped_fwd: the decoder's 13 style affines in one launch -- bitwise equal to 13 spk_fc_fwd calls
+    (same wave-per-row arithmetic), and equal to the oracle."""
+    torch.manual_seed(4)
+    B = 5
+    wlat = recipe_input("fcg.w", (B, 14, 512)).to(dev)
+    items, refs = [], []
+    for j, O in enumerate([1024, 1024, 1024, 512, 512, 256, 128, 130, 64, 6]):
+        weight, bias = torch.randn(O, 512, device=dev), torch.randn(O, device=dev)
+        items.append((wlat[:, j], weight, bias, 0.0442 + 0.001 * j, 1.0, 0.2))
+        refs.append(pkg.ops.fc(wlat[:, j], weight, bias, 0.0442 + 0.001 * j, 1.0, 0.2))
+    outs = pkg.ops.fc_grouped(items)
+    for o, r, it in zip(outs, refs, items):
+        assert torch.equal(o, r)
+        cpu = F.leaky_relu(F.linear(it[0].cpu().double(), it[1].cpu().double() * it[3], it[2].cpu().double()), 0.2)
+        assert rel_l2(o, cpu) < TOL_OP
+    with pytest.raises(pkg._lib.SpkError):
+        pkg.ops.fc_grouped(items * 2)          # more than SPK_FC_MAX_GROUPS
