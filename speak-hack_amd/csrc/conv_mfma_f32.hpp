@@ -92,6 +92,12 @@ struct Shape {
     static constexpr int NSLOT = (PPW * PH_MAX * PW_MAX + 63) / 64;
 };
 
+// staging pieces per k-step so that a store phase of p_s pieces and a load phase of p_l pieces fit `steps` k-steps
+constexpr int pieces_per_step(int p_s, int p_l, int steps) {
+    for (int per = 1;; ++per)
+        if ((p_s + per - 1) / per + (p_l + per - 1) / per <= steps) return per;
+}
+
 // fragment prefetch distance: the ring size PD + 1 must divide the number of k-steps of a chunk (so that ring indices
 // line up across chunks) and leave room for the barrier before the cross-chunk reads; prefer the smallest such
 // distance >= want, else the largest one below it
@@ -283,18 +289,33 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
         if (BSC) v *= xsc[s_];                                                                                \
         *reinterpret_cast<float*>(reinterpret_cast<char*>(buf_) + s_dst[s_]) = s_vc[s_] > ((lastc_) ? 1u : 0u) ? v : 0.f; \
     }
-    // piece j of a chunk's staging (store order: weight vectors, then gather slots)
-#define SPK_LOAD_PIECE(chunk_, j_) /* load order: gather slots, then weight vectors */                       \
+    // Weights by LDS-DMA (global_load_lds_dwordx4: global -> LDS without touching VGPRs; each wave copies 64-vector
+    // = 1 KB blocks of the chunk's packed image to the same offset of a ring slot) when the image is a whole number
+    // of such blocks; waves beyond the last block repeat it (same bytes to the same place).  Completion is tracked by
+    // vmcnt: the issuing wave waits vmcnt(0) before the chunk barrier that publishes the slot.
+    constexpr bool ROWLOOP = KH * KW > 9;
+    constexpr bool DMA = !ROWLOOP && (W_FLOATS / 4) % 64 == 0;
+#define SPK_DMA_W(chunk_, buf_, i_)                                                                           \
+    {                                                                                                         \
+        const int blk_ = min((i_) * C::NW + wave, W_FLOATS / 4 / 64 - 1);                                     \
+        const f32x4* src_ = wsrc + (size_t)((chunk_) - c_begin) * (W_FLOATS / 4) + blk_ * 64 + lane;          \
+        __builtin_amdgcn_global_load_lds(src_, reinterpret_cast<char*>(buf_) + blk_ * 1024, 16, 0, 0);        \
+    }
+    // piece j of a chunk's loads: gather slots first (they miss L2: longest flight), then weight vectors; W goes to
+    // ``wbuf_`` directly when DMA, else into the prefetch registers
+#define SPK_LOAD_PIECE(chunk_, wbuf_, j_)                                                                     \
     {                                                                                                         \
         if constexpr ((j_) < NSLOT) { SPK_LOAD_X(chunk_, ((j_) < NSLOT ? (j_) : 0)); }                        \
+        else if constexpr (DMA) { SPK_DMA_W(chunk_, wbuf_, ((j_) < NSLOT ? 0 : (j_) - NSLOT)); }              \
         else { SPK_LOAD_W(chunk_, ((j_) < NSLOT ? 0 : (j_) - NSLOT)); }                                       \
     }
-#define SPK_STORE_PIECE(buf_, lastc_, j_)                                                                   \
+    // piece j of a chunk's LDS stores out of the prefetch registers: (weight vectors unless DMA, then) gather slots
+#define SPK_STORE_PIECE(buf_, lastc_, j_)                                                                     \
     {                                                                                                         \
-        if constexpr ((j_) < WV) { SPK_STORE_W(buf_, ((j_) < WV ? (j_) : 0)); }                               \
-        else { SPK_STORE_X(buf_, lastc_, ((j_) < WV ? 0 : (j_) - WV)); }                                    \
+        if constexpr (!DMA && (j_) < WV) { SPK_STORE_W(buf_, ((j_) < WV ? (j_) : 0)); }                       \
+        else { SPK_STORE_X(buf_, lastc_, (DMA ? (j_) : ((j_) < WV ? 0 : (j_) - WV))); }                       \
     }
-    constexpr int PIECES = WV + NSLOT;
+    constexpr int P_L = WV + NSLOT, P_S = DMA ? NSLOT : WV + NSLOT;
     // VMEM instructions of one load piece (for the scheduling groups)
     constexpr int X_LOADS = (UPS ? 4 : 1) + (BSC ? 1 : 0) + (AFF ? 2 : 0);
 
@@ -304,34 +325,36 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
     float* ring1 = smem + BUF_FLOATS;
     float* ring2 = smem + 2 * BUF_FLOATS;
     if (n_my > 0) {
-        static_for<0, PIECES>([&](auto j) { SPK_LOAD_PIECE(c_begin, decltype(j)::value); });
+        static_for<0, P_L>([&](auto j) { SPK_LOAD_PIECE(c_begin, ring0, decltype(j)::value); });
         const bool l0 = c_begin == p.n_chunks - 1;
-        static_for<0, PIECES>([&](auto j) { SPK_STORE_PIECE(ring0, l0, decltype(j)::value); });
+        static_for<0, P_S>([&](auto j) { SPK_STORE_PIECE(ring0, l0, decltype(j)::value); });
         const int c1 = min(c_begin + 1, c_end - 1);
-        static_for<0, PIECES>([&](auto j) { SPK_LOAD_PIECE(c1, decltype(j)::value); });
+        static_for<0, P_L>([&](auto j) { SPK_LOAD_PIECE(c1, ring1, decltype(j)::value); });
     }
+    if constexpr (DMA) __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's LDS-DMA blocks have landed
     __syncthreads();
 
     // ---- main loop -------------------------------------------------------------------------------------------
     // Invariant at the top of chunk i: ring slot i%3 holds chunk i (complete, visible); the prefetch registers hold
     // chunk i+1; ring slot (i+1)%3 was last read during chunk i-2.  During chunk i, between its MFMAs:
-    //   steps [0, NST)     the registers are stored to slot (i+1)%3 (ds_write pieces: weights first, gathers last)
-    //   end of step SB     s_waitcnt lgkmcnt(0) + s_barrier: slot (i+1)%3 becomes readable; every wave is past chunk i-1
-    //   steps (SB, ...)    the global loads of chunk i+2 are issued into the registers (VMEM pieces: gathers first --
-    //                      they are the ones that miss L2 -- so that they get the longest flight time)
+    //   steps [0, NST_S)   the registers are stored to slot (i+1)%3 (ds_write pieces: weights first, gathers last)
+    //   end of step SB     s_waitcnt lgkmcnt(0) [+ vmcnt(0)] + s_barrier: slot (i+1)%3 becomes readable; every wave is
+    //                      past chunk i-1, so slot (i+2)%3 may be overwritten
+    //   steps (SB, ...)    the global loads of chunk i+2 are issued (VMEM pieces: gathers first -- they are the ones
+    //                      that miss L2 -- so that they get the longest flight time): gathers into the registers,
+    //                      weights into the registers or, by LDS-DMA, straight into slot (i+2)%3 -- those land before
+    //                      the barrier of chunk i+1, a whole chunk later
     //   last PD steps      the fragment ring already reads chunk i+1 from slot (i+1)%3
     // so a wave issues MFMAs without interruption from the first chunk to the last: there is no barrier, no load
     // burst and no LDS-latency bubble at the chunk boundary.  Three slots are what allows the single barrier to sit
     // in the middle of a chunk.
-    constexpr bool ROWLOOP = KH * KW > 9;
     constexpr int ROWS = ROWLOOP ? KH : 1;
     constexpr int STEPS = SH::STEPS / ROWS;
     constexpr int PD = pick_pd(C::PD, STEPS);          // (PD + 1) divides STEPS: ring indices line up across chunks
-    constexpr int HALF = STEPS / 2;                    // steps available to each of the store / load phases
-    constexpr int PER = (PIECES + HALF - 1) / HALF;    // pieces per step
-    constexpr int NST = (PIECES + PER - 1) / PER;      // steps that carry pieces
-    constexpr int SB = NST - 1;                        // the barrier closes the last store step
-    static_assert(ROWLOOP || (2 * NST <= STEPS && SB <= STEPS - PD - 1), "staging pieces do not fit the k-steps");
+    constexpr int PER = pieces_per_step(P_S, P_L, STEPS);   // staging pieces carried by one k-step
+    constexpr int NST_S = (P_S + PER - 1) / PER, NST_L = (P_L + PER - 1) / PER;   // steps of the store / load phase
+    constexpr int SB = NST_S - 1;                      // the barrier closes the last store step
+    static_assert(ROWLOOP || (NST_S + NST_L <= STEPS && SB <= STEPS - PD - 1), "staging pieces do not fit the k-steps");
     float fa[PD + 1][C::MT], fb[PD + 1][C::NT];
 
 #define SPK_LOAD_FRAG(abuf_, bbuf_, step_, slot_)                                                             \
@@ -363,9 +386,9 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
         const bool l1 = min(chunk + 1, c_end - 1) == p.n_chunks - 1;   // the chunk held in registers is the ragged last one
         if constexpr (ROWLOOP) {
             // large kernels (7x7): the tap rows stay a runtime loop of KW*CI_T/2 static steps; staging is not interleaved
-            static_for<0, PIECES>([&](auto j) { SPK_STORE_PIECE(nxt, l1, decltype(j)::value); });
+            static_for<0, P_S>([&](auto j) { SPK_STORE_PIECE(nxt, l1, decltype(j)::value); });
             __syncthreads();
-            static_for<0, PIECES>([&](auto j) { SPK_LOAD_PIECE(chunk2, decltype(j)::value); });
+            static_for<0, P_L>([&](auto j) { SPK_LOAD_PIECE(chunk2, oth, decltype(j)::value); });
 #pragma unroll 1
             for (int row = 0; row < ROWS; ++row) {
                 const float* abuf = cur + row * (KW * C::CI_T * C::CO_T);
@@ -388,12 +411,12 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
                 if constexpr (st + PD < STEPS) { SPK_LOAD_FRAG(cur, cur, st + PD, (st + PD) % (PD + 1)); }
                 else { SPK_LOAD_FRAG(nxt, nxt, st + PD - STEPS, (st + PD) % (PD + 1)); }
                 SPK_MFMA_STEP(st % (PD + 1));
-                constexpr int sj = st * PER, lj = (st - NST) * PER;
-                if constexpr (st < NST) {
-                    static_for<sj, (sj + PER < PIECES ? sj + PER : PIECES)>([&](auto j) { SPK_STORE_PIECE(nxt, l1, decltype(j)::value); });
+                constexpr int sj = st * PER, lj = (st - NST_S) * PER;
+                if constexpr (st < NST_S) {
+                    static_for<sj, (sj + PER < P_S ? sj + PER : P_S)>([&](auto j) { SPK_STORE_PIECE(nxt, l1, decltype(j)::value); });
                 }
-                if constexpr (st >= NST && st < 2 * NST) {
-                    static_for<lj, (lj + PER < PIECES ? lj + PER : PIECES)>([&](auto j) { SPK_LOAD_PIECE(chunk2, decltype(j)::value); });
+                if constexpr (st >= NST_S && st < NST_S + NST_L) {
+                    static_for<lj, (lj + PER < P_L ? lj + PER : P_L)>([&](auto j) { SPK_LOAD_PIECE(chunk2, oth, decltype(j)::value); });
                 }
                 // pin the interleave: one LDS fragment read behind each of the first MFMAs, the staging piece behind the last
                 static_for<0, C::MT * C::NT>([&](auto q) {
@@ -401,12 +424,15 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
                     if constexpr (decltype(q)::value < C::MT + C::NT) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
                 });
                 if constexpr (C::MT * C::NT < C::MT + C::NT) __builtin_amdgcn_sched_group_barrier(0x100, C::MT + C::NT - C::MT * C::NT, 0);
-                if constexpr (st < NST) __builtin_amdgcn_sched_group_barrier(0x200, (sj + PER < PIECES ? PER : PIECES - sj), 0);
-                if constexpr (st >= NST && st < 2 * NST) {
-                    constexpr int np = (lj + PER < PIECES ? PER : PIECES - lj);
+                if constexpr (st < NST_S) __builtin_amdgcn_sched_group_barrier(0x200, (sj + PER < P_S ? PER : P_S - sj), 0);
+                if constexpr (st >= NST_S && st < NST_S + NST_L) {
+                    constexpr int np = (lj + PER < P_L ? PER : P_L - lj);
                     __builtin_amdgcn_sched_group_barrier(0x20, np * (X_LOADS > 1 ? X_LOADS : 1), 0);
                 }
-                if constexpr (st == SB) __syncthreads();
+                if constexpr (st == SB) {
+                    if constexpr (DMA) __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): the DMA blocks of slot (i+1)%3 have landed
+                    __syncthreads();
+                }
 #ifdef SPK_LAB_STEPTIME
                 if (i == 10) lab_ts[st] = __builtin_readcyclecounter();
 #endif
@@ -425,6 +451,7 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
 #undef SPK_LOAD_FRAG
 #undef SPK_STORE_PIECE
 #undef SPK_LOAD_PIECE
+#undef SPK_DMA_W
 #undef SPK_STORE_X
 #undef SPK_BYTES
 #undef SPK_STORE_W
