@@ -86,6 +86,56 @@ __global__ __launch_bounds__(256) void conv1x1_small_kernel(const float* __restr
     }
 }
 
+// Same op for small images with many channels (StyleGAN2's toRGB at 4^2..64^2 with 256-512 channels): too few pixels to
+// fill the chip with one thread per 4 pixels, so the channel range is split over the 4 waves of a workgroup (64 pixel
+// quads x 4 channel slices) and the partial sums meet in LDS.
+__global__ __launch_bounds__(256) void conv1x1_small_csplit_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                                  const float* __restrict__ bias, float* __restrict__ y, int C,
+                                                                  int O, long long HW, float in_scale,
+                                                                  const float* __restrict__ mod) {
+    extern __shared__ float sm[];           // [O][C] weights, then [4 waves][4 outputs][64 lanes] float4 partials
+    float* w_s = sm;
+    float4* part = reinterpret_cast<float4*>(sm + ((O * C + 3) & ~3));
+    const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int i = threadIdx.x; i < O * C; i += 256) w_s[i] = w[i] * in_scale * (mod ? mod[(size_t)b * C + (i % C)] : 1.f);
+    __syncthreads();
+    const float* xb = x + (size_t)b * C * HW;
+    float* yb = y + (size_t)b * O * HW;
+    const long long n4 = HW / 4;
+    const long long p4 = (long long)blockIdx.x * 64 + lane;
+    const int c0 = (int)((long long)C * wave / 4), c1 = (int)((long long)C * (wave + 1) / 4);
+    float4 acc[4];
+#pragma unroll
+    for (int o = 0; o < 4; ++o) acc[o] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (p4 < n4) {
+#pragma unroll 8
+        for (int c = c0; c < c1; ++c) {
+            const float4 xv = reinterpret_cast<const float4*>(xb + (size_t)c * HW)[p4];
+#pragma unroll
+            for (int o = 0; o < 4; ++o) {
+                if (o < O) {
+                    const float wv = w_s[o * C + c];
+                    acc[o].x += wv * xv.x; acc[o].y += wv * xv.y; acc[o].z += wv * xv.z; acc[o].w += wv * xv.w;
+                }
+            }
+        }
+    }
+#pragma unroll
+    for (int o = 0; o < 4; ++o) part[(wave * 4 + o) * 64 + lane] = acc[o];
+    __syncthreads();
+    if (wave < O && p4 < n4) {              // wave o finishes output channel o
+        const int o = wave;
+        const float bo = bias ? bias[o] : 0.f;
+        float4 r = make_float4(bo, bo, bo, bo);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+            const float4 t = part[(k * 4 + o) * 64 + lane];
+            r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
+        }
+        reinterpret_cast<float4*>(yb + (size_t)o * HW)[p4] = r;
+    }
+}
+
 // bilinear x2, align_corners=False (torch area_pixel_compute_source_index with scale 0.5).
 // One thread makes 4 consecutive outputs of a row (Wo % 4 == 0 always: Wo = 2*Win, handled per pair otherwise).
 __global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict__ x, float* __restrict__ y,
@@ -149,6 +199,13 @@ static int conv1x1_small_launch(const float* x, const float* w, const float* mod
     SPK_REQUIRE((size_t)O * C * sizeof(float) <= 48 * 1024, "conv1x1_small: weight too large for LDS");
     const bool vec = (HW % 4 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0);
     const size_t lds = (size_t)O * C * sizeof(float);
+    if (vec && C >= 64 && (HW / 4 + 255) / 256 * B < 512) {   // too few pixel quads for one thread each: split the channels
+        dim3 grid((unsigned)((HW / 4 + 63) / 64), (unsigned)B);
+        const size_t lds2 = ((size_t)((O * C + 3) & ~3) + 4 * 4 * 64 * 4) * sizeof(float);
+        hipLaunchKernelGGL(conv1x1_small_csplit_kernel, grid, dim3(256), lds2, (hipStream_t)stream, x, w, bias, y, C, O,
+                           (long long)HW, in_scale, mod);
+        return spk::check_launch("conv1x1_small_csplit_kernel");
+    }
     if (vec) {
         dim3 grid(stream_grid(HW / 4, 256), (unsigned)B);
         hipLaunchKernelGGL(conv1x1_small_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, x, w, bias, y, C, O,

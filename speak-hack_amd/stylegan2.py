@@ -63,8 +63,10 @@ class ModulatedConv2d(nn.Module):
         self.modulation = EqualLinear(style_dim, in_channel, bias_init=1.0)
         self._pk = ops.PackedConvWeight()
 
-    def forward(self, x, style, bias=None, noise_w=None, noise=None, lrelu=None, act_gain=1.0, upsample=False):
-        s = self.modulation(style)
+    def forward(self, x, style, bias=None, noise_w=None, noise=None, lrelu=None, act_gain=1.0, upsample=False, s=None):
+        """``s`` (optional): the modulation ``self.modulation(style)`` computed elsewhere (grouped launch)."""
+        if s is None:
+            s = self.modulation(style)
         if self.kernel_size == 1 and self.out_channel <= 4 and not self.demodulate:
             return ops.conv1x1_small_mod(x.contiguous(), self.weight, s, bias, in_scale=self.scale)
         if self.kernel_size != 3:
@@ -100,7 +102,7 @@ class StyledConv(nn.Module):
         self.noise = NoiseInjection()
         self.activate = FusedLeakyReLU(out_channel)
 
-    def forward(self, x, style, noise=None):
+    def forward(self, x, style, noise=None, s=None):
         B, _, H, W = x.shape
         if self.upsample:
             H, W = 2 * H, 2 * W
@@ -109,7 +111,7 @@ class StyledConv(nn.Module):
         nw = self.noise.weight.expand(self.conv.out_channel).contiguous()
         # conv*demod + noise_w*noise + bias -> lrelu(0.2) * sqrt2: one launch
         return self.conv(x, style, bias=self.activate.bias, noise_w=nw, noise=noise.contiguous(), lrelu=0.2, act_gain=SQRT2,
-                         upsample=self.upsample)
+                         upsample=self.upsample, s=s)
 
 
 class ToRGB(nn.Module):
@@ -119,8 +121,8 @@ class ToRGB(nn.Module):
         self.conv = ModulatedConv2d(in_channel, 3, 1, style_dim, demodulate=False)
         self.bias = nn.Parameter(torch.zeros(1, 3, 1, 1))
 
-    def forward(self, x, style, skip=None):
-        out = self.conv(x, style, bias=self.bias.view(-1))
+    def forward(self, x, style, skip=None, s=None):
+        out = self.conv(x, style, bias=self.bias.view(-1), s=s)
         if skip is not None:
             out = out + self.upsample(skip)         # 3-channel skip sum
         return out
@@ -162,11 +164,19 @@ class StyleGAN2Generator(nn.Module):
         B = w.size(0)
         nz = iter(noises) if noises is not None else None
         nxt = (lambda: next(nz)) if nz is not None else (lambda: None)
+        # every modulation is an affine of the same w: all of them in two grouped launches instead of 20
+        layers = [self.conv1, self.to_rgb1] + [m for i in range(len(self.to_rgbs))
+                                               for m in (self.convs[2 * i], self.convs[2 * i + 1], self.to_rgbs[i])]
+        mods = [m.conv.modulation for m in layers]
+        ss = []
+        for k in range(0, len(mods), ops.L.FC_MAX_GROUPS):
+            ss += ops.fc_grouped((w, m.weight, m.bias, m.scale, m.lr_mul, 1.0) for m in mods[k:k + ops.L.FC_MAX_GROUPS])
+        sit = iter(ss)
         out = self.input.input.expand(B, -1, -1, -1).contiguous()
-        out = self.conv1(out, w, nxt())
-        skip = self.to_rgb1(out, w)
+        out = self.conv1(out, w, nxt(), s=next(sit))
+        skip = self.to_rgb1(out, w, s=next(sit))
         for i, rgb in enumerate(self.to_rgbs):
-            out = self.convs[2 * i](out, w, nxt())
-            out = self.convs[2 * i + 1](out, w, nxt())
-            skip = rgb(out, w, skip)
+            out = self.convs[2 * i](out, w, nxt(), s=next(sit))
+            out = self.convs[2 * i + 1](out, w, nxt(), s=next(sit))
+            skip = rgb(out, w, skip, s=next(sit))
         return skip
