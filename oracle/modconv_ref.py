@@ -32,7 +32,7 @@ def upfirdn2d(x, kernel, up=1, down=1, pad=(0, 0)):
     p0, p1 = pad
     x = F.pad(x, (max(p0, 0), max(p1, 0), max(p0, 0), max(p1, 0)))
     x = x[:, :, max(-p0, 0):x.shape[2] - max(-p1, 0), max(-p0, 0):x.shape[3] - max(-p1, 0)]
-    w = torch.flip(kernel, [0, 1])[None, None].expand(C, -1, -1, -1)
+    w = torch.flip(kernel.to(x.dtype), [0, 1])[None, None].expand(C, -1, -1, -1)
     return F.conv2d(x, w, groups=C)[:, :, ::down, ::down]
 
 

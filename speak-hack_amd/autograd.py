@@ -250,6 +250,113 @@ class GlobalAvgPoolFn(torch.autograd.Function):
         return (dy / float(H * W)).expand(B, C, H, W)
 
 
+def _scale_rows(t):
+    """[B,C] per-plane factors -> the [B,2C] style rows (s0 | s1) with s0 + 1 = t, s1 = 0."""
+    return torch.cat([t - 1.0, torch.zeros_like(t)], dim=1).contiguous()
+
+
+class ModConvFn(torch.autograd.Function):
+    """StyleGAN2 styled conv (build-defined variant):
+    y = gain * lrelu(d[b,co] * scale * conv3x3(up?(x) * s[b,ci], w) + noise_w*noise + bias), with the modulation ``s`` and
+    the demodulation ``d`` as independent inputs (``d``'s own dependence on (w, s) is a [B,Cout] torch expression in
+    the caller, so autograd adds that path).  Backward, all on the HIP kernels: epilogue adjoint (+ the plane sums that
+    give d bias, d noise_w and d d), data gradient = the same modulated MFMA conv with the roles of s and d swapped
+    (batch_scale = d*gain on the way in, then x s on the way out), d s = per-plane <up(x), dx~>, upfirdn adjoint, and
+    the weight gradient on the wgrad kernel over the two rescaled operands."""
+
+    @staticmethod
+    def forward(ctx, x, weight, s, d, bias, noise_w, noise, scale, upsample, slope, gain, fir, packed, grad_mode):
+        B, Cin, Hs, Ws = x.shape
+        Cout = weight.shape[0]
+        H, W = (2 * Hs, 2 * Ws) if upsample else (Hs, Ws)
+        cfg = ops.conv2d_pick_config(3, 1, B, Cin, Cout, H, W)
+        cfg = cfg + 4 if cfg < 4 else cfg
+        y = ops.conv2d_fused(x, packed.get(weight, cfg), Cout, 3, 1, bias=bias, noise_w=noise_w, noise=noise, lrelu_slope=slope,
+                             out_scale=scale, batch_scale=s, demod=d, act_gain=gain, config=cfg, upsample=upsample, up_fir=True)
+        if _needs(ctx, grad_mode):
+            ctx.save_for_backward(x, weight, s, d, y, noise, bias, noise_w)
+            ctx.conf = (scale, upsample, slope, gain, fir, packed)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, s, d, y, noise, bias, noise_w = ctx.saved_tensors
+        scale, upsample, slope, gain, fir, packed = ctx.conf
+        B, Cin = x.shape[:2]
+        Cout, H, W = y.shape[1:]
+        dt, sums = ops.epilogue_bwd(dy.contiguous(), y, noise, None, slope if slope is not None else 1.0)   # dz = gain * dt
+        s_dyy, s_dt, s_dtn = sums[..., 1], sums[..., 2], sums[..., 3]
+        dbias = gain * s_dt.sum(0) if bias is not None else None
+        dnw = gain * s_dtn.sum(0) if noise_w is not None else None
+        dd = None
+        if d is not None:
+            r = s_dyy
+            if noise_w is not None:
+                r = r - gain * noise_w.view(1, -1) * s_dtn
+            if bias is not None:
+                r = r - gain * bias.view(1, -1) * s_dt
+            dd = r / d
+        dprime = (d * gain if d is not None else torch.full((B, Cout), float(gain), device=x.device)).contiguous()
+        x_up = ops.upfirdn2d(x, fir, up=2, down=1, pad=(2, 1)) if upsample else x
+        dx = dw = ds = None
+        if ctx.needs_input_grad[0] or ctx.needs_input_grad[2]:
+            cfg = ops.conv2d_pick_config(3, 1, B, Cout, Cin, H, W)
+            cfg = cfg + 4 if cfg < 4 else cfg
+            dxt = ops.conv2d_fused(dt, packed.get(weight, cfg, transpose_flip=True), Cin, 3, 1, out_scale=scale,
+                                   batch_scale=dprime, config=cfg)                     # d (up(x) * s)
+            dxu, sums2 = ops.epilogue_bwd(dxt, x_up, None, _scale_rows(s), 1.0)       # x s on the way out; <dx~, up(x)> per plane
+            ds = sums2[..., 1]
+            if ctx.needs_input_grad[0]:
+                dx = ops.upfirdn2d(dxu, torch.flip(fir, [0, 1]), up=1, down=2, pad=(1, 1)) if upsample else dxu
+        if ctx.needs_input_grad[1]:
+            g2 = ops.bias_noise_style(dt, B, None, None, None, _scale_rows(dprime))
+            xs = ops.bias_noise_style(x_up, B, None, None, None, _scale_rows(s))
+            dw = ops.conv2d_wgrad(g2, xs, Cout, Cin, 3, 1, scale=scale)
+        return dx, dw, ds, dd, dbias, dnw, None, None, None, None, None, None, None, None
+
+
+class ModToRGBFn(torch.autograd.Function):
+    """y = scale * conv1x1(x * s[b,ci], w) + bias to <= 4 channels (StyleGAN2 toRGB, no demodulation)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, s, bias, scale, grad_mode):
+        y = ops.conv1x1_small_mod(x, weight, s, bias, in_scale=scale)
+        if _needs(ctx, grad_mode):
+            ctx.save_for_backward(x, weight, s)
+            ctx.conf = (scale, bias is not None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight, s = ctx.saved_tensors
+        scale, has_bias = ctx.conf
+        B = x.shape[0]
+        rows = _scale_rows(s)
+        xs = ops.bias_noise_style(x, B, None, None, None, rows)
+        dxs, dw, db = ops.conv1x1_small_bwd(xs, weight, dy.contiguous(), need_dx=True, in_scale=scale)
+        dx, sums = ops.epilogue_bwd(dxs, x, None, rows, 1.0)
+        return dx, dw, sums[..., 1], (db if has_bias else None), None, None
+
+
+class UpFirDnFn(torch.autograd.Function):
+    """upfirdn2d with a host FIR; the adjoint is upfirdn2d with up/down swapped and the flipped FIR."""
+
+    @staticmethod
+    def forward(ctx, x, fir, up, down, pad):
+        ctx.conf = (fir, up, down, pad, x.shape[-2:])
+        return ops.upfirdn2d(x, fir, up=up, down=down, pad=pad)
+
+    @staticmethod
+    def backward(ctx, g):
+        fir, up, down, pad, (h, w) = ctx.conf
+        k = fir.shape[0]
+        ho, wo = g.shape[-2:]
+        assert h == w and ho == wo, "square images only"
+        gp0 = k - pad[0] - 1
+        gp1 = h * up - ho * down + pad[0] - up + 1
+        return ops.upfirdn2d(g.contiguous(), torch.flip(fir, [0, 1]), up=down, down=up, pad=(gp0, gp1)), None, None, None, None
+
+
 # call-site spellings: sample the grad mode where it is still visible
 def fused_conv(x, weight, bias, noise_w, noise, style, upsample, slope, packed):
     return FusedConvFn.apply(x, weight, bias, noise_w, noise, style, upsample, slope, packed, torch.is_grad_enabled())
@@ -273,3 +380,15 @@ def conv_bias_lrelu(x, weight, bias, k, stride, slope):
 
 def global_avgpool(x):
     return GlobalAvgPoolFn.apply(x)
+
+
+def mod_conv(x, weight, s, d, bias, noise_w, noise, scale, upsample, slope, gain, fir, packed):
+    return ModConvFn.apply(x, weight, s, d, bias, noise_w, noise, scale, upsample, slope, gain, fir, packed, torch.is_grad_enabled())
+
+
+def mod_to_rgb(x, weight, s, bias, scale):
+    return ModToRGBFn.apply(x, weight, s, bias, scale, torch.is_grad_enabled())
+
+
+def upfirdn(x, fir, up, down, pad):
+    return UpFirDnFn.apply(x, fir, up, down, pad)

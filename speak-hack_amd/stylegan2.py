@@ -2,7 +2,9 @@
 (modulated 3x3 conv + demodulation, upfirdn2d, noise injection, FusedLeakyReLU, PixelNorm) on the HIP path.
 The reference has no StyleGAN2 code; module layout and formulas follow the published
 StyleGAN2 / the common stylegan2-pytorch naming, with the reference decoder's channel schedule and I/O
-signature ([B,6144] latent -> [B,3,256,256]) so it can stand in for ``IRFD.Gd``.  Forward only.
+signature ([B,6144] latent -> [B,3,256,256]) so it can stand in for ``IRFD.Gd``.  Forward and backward
+(``autograd.ModConvFn`` / ``ModToRGBFn`` / ``UpFirDnFn``): the data gradient of a modulated conv is the same modulated MFMA
+conv with the roles of s and d swapped; d's dependence on (w, s) is a [B,Cout] torch expression in training mode.
 
 How the modulated conv maps to the MI355X kernel: StyleGAN2's per-sample weight
 ``w'' = w * s[b,ci] * d[b,co]`` is never formed.  ``s`` multiplies the *input* while it is staged into LDS
@@ -17,6 +19,7 @@ import math
 import torch
 import torch.nn as nn
 
+from . import autograd as AG
 from . import ops
 
 SQRT2 = math.sqrt(2.0)
@@ -38,8 +41,8 @@ class EqualLinear(nn.Module):
 
     def forward(self, x):
         if self.activation:     # sqrt2 * lrelu(v) == lrelu(sqrt2 * v): fold the gain into the FC's multipliers
-            return ops.fc(x.contiguous(), self.weight, self.bias, self.scale * SQRT2, self.lr_mul * SQRT2, 0.2)
-        return ops.fc(x.contiguous(), self.weight, self.bias, self.scale, self.lr_mul, 1.0)
+            return AG.fc(x.contiguous(), self.weight, self.bias, self.scale * SQRT2, self.lr_mul * SQRT2, 0.2)
+        return AG.fc(x.contiguous(), self.weight, self.bias, self.scale, self.lr_mul, 1.0)
 
 
 class Upsample(nn.Module):
@@ -51,7 +54,9 @@ class Upsample(nn.Module):
         self.pad = ((p + 1) // 2 + factor - 1, p // 2)
 
     def forward(self, x):
-        return ops.upfirdn2d(x.contiguous(), self.kernel.cpu(), up=self.factor, down=1, pad=self.pad)
+        if not hasattr(self, "_k_host"):
+            self._k_host = self.kernel.detach().cpu()
+        return AG.upfirdn(x.contiguous(), self._k_host, self.factor, 1, self.pad)
 
 
 class ModulatedConv2d(nn.Module):
@@ -68,18 +73,23 @@ class ModulatedConv2d(nn.Module):
         if s is None:
             s = self.modulation(style)
         if self.kernel_size == 1 and self.out_channel <= 4 and not self.demodulate:
-            return ops.conv1x1_small_mod(x.contiguous(), self.weight, s, bias, in_scale=self.scale)
+            return AG.mod_to_rgb(x.contiguous(), self.weight, s.contiguous(), bias, self.scale)
         if self.kernel_size != 3:
             raise NotImplementedError("ModulatedConv2d: 3x3 (styled convs) and 1x1 toRGB are on the HIP path")
-        d = ops.modconv_demod(self.weight, s, self.scale) if self.demodulate else None
-        B, Cin, H, W = x.shape
-        if upsample:            # upfirdn2d(up=2, [1,3,3,1]) folded into the conv's input staging: no 4x tensor in HBM
-            H, W = 2 * H, 2 * W
-        cfg = ops.conv2d_pick_config(3, 1, B, Cin, self.out_channel, H, W)
-        cfg = cfg + 4 if cfg < 4 else cfg
-        return ops.conv2d_fused(x.contiguous(), self._pk.get(self.weight, cfg), self.out_channel, 3, 1, bias=bias, noise_w=noise_w,
-                                noise=noise, lrelu_slope=lrelu, out_scale=self.scale, batch_scale=s, demod=d, act_gain=act_gain,
-                                config=cfg, upsample=upsample, up_fir=True)
+        d = None
+        if self.demodulate:
+            if torch.is_grad_enabled() and (s.requires_grad or self.weight.requires_grad):
+                # training: d as a differentiable [B,Cout] expression of (w, s) -- a [B,Cin] x [Cin,Cout] product
+                w2 = self.weight.pow(2).sum((2, 3))
+                d = torch.rsqrt((self.scale ** 2) * (s.pow(2) @ w2.t()) + 1e-8)
+            else:
+                d = ops.modconv_demod(self.weight, s, self.scale)
+        # upfirdn2d(up=2, [1,3,3,1]) is folded into the conv's input staging: no 4x tensor in HBM
+        return AG.mod_conv(x.contiguous(), self.weight, s.contiguous(), d, bias, noise_w, noise, self.scale, upsample, lrelu,
+                           act_gain, _UP_FIR, self._pk)
+
+
+_UP_FIR = make_kernel((1, 3, 3, 1)) * 4.0        # host copy of the x2 FIR (gain up^2), for the backward's materialised passes
 
 
 class NoiseInjection(nn.Module):
@@ -156,9 +166,11 @@ class StyleGAN2Generator(nn.Module):
             cin = cout
 
     def forward(self, features, noises=None):
-        if torch.is_grad_enabled():
-            raise NotImplementedError("StyleGAN2Generator: forward only (call under torch.no_grad())")
-        w = ops.pixelnorm(features.contiguous(), 1e-8, sqrt_form=False)
+        train = torch.is_grad_enabled() and (features.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if train:       # [B,6144] vector: the normalisation's gradient is plain torch algebra
+            w = features * torch.rsqrt(features.pow(2).mean(dim=1, keepdim=True) + 1e-8)
+        else:
+            w = ops.pixelnorm(features.contiguous(), 1e-8, sqrt_form=False)
         for layer in self.style:
             w = layer(w)
         B = w.size(0)
@@ -168,9 +180,12 @@ class StyleGAN2Generator(nn.Module):
         layers = [self.conv1, self.to_rgb1] + [m for i in range(len(self.to_rgbs))
                                                for m in (self.convs[2 * i], self.convs[2 * i + 1], self.to_rgbs[i])]
         mods = [m.conv.modulation for m in layers]
-        ss = []
-        for k in range(0, len(mods), ops.L.FC_MAX_GROUPS):
-            ss += ops.fc_grouped((w, m.weight, m.bias, m.scale, m.lr_mul, 1.0) for m in mods[k:k + ops.L.FC_MAX_GROUPS])
+        if train:
+            ss = [None] * len(mods)          # each layer computes its own modulation through autograd
+        else:
+            ss = []
+            for k in range(0, len(mods), ops.L.FC_MAX_GROUPS):
+                ss += ops.fc_grouped((w, m.weight, m.bias, m.scale, m.lr_mul, 1.0) for m in mods[k:k + ops.L.FC_MAX_GROUPS])
         sit = iter(ss)
         out = self.input.input.expand(B, -1, -1, -1).contiguous()
         out = self.conv1(out, w, nxt(), s=next(sit))

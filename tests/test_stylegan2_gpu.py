@@ -1,7 +1,8 @@
 """GPU parity of the build-defined StyleGAN2 variant (parity unpinned by the reference,
 which has no StyleGAN2 code): modulated conv with the modulation folded into the input staging and the
 demodulation into the epilogue, upfirdn2d, modulated toRGB, and the whole variant decoder, against the CPU
-restatement of the published formulas (oracle/modconv_ref.py).  Tolerance 2e-5 per op, 2e-4 end to end."""
+restatement of the published formulas (oracle/modconv_ref.py).  Tolerance 2e-5 per op, 2e-4 end to end; backward
+against autograd of those formulas in fp64 (mask-flip-robust criterion)."""
 import importlib
 
 import pytest
@@ -130,5 +131,85 @@ def test_variant_generator_vs_oracle(sg2, dev, B, res):
         y2 = g(feats.to(dev))                       # device-drawn noise path
     assert y.shape == (B, 3, res, res) and torch.isfinite(y2).all()
     assert rel_l2(y, ref) < 2e-4
-    with pytest.raises(NotImplementedError):
-        g(feats.to(dev))                            # grad mode
+
+
+def _close(got, ref32, ref64):
+    """Mask-flip-robust gradient criterion (see tests/test_discriminator_gpu.py): both parts against fp64."""
+    got, ref32, ref64 = (t.detach().cpu().double() for t in (got, ref32, ref64))
+    e_got, e_ref = rel_l2(got, ref64), rel_l2(ref32, ref64)
+    rms = float(ref64.pow(2).mean().sqrt())
+    p90 = float(torch.quantile((got - ref64).abs().flatten()[:4_000_000], 0.9))
+    return e_got <= max(5e-3, 3 * e_ref) and p90 <= 1e-4 * rms, (e_got, e_ref, p90 / max(rms, 1e-300))
+
+
+@pytest.mark.parametrize("upsample", [False, True])
+def test_styled_conv_backward(sg2, dev, upsample):
+    """Backward of the modulated conv (data, weight, modulation incl. the demodulation path, noise weight, bias) vs
+    autograd of the published formulas evaluated in fp64."""
+    B, Cin, Cout, H = 2, 20, 24, 8
+    m = sg2.StyledConv(Cin, Cout, 3, 32, upsample=upsample)
+    with torch.no_grad():
+        m.noise.weight.fill_(0.37)
+        m.activate.bias.copy_(recipe_tensor("scb.act.bias", (Cout,), 0.3))
+    Ho = 2 * H if upsample else H
+    x, st, nz = recipe_input("scb.x", (B, Cin, H, H)), recipe_input("scb.st", (B, 32)), recipe_input(f"scb.nz.{Ho}", (B, 1, Ho, Ho))
+    gy = recipe_input(f"scb.gy.{Ho}", (B, Cout, Ho, Ho))
+    res = {}
+    for name, dt_, device in (("ref32", torch.float32, "cpu"), ("ref64", torch.float64, "cpu"), ("hip", torch.float32, dev)):
+        xi = x.detach().clone().to(device, dt_).requires_grad_(True)
+        si = st.detach().clone().to(device, dt_).requires_grad_(True)
+        if name == "hip":
+            mm = m.to(dev)
+            y = mm(xi, si, nz.to(dev))
+            params = dict(mm.named_parameters())
+        else:
+            params = {k: v.detach().clone().to(dt_).requires_grad_(True) for k, v in m.state_dict().items()}
+            y = M.styled_conv(xi, si, params, "", nz.to(dt_), upsample)
+        (y * gy.to(device, dt_)).sum().backward()
+        g = {k: p.grad for k, p in params.items() if p.grad is not None}
+        g["x"], g["style"] = xi.grad, si.grad
+        res[name] = (y, g)
+        if name == "hip":
+            for p in mm.parameters():
+                p.grad = None
+    assert rel_l2(res["hip"][0], res["ref64"][0]) < 2e-5
+    assert set(res["hip"][1]) == set(res["ref64"][1]) and "conv.modulation.weight" in res["hip"][1] and "noise.weight" in res["hip"][1]
+    for k in res["ref64"][1]:
+        ok, info = _close(res["hip"][1][k], res["ref32"][1][k], res["ref64"][1][k])
+        assert ok, (k, info)
+
+
+def test_variant_generator_backward(sg2, dev):
+    """Whole variant decoder, fwd + bwd of a quadratic loss, every parameter and the input latent."""
+    B, res = 2, 32
+    torch.manual_seed(6)
+    g = sg2.StyleGAN2Generator(6144, resolution=res).train()
+    with torch.no_grad():
+        for n, p in g.named_parameters():
+            if n.endswith("noise.weight"):
+                p.fill_(0.1)
+            elif n.endswith("activate.bias") or (n.endswith("bias") and "to_rgb" in n and "modulation" not in n):
+                p.normal_(0, 0.1)
+    feats = recipe_input(f"sg2b.f.{B}", (B, 6144))
+    noises = [recipe_input(f"sg2b.n{i}.{B}.{res}", s) for i, s in enumerate(M.noise_shapes(B, res))]
+    target = recipe_input("sg2b.t", (B, 3, res, res))
+    out = {}
+    for name, dt_, device in (("ref32", torch.float32, "cpu"), ("ref64", torch.float64, "cpu"), ("hip", torch.float32, dev)):
+        f = feats.detach().clone().to(device, dt_).requires_grad_(True)
+        if name == "hip":
+            gg = g.to(dev)
+            y = gg(f, [n.to(dev) for n in noises])
+            params = dict(gg.named_parameters())
+        else:
+            params = {k: v.detach().clone().to(dt_).requires_grad_(True) for k, v in g.state_dict().items() if v.dtype.is_floating_point}
+            y = M.generator(f, params, [n.to(dt_) for n in noises], resolution=res)
+        ((y - target.to(device, dt_)) ** 2).mean().backward()
+        gr = {k: p.grad for k, p in params.items() if p.grad is not None}
+        gr["features"] = f.grad
+        out[name] = (y, gr)
+    assert rel_l2(out["hip"][0], out["ref64"][0]) < 2e-4
+    missing = set(out["ref64"][1]) - set(out["hip"][1])
+    assert not missing, sorted(missing)[:5]
+    for k in out["ref64"][1]:
+        ok, info = _close(out["hip"][1][k], out["ref32"][1][k], out["ref64"][1][k])
+        assert ok, (k, info)
