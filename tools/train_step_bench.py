@@ -29,6 +29,8 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--decoder-only", action="store_true")
+    ap.add_argument("--sg2-decoder", action="store_true", help="swap IRFD.Gd for the build-defined StyleGAN2 variant "
+                    "(BASELINE config 3 read literally)")
     ap.add_argument("--d-step", action="store_true", help="the discriminator step of train.py:155-183 instead "
                     "(4 D passes with BCE + 2 R1 penalties, backward, Adam on D); fakes are synthetic images")
     args = ap.parse_args()
@@ -45,7 +47,10 @@ def main():
     import model as M
     dp = importlib.import_module("speak-hack_amd.dp")
     torch.manual_seed(0)                       # identical initial weights on every rank
-    net = M.IRFD().to(dev).train()
+    net = M.IRFD()
+    if args.sg2_decoder:
+        net.Gd = importlib.import_module("speak-hack_amd.stylegan2").StyleGAN2Generator(6144)
+    net = net.to(dev).train()
     if args.d_step:
         for n, p in net.named_parameters():
             p.requires_grad_(n.startswith("D."))
