@@ -59,7 +59,7 @@ def host_cores():
 
 
 def cpu_baseline(threads):
-    """Oracle (port) on the host cores: 1 warm-up + 3 timed B=8 forwards."""
+    """Oracle (port) on the host cores: 1 warm-up + 9 timed B=8 forwards (about 10 s of CPU work)."""
     from oracle import decoder_ref as R
     from oracle.weights_recipe import recipe_input, recipe_noises
     pkg = importlib.import_module("speak-hack_amd")
@@ -70,14 +70,14 @@ def cpu_baseline(threads):
     noises = recipe_noises("bench.cpu", BATCH, RES)
     times = []
     with torch.no_grad():
-        for i in range(4):
+        for i in range(10):
             t0 = time.perf_counter()
             R.style_generator(feats, sd, noises)
             times.append(time.perf_counter() - t0)
     times = sorted(times[1:])
     med = times[len(times) // 2]
     return {"value": round(BATCH / med, 3), "unit": "frames/s", "cores": threads, "kind": "port",
-            "sample": f"oracle.decoder_ref.style_generator, B={BATCH}, 256^2, fp32, median of 3 after 1 warm-up "
+            "sample": f"oracle.decoder_ref.style_generator, B={BATCH}, 256^2, fp32, median of 9 after 1 warm-up "
                       f"({med * 1e3:.0f} ms/step)"}
 
 

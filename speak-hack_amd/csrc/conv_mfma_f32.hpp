@@ -27,6 +27,7 @@
 #include "spk_common.hpp"
 
 #include <algorithm>
+#include <cstdlib>
 #include <type_traits>
 
 namespace spkconv {
@@ -329,7 +330,9 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
         const bool l0 = c_begin == p.n_chunks - 1;
         static_for<0, P_S>([&](auto j) { SPK_STORE_PIECE(ring0, l0, decltype(j)::value); });
         const int c1 = min(c_begin + 1, c_end - 1);
-        static_for<0, P_L>([&](auto j) { SPK_LOAD_PIECE(c1, ring1, decltype(j)::value); });
+        if (!ROWLOOP || n_my > 1) {   // a single-chunk rolled-loop problem (the 7x7 stem: Cin = 3) lives in slot 0 alone
+            static_for<0, P_L>([&](auto j) { SPK_LOAD_PIECE(c1, ring1, decltype(j)::value); });
+        }
     }
     if constexpr (DMA) __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): this wave's LDS-DMA blocks have landed
     __syncthreads();
@@ -386,9 +389,11 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
         const bool l1 = min(chunk + 1, c_end - 1) == p.n_chunks - 1;   // the chunk held in registers is the ragged last one
         if constexpr (ROWLOOP) {
             // large kernels (7x7): the tap rows stay a runtime loop of KW*CI_T/2 static steps; staging is not interleaved
-            static_for<0, P_S>([&](auto j) { SPK_STORE_PIECE(nxt, l1, decltype(j)::value); });
-            __syncthreads();
-            static_for<0, P_L>([&](auto j) { SPK_LOAD_PIECE(chunk2, oth, decltype(j)::value); });
+            if (n_my > 1) {
+                static_for<0, P_S>([&](auto j) { SPK_STORE_PIECE(nxt, l1, decltype(j)::value); });
+                __syncthreads();
+                static_for<0, P_L>([&](auto j) { SPK_LOAD_PIECE(chunk2, oth, decltype(j)::value); });
+            }
 #pragma unroll 1
             for (int row = 0; row < ROWS; ++row) {
                 const float* abuf = cur + row * (KW * C::CI_T * C::CO_T);
@@ -556,7 +561,8 @@ Geometry geometry(int B, int Cin, int Cout, int H, int W) {
     g.n_chunks = spk::ceil_div(Cin, C::CI_T);
     g.co_tiles = spk::ceil_div(Cout, C::CO_T);
     const size_t in_floats = ((size_t)C::CI_T * g.TB * g.PLANE + 3) & ~(size_t)3;
-    g.lds_bytes = 3 * (SH::W_FLOATS + in_floats + 4) * sizeof(float);   // three-slot ring
+    const bool one_slot = KH * KW > 9 && g.n_chunks == 1;   // rolled-loop kernel with a single chunk: no ring needed
+    g.lds_bytes = (one_slot ? 1 : 3) * (SH::W_FLOATS + in_floats + 4) * sizeof(float);   // three-slot ring
     if (g.lds_bytes > 160 * 1024) g.ok = false;
     return g;
 }
@@ -564,8 +570,9 @@ Geometry geometry(int B, int Cin, int Cout, int H, int W) {
 // number of ci-chunk slices so that the grid fills the chip (about 2 workgroups per CU)
 inline int pick_ksplit(const Geometry& g) {
     const long long tiles = (long long)g.tiles_x * g.tiles_y * g.tiles_b * g.co_tiles;
+    static const int target = [] { const char* e = getenv("SPK_KSPLIT_TARGET"); return e ? atoi(e) : 512; }();
     int ks = 1;
-    while (tiles * ks < 512 && g.n_chunks / (ks * 2) >= 4 && ks < 64) ks *= 2;
+    while (tiles * ks < target && g.n_chunks / (ks * 2) >= 4 && ks < 64) ks *= 2;
     return ks;
 }
 
