@@ -283,6 +283,10 @@ int spk_conv1x1_small_mod_fwd(const float* x, const float* w, const float* mod, 
 int spk_pixelnorm_fwd(const float* x, float* y, int B, int C, int64_t HW, float eps, int sqrt_form, void* stream);
 int spk_instance_norm_affine_fwd(const float* x, float* y, const float* scale, const float* bias, int64_t sb_stride, int B, int C,
                                  int64_t HW, float eps, void* stream);
+/* its adjoint (autograd of stylegan.py:84-95): dx [B,C,HW] (or NULL), dscale / dbias [B,C] contiguous (or NULL);
+ * `scale` as in the forward (NULL = 1). */
+int spk_instance_norm_affine_bwd(const float* x, const float* dy, const float* scale, int64_t sb_stride, float* dx, float* dscale,
+                                 float* dbias, int B, int C, int64_t HW, float eps, void* stream);
 int spk_blur2d_fwd(const float* x, float* y, const float* filter_host, int k, int64_t planes, int H, int W, int stride, void* stream);
 int spk_upscale2d_nearest_fwd(const float* x, float* y, int64_t planes, int H, int W, int factor, float gain, void* stream);
 int spk_fade_in_tanh_fwd(const float* a, const float* b, float* y, float alpha, int64_t n, void* stream);

@@ -67,6 +67,8 @@ _PROTOTYPES = {
     "spk_pixelnorm_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_float, C.c_int, C.c_void_p]),
     "spk_instance_norm_affine_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
                                                C.c_int64, C.c_float, C.c_void_p]),
+    "spk_instance_norm_affine_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p,
+                                               C.c_int, C.c_int, C.c_int64, C.c_float, C.c_void_p]),
     "spk_blur2d_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int,
                                  C.c_void_p]),
     "spk_upscale2d_nearest_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),

@@ -357,6 +357,36 @@ class UpFirDnFn(torch.autograd.Function):
         return ops.upfirdn2d(g.contiguous(), torch.flip(fir, [0, 1]), up=down, down=up, pad=(gp0, gp1)), None, None, None, None
 
 
+class InstanceNormAffineFn(torch.autograd.Function):
+    """AdaIN (stylegan.py:84-95): InstanceNorm2d(x) * scale[b,c] + bias[b,c]."""
+
+    @staticmethod
+    def forward(ctx, x, scale, bias, eps, grad_mode):
+        y = ops.instance_norm_affine(x, scale, bias, eps)
+        if _needs(ctx, grad_mode):
+            ctx.save_for_backward(x, scale)
+            ctx.eps = eps
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, scale = ctx.saved_tensors
+        dx, dscale, dbias = ops.instance_norm_affine_bwd(x, dy.contiguous(), scale, ctx.eps, need_dx=ctx.needs_input_grad[0])
+        return dx, dscale, dbias, None, None
+
+
+class Upsample2xFn(torch.autograd.Function):
+    """F.interpolate(scale_factor=2, mode="bilinear") and its adjoint."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return ops.upsample2x_bilinear(x)
+
+    @staticmethod
+    def backward(ctx, dy):
+        return ops.upsample2x_bilinear_bwd(dy.contiguous())
+
+
 # call-site spellings: sample the grad mode where it is still visible
 def fused_conv(x, weight, bias, noise_w, noise, style, upsample, slope, packed):
     return FusedConvFn.apply(x, weight, bias, noise_w, noise, style, upsample, slope, packed, torch.is_grad_enabled())
@@ -392,3 +422,11 @@ def mod_to_rgb(x, weight, s, bias, scale):
 
 def upfirdn(x, fir, up, down, pad):
     return UpFirDnFn.apply(x, fir, up, down, pad)
+
+
+def instance_norm_affine(x, scale, bias, eps):
+    return InstanceNormAffineFn.apply(x, scale, bias, eps, torch.is_grad_enabled())
+
+
+def upsample2x(x):
+    return Upsample2xFn.apply(x)

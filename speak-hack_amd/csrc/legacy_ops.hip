@@ -67,6 +67,39 @@ __global__ __launch_bounds__(256) void instance_norm_affine_kernel(const float* 
 
 struct Fir { float f[49]; int k; };
 
+// Adjoint of instance_norm_affine_kernel, one workgroup per (b,c) plane.  With xh = (x-mean)*invstd, g = scale[b,c]:
+//   dx = g * invstd * (dy - mean(dy) - xh * mean(dy*xh)),   dscale[b,c] = sum dy*xh,   dbias[b,c] = sum dy
+__global__ __launch_bounds__(256) void instance_norm_affine_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                      const float* __restrict__ scale, long long sb_stride,
+                                                                      float* __restrict__ dx, float* __restrict__ dscale,
+                                                                      float* __restrict__ dbias, int C, long long HW, float eps) {
+    __shared__ float red[4];
+    const long long plane = blockIdx.x;
+    const int c = (int)(plane % C);
+    const long long b = plane / C;
+    const float* xp = x + plane * HW;
+    const float* gp = dy + plane * HW;
+    float s = 0.f;
+    for (long long i = threadIdx.x; i < HW; i += 256) s += xp[i];
+    const float mean = lg_block_sum(s, red) / (float)HW;
+    float v = 0.f;
+    for (long long i = threadIdx.x; i < HW; i += 256) { const float d = xp[i] - mean; v += d * d; }
+    const float invstd = rsqrtf(lg_block_sum(v, red) / (float)HW + eps);
+    float s1 = 0.f, s2 = 0.f;
+    for (long long i = threadIdx.x; i < HW; i += 256) { const float g = gp[i]; s1 += g; s2 += g * (xp[i] - mean) * invstd; }
+    const float sum_dy = lg_block_sum(s1, red), sum_dyxh = lg_block_sum(s2, red);
+    if (threadIdx.x == 0) {
+        if (dscale) dscale[plane] = sum_dyxh;
+        if (dbias) dbias[plane] = sum_dy;
+    }
+    if (dx) {
+        const float g = scale ? scale[b * sb_stride + c] : 1.f;
+        const float m1 = sum_dy / (float)HW, m2 = sum_dyxh / (float)HW;
+        float* dp = dx + plane * HW;
+        for (long long i = threadIdx.x; i < HW; i += 256) dp[i] = g * invstd * (gp[i] - m1 - (xp[i] - mean) * invstd * m2);
+    }
+}
+
 // depthwise k x k FIR, zero padding (k-1)/2, stride 1 or 2
 __global__ __launch_bounds__(256) void blur2d_kernel(const float* __restrict__ x, float* __restrict__ y, Fir fir, long long planes,
                                                     int H, int W, int Ho, int Wo, int stride) {
@@ -130,6 +163,14 @@ int spk_instance_norm_affine_fwd(const float* x, float* y, const float* scale, c
     hipLaunchKernelGGL(instance_norm_affine_kernel, dim3((unsigned)(B * C)), dim3(256), 0, (hipStream_t)stream, x, y, scale, bias,
                        (long long)sb_stride, C, (long long)HW, eps);
     return spk::check_launch("instance_norm_affine_kernel");
+}
+
+int spk_instance_norm_affine_bwd(const float* x, const float* dy, const float* scale, int64_t sb_stride, float* dx, float* dscale,
+                                 float* dbias, int B, int C, int64_t HW, float eps, void* stream) {
+    SPK_REQUIRE(x && dy && B > 0 && C > 0 && HW > 0, "instance_norm_bwd: bad arguments");
+    hipLaunchKernelGGL(instance_norm_affine_bwd_kernel, dim3((unsigned)(B * C)), dim3(256), 0, (hipStream_t)stream, x, dy, scale,
+                       (long long)sb_stride, dx, dscale, dbias, C, (long long)HW, eps);
+    return spk::check_launch("instance_norm_affine_bwd_kernel");
 }
 
 int spk_blur2d_fwd(const float* x, float* y, const float* filter_host, int k, int64_t planes, int H, int W, int stride, void* stream) {

@@ -404,6 +404,19 @@ def instance_norm_affine(x, scale=None, bias=None, eps=1e-5):
     return y
 
 
+def instance_norm_affine_bwd(x, dy, scale=None, eps=1e-5, need_dx=True):
+    """Adjoint of ``instance_norm_affine`` -> (dx | None, dscale [B,C], dbias [B,C])."""
+    B, Cc, H, W = x.shape
+    dx = torch.empty_like(x) if need_dx else None
+    dscale = torch.empty((B, Cc), device=x.device, dtype=torch.float32)
+    dbias = torch.empty((B, Cc), device=x.device, dtype=torch.float32)
+    L.check(L.lib().spk_instance_norm_affine_bwd(L.dptr(x, "x"), L.dptr(dy, "dy"), _style_ptr(scale),
+                                                 scale.stride(0) if scale is not None else 0, L.dptr(dx), L.dptr(dscale),
+                                                 L.dptr(dbias), B, Cc, H * W, float(eps), L.stream_ptr()),
+            "spk_instance_norm_affine_bwd")
+    return dx, dscale, dbias
+
+
 def blur2d(x, filt2d, stride=1):
     """Depthwise FIR with the k x k filter ``filt2d`` (a CPU tensor / nested list), zero pad (k-1)/2."""
     B, Cc, H, W = x.shape

@@ -1,7 +1,7 @@
 """Mirror of the reference's ``stylegan.py`` (ProGAN-style StyleGAN1): the same
 class names, constructor arguments, ``forward`` signatures and ``state_dict`` keys (145 entries for
-``Generator(512, 512)``, ``rgb_layers.0`` aliasing ``initial_rgb`` as in the reference).  Forward only,
-on the HIP kernels:
+``Generator(512, 512)``, ``rgb_layers.0`` aliasing ``initial_rgb`` as in the reference).  Forward and backward
+on the HIP kernels (backward through ``autograd.FusedConvFn`` / ``InstanceNormAffineFn`` / ``ToRGBFn`` / ``FCFn``):
 
 * ``WSConv2d`` = the MFMA conv with ``out_scale`` folding the ``x * scale`` pre-multiply (stylegan.py:45-46);
   inside ``GenBlock`` the bilinear x2, bias, noise and LeakyReLU ride in the same launch;
@@ -16,15 +16,10 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
+from . import autograd as AG
 from . import ops
 
 factors = [1, 1, 1, 1, 1 / 2, 1 / 4, 1 / 8, 1 / 16, 1 / 32]
-
-
-def _no_grad_only(name):
-    if torch.is_grad_enabled():
-        raise NotImplementedError(f"{name}: backward of the stylegan.py generator is not built (orphan module in the "
-                                  f"reference, SURVEY.md 8a A12); call it under torch.no_grad()")
 
 
 class WSLinear(nn.Module):
@@ -38,8 +33,7 @@ class WSLinear(nn.Module):
         nn.init.zeros_(self.bias)
 
     def forward(self, x, relu=False):
-        _no_grad_only("WSLinear")
-        return ops.fc(x.contiguous(), self.linear.weight, self.bias, self.scale, 1.0, 0.0 if relu else 1.0)
+        return AG.fc(x.contiguous(), self.linear.weight, self.bias, self.scale, 1.0, 0.0 if relu else 1.0)
 
 
 class PixelNorm(nn.Module):
@@ -48,6 +42,8 @@ class PixelNorm(nn.Module):
         self.epsilon = 1e-8
 
     def forward(self, x):
+        if torch.is_grad_enabled() and x.requires_grad:      # [B,512] latent: the gradient is plain torch algebra
+            return x / torch.sqrt(torch.mean(x ** 2, dim=1, keepdim=True) + self.epsilon)
         return ops.pixelnorm(x.contiguous(), self.epsilon, sqrt_form=True)
 
 
@@ -63,13 +59,19 @@ class WSConv2d(nn.Module):
         self._pk = ops.PackedConvWeight()
 
     def forward(self, x, noise_w=None, noise=None, lrelu=None, upsample=False):
-        _no_grad_only("WSConv2d")
         w = self.conv.weight
         Cout, Cin, k, _ = w.shape
+        train = torch.is_grad_enabled() and (x.requires_grad or w.requires_grad)
         if k == 1 and Cout <= 4:
+            if train:       # conv(x * scale, w) = conv(x, w * scale): the scale rides on the (tiny) weight tensor
+                return AG.to_rgb(x.contiguous(), w * self.scale, self.bias)
             return ops.conv1x1_small(x.contiguous(), w, self.bias, in_scale=self.scale)
         if self.conv.padding[0] != (k - 1) // 2 or k not in (1, 3):
             raise NotImplementedError(f"WSConv2d: kernel {k} / padding {self.conv.padding} is not on the HIP path")
+        if train:
+            if k != 3:
+                raise NotImplementedError("WSConv2d backward: 3x3 and the 1x1 toRGB are on the HIP path")
+            return AG.fused_conv(x.contiguous(), w * self.scale, self.bias, noise_w, noise, None, upsample, lrelu, self._pk)
         B, _, H, W = x.shape
         Ho, Wo = (2 * H, 2 * W) if upsample else (H, W)
         cfg = ops.conv2d_pick_config(k, 1, B, Cin, Cout, Ho, Wo)
@@ -106,7 +108,7 @@ class InjectNoise(nn.Module):
             return x
         if noise is None:
             noise = torch.randn((x.shape[0], 1, x.shape[2], x.shape[3]), device=x.device)
-        return ops.bias_noise_style(x.contiguous(), noise.shape[0], noise_w=self.weight.view(-1), noise=noise.contiguous())
+        return AG.bias_noise_style(x.contiguous(), None, self.weight.view(-1), noise.contiguous(), None, noise.shape[0])
 
 
 class AdaIN(nn.Module):
@@ -119,7 +121,7 @@ class AdaIN(nn.Module):
     def forward(self, x, w):
         if x.size(0) != w.size(0):                 # the 4x4 constant is [1,C,4,4]: normalise once, style per sample
             x = x.expand(w.size(0), -1, -1, -1).contiguous()
-        return ops.instance_norm_affine(x.contiguous(), self.style_scale(w), self.style_bias(w), self.instance_norm.eps)
+        return AG.instance_norm_affine(x.contiguous(), self.style_scale(w), self.style_bias(w), self.instance_norm.eps)
 
 
 class GenBlock(nn.Module):
@@ -177,33 +179,36 @@ class Generator(nn.Module):
         self._pk0 = ops.PackedConvWeight()
 
     def fade_in(self, alpha, upscaled, generated):
+        if torch.is_grad_enabled() and (upscaled.requires_grad or generated.requires_grad):
+            return torch.tanh(alpha * generated + (1 - alpha) * upscaled)       # [B,3,H,W] images: torch elementwise
         return ops.fade_in_tanh(generated.contiguous(), upscaled.contiguous(), alpha)
 
     def forward(self, w, alpha, steps, zero_noise=False, noises=None):
         """``noises`` (optional): the 2 + 2*steps noise tensors in the reference's draw order (stylegan.py:81)."""
-        _no_grad_only("Generator")
         nz = iter(noises) if noises is not None else None
         nxt = (lambda: next(nz)) if nz is not None else (lambda: None)
         B = w.size(0)
         x = self.initial_adain1(self.initial_noise1(self.starting_constant, zero_noise, None if zero_noise else nxt()), w)
         Cc = x.size(1)
-        cfg = ops.conv2d_pick_config(3, 1, B, Cc, Cc, 4, 4)
         n2 = None if zero_noise else nxt()
         if not zero_noise and n2 is None:
             n2 = torch.randn((B, 1, 4, 4), device=w.device)
         # initial_conv (plain nn.Conv2d, stylegan.py:135) -> x; leaky(noise2(x)) -> adain2 -> out (stylegan.py:161-162).
         # Reference quirk kept: the LeakyReLU is in-place (stylegan.py:136) and with zero_noise InjectNoise returns
         # its input, so `x` itself is overwritten before `initial_rgb(x)` at steps == 0; with noise it is not.
-        wp0, cb = self._pk0.get(self.initial_conv.weight, cfg), self.initial_conv.bias
+        cw, cb = self.initial_conv.weight, self.initial_conv.bias
+
+        def conv0(noise_w, noise, slope):
+            return AG.fused_conv(x.contiguous(), cw, cb, noise_w, noise, None, False, slope, self._pk0)
+
         if zero_noise:
-            pre = ops.conv2d_fused(x, wp0, Cc, 3, 1, bias=cb, lrelu_slope=0.2, config=cfg)
+            pre = conv0(None, None, 0.2)
             if steps == 0:
                 return self.initial_rgb(pre)
         else:
             if steps == 0:
-                return self.initial_rgb(ops.conv2d_fused(x, wp0, Cc, 3, 1, bias=cb, config=cfg))
-            pre = ops.conv2d_fused(x, wp0, Cc, 3, 1, bias=cb, noise_w=self.initial_noise2.weight.view(-1),
-                                   noise=n2.contiguous(), lrelu_slope=0.2, config=cfg)
+                return self.initial_rgb(conv0(None, None, None))
+            pre = conv0(self.initial_noise2.weight.view(-1), n2.contiguous(), 0.2)
         out = self.initial_adain2(pre, w)
         prev = out
         for step in range(steps):
@@ -211,7 +216,7 @@ class Generator(nn.Module):
             ns = (None, None) if zero_noise else (nxt(), nxt())
             out = self.prog_blocks[step](out, w, zero_noise, ns, upsample=True)
         # rgb(upsample(prev)) == upsample(rgb(prev)): a 1x1 conv commutes with the bilinear resize
-        final_upscaled = ops.upsample2x_bilinear(self.rgb_layers[steps - 1](prev))
+        final_upscaled = AG.upsample2x(self.rgb_layers[steps - 1](prev))
         final_out = self.rgb_layers[steps](out)
         return self.fade_in(alpha, final_upscaled, final_out)
 
