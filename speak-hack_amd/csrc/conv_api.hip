@@ -60,8 +60,87 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const ConvArgs p, 
     }
 }
 
+// Vector form for planes that are a multiple of 4 floats: one thread finishes 4 consecutive outputs of one (b, co)
+// plane with 16-byte loads of every slice; BatchNorm sums are reduced over the lanes that share the plane (the whole
+// wave, or a power-of-two lane segment for tiny planes) before the fp64 atomics.
+__global__ __launch_bounds__(256) void splitk_epilogue_vec_kernel(const ConvArgs p, const float* __restrict__ ws, int ksplit) {
+    const size_t HW = (size_t)p.H * p.W;
+    const size_t total4 = (size_t)p.B * p.Cout * HW / 4, total = total4 * 4;
+    const bool f_bias = p.flags & SPK_EPI_BIAS, f_noise = p.flags & SPK_EPI_NOISE;
+    const bool f_lrelu = p.flags & SPK_EPI_LRELU, f_style = p.flags & SPK_EPI_STYLE;
+    const bool f_accum = p.flags & SPK_EPI_ACCUM, f_stats = p.flags & SPK_EPI_STATS;
+    const size_t q4 = HW / 4;                        // float4s per plane
+    const int seg = q4 >= 64 ? 64 : (int)q4;         // lanes that share a plane (q4 is a power of two when < 64: checked on the host)
+    const size_t nthreads = (size_t)gridDim.x * blockDim.x;
+    const size_t rounds = (total4 + nthreads - 1) / nthreads;
+    for (size_t it = 0; it < rounds; ++it) {         // every lane runs every round (wave-wide shuffles below)
+        const size_t i4 = it * nthreads + (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+        const bool in = i4 < total4;
+        float v[4] = {0.f, 0.f, 0.f, 0.f};
+        int co = 0;
+        if (in) {
+            const size_t idx = i4 * 4;
+            float4 acc = *reinterpret_cast<const float4*>(ws + idx);
+            for (int z = 1; z < ksplit; ++z) {
+                const float4 t = *reinterpret_cast<const float4*>(ws + (size_t)z * total + idx);
+                acc.x += t.x; acc.y += t.y; acc.z += t.z; acc.w += t.w;
+            }
+            v[0] = acc.x; v[1] = acc.y; v[2] = acc.z; v[3] = acc.w;
+            const size_t pix = idx % HW;
+            co = (int)((idx / HW) % p.Cout);
+            const int b = (int)(idx / (HW * p.Cout));
+            float scale = p.out_scale;
+            if (p.out_scale_bc) scale *= p.out_scale_bc[(size_t)b * p.Cout + co];
+            const float bb = f_bias ? p.bias[co] : 0.f;
+            const float nw = f_noise ? p.noise_w[co] : 0.f;
+            float s0 = 1.f, s1 = 0.f;
+            if (f_style) {
+                const float* st = p.style + (size_t)b * p.style_stride;
+                s0 = st[co] + 1.f; s1 = st[p.Cout + co];
+            }
+            float4 nz = make_float4(0.f, 0.f, 0.f, 0.f), old = nz;
+            if (f_noise) nz = *reinterpret_cast<const float4*>(p.noise + (size_t)b * HW + pix);
+            if (f_accum) old = *reinterpret_cast<const float4*>(p.y + idx);
+            const float nzv[4] = {nz.x, nz.y, nz.z, nz.w}, oldv[4] = {old.x, old.y, old.z, old.w};
+            float pre[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float t = v[k] * scale + bb + nw * nzv[k];
+                if (f_lrelu) t = (t > 0.f ? t : t * p.slope) * p.act_gain;
+                pre[k] = t;
+                if (f_style) t = t * s0 + s1;
+                v[k] = t + oldv[k];
+            }
+            if (p.y_pre) *reinterpret_cast<float4*>(p.y_pre + idx) = make_float4(pre[0], pre[1], pre[2], pre[3]);
+            *reinterpret_cast<float4*>(p.y + idx) = make_float4(v[0], v[1], v[2], v[3]);
+        }
+        if (f_stats) {
+            float s = (v[0] + v[1]) + (v[2] + v[3]);
+            float ss = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+            for (int off = seg >> 1; off >= 1; off >>= 1) {
+                s += __shfl_xor(s, off);
+                ss += __shfl_xor(ss, off);
+            }
+            if (in && (threadIdx.x & (seg - 1)) == 0) {
+                atomicAdd(p.stats + co, (double)s);
+                atomicAdd(p.stats + p.Cout + co, (double)ss);
+            }
+        }
+    }
+}
+
 int launch_splitk_epilogue(const ConvArgs& a, const float* ws, int ksplit, hipStream_t stream) {
     const size_t out_floats = (size_t)a.B * a.Cout * a.H * a.W;
+    const size_t HW = (size_t)a.H * a.W, q4 = HW / 4;
+    // lanes of a wave must split evenly into planes for the segmented sums: q4 a multiple of 64, or a power of two below
+    const bool seg_ok = HW % 4 == 0 && (q4 % 64 == 0 || (q4 < 64 && (q4 & (q4 - 1)) == 0));
+    const bool aligned = (uintptr_t)ws % 16 == 0 && (uintptr_t)a.y % 16 == 0 && (!a.y_pre || (uintptr_t)a.y_pre % 16 == 0) &&
+                         (!a.noise || (uintptr_t)a.noise % 16 == 0);
+    if (seg_ok && aligned) {
+        const unsigned blocks = (unsigned)std::min<size_t>((out_floats / 4 + 255) / 256, 256 * 8);
+        hipLaunchKernelGGL(splitk_epilogue_vec_kernel, dim3(blocks), dim3(256), 0, stream, a, ws, ksplit);
+        return spk::check_launch("splitk_epilogue_vec_kernel");
+    }
     const unsigned blocks = (unsigned)std::min<size_t>((out_floats + 255) / 256, 256 * 8);
     hipLaunchKernelGGL(splitk_epilogue_kernel, dim3(blocks), dim3(256), 0, stream, a, ws, ksplit);
     return spk::check_launch("splitk_epilogue_kernel");

@@ -197,9 +197,16 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         const int ci = (int)(src % Cin);
         const int tap = (int)((src / Cin) % taps);
         const int co = (int)(src / ((size_t)Cin * taps));
-        float v = 0.f;
-        for (int s = 0; s < n_slabs; ++s) v += slabs[(size_t)s * total + src];
-        v *= scale;
+        // four interleaved partial sums (slab s goes to sum s % 4): still one fixed order, but four loads in flight
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+        int s = 0;
+        for (; s + 4 <= n_slabs; s += 4) {
+            const float a0 = slabs[(size_t)s * total + src], a1 = slabs[(size_t)(s + 1) * total + src];
+            const float a2 = slabs[(size_t)(s + 2) * total + src], a3 = slabs[(size_t)(s + 3) * total + src];
+            v0 += a0; v1 += a1; v2 += a2; v3 += a3;
+        }
+        for (; s < n_slabs; ++s) v0 += slabs[(size_t)s * total + src];
+        float v = ((v0 + v1) + (v2 + v3)) * scale;
         const size_t idx = ((size_t)co * Cin + ci) * taps + tap;
         dw[idx] = accumulate ? dw[idx] + v : v;
     }
