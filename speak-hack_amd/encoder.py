@@ -72,7 +72,10 @@ class _ConvBN:
                              stats=stats, config=cfg)
         if training:
             if bn.num_batches_tracked is not None:
-                bn.num_batches_tracked += 1
+                if bn.momentum is None:
+                    bn.num_batches_tracked += 1                      # cumulative average: the count is needed right now
+                else:
+                    stats_pool.counters.append(bn.num_batches_tracked)   # bumped together at the end of the pass
             momentum = bn.momentum if bn.momentum is not None else 1.0 / float(bn.num_batches_tracked)
             fin = ops.bn_finalize(stats, B * Ho * Wo, bn.weight, bn.bias, bn.running_mean, bn.running_var, momentum,
                                   bn.eps, save=keep)
@@ -109,6 +112,7 @@ class _StatsPool:
     def __init__(self, device, total):
         self.buf = torch.zeros(total, device=device, dtype=torch.float64)
         self.pos = 0
+        self.counters = []       # num_batches_tracked buffers of the BatchNorms this pass went through
 
     def take(self, n):
         out = self.buf[self.pos:self.pos + n]
@@ -197,6 +201,8 @@ class ResNet50Trunk(nn.Sequential):
             if keep:
                 recs["blocks"].append((r1, r2, r3, rd, out))
             cur = out
+        if pool is not None and pool.counters:
+            torch._foreach_add_(pool.counters, 1)                    # 53 one-element kernels -> one fused launch
         return ops.global_avgpool(cur), recs
 
     def _backward(self, recs, dfeat):
