@@ -67,6 +67,7 @@ struct ConvArgs {
     int style_stride;
     unsigned flags;
     float slope, out_scale, act_gain;
+    unsigned magic_plane, magic_pw;   // ceil(2^32 / PLANE), ceil(2^32 / PW): exact division of the small tile indices
 };
 
 template <int WM_, int WN_, int MT_, int NT_, int CIT_>
@@ -170,10 +171,11 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
         if (AFF || BSC) s_sc[s] = s_scl[s] = 0;
         const int e = s * 64 + lane;
         if (e < wave_elems) {
-            const int pl = e / PLANE, pidx = e - pl * PLANE;
+            // e < 2^16 and PLANE, PW < 2^16: __umulhi with ceil(2^32/d) is the exact quotient (no integer-divide sequences)
+            const int pl = p.magic_plane ? (int)__umulhi((unsigned)e, p.magic_plane) : e, pidx = e - pl * PLANE;
             const int q = wave * ppw + pl;
             const int ci = q >> p.lgTB, tb = q & (TB - 1);
-            const int r = pidx / PW, c = pidx - r * PW;
+            const int r = p.magic_pw ? (int)__umulhi((unsigned)pidx, p.magic_pw) : pidx, c = pidx - r * PW;
             const int uy = (y0 * SL + r) * (S / SL) - PAD, ux = (x0 * SL + c) * (S / SL) - PAD;
             const bool past = ci >= ci_left_last;
             s_dst[s] = (unsigned)(W_FLOATS + wave * wave_elems + e) * 4u;
@@ -597,6 +599,12 @@ int run(const spk_conv2d_desc* d, hipStream_t stream) {
     SPK_REQUIRE(g.ok, "conv2d: config %d does not fit this shape (%dx%d, B=%d)", d->config, d->H, d->W, d->B);
     SPK_REQUIRE((size_t)g.TB * d->Cin * a.Hs * a.Ws < (1ull << 31), "conv2d: image group too large for 32-bit offsets");
     a.lgTW = spk::ilog2(g.TW); a.lgTH = spk::ilog2(g.TH); a.lgTB = spk::ilog2(g.TB);
+    {
+        const unsigned pw = (unsigned)((g.TW - 1) * Shape<C, KH, KW, S>::SL + KW), plane = (unsigned)g.PLANE;
+        a.magic_plane = plane > 1 ? (unsigned)(((1ull << 32) + plane - 1) / plane) : 0u;   // 0: divisor 1
+        a.magic_pw = pw > 1 ? (unsigned)(((1ull << 32) + pw - 1) / pw) : 0u;
+        SPK_REQUIRE((size_t)C::CI_T * g.TB * g.PLANE < 65536, "conv2d: tile too large for the index arithmetic");
+    }
     a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y;
     a.n_chunks = g.n_chunks;
     a.style_stride = d->style_stride; a.flags = d->flags; a.slope = d->lrelu_slope; a.out_scale = d->out_scale; a.act_gain = d->act_gain != 0.f ? d->act_gain : 1.f;
