@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="launch the step's kernels one by one instead of replaying "
+                    "the hipGraph captured from them")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -114,8 +116,38 @@ def main():
                 p.normal_(0, 0.1)
     feats = torch.randn(BATCH, 6144, device=dev)            # synthetic latents, resident in HBM
 
-    def step():
+    def eager_step():
         return gen(feats)
+
+    # The step is ~35 launches of 30-700 us each; captured once into a hipGraph (the C ABI neither allocates nor
+    # synchronises, the noise draw is graph-safe Philox), every timed step is ONE graph launch -- the same kernels
+    # with the same arguments, and a fresh noise draw per replay, but no dependence on how fast this box's host
+    # thread can issue launches.
+    graph = None
+    if not args.no_graph:
+        try:
+            with torch.no_grad():
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(3):
+                        eager_step()                      # warm every cache (packed weights, workspace) before capture
+                torch.cuda.current_stream().wait_stream(side)
+                torch.cuda.synchronize()
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    graph_out = eager_step()
+            torch.cuda.synchronize()
+        except Exception as e:                            # capture is an optimisation, never a requirement
+            print(f"bench: hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+            graph = None
+            torch.cuda.synchronize()
+
+    def step():
+        if graph is not None:
+            graph.replay()
+            return graph_out
+        return eager_step()
 
     def barrier():
         torch.cuda.synchronize()
@@ -141,7 +173,7 @@ def main():
         pkg.ops.CONV_EVENTS = []
         prof_steps = 5
         for _ in range(prof_steps):
-            step()
+            eager_step()                                  # events sit between the individual launches: eager
         torch.cuda.synchronize()
         conv_ms = sum(a.elapsed_time(b) for a, b in pkg.ops.CONV_EVENTS) / prof_steps
         n_launch = len(pkg.ops.CONV_EVENTS) // prof_steps
@@ -156,10 +188,22 @@ def main():
         for _ in range(max(2, args.warmup // 2)):
             gen2(feats)
         torch.cuda.synchronize()
+        step2 = lambda: gen2(feats)
+        if graph is not None:                             # same launch mode as the headline
+            try:
+                graph2 = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph2):
+                    gen2(feats)
+                step2 = graph2.replay
+            except Exception as e:
+                print(f"bench: hipGraph capture of the StyleGAN2 variant failed ({e}); eager", file=sys.stderr)
+            torch.cuda.synchronize()
+        step2()
+        torch.cuda.synchronize()
         t1 = time.perf_counter()
         sg2_steps = max(5, args.steps // 2)
         for _ in range(sg2_steps):
-            gen2(feats)
+            step2()
         torch.cuda.synchronize()
         sg2_ms = (time.perf_counter() - t1) / sg2_steps * 1e3
         del gen2
@@ -185,7 +229,8 @@ def main():
             "config": {"workload": "StyleGAN decoder (styleganv1.StyleGenerator) 256^2 forward only, batch 8/GPU, "
                                    "fp32, random-init weights, synthetic [8,6144] latents, device-drawn noise",
                        "global_batch": BATCH * world, "resolution": RES,
-                       "parallelism": f"replicas x{world} (no data-path collective)"},
+                       "parallelism": f"replicas x{world} (no data-path collective)",
+                       "launch": "hipGraph replay of the step" if graph is not None else "eager launches"},
             "roofline": {"bound": "mfma", "kernel": "spkconv::conv_kernel<Cfg,3,3,1,MODE> (f32 MFMA implicit GEMM, fused upsample + epilogue)",
                          "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,

@@ -238,3 +238,35 @@ def test_fc_grouped_equals_separate_launches(pkg, dev):
         assert rel_l2(o, cpu) < TOL_OP
     with pytest.raises(pkg._lib.SpkError):
         pkg.ops.fc_grouped(items * 2)          # more than SPK_FC_MAX_GROUPS
+
+
+def test_hipgraph_replay_matches_eager(pkg, dev):
+    """The C ABI neither allocates nor synchronises, so a decoder step can be captured into a hipGraph (what bench.py
+    times): the replay is bitwise the eager result, also after the inputs change in place."""
+    torch.manual_seed(2)
+    g = pkg.StyleGenerator(6144).eval().to(dev)
+    with torch.no_grad():
+        for n, p in g.named_parameters():
+            if "noise" in n:
+                p.normal_(0, 0.1)
+    B = 2
+    feats = torch.randn(B, 6144, device=dev)
+    noises = [torch.randn(s, device=dev) for s in g.synthesis.noise_shapes(B)]
+    with torch.no_grad():
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                g(feats, noises)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            out = g(feats, noises)
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, g(feats, noises))
+        feats.copy_(torch.randn(B, 6144, device=dev))      # new latents, same buffers
+        graph.replay()
+        torch.cuda.synchronize()
+        assert torch.equal(out, g(feats, noises))
