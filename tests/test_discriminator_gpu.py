@@ -18,7 +18,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import rel_l2
+from conftest import grad_close, rel_l2
 from oracle.weights_recipe import recipe_input
 
 pytestmark = pytest.mark.gpu
@@ -65,18 +65,10 @@ def grads(mod):
     return {n: p.grad.detach().cpu().double() for n, p in mod.named_parameters() if p.grad is not None}
 
 
-def close(got, ref32, ref64):
-    got, ref32, ref64 = (t.detach().cpu().double() for t in (got, ref32, ref64))
-    e_got, e_ref = rel_l2(got, ref64), rel_l2(ref32, ref64)
-    rms = float(ref64.pow(2).mean().sqrt())
-    p90 = float(torch.quantile((got - ref64).abs().flatten()[:4_000_000], 0.9))
-    return e_got <= max(5e-3, 3 * e_ref) and p90 <= 1e-4 * rms, (e_got, e_ref, p90 / max(rms, 1e-300))
-
-
 def check(got, ref32, ref64, what):
     assert set(got) == set(ref64), what
     for k in ref64:
-        ok, info = close(got[k], ref32[k], ref64[k])
+        ok, info = grad_close(got[k], ref32[k], ref64[k])
         assert ok, (what, k, info)
 
 
@@ -138,5 +130,5 @@ def test_generator_step_gradient_flows_through_discriminator(disc):
         xin.requires_grad_(True)
         d_loss(fwd(mod, xin)).backward()
         res[name] = xin.grad.detach().cpu().double()
-    ok, info = close(res["hip"], res["ref32"], res["ref64"])
+    ok, info = grad_close(res["hip"], res["ref32"], res["ref64"])
     assert ok, info

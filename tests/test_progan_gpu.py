@@ -6,7 +6,7 @@ import numpy as np
 import pytest
 import torch
 
-from conftest import rel_l2
+from conftest import grad_close, rel_l2
 from oracle import progan_ref as P
 from oracle.weights_recipe import recipe_input
 from test_progan_oracle import CASES, case_inputs
@@ -76,15 +76,6 @@ def test_legacy_ops_vs_reference_goldens(dev, golden):
     assert rel_l2(ops.blur2d(x, k2), ref) < 2e-6
 
 
-def _close(got, ref32, ref64):
-    """Mask-flip-robust gradient criterion (see tests/test_discriminator_gpu.py): both parts against fp64."""
-    got, ref32, ref64 = (t.detach().cpu().double() for t in (got, ref32, ref64))
-    e_got, e_ref = rel_l2(got, ref64), rel_l2(ref32, ref64)
-    rms = float(ref64.pow(2).mean().sqrt())
-    p90 = float(torch.quantile((got - ref64).abs().flatten()[:4_000_000], 0.9))
-    return e_got <= max(5e-3, 3 * e_ref) and p90 <= 1e-4 * rms, (e_got, e_ref, p90 / max(rms, 1e-300))
-
-
 @pytest.mark.parametrize("steps,alpha", [(0, 1.0), (2, 0.3), (3, 1.0)])
 def test_generator_backward_vs_oracle_autograd(dev, steps, alpha):
     """A12 backward: mapping network + generator, gradients of a quadratic loss w.r.t. every parameter and z, against
@@ -130,5 +121,5 @@ def test_generator_backward_vs_oracle_autograd(dev, steps, alpha):
     assert not missing, sorted(missing)[:6]
     for k in sorted(ref_keys):
         kk = k if k in hip else k.replace("g.rgb_layers.0.", "g.initial_rgb.")
-        ok, info = _close(hip[kk], out["ref32"][1][k], out["ref64"][1][k])
+        ok, info = grad_close(hip[kk], out["ref32"][1][k], out["ref64"][1][k])
         assert ok, (k, info)

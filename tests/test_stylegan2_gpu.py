@@ -9,7 +9,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import rel_l2
+from conftest import grad_close, rel_l2
 from oracle import modconv_ref as M
 from oracle.weights_recipe import recipe_input, recipe_tensor
 
@@ -133,15 +133,6 @@ def test_variant_generator_vs_oracle(sg2, dev, B, res):
     assert rel_l2(y, ref) < 2e-4
 
 
-def _close(got, ref32, ref64):
-    """Mask-flip-robust gradient criterion (see tests/test_discriminator_gpu.py): both parts against fp64."""
-    got, ref32, ref64 = (t.detach().cpu().double() for t in (got, ref32, ref64))
-    e_got, e_ref = rel_l2(got, ref64), rel_l2(ref32, ref64)
-    rms = float(ref64.pow(2).mean().sqrt())
-    p90 = float(torch.quantile((got - ref64).abs().flatten()[:4_000_000], 0.9))
-    return e_got <= max(5e-3, 3 * e_ref) and p90 <= 1e-4 * rms, (e_got, e_ref, p90 / max(rms, 1e-300))
-
-
 @pytest.mark.parametrize("upsample", [False, True])
 def test_styled_conv_backward(sg2, dev, upsample):
     """Backward of the modulated conv (data, weight, modulation incl. the demodulation path, noise weight, bias) vs
@@ -175,7 +166,7 @@ def test_styled_conv_backward(sg2, dev, upsample):
     assert rel_l2(res["hip"][0], res["ref64"][0]) < 2e-5
     assert set(res["hip"][1]) == set(res["ref64"][1]) and "conv.modulation.weight" in res["hip"][1] and "noise.weight" in res["hip"][1]
     for k in res["ref64"][1]:
-        ok, info = _close(res["hip"][1][k], res["ref32"][1][k], res["ref64"][1][k])
+        ok, info = grad_close(res["hip"][1][k], res["ref32"][1][k], res["ref64"][1][k])
         assert ok, (k, info)
 
 
@@ -211,5 +202,5 @@ def test_variant_generator_backward(sg2, dev):
     missing = set(out["ref64"][1]) - set(out["hip"][1])
     assert not missing, sorted(missing)[:5]
     for k in out["ref64"][1]:
-        ok, info = _close(out["hip"][1][k], out["ref32"][1][k], out["ref64"][1][k])
+        ok, info = grad_close(out["hip"][1][k], out["ref32"][1][k], out["ref64"][1][k])
         assert ok, (k, info)

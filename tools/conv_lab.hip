@@ -1,6 +1,8 @@
-// Knock-out experiments on the conv kernel (SPK_LAB in conv_mfma_f32.hpp): which stage costs what.
-//   for L in 0 1 2 3 4; do hipcc --offload-arch=gfx950 -O3 -std=c++17 -DSPK_LAB=$L tools/conv_lab.hip -o tools/_bin/conv_lab$L; done
-// Each binary times the decoder's heavy layers (B = 8) with the production tile configs and prints TFLOP/s.
+// Stand-alone timing of the conv kernel on the decoder's heavy layers (B = 8, production tile configs, zero data),
+// without PyTorch in the process:
+//   hipcc --offload-arch=gfx950 -O3 -std=c++17 tools/conv_lab.hip -o tools/_bin/conv_lab && tools/_bin/conv_lab
+// With -DSPK_LAB_STEPTIME the kernel stamps s_memtime after every k-step of chunk 10 of one workgroup and the tool
+// prints the per-step cycle counts of its four waves (how profiles/r01_e_* located the staging costs).
 #include "../speak-hack_amd/csrc/conv_mfma_f32.hpp"
 #ifndef SPK_LAB
 #define SPK_LAB 0
@@ -35,20 +37,6 @@ static int bench(const char* name, int B, int Cin, int Cout, int H, float* x, fl
     CK(hipEventRecord(e1)); CK(hipEventSynchronize(e1));
     float ms; CK(hipEventElapsedTime(&ms, e0, e1));
     ms /= reps;
-#if SPK_LAB == 10
-    {   // per-wave cycle accounting of one launch (s_memtime ticks at 100 MHz on gfx9: constant clock)
-        unsigned long long* dbg; CK(hipMalloc(&dbg, 4096)); CK(hipMemset(dbg, 0, 4096));
-        d.stats = reinterpret_cast<double*>(dbg);
-        run<C, 3, 3, 1, MODE>(&d, 0);
-        CK(hipDeviceSynchronize());
-        unsigned long long h[120]; CK(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
-        for (int w = 0; w < 20; ++w)
-            printf("   wg%d wave%d: issue %8llu  ksteps %8llu  barrier %8llu  loop-total %8llu  start %llu hwid %llx\n", w / 4, w % 4, h[w * 6], h[w * 6 + 1],
-                   h[w * 6 + 2], h[w * 6 + 3], h[w * 6 + 4] % 100000000ull, h[w * 6 + 5]);
-        d.stats = nullptr;
-        CK(hipFree(dbg));
-    }
-#endif
 #ifdef SPK_LAB_STEPTIME
     {   // time stamps after every k-step of chunk 10 (workgroup 8, its four waves)
         unsigned long long* dbg; CK(hipMalloc(&dbg, 4096)); CK(hipMemset(dbg, 0, 4096));
@@ -61,22 +49,6 @@ static int bench(const char* name, int B, int Cin, int Cout, int H, float* x, fl
             for (int k = 1; k < 64 && h[w * 64 + k]; ++k) printf(" %lld", (long long)(h[w * 64 + k] - h[w * 64 + k - 1]));
             printf("\n");
         }
-        d.stats = nullptr;
-        CK(hipFree(dbg));
-    }
-#endif
-#if SPK_LAB == 11
-    {   // chunk-start timeline of two workgroups that share a CU (linear ids 8 and 264)
-        unsigned long long* dbg; CK(hipMalloc(&dbg, 8192)); CK(hipMemset(dbg, 0, 8192));
-        d.stats = reinterpret_cast<double*>(dbg);
-        run<C, 3, 3, 1, MODE>(&d, 0);
-        CK(hipDeviceSynchronize());
-        unsigned long long h[512]; CK(hipMemcpy(h, dbg, sizeof(h), hipMemcpyDeviceToHost));
-        printf("   hwid A %llx  B %llx ; chunk-start times (cycles, relative to A's first) / per-chunk duration A | B\n", h[250], h[506]);
-        const int n = (Cin + C::CI_T - 1) / C::CI_T;
-        for (int c = 0; c < n && c < 200; c += (c < 12 ? 1 : 8))
-            printf("   c%3d  A %9lld (+%6lld)   B %9lld (+%6lld)\n", c, (long long)(h[c] - h[0]), c ? (long long)(h[c] - h[c - 1]) : 0ll,
-                   (long long)(h[256 + c] - h[0]), c ? (long long)(h[256 + c] - h[256 + c - 1]) : 0ll);
         d.stats = nullptr;
         CK(hipFree(dbg));
     }
