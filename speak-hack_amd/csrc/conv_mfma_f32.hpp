@@ -597,7 +597,8 @@ int run(const spk_conv2d_desc* d, hipStream_t stream) {
     a.B = d->B; a.Cin = d->Cin; a.Cout = d->Cout; a.H = d->H; a.W = d->W; a.Hs = d->Hin; a.Ws = d->Win;
     const Geometry g = geometry<C, KH, KW, S>(d->B, d->Cin, d->Cout, d->H, d->W);
     SPK_REQUIRE(g.ok, "conv2d: config %d does not fit this shape (%dx%d, B=%d)", d->config, d->H, d->W, d->B);
-    SPK_REQUIRE((size_t)g.TB * d->Cin * a.Hs * a.Ws < (1ull << 31), "conv2d: image group too large for 32-bit offsets");
+    // the staging tables hold 32-bit BYTE offsets relative to the image group's first plane
+    SPK_REQUIRE((size_t)g.TB * d->Cin * a.Hs * a.Ws < (1ull << 30), "conv2d: image group too large for 32-bit byte offsets");
     a.lgTW = spk::ilog2(g.TW); a.lgTH = spk::ilog2(g.TH); a.lgTB = spk::ilog2(g.TB);
     {
         const unsigned pw = (unsigned)((g.TW - 1) * Shape<C, KH, KW, S>::SL + KW), plane = (unsigned)g.PLANE;

@@ -84,7 +84,19 @@ class _ConvBN:
         rec = {"y": y, "affine": (fin[0], fin[1])}
         if keep:
             rec.update(x=x, in_affine=in_affine, mean=fin[2], invstd=fin[3], training=training)
+            if training:
+                rec.update(stats=stats, count=B * Ho * Wo, momentum=momentum)
         return rec
+
+    def second_update(self, rec, counters):
+        """The running-statistics update the reference's re-entrant checkpoint performs a second time when it re-runs
+        the forward inside backward (model.py:84-90): same batch sums, same arithmetic, without recomputing the conv."""
+        bn = self.bn
+        if not rec.get("training") or "stats" not in rec:
+            return
+        if bn.num_batches_tracked is not None:
+            counters.append(bn.num_batches_tracked)
+        ops.bn_finalize(rec["stats"], rec["count"], bn.weight, bn.bias, bn.running_mean, bn.running_var, rec["momentum"], bn.eps)
 
     def bn_bwd(self, rec, g, mask_mode, mask_src=None, want_dz=False, **kw):
         """Gradient w.r.t. the raw conv output + BatchNorm parameter gradients (into ``grads``)."""
@@ -121,31 +133,49 @@ class _StatsPool:
 
 
 class TrunkFn(torch.autograd.Function):
-    """Checkpointed trunk: forward keeps the input only; backward recomputes, then back-propagates."""
+    """The trunk under the reference's ``checkpoint(E, x)`` (model.py:84-90).
+
+    ``trunk.recompute`` True: forward keeps the input only, backward re-runs the forward, then back-propagates -- the
+    reference's memory-saving schedule.  False (default here: 288 GB of HBM, ~1 GB of activations per B=8 pass): the
+    forward keeps the raw conv outputs, backward uses them directly and replays only the checkpoint's visible side
+    effect, the second running-statistics update of every BatchNorm.  Gradients and buffers are identical either way;
+    the stored form saves one encoder forward per pass."""
 
     @staticmethod
     def forward(ctx, x, trunk, grad_mode, *params):
-        y = trunk._run(x, keep=False)[0]
-        if grad_mode and any(ctx.needs_input_grad):
+        need = grad_mode and any(ctx.needs_input_grad)
+        if need and not trunk.recompute:
+            y, ctx.recs = trunk._run(x, keep=True)
             ctx.trunk, ctx.training = trunk, trunk.training
+            return y
+        y = trunk._run(x, keep=False)[0]
+        if need:
+            ctx.trunk, ctx.training, ctx.recs = trunk, trunk.training, None
             ctx.save_for_backward(x)
         return y
 
     @staticmethod
     def backward(ctx, dfeat):
-        (x,) = ctx.saved_tensors
         trunk = ctx.trunk
-        was_training = trunk.training
-        trunk.train(ctx.training)
-        try:
-            _, recs = trunk._run(x, keep=True)          # the checkpoint recomputation
-        finally:
-            trunk.train(was_training)
+        if ctx.recs is not None:
+            recs, ctx.recs = ctx.recs, None
+            if ctx.training:
+                trunk._second_bn_update(recs)
+        else:
+            (x,) = ctx.saved_tensors
+            was_training = trunk.training
+            trunk.train(ctx.training)
+            try:
+                _, recs = trunk._run(x, keep=True)          # the checkpoint recomputation
+            finally:
+                trunk.train(was_training)
         grads = trunk._backward(recs, dfeat.contiguous())
         return (None, None, None) + tuple(grads.get(p) for p in trunk.parameters())
 
 
 class ResNet50Trunk(nn.Sequential):
+    recompute = False        # see TrunkFn: keep activations (default) or re-run the forward inside backward
+
     def __init__(self):
         layers = []
         inplanes = 64
@@ -204,6 +234,19 @@ class ResNet50Trunk(nn.Sequential):
         if pool is not None and pool.counters:
             torch._foreach_add_(pool.counters, 1)                    # 53 one-element kernels -> one fused launch
         return ops.global_avgpool(cur), recs
+
+    def _second_bn_update(self, recs):
+        stem, blocks = self._plan
+        counters = []
+        stem.second_update(recs["stem"], counters)
+        for (c1, c2, c3, down), (r1, r2, r3, rd, _) in zip(blocks, recs["blocks"]):
+            c1.second_update(r1, counters)
+            c2.second_update(r2, counters)
+            c3.second_update(r3, counters)
+            if down is not None:
+                down.second_update(rd, counters)
+        if counters:
+            torch._foreach_add_(counters, 1)
 
     def _backward(self, recs, dfeat):
         """dfeat [B,2048,1,1] -> {parameter: gradient}."""

@@ -169,3 +169,25 @@ def test_trunk_backward_vs_autograd_oracle(pkg, dev, training, B, H):
           f"(fp32 oracle itself: {worst[1]:.2e}) at {worst[2]}")
     if training:    # checkpoint semantics: the recomputation updates the running statistics a second time
         assert int(m.state_dict()["1.num_batches_tracked"]) == 2
+
+
+def test_stored_activations_equal_checkpoint_recompute(pkg, dev):
+    """``ResNet50Trunk.recompute`` False (default: keep the raw conv outputs, replay only the checkpoint's second
+    running-statistics update) vs True (the reference's schedule: re-run the forward inside backward): bitwise the same
+    features, parameter gradients, running statistics and batch counters (the trunk defines no image gradient)."""
+    x = recipe_input("trs.x", (3, 3, 64, 64), "uniform")
+    gfeat = recipe_input("trs.g", (3, 2048, 1, 1))
+    res = {}
+    for mode in (False, True):
+        m, _ = _trunk(dev, "Ee.")
+        m.train(True)
+        m.recompute = mode
+        y = m(x.to(dev))
+        y.backward(gfeat.to(dev))
+        res[mode] = (y.detach(), None, {k: p.grad for k, p in m.named_parameters()},
+                     {k: v.clone() for k, v in m.state_dict().items() if "running" in k or "num_batches" in k})
+    a, b = res[False], res[True]
+    assert torch.equal(a[0], b[0])
+    assert all(torch.equal(a[2][k], b[2][k]) for k in a[2])
+    assert all(torch.equal(a[3][k], b[3][k]) for k in a[3]), [k for k in a[3] if not torch.equal(a[3][k], b[3][k])][:4]
+    assert int(a[3]["1.num_batches_tracked"]) == 2
