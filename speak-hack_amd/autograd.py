@@ -10,6 +10,26 @@ import torch
 from . import ops
 
 
+import contextlib
+
+_INPUT_GRAD_ONLY = False
+
+
+@contextlib.contextmanager
+def input_grad_only():
+    """Inside this context a *recorded* backward (``create_graph=True``) of the discriminator layers computes the data
+    gradient only.  ``torch.autograd.grad(D(x).sum(), x, create_graph=True)`` (the R1 penalty, train.py:246-255) asks
+    for dD/dx alone, but a custom Function cannot see that and would also run one weight-gradient kernel per layer
+    whose results autograd then throws away; the penalty's own gradient w.r.t. the weights does not use them (it flows
+    through ``ConvDgradFn``).  Leave the context before calling ``backward`` on the penalty."""
+    global _INPUT_GRAD_ONLY
+    prev, _INPUT_GRAD_ONLY = _INPUT_GRAD_ONLY, True
+    try:
+        yield
+    finally:
+        _INPUT_GRAD_ONLY = prev
+
+
 def _needs(ctx, grad_mode):
     """Whether to keep tensors for backward.  Grad mode is always off *inside* Function.forward and
     ``needs_input_grad`` ignores ``torch.no_grad()``, so the caller samples the mode and passes it in."""
@@ -218,12 +238,13 @@ class ConvBiasLReLUFn(torch.autograd.Function):
             dt = _LReluMaskFn.apply(dy, y, slope) if slope is not None else dy.contiguous()
             if ctx.needs_input_grad[0]:
                 dx = ConvDgradFn.apply(dt, weight, k, stride, tuple(x.shape[-2:]))
-            with torch.no_grad():
-                dtd = dt.detach()
-                if ctx.needs_input_grad[1]:
-                    dw = ops.conv2d_wgrad(dtd, x, Cout, Cin, k, stride)
-                if has_bias and ctx.needs_input_grad[2]:
-                    db = dtd.sum((0, 2, 3))
+            if not _INPUT_GRAD_ONLY:
+                with torch.no_grad():
+                    dtd = dt.detach()
+                    if ctx.needs_input_grad[1]:
+                        dw = ops.conv2d_wgrad(dtd, x, Cout, Cin, k, stride)
+                    if has_bias and ctx.needs_input_grad[2]:
+                        db = dtd.sum((0, 2, 3))
             return dx, dw, db, None, None, None, None
         dt, sums = ops.epilogue_bwd(dy.contiguous(), y, None, None, slope if slope is not None else 1.0)
         if ctx.needs_input_grad[0]:

@@ -18,9 +18,11 @@ def add_instance_noise(x, std=0.05):
 
 def compute_r1_reg(D, real_img):
     """train.py:246-255 verbatim in behaviour: mean over the batch of |dD/dx|^2, differentiable w.r.t. D's weights."""
+    from . import autograd as AG
     real_img = real_img.detach().requires_grad_(True)
     real_pred = D(real_img)
-    (grad_real,) = torch.autograd.grad(outputs=real_pred.sum(), inputs=real_img, create_graph=True)
+    with AG.input_grad_only():      # dD/dx only: skip the per-layer weight-gradient kernels autograd would discard
+        (grad_real,) = torch.autograd.grad(outputs=real_pred.sum(), inputs=real_img, create_graph=True)
     return grad_real.pow(2).reshape(grad_real.shape[0], -1).sum(1).mean()
 
 

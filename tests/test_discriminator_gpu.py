@@ -115,6 +115,22 @@ def test_discriminator_r1_double_backward(disc, res, B):
         assert float(got[k].abs().max()) == 0.0, k
 
 
+def test_r1_input_grad_only_context_changes_nothing(disc):
+    """``training.compute_r1_reg`` skips the weight-gradient kernels of the recorded backward (autograd discards them):
+    the penalty and its parameter gradients are bitwise those of the plain formulation."""
+    T = importlib.import_module("speak-hack_amd.training")
+    dev = torch.device("cuda:0")
+    x = recipe_input("discr1c.x", (2, 3, 64, 64), "uniform").to(dev)
+    res = []
+    for fast in (False, True):
+        d = make(disc, 64, 14, True).to(dev)
+        pen = T.compute_r1_reg(d, x) if fast else r1(lambda m, t: m(t), d, x.clone())
+        pen.backward()
+        res.append((pen.detach(), grads(d)))
+    assert torch.equal(res[0][0], res[1][0]) and set(res[0][1]) == set(res[1][1])
+    assert all(torch.equal(res[0][1][k], res[1][1][k]) for k in res[0][1])
+
+
 def test_generator_step_gradient_flows_through_discriminator(disc):
     """train.py:194-199: loss_G_adv = BCE(D(x_recon), real) -- the data gradient the generator receives."""
     dev = torch.device("cuda:0")

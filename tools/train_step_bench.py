@@ -69,10 +69,10 @@ def main():
     fake_s = torch.rand(B, 3, 256, 256, device=dev) * 2 - 1
     fake_t = torch.rand(B, 3, 256, 256, device=dev) * 2 - 1
 
+    T = importlib.import_module("speak-hack_amd.training")
+
     def r1(x):                                 # train.py:246-255
-        x = x.detach().requires_grad_(True)
-        (g,) = torch.autograd.grad(outputs=net.D(x).sum(), inputs=x, create_graph=True)
-        return g.pow(2).reshape(g.shape[0], -1).sum(1).mean()
+        return T.compute_r1_reg(net.D, x)
 
     def bce(pred, label):
         return F.binary_cross_entropy_with_logits(pred, torch.full_like(pred, label))
