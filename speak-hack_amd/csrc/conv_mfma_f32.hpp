@@ -134,7 +134,16 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
     const int PW = (TW - 1) * SL + KW, PLANE = ((TH - 1) * SL + KH) * PW;
     const int IN_FLOATS = C::CI_T * TB * PLANE;
     const int BUF_FLOATS = W_FLOATS + ((IN_FLOATS + 3) & ~3) + 4;  // +4: dump slot for lanes without an element
-    int bx = blockIdx.x;
+    // XCD-aware tile order: the hardware deals workgroup i to XCD i % 8 (profiles/r01_e_workgroup_placement.txt), so in
+    // launch order neighbouring pixel tiles land on different L2s and each re-fetches the halo rows they share.  Remap
+    // so that every XCD walks ONE contiguous run of tiles (a bijection of [0, gridDim.x)): halos and the rows a tile's
+    // successor needs are L2 hits.
+    int bx;
+    {
+        const int n = (int)gridDim.x, q = n >> 3, r = n & 7;
+        const int xcd = (int)blockIdx.x & 7, k = (int)blockIdx.x >> 3;
+        bx = xcd * q + min(xcd, r) + k;
+    }
     const int tx = bx % p.tiles_x;
     bx /= p.tiles_x;
     const int ty = bx % p.tiles_y;

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""Per-layer timing of the weight-gradient kernel on the decoder's 3x3 convs (B = 8): kernel + slab reduce.
+
+    python tools/bench_wgrad.py [--batch 8] [--res 256]
+"""
+import argparse
+import importlib
+import os
+import sys
+
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+pkg = importlib.import_module("speak-hack_amd")
+ops = pkg.ops
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--res", type=int, default=256)
+    args = ap.parse_args()
+    dev, B = torch.device("cuda:0"), args.batch
+    r, cin, tot_t, tot_f = 8, 512, 0.0, 0.0
+    while r <= args.res:
+        cout = min(int(8192 / (2.0 ** (r.bit_length() - 2))), 512)
+        for ci, co in ((cin, cout), (cout, cout)):
+            g = torch.randn(B, co, r, r, device=dev)
+            x = torch.randn(B, ci, r, r, device=dev)
+            for splits in (0,):
+                for _ in range(2):
+                    ops.conv2d_wgrad(g, x, co, ci, 3, 1, splits=splits)
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(5):
+                    ops.conv2d_wgrad(g, x, co, ci, 3, 1, splits=splits)
+                e1.record()
+                torch.cuda.synchronize()
+                ms = e0.elapsed_time(e1) / 5
+                fl = 2 * 9 * ci * co * r * r * B
+                tot_t += ms
+                tot_f += fl
+                print(f"{ci:4d}->{co:4d} @{r:3d}^2 splits={splits}: {ms * 1e3:8.1f} us  {fl / ms / 1e9:6.1f} TFLOP/s")
+        cin, r = cout, r * 2
+    print(f"total {tot_t:.2f} ms, {tot_f / tot_t / 1e9:.1f} TFLOP/s")
+
+
+if __name__ == "__main__":
+    main()
