@@ -14,10 +14,22 @@
 // replaces: the weight-gradient half of F.conv2d's backward for every conv on the path
 // (styleganv1.py:625,630 conv1/conv2; the torchvision trunk convs of model.py:60-62).
 #include "spk_common.hpp"
+#ifndef WGRAD_CI32
+#define WGRAD_CI32 0
+#endif
 
 #include <algorithm>
+#include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+template <int I, int N, class F>
+__device__ __forceinline__ void wg_static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        wg_static_for<I + 1, N>(f);
+    }
+}
 
 namespace {
 
@@ -39,7 +51,7 @@ struct WShape {
     static constexpr int TAPS = KH * KW;
     static constexpr bool ROWPASS = TAPS > 9;               // 7x7: one tap row per workgroup
     static constexpr int TP = ROWPASS ? KW : TAPS;          // taps per pass (accumulator tiles per wave)
-    static constexpr int CI_T = (S == 2 || KH == 7) ? 32 : 64;
+    static constexpr int CI_T = (S == 2 || KH == 7 || WGRAD_CI32) ? 32 : 64;
     static constexpr int WCI = CI_T / 32, WPX = 2 / WCI;    // 4 waves = 2 (co) x WCI x WPX
     static constexpr int CO_T = 64, PIX_T = 64, PAD = (KH - 1) / 2;
     static constexpr int KX = KH == 7 ? 3 : (S == 2 ? 2 : 1);   // plane positions (x256) a thread stages
@@ -155,20 +167,36 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
         const float* ga = g_s + (wco * 32 + l32) * GPITCH;
         const float* xb = x_s + (wci * 32 + l32) * XPITCH;
         constexpr int STEPS = PIX_T / 2 / SH::WPX;
-#pragma unroll 4
-        for (int st = 0; st < STEPS; ++st) {
-            const int pix = wpx * (PIX_T / SH::WPX) + 2 * st + half;
-            const int px = pix & (TW - 1), py = (pix >> p.lgTW) & (TH - 1);
-            const int tb = min(pix >> (p.lgTW + p.lgTH), TB - 1);   // idle pixel groups hold zeros in g_s
-            const float a = ga[pix];
-            const float* xp = xb + tb * PLANE + (py * S) * PW + px * S;
-#pragma unroll
-            for (int t = 0; t < TP; ++t) {
-                const int tap = tap0 + t;                         // tap0 is 0 unless ROWPASS
-                const int ky = SH::ROWPASS ? pass : tap / KW, kx = SH::ROWPASS ? t : tap % KW;
-                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, xp[ky * PW + kx], acc[t], 0, 0, 0);
+        // Fragments are read one k-step ahead of the MFMAs that use them (two register sets, static indices after full
+        // unrolling; sched_group_barrier pins the ds_read / MFMA interleave): with 144 accumulator registers the kernel
+        // runs one wave per SIMD, so nothing else would hide the LDS latency.
+        float fa[2], fb[2][TP];
+#define SPK_WG_FRAG(st_, slot_)                                                                             \
+    {                                                                                                       \
+        const int pix = wpx * (PIX_T / SH::WPX) + 2 * (st_) + half;                                         \
+        const int px = pix & (TW - 1), py = (pix >> p.lgTW) & (TH - 1);                                     \
+        const int tb = min(pix >> (p.lgTW + p.lgTH), TB - 1);   /* idle pixel groups hold zeros in g_s */   \
+        fa[slot_] = ga[pix];                                                                                \
+        const float* xp = xb + tb * PLANE + (py * S) * PW + px * S;                                         \
+        _Pragma("unroll") for (int t = 0; t < TP; ++t) {                                                    \
+            const int tap = tap0 + t;                         /* tap0 is 0 unless ROWPASS */                \
+            const int ky = SH::ROWPASS ? pass : tap / KW, kx = SH::ROWPASS ? t : tap % KW;                  \
+            fb[slot_][t] = xp[ky * PW + kx];                                                                \
+        }                                                                                                   \
+    }
+        SPK_WG_FRAG(0, 0);
+        wg_static_for<0, STEPS>([&](auto s_) {
+            constexpr int st = decltype(s_)::value;
+            if constexpr (st + 1 < STEPS) {
+                SPK_WG_FRAG(st + 1, (st + 1) & 1);
+                __builtin_amdgcn_sched_group_barrier(0x100, TP + 1, 0);
             }
-        }
+#pragma unroll
+            for (int t = 0; t < TP; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[st & 1], fb[st & 1][t], acc[t], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x8, TP, 0);
+        });
+#undef SPK_WG_FRAG
     }
 #undef SPK_WG_PREFETCH
 #undef SPK_WG_STORE
