@@ -94,6 +94,14 @@ typedef struct spk_conv2d_desc {
      * act_gain (0 = 1) multiplies the LeakyReLU output (sqrt 2 of FusedLeakyReLU). */
     const float* out_scale_bc;
     float act_gain;
+    /* Grouped convolution: `groups` (0 or 1 = ordinary) independent convs of the same shape in one launch -- the three
+     * IRFD encoders Ei / Ee / Ep run the same ResNet-50 on the same image (model.py:84-90), so every layer of the three
+     * is one launch here.  With groups > 1, Cin / Cout are PER GROUP; x has group_in_stride*(groups-1) + Cin channels,
+     * group g reading [g*group_in_stride, +Cin) (group_in_stride = 0: all groups read the same input, the stem);
+     * y, bias, stats have groups*Cout channels; w_packed is the groups' packed images one after another.
+     * Allowed flags: SPK_EPI_BIAS | LRELU | ACCUM | STATS, SPK_CONV_IN_AFFINE_RELU (in_scale / in_shift per x channel). */
+    int32_t groups;
+    int32_t group_in_stride;
 } spk_conv2d_desc;
 
 int spk_conv2d_num_configs(void);
@@ -109,6 +117,9 @@ int64_t spk_conv2d_packed_floats(int config, int kh, int kw, int Cin, int Cout);
  * host the shape).  config = -1 / ksplit = 0 ask for the library's own choices. */
 int64_t spk_conv2d_workspace_bytes(int config, int ksplit, int kh, int kw, int stride, int B, int Cin, int Cout,
                                    int H, int W);
+/* the same for a grouped launch (Cin, Cout per group) */
+int64_t spk_conv2d_workspace_bytes_grouped(int config, int ksplit, int kh, int kw, int stride, int B, int Cin, int Cout,
+                                           int H, int W, int groups);
 /* w[Cout,Cin,kh,kw] -> packed [co_tile][ci_chunk][tap][ci][co] (zero padded).
  * transpose_flip != 0 packs the data-gradient operator instead: w'[ci,co,ky,kx] = w[co,ci,kh-1-ky,kw-1-kx]
  * (then the packed image is that of a [Cin,Cout,kh,kw] weight).

@@ -31,7 +31,8 @@ class Conv2dDesc(C.Structure):
                 ("style_stride", C.c_int32), ("flags", C.c_uint32), ("lrelu_slope", C.c_float),
                 ("out_scale", C.c_float), ("config", C.c_int32), ("ksplit", C.c_int32),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
-                ("out_scale_bc", C.c_void_p), ("act_gain", C.c_float)]
+                ("out_scale_bc", C.c_void_p), ("act_gain", C.c_float),
+                ("groups", C.c_int32), ("group_in_stride", C.c_int32)]
 
 
 CONV_IN_BATCH_SCALE = 256
@@ -96,6 +97,7 @@ _PROTOTYPES = {
     "spk_conv2d_config_info": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "spk_conv2d_packed_floats": (C.c_int64, [C.c_int] * 5),
     "spk_conv2d_workspace_bytes": (C.c_int64, [C.c_int] * 10),
+    "spk_conv2d_workspace_bytes_grouped": (C.c_int64, [C.c_int] * 11),
     "spk_conv2d_pack_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_void_p]),
     "spk_conv2d_fwd": (C.c_int, [C.POINTER(Conv2dDesc), C.c_void_p]),

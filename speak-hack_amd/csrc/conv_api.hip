@@ -129,7 +129,9 @@ __global__ __launch_bounds__(256) void splitk_epilogue_vec_kernel(const ConvArgs
     }
 }
 
-int launch_splitk_epilogue(const ConvArgs& a, const float* ws, int ksplit, hipStream_t stream) {
+int launch_splitk_epilogue(const ConvArgs& a_in, const float* ws, int ksplit, hipStream_t stream) {
+    ConvArgs a = a_in;
+    a.Cout = a_in.Cy;            // the finisher walks the output tensor: every group's channels
     const size_t out_floats = (size_t)a.B * a.Cout * a.H * a.W;
     const size_t HW = (size_t)a.H * a.W, q4 = HW / 4;
     // lanes of a wave must split evenly into planes for the segmented sums: q4 a multiple of 64, or a power of two below
@@ -259,14 +261,20 @@ int64_t spk_conv2d_packed_floats(int config, int kh, int kw, int Cin, int Cout) 
     return (int64_t)spk::ceil_div(Cout, c.co_t) * spk::ceil_div(Cin, c.ci_t) * kh * kw * c.ci_t * c.co_t;
 }
 
+int64_t spk_conv2d_workspace_bytes_grouped(int config, int ksplit, int kh, int kw, int stride, int B, int Cin, int Cout,
+                                           int H, int W, int groups) {
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || groups < 1 || !supported_kernel(kh, kw, stride)) return -1;
+    if (config < 0) config = pick_config(kh, stride, B, Cin, Cout, H, W);
+    Geometry g = geometry_any(kh, stride, config, B, Cin, Cout, H, W);
+    if (!g.ok) return -1;
+    g.co_tiles *= groups;
+    const int ks = resolve_ksplit(g, ksplit, nullptr);
+    return ks > 1 ? (int64_t)ks * B * groups * Cout * H * W * (int64_t)sizeof(float) : 0;
+}
+
 int64_t spk_conv2d_workspace_bytes(int config, int ksplit, int kh, int kw, int stride, int B, int Cin, int Cout,
                                    int H, int W) {
-    if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || !supported_kernel(kh, kw, stride)) return -1;
-    if (config < 0) config = pick_config(kh, stride, B, Cin, Cout, H, W);
-    const Geometry g = geometry_any(kh, stride, config, B, Cin, Cout, H, W);
-    if (!g.ok) return -1;
-    const int ks = resolve_ksplit(g, ksplit, nullptr);
-    return ks > 1 ? (int64_t)ks * B * Cout * H * W * (int64_t)sizeof(float) : 0;
+    return spk_conv2d_workspace_bytes_grouped(config, ksplit, kh, kw, stride, B, Cin, Cout, H, W, 1);
 }
 
 int spk_conv2d_pack_weights(const float* w, float* w_packed, int kh, int kw, int Cin, int Cout, int config,
@@ -306,6 +314,11 @@ int spk_conv2d_fwd(const spk_conv2d_desc* d, void* stream) {
     SPK_REQUIRE(!(d->flags & SPK_EPI_STATS) || d->stats, "conv2d: SPK_EPI_STATS without stats");
     SPK_REQUIRE(!aff || (d->in_scale && d->in_shift), "conv2d: IN_AFFINE_RELU without in_scale/in_shift");
     SPK_REQUIRE((long long)d->B * d->Cout * d->H * d->W < (1ll << 40), "conv2d: tensor too large");
+    if (d->groups > 1) {
+        SPK_REQUIRE(!(d->flags & ~(SPK_EPI_BIAS | SPK_EPI_LRELU | SPK_EPI_ACCUM | SPK_EPI_STATS | SPK_CONV_IN_AFFINE_RELU)) && !d->out_scale_bc,
+                    "conv2d: a grouped launch takes bias / lrelu / accum / stats / in-affine only");
+        SPK_REQUIRE(d->group_in_stride == 0 || d->group_in_stride >= d->Cin, "conv2d: group_in_stride must be 0 (shared input) or >= Cin");
+    }
     int cfg = d->config;
     if (cfg < 0) cfg = pick_config(d->kh, d->stride, d->B, d->Cin, d->Cout, d->H, d->W);
     SPK_REQUIRE(!bsc || cfg >= 4, "conv2d: IN_BATCH_SCALE is built for the half-depth configs (4-7)");

@@ -68,6 +68,11 @@ struct ConvArgs {
     unsigned flags;
     float slope, out_scale, act_gain;
     unsigned magic_plane, magic_pw;   // ceil(2^32 / PLANE), ceil(2^32 / PW): exact division of the small tile indices
+    // Grouped convolution (G independent convs of the same shape in one launch -- the three IRFD encoders): Cin / Cout
+    // above are PER GROUP; x has Cx channels, group g reading [g*gin, g*gin + Cin) (gin = 0: every group reads the same
+    // input); y, bias, stats, ... have Cy = G*Cout channels; blockIdx.y = g * co_tiles_g + co tile.  G = 1: Cx = gin =
+    // Cin, Cy = Cout.
+    int G, Cx, Cy, gin, co_tiles_g;
 };
 
 template <int WM_, int WN_, int MT_, int NT_, int CIT_>
@@ -149,7 +154,8 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
     const int ty = bx % p.tiles_y;
     const int tbi = bx / p.tiles_y;
     const int b0 = tbi << p.lgTB, y0 = ty << p.lgTH, x0 = tx << p.lgTW;
-    const int co_tile0 = blockIdx.y * C::CO_T;
+    const int grp = (int)blockIdx.y / p.co_tiles_g;
+    const int co_tile0 = ((int)blockIdx.y - grp * p.co_tiles_g) * C::CO_T;   // within the group
     const int c_begin = blockIdx.z * p.chunks_per_split;
     const int c_end = min(p.n_chunks, c_begin + p.chunks_per_split);
     // extent of the (virtual) input image the taps index: the x2-upsampled image in MODE_UPSAMPLE
@@ -188,7 +194,7 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
             const int uy = (y0 * SL + r) * (S / SL) - PAD, ux = (x0 * SL + c) * (S / SL) - PAD;
             const bool past = ci >= ci_left_last;
             s_dst[s] = (unsigned)(W_FLOATS + wave * wave_elems + e) * 4u;
-            unsigned off = (unsigned)ci * (unsigned)src_plane;  // padding elements read any address inside the tensor
+            unsigned off = (unsigned)(grp * p.gin + ci) * (unsigned)src_plane;  // padding elements read any address inside the tensor
             if (uy >= 0 && uy < Hv && ux >= 0 && ux < Wv && b0 + tb < p.B) {
                 s_vc[s] = past ? 1u : 2u;
                 int goff;
@@ -209,22 +215,22 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
                     s_ly0[s] = w0_of(ly); s_ly1[s] = w1_of(ly);
                     goff = iy0 * p.Ws + ix0;
                 }
-                off = (unsigned)((size_t)(tb * p.Cin + ci) * src_plane) + (unsigned)goff;
+                off = (unsigned)((size_t)(tb * p.Cx + grp * p.gin + ci) * src_plane) + (unsigned)goff;
             }
             s_xoff[s] = off * 4u;
-            s_xoffl[s] = (off - (past ? (unsigned)ci * (unsigned)src_plane : 0u)) * 4u;
+            s_xoffl[s] = (off - (past ? (unsigned)ci * (unsigned)src_plane : 0u)) * 4u;   // stays >= the group's first plane
             if (BSC) {   // modulation s[b,ci]: the per-sample input scale of a modulated convolution
                 const unsigned b_ = (unsigned)min(b0 + tb, p.B - 1);
-                s_sc[s] = (b_ * (unsigned)p.Cin + (unsigned)ci) * 4u;
-                s_scl[s] = (b_ * (unsigned)p.Cin + (past ? 0u : (unsigned)ci)) * 4u;
+                s_sc[s] = (b_ * (unsigned)p.Cx + (unsigned)(grp * p.gin + ci)) * 4u;
+                s_scl[s] = (b_ * (unsigned)p.Cx + (unsigned)(grp * p.gin) + (past ? 0u : (unsigned)ci)) * 4u;
             }
-            if (AFF) { s_sc[s] = (unsigned)ci * 4u; s_scl[s] = past ? 0u : (unsigned)ci * 4u; }
+            if (AFF) { s_sc[s] = (unsigned)(grp * p.gin + ci) * 4u; s_scl[s] = (unsigned)(grp * p.gin + (past ? 0 : ci)) * 4u; }
         }
     }
     // weight vectors: lane offsets inside a chunk's packed block; the ragged last vector is clamped
     const unsigned w_tid16 = (unsigned)tid * 16u;
     const unsigned w_last16 = (unsigned)(min(tid + (WV - 1) * C::NTHREADS, W_FLOATS / 4 - 1) - (WV - 1) * C::NTHREADS) * 16u;
-    const float* xblk = p.x + (size_t)b0 * p.Cin * src_plane;
+    const float* xblk = p.x + (size_t)b0 * p.Cx * src_plane;
 
     // ---- per-lane fragment addresses ----
     int b_off[C::NT];
@@ -480,7 +486,7 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
     const bool f_lrelu = p.flags & SPK_EPI_LRELU, f_style = p.flags & SPK_EPI_STYLE;
     const bool f_accum = p.flags & SPK_EPI_ACCUM, f_stats = (p.flags & SPK_EPI_STATS) && !split;
     const size_t HW = (size_t)p.H * p.W;
-    float* ybase = p.y + (split ? (size_t)blockIdx.z * p.B * p.Cout * HW : 0);
+    float* ybase = p.y + (split ? (size_t)blockIdx.z * p.B * p.Cy * HW : 0);
     // per pixel group: validity, output offset, noise value, style row
     bool pv[C::NT];
     size_t poff[C::NT];
@@ -494,7 +500,7 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
         const int b = b0 + tb, yy = y0 + py, xx = x0 + px;
         pv[n] = tb < TB && b < p.B && yy < p.H && xx < p.W;
         const size_t pix = (size_t)yy * p.W + xx;
-        poff[n] = pv[n] ? (size_t)b * p.Cout * HW + pix : 0;
+        poff[n] = pv[n] ? (size_t)b * p.Cy * HW + pix : 0;
         pb[n] = pv[n] ? b : 0;
         nz[n] = (f_noise && pv[n] && !split) ? p.noise[(size_t)b * HW + pix] : 0.f;
         st[n] = (f_style && pv[n]) ? p.style + (size_t)b * p.style_stride : nullptr;
@@ -505,25 +511,26 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
         for (int r = 0; r < 16; ++r) {
             const int co = co_tile0 + (wm * C::MT + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
             const bool cv = co < p.Cout;
+            const int cg = grp * p.Cout + co;              // channel in the output tensor (all groups)
             float ssum = 0.f, ssq = 0.f;
             if (cv) {
-                const float bb = (f_bias && !split) ? p.bias[co] : 0.f;
-                const float nwc = (f_noise && !split) ? p.noise_w[co] : 0.f;
+                const float bb = (f_bias && !split) ? p.bias[cg] : 0.f;
+                const float nwc = (f_noise && !split) ? p.noise_w[cg] : 0.f;
 #pragma unroll
                 for (int n = 0; n < C::NT; ++n) {
                     if (!pv[n]) continue;
-                    float* dst = ybase + poff[n] + (size_t)co * HW;
+                    float* dst = ybase + poff[n] + (size_t)cg * HW;
                     if (split) {  // raw partial sums; splitk_epilogue_kernel finishes
                         *dst = acc[m][n][r];
                         continue;
                     }
                     float v = acc[m][n][r] * p.out_scale;
-                    if (p.out_scale_bc) v *= p.out_scale_bc[(size_t)pb[n] * p.Cout + co];   // demodulation d[b,co]
+                    if (p.out_scale_bc) v *= p.out_scale_bc[(size_t)pb[n] * p.Cy + cg];   // demodulation d[b,co]
                     v += bb;
                     if (f_noise) v += nwc * nz[n];
                     if (f_lrelu) v = (v > 0.f ? v : v * p.slope) * p.act_gain;
-                    if (p.y_pre) p.y_pre[poff[n] + (size_t)co * HW] = v;
-                    if (f_style) v = v * (st[n][co] + 1.f) + st[n][p.Cout + co];
+                    if (p.y_pre) p.y_pre[poff[n] + (size_t)cg * HW] = v;
+                    if (f_style) v = v * (st[n][cg] + 1.f) + st[n][p.Cy + cg];
                     if (f_accum) v += *dst;
                     *dst = v;
                     ssum += v;
@@ -537,8 +544,8 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
                     ssq += __shfl_xor(ssq, off);
                 }
                 if (l32 == 0 && cv) {
-                    atomicAdd(p.stats + co, (double)ssum);
-                    atomicAdd(p.stats + p.Cout + co, (double)ssq);
+                    atomicAdd(p.stats + cg, (double)ssum);
+                    atomicAdd(p.stats + p.Cy + cg, (double)ssq);
                 }
             }
         }
@@ -604,10 +611,16 @@ int run(const spk_conv2d_desc* d, hipStream_t stream) {
     a.x = d->x; a.wp = d->w_packed; a.bias = d->bias; a.noise_w = d->noise_w; a.noise = d->noise;
     a.style = d->style; a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.stats = d->stats; a.y = d->y; a.y_pre = d->y_pre; a.out_scale_bc = d->out_scale_bc;
     a.B = d->B; a.Cin = d->Cin; a.Cout = d->Cout; a.H = d->H; a.W = d->W; a.Hs = d->Hin; a.Ws = d->Win;
-    const Geometry g = geometry<C, KH, KW, S>(d->B, d->Cin, d->Cout, d->H, d->W);
+    a.G = d->groups > 1 ? d->groups : 1;
+    a.gin = a.G > 1 ? d->group_in_stride : d->Cin;
+    a.Cx = a.gin * (a.G - 1) + d->Cin;
+    a.Cy = a.G * d->Cout;
+    Geometry g = geometry<C, KH, KW, S>(d->B, d->Cin, d->Cout, d->H, d->W);
+    a.co_tiles_g = g.co_tiles;
+    g.co_tiles *= a.G;                                   // grid.y and the split-K fill heuristic count every group
     SPK_REQUIRE(g.ok, "conv2d: config %d does not fit this shape (%dx%d, B=%d)", d->config, d->H, d->W, d->B);
     // the staging tables hold 32-bit BYTE offsets relative to the image group's first plane
-    SPK_REQUIRE((size_t)g.TB * d->Cin * a.Hs * a.Ws < (1ull << 30), "conv2d: image group too large for 32-bit byte offsets");
+    SPK_REQUIRE((size_t)g.TB * a.Cx * a.Hs * a.Ws < (1ull << 30), "conv2d: image group too large for 32-bit byte offsets");
     a.lgTW = spk::ilog2(g.TW); a.lgTH = spk::ilog2(g.TH); a.lgTB = spk::ilog2(g.TB);
     {
         const unsigned pw = (unsigned)((g.TW - 1) * Shape<C, KH, KW, S>::SL + KW), plane = (unsigned)g.PLANE;
@@ -619,7 +632,7 @@ int run(const spk_conv2d_desc* d, hipStream_t stream) {
     a.n_chunks = g.n_chunks;
     a.style_stride = d->style_stride; a.flags = d->flags; a.slope = d->lrelu_slope; a.out_scale = d->out_scale; a.act_gain = d->act_gain != 0.f ? d->act_gain : 1.f;
     const int ksplit = resolve_ksplit(g, d->ksplit, &a.chunks_per_split);
-    const size_t out_floats = (size_t)d->B * d->Cout * d->H * d->W;
+    const size_t out_floats = (size_t)d->B * a.Cy * d->H * d->W;
     if (ksplit > 1) {
         SPK_REQUIRE(d->workspace && (size_t)d->workspace_bytes >= ksplit * out_floats * sizeof(float),
                     "conv2d: split-K x%d needs a %zu-byte workspace (see spk_conv2d_workspace_bytes)", ksplit,

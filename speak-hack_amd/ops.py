@@ -89,8 +89,12 @@ def conv_out_size(n, k, stride):
 def conv2d_fused(x, w_packed, Cout: int, k: int = 3, stride: int = 1, *, bias=None, noise_w=None, noise=None,
                  style=None, style_stride=None, upsample=False, lrelu_slope=None, out_scale=1.0, in_affine=None,
                  stats=None, config=-1, ksplit=0, out=None, accumulate=False, out_pre=None, batch_scale=None, demod=None,
-                 act_gain=1.0, up_fir=False):
+                 act_gain=1.0, up_fir=False, groups=1, shared_input=False):
     """y = style(lrelu(conv_kxk(in(x)) * out_scale + bias + noise_w*noise)) -- one launch.
+
+    ``groups`` > 1: that many independent convs of the same shape in one launch (``Cout`` per group; ``w_packed`` = the
+    groups' packed images concatenated; x carries the groups' input channels side by side, or -- ``shared_input`` -- one
+    set of channels every group reads); y has ``groups * Cout`` channels.
 
     ``in``: identity; or bilinear x2 (``upsample``; x is [B,Cin,H/2,W/2]); or ``max(x*a+b, 0)`` per
     input channel (``in_affine=(a, b)``: the producer's BatchNorm+ReLU, folded into staging).
@@ -98,12 +102,17 @@ def conv2d_fused(x, w_packed, Cout: int, k: int = 3, stride: int = 1, *, bias=No
     accumulates sum / sum of squares of y over (b,h,w) (BatchNorm batch statistics).
     """
     B, Cin, Hs, Ws = x.shape
+    G = int(groups)
+    if G > 1 and not shared_input:
+        if Cin % G:
+            raise L.SpkError(f"conv2d_fused: {Cin} input channels do not split into {G} groups")
+        Cin //= G
     if upsample:
         H, W = 2 * Hs, 2 * Ws
     else:
         H, W = conv_out_size(Hs, k, stride), conv_out_size(Ws, k, stride)
     if out is None:
-        out = torch.empty((B, Cout, H, W), device=x.device, dtype=torch.float32)
+        out = torch.empty((B, G * Cout, H, W), device=x.device, dtype=torch.float32)
     flags = 0
     if bias is not None:
         flags |= L.EPI_BIAS
@@ -130,14 +139,14 @@ def conv2d_fused(x, w_packed, Cout: int, k: int = 3, stride: int = 1, *, bias=No
     if demod is not None and tuple(demod.shape) != (B, Cout):
         raise L.SpkError("conv2d_fused: demod must be [B,Cout]")
     if stats is not None:
-        if stats.dtype != torch.float64 or stats.numel() != 2 * Cout or not stats.is_cuda:
-            raise L.SpkError("conv2d_fused: stats must be a float64 HIP tensor of 2*Cout elements")
+        if stats.dtype != torch.float64 or stats.numel() != 2 * G * Cout or not stats.is_cuda:
+            raise L.SpkError("conv2d_fused: stats must be a float64 HIP tensor of 2*groups*Cout elements")
         flags |= L.EPI_STATS
     if config < 0:
         config = conv2d_pick_config(k, stride, B, Cin, Cout, H, W)
         if batch_scale is not None and config < 4:
             config += 4                  # the modulated variant is built for the half-depth-chunk configs
-    ws_bytes = L.lib().spk_conv2d_workspace_bytes(int(config), int(ksplit), k, k, stride, B, Cin, Cout, H, W)
+    ws_bytes = L.lib().spk_conv2d_workspace_bytes_grouped(int(config), int(ksplit), k, k, stride, B, Cin, Cout, H, W, G)
     if ws_bytes < 0:
         raise L.SpkError(f"conv2d_fused: config {config} cannot host k={k} s={stride} shape {(B, Cin, Cout, H, W)}")
     ws = _workspace(x.device, ws_bytes) if ws_bytes > 0 else None
@@ -153,7 +162,8 @@ def conv2d_fused(x, w_packed, Cout: int, k: int = 3, stride: int = 1, *, bias=No
                      style_stride=int(style_stride or 0), flags=flags,
                      lrelu_slope=float(lrelu_slope if lrelu_slope is not None else 1.0), out_scale=float(out_scale),
                      config=int(config), ksplit=int(ksplit), workspace=ws.data_ptr() if ws is not None else None,
-                     workspace_bytes=ws.numel() * 4 if ws is not None else 0)
+                     workspace_bytes=ws.numel() * 4 if ws is not None else 0, groups=G,
+                     group_in_stride=0 if (shared_input or G == 1) else Cin)
     if CONV_EVENTS is not None:
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
