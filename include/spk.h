@@ -150,7 +150,12 @@ typedef struct spk_wgrad_desc {
     int32_t accumulate;      /* dw += instead of dw = */
     int32_t splits;          /* pixel-range splits; 0 = auto */
     void*   workspace;
-    int64_t workspace_bytes; /* >= spk_conv2d_wgrad_workspace_bytes(...) */
+    int64_t workspace_bytes; /* >= spk_conv2d_wgrad_workspace_bytes(...) (with Cout = groups * Cout when grouped) */
+    /* grouped form, as in spk_conv2d_desc: Cin / Cout per group, g has groups*Cout channels, x has
+     * group_in_stride*(groups-1) + Cin, dw is [groups*Cout, Cin, kh, kw] (the groups' gradients one after another);
+     * Cout must be a multiple of 64.  0 / 1 = ordinary. */
+    int32_t groups;
+    int32_t group_in_stride;
 } spk_wgrad_desc;
 int64_t spk_conv2d_wgrad_workspace_bytes(int kh, int kw, int stride, int splits, int B, int Cin, int Cout, int H, int W);
 int spk_conv2d_wgrad(const spk_wgrad_desc* desc, void* stream);

@@ -41,9 +41,12 @@ struct WgradArgs {
     const float* in_scale; // WG_AFFINE_RELU
     const float* in_shift;
     float* slabs;          // [n_slabs][Cout][TAPS][Cin]
-    int B, Cin, Cout, H, W, Hs, Ws;
+    int B, Cin, Cout, H, W, Hs, Ws;   // Cin / Cout PER GROUP
     int lgTW, lgTH, lgTB;
     int tiles_x, tiles_y, n_tiles;
+    // grouped form (G independent convs per launch): g has Cy = G*Cout channels, x has Cx, group q reads x channels
+    // [q*gin, q*gin + Cin); Cout is a multiple of CO_T so that a workgroup's co block lies in one group
+    int Cx, Cy, gin;
 };
 
 template <int KH, int KW, int S>
@@ -76,7 +79,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     float* const g_s = smem;
     float* const x_s = smem + CO_T * GPITCH;
 
-    const int co0 = blockIdx.x * CO_T;
+    const int co0 = blockIdx.x * CO_T;                  // in the gradient tensor (all groups)
+    const int grp = co0 / p.Cout;
+    const int co_end = (grp + 1) * p.Cout;
+    const int cx0 = grp * p.gin;                        // the group's first channel in x
     const int ci_blocks = (p.Cin + CI_T - 1) / CI_T;
     const int ci0 = (blockIdx.y % ci_blocks) * CI_T;
     const int pass = blockIdx.y / ci_blocks;            // tap row for ROWPASS kernels, else 0
@@ -119,8 +125,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
             const int co = e / PIX_T, pix = e % PIX_T;                                                      \
             const int px = pix & (TW - 1), py = (pix >> p.lgTW) & (TH - 1), tb = pix >> (p.lgTW + p.lgTH);  \
             const int b = b0_ + tb, yy = y0_ + py, xx = x0_ + px;                                           \
-            const bool ok = tb < TB && b < p.B && yy < p.H && xx < p.W && co0 + co < p.Cout;                \
-            const size_t off = ok ? ((size_t)b * p.Cout + co0 + co) * HW + (size_t)yy * p.W + xx : 0;       \
+            const bool ok = tb < TB && b < p.B && yy < p.H && xx < p.W && co0 + co < co_end;                \
+            const size_t off = ok ? ((size_t)b * p.Cy + co0 + co) * HW + (size_t)yy * p.W + xx : 0;         \
             gg[i] = p.g[off];          /* masked at store time: no wait on the load here */                \
             if (ok) gok |= 1u << i;                                                                         \
         }                                                                                                   \
@@ -129,7 +135,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
             const int uy = y0_ * S + xs_r[k] - PAD, ux = x0_ * S + xs_c[k] - PAD, b = b0_ + xs_tb[k];       \
             const bool ok = xs_rem[k] >= 0 && uy >= 0 && uy < p.Hs && ux >= 0 && ux < p.Ws && b < p.B;      \
             if (ok) xok |= 1u << k;                                                                         \
-            const float* src = p.x + ((size_t)(ok ? b : 0) * p.Cin + ci0) * src_plane +                     \
+            const float* src = p.x + ((size_t)(ok ? b : 0) * p.Cx + cx0 + ci0) * src_plane +                \
                                (ok ? (size_t)uy * p.Ws + ux : 0);                                           \
             _Pragma("unroll") for (int ci = 0; ci < CI_T; ++ci)                                             \
                 xg[k * CI_T + ci] = src[(size_t)(ci < nci ? ci : 0) * src_plane];                           \
@@ -148,8 +154,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
                 float* dst = x_s + xs_rem[k];                                                               \
                 _Pragma("unroll") for (int ci = 0; ci < CI_T; ++ci) {                                       \
                     float v = xg[k * CI_T + ci];                                                            \
-                    if (AFF) v = fmaxf(v * p.in_scale[ci0 + (ci < nci ? ci : 0)] +                          \
-                                       p.in_shift[ci0 + (ci < nci ? ci : 0)], 0.f);                         \
+                    if (AFF) v = fmaxf(v * p.in_scale[cx0 + ci0 + (ci < nci ? ci : 0)] +                    \
+                                       p.in_shift[cx0 + ci0 + (ci < nci ? ci : 0)], 0.f);                   \
                     dst[ci * XPITCH] = (ok && ci < nci) ? v : 0.f;                                          \
                 }                                                                                           \
             }                                                                                               \
@@ -203,14 +209,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
 
     // ---- partial block -> slab [slab][co][tap][ci] (ci contiguous: 128-B stores per half wave) ----
     const int slab = blockIdx.z * SH::WPX + wpx;
-    float* out = p.slabs + (size_t)slab * p.Cout * TAPS * p.Cin;
+    float* out = p.slabs + (size_t)slab * p.Cy * TAPS * p.Cin;
     const int ci = ci0 + wci * 32 + l32;
 #pragma unroll
     for (int t = 0; t < TP; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = co0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (co < p.Cout && ci < p.Cin) out[((size_t)co * TAPS + tap0 + t) * p.Cin + ci] = acc[t][r];
+            if (co < co_end && ci < p.Cin) out[((size_t)co * TAPS + tap0 + t) * p.Cin + ci] = acc[t][r];
         }
 }
 
@@ -274,14 +280,19 @@ WGeom wgeom(int B, int Cin, int Cout, int H, int W, int want_splits) {
 template <int KH, int KW, int S, int MODE>
 int run_wgrad(const spk_wgrad_desc* d, hipStream_t stream) {
     using SH = WShape<KH, KW, S>;
-    const WGeom g = wgeom<KH, KW, S>(d->B, d->Cin, d->Cout, d->H, d->W, d->splits);
+    const int G = d->groups > 1 ? d->groups : 1;
+    SPK_REQUIRE(G == 1 || d->Cout % SH::CO_T == 0, "wgrad: grouped launches need Cout (per group) to be a multiple of %d", SH::CO_T);
+    const WGeom g = wgeom<KH, KW, S>(d->B, d->Cin, G * d->Cout, d->H, d->W, d->splits);
     SPK_REQUIRE(g.lds_bytes <= 160 * 1024, "wgrad: input tile does not fit LDS");
-    const size_t slab_floats = (size_t)d->Cout * d->Cin * SH::TAPS;
+    const size_t slab_floats = (size_t)G * d->Cout * d->Cin * SH::TAPS;
     SPK_REQUIRE(d->workspace && (size_t)d->workspace_bytes >= g.n_slabs * slab_floats * sizeof(float),
                 "wgrad: needs a %zu-byte workspace (see spk_conv2d_wgrad_workspace_bytes)", g.n_slabs * slab_floats * sizeof(float));
     WgradArgs a;
     a.g = d->g; a.x = d->x; a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.slabs = static_cast<float*>(d->workspace);
     a.B = d->B; a.Cin = d->Cin; a.Cout = d->Cout; a.H = d->H; a.W = d->W; a.Hs = d->Hin; a.Ws = d->Win;
+    a.gin = G > 1 ? d->group_in_stride : d->Cin;
+    a.Cx = a.gin * (G - 1) + d->Cin;
+    a.Cy = G * d->Cout;
     a.lgTW = spk::ilog2(g.TW); a.lgTH = spk::ilog2(g.TH); a.lgTB = spk::ilog2(g.TB);
     a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y; a.n_tiles = g.n_tiles;
     auto kern = &wgrad_kernel<KH, KW, S, MODE>;
@@ -293,13 +304,13 @@ int run_wgrad(const spk_wgrad_desc* d, hipStream_t stream) {
             raised = true;
         }
     }
-    dim3 grid((unsigned)spk::ceil_div(d->Cout, SH::CO_T),
+    dim3 grid((unsigned)spk::ceil_div(G * d->Cout, SH::CO_T),
               (unsigned)(spk::ceil_div(d->Cin, SH::CI_T) * (SH::ROWPASS ? KH : 1)), (unsigned)g.splits);
     hipLaunchKernelGGL(kern, grid, dim3(256), g.lds_bytes, stream, a);
     int rc = spk::check_launch("wgrad_kernel");
     if (rc != SPK_OK) return rc;
     const unsigned blocks = (unsigned)std::min<size_t>((slab_floats + 255) / 256, 2048);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, a.slabs, d->dw, g.n_slabs, d->Cout,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, a.slabs, d->dw, g.n_slabs, G * d->Cout,
                        d->Cin, SH::TAPS, d->scale, d->accumulate ? 1 : 0);
     return spk::check_launch("wgrad_reduce_kernel");
 }

@@ -69,3 +69,28 @@ def test_grouped_data_gradient(ops):
     wp = torch.cat([ops.pack_conv_weight(ws[g], cfg, transpose_flip=True) for g in range(G)])
     dx = ops.conv2d_fused(g_out, wp, Cin, 3, 1, config=cfg, groups=G)
     assert torch.equal(dx, torch.cat(sep, dim=1))
+
+
+@pytest.mark.parametrize("k,stride,B,Cin,Cout,H,shared,aff", [
+    (1, 1, 2, 64, 256, 16, False, True),
+    (3, 1, 2, 64, 64, 16, False, True),
+    (3, 2, 2, 128, 128, 16, False, False),
+    (7, 2, 2, 3, 64, 32, True, False),
+    (1, 1, 4, 1024, 2048, 4, False, True),
+])
+def test_grouped_weight_gradient(ops, k, stride, B, Cin, Cout, H, shared, aff):
+    """Grouped wgrad = the groups' weight gradients one after another (bitwise, with the pixel split pinned)."""
+    dev, G = torch.device("cuda:0"), 3
+    torch.manual_seed(2)
+    Ho = ops.conv_out_size(H, k, stride)
+    xs = [torch.randn(B, Cin, H, H, device=dev) for _ in range(1 if shared else G)]
+    gs = [torch.randn(B, Cout, Ho, Ho, device=dev) for _ in range(G)]
+    sc = [torch.rand(Cin, device=dev) + 0.5 for _ in range(G)] if aff else None
+    sh = [torch.randn(Cin, device=dev) * 0.1 for _ in range(G)] if aff else None
+    sep = [ops.conv2d_wgrad(gs[q], xs[0 if shared else q], Cout, Cin, k, stride, splits=2,
+                            in_affine=(sc[q], sh[q]) if aff else None) for q in range(G)]
+    x_all = xs[0] if shared else torch.cat(xs, dim=1).contiguous()
+    dw = ops.conv2d_wgrad(torch.cat(gs, dim=1).contiguous(), x_all, Cout, Cin, k, stride, splits=2, groups=G, shared_input=shared,
+                          in_affine=(torch.cat(sc), torch.cat(sh)) if aff else None)
+    assert dw.shape == (G * Cout, Cin, k, k)
+    assert torch.equal(dw, torch.cat(sep, dim=0))
