@@ -98,6 +98,9 @@ class _ConvBN:
             counters.append(bn.num_batches_tracked)
         ops.bn_finalize(rec["stats"], rec["count"], bn.weight, bn.bias, bn.running_mean, bn.running_var, rec["momentum"], bn.eps)
 
+    def put_bn_grads(self, grads, dg, db):
+        grads[self.bn.weight], grads[self.bn.bias] = dg, db
+
     def bn_bwd(self, rec, g, mask_mode, mask_src=None, want_dz=False, **kw):
         """Gradient w.r.t. the raw conv output + BatchNorm parameter gradients (into ``grads``)."""
         out = ops.bn_backward(g, rec["y"], rec["affine"], rec["mean"], rec["invstd"], mask_mode, mask_src,
@@ -130,6 +133,174 @@ class _StatsPool:
         out = self.buf[self.pos:self.pos + n]
         self.pos += n
         return out
+
+
+class _GroupPacked:
+    """The packed images of a group's weights one after another (what a grouped launch reads), cached like
+    ``ops.PackedConvWeight``."""
+
+    def __init__(self):
+        self._cache = {}
+
+    def get(self, weights, config, transpose_flip=False):
+        key = (config, transpose_flip)
+        stamp = tuple((w.data_ptr(), w._version) for w in weights)
+        hit = self._cache.get(key)
+        if hit is not None and hit[0] == stamp:
+            return hit[1]
+        packed = torch.cat([ops.pack_conv_weight(w.detach(), config, transpose_flip) for w in weights])
+        self._cache[key] = (stamp, packed)
+        return packed
+
+
+class _GroupedConvBN:
+    """The same conv + BatchNorm position of G trunks as ONE grouped launch (channels of the groups side by side).
+    BatchNorm is per channel, so statistics, the folded affine, the residual add, the pools and the BatchNorm backward
+    need nothing new: they simply see G*C channels.  ``flat`` = (gamma, beta, running_mean, running_var) of the G
+    BatchNorms concatenated, provided per pass by ``GroupedTrunks``."""
+
+    def __init__(self, members, shared_input=False):
+        self.convs, self.bns = [m.conv for m in members], [m.bn for m in members]
+        self.G = len(members)
+        self.k, self.stride = members[0].k, members[0].stride
+        self.shared_input = shared_input
+        self.packed = _GroupPacked()
+        self.flat = None
+
+    def _weights(self):
+        return [c.weight for c in self.convs]
+
+    def fwd(self, x, in_affine, training, stats_pool, keep):
+        conv, bn, G = self.convs[0], self.bns[0], self.G
+        B, _, H, W = x.shape
+        Cin, Cout = conv.in_channels, conv.out_channels
+        Ho, Wo = ops.conv_out_size(H, self.k, self.stride), ops.conv_out_size(W, self.k, self.stride)
+        cfg = ops.conv2d_pick_config(self.k, self.stride, B, Cin, Cout, Ho, Wo)
+        stats = stats_pool.take(2 * G * Cout) if training else None
+        y = ops.conv2d_fused(x, self.packed.get(self._weights(), cfg), Cout, self.k, self.stride, in_affine=in_affine,
+                             stats=stats, config=cfg, groups=G, shared_input=self.shared_input)
+        gamma, beta, rm, rv = self.flat
+        if training:
+            if bn.momentum is None:
+                raise NotImplementedError("grouped encoders: cumulative-average BatchNorm (momentum=None) is not supported")
+            stats_pool.counters.extend(b.num_batches_tracked for b in self.bns if b.num_batches_tracked is not None)
+            fin = ops.bn_finalize(stats, B * Ho * Wo, gamma, beta, rm, rv, bn.momentum, bn.eps, save=keep)
+        else:
+            fin = ops.bn_finalize(None, 1, gamma, beta, rm, rv, 0.0, bn.eps, save=keep)
+        rec = {"y": y, "affine": (fin[0], fin[1])}
+        if keep:
+            rec.update(x=x, in_affine=in_affine, mean=fin[2], invstd=fin[3], training=training)
+            if training:
+                rec.update(stats=stats, count=B * Ho * Wo, momentum=bn.momentum)
+        return rec
+
+    def second_update(self, rec, counters):
+        if not rec.get("training") or "stats" not in rec:
+            return
+        counters.extend(b.num_batches_tracked for b in self.bns if b.num_batches_tracked is not None)
+        gamma, beta, rm, rv = self.flat
+        ops.bn_finalize(rec["stats"], rec["count"], gamma, beta, rm, rv, rec["momentum"], self.bns[0].eps)
+
+    def put_bn_grads(self, grads, dg, db):
+        C = self.bns[0].num_features
+        for q, bn in enumerate(self.bns):
+            grads[bn.weight], grads[bn.bias] = dg[q * C:(q + 1) * C], db[q * C:(q + 1) * C]
+
+    def bn_bwd(self, rec, g, mask_mode, mask_src=None, want_dz=False, **kw):
+        return ops.bn_backward(g, rec["y"], rec["affine"], rec["mean"], rec["invstd"], mask_mode, mask_src,
+                               want_dz=want_dz, batch_stats=rec["training"], **kw)
+
+    def conv_bwd(self, rec, dr, grads, need_dx, dx_out=None, accumulate=False):
+        conv, G = self.convs[0], self.G
+        Cout, Cin = conv.out_channels, conv.in_channels
+        x = rec["x"]
+        B, _, H, W = x.shape
+        dw = ops.conv2d_wgrad(dr, x, Cout, Cin, self.k, self.stride, in_affine=rec["in_affine"], groups=G,
+                              shared_input=self.shared_input)
+        for q, c in enumerate(self.convs):
+            grads[c.weight] = dw[q * Cout:(q + 1) * Cout]
+        if not need_dx:
+            return None
+        cfg = ops.conv2d_pick_config(self.k, 1, B, Cout, Cin, H, W)
+        return ops.conv2d_dgrad(dr, self.packed.get(self._weights(), cfg, transpose_flip=True), Cin, self.k, self.stride,
+                                (H, W), cfg, out=dx_out, accumulate=accumulate, groups=G)
+
+
+class GroupedTrunks:
+    """G trunks of one architecture that see the same image -- IRFD's Ei, Ee, Ep (model.py:84-90) -- run as ONE network
+    of grouped launches: a third of the launches, three times the work per launch (the 8x8 .. 32x32 layers of a single
+    ResNet-50 at batch 8 cannot fill 256 CUs).  Feature order = trunk order: [B, G*2048, 1, 1].  Parameters stay where
+    they are (each trunk's own modules, so ``state_dict`` and checkpoints are unchanged); per pass the BatchNorm vectors
+    are gathered into flat tensors with four ``torch.cat`` calls and the running statistics written back with two
+    ``torch._foreach_copy_`` calls."""
+
+    def __init__(self, trunks):
+        self.trunks = list(trunks)
+        self._plan = None
+        self.recompute = False
+
+    @property
+    def training(self):
+        return self.trunks[0].training
+
+    def train(self, mode=True):
+        for t in self.trunks:
+            t.train(mode)
+        return self
+
+    def parameters(self):
+        for t in self.trunks:
+            yield from t.parameters()
+
+    def _build_plan(self):
+        plans = []
+        for t in self.trunks:
+            t._build_plan()
+            plans.append(t._plan)
+        stem = _GroupedConvBN([p[0] for p in plans], shared_input=True)
+        blocks = []
+        for parts in zip(*[p[1] for p in plans]):
+            blocks.append(tuple(_GroupedConvBN([b[i] for b in parts]) if parts[0][i] is not None else None for i in range(4)))
+        self._stats_total = len(self.trunks) * self.trunks[0]._stats_total
+        self._plan = (stem, blocks)
+        self._members = [stem] + [c for blk in blocks for c in blk if c is not None]
+
+    def _load_flats(self):
+        ms = self._members
+        cat = lambda get: torch.cat([get(bn).detach() for m in ms for bn in m.bns])
+        flats = [cat(lambda bn: bn.weight), cat(lambda bn: bn.bias), cat(lambda bn: bn.running_mean), cat(lambda bn: bn.running_var)]
+        pos = 0
+        for m in ms:
+            n = m.G * m.bns[0].num_features
+            m.flat = tuple(f[pos:pos + n] for f in flats)
+            pos += n
+        self._flat_running = (flats[2], flats[3])
+
+    def _store_running(self):
+        ms = self._members
+        sizes = [bn.num_features for m in ms for bn in m.bns]
+        torch._foreach_copy_([bn.running_mean for m in ms for bn in m.bns], list(self._flat_running[0].split(sizes)))
+        torch._foreach_copy_([bn.running_var for m in ms for bn in m.bns], list(self._flat_running[1].split(sizes)))
+
+    def _run(self, x, keep):
+        if self._plan is None:
+            self._build_plan()
+        self._load_flats()
+        out = ResNet50Trunk._run(self, x, keep)
+        if self.training:
+            self._store_running()
+        return out
+
+    def _second_bn_update(self, recs):
+        self._load_flats()
+        ResNet50Trunk._second_bn_update(self, recs)
+        self._store_running()
+
+    def _backward(self, recs, dfeat):
+        return ResNet50Trunk._backward(self, recs, dfeat)
+
+    def __call__(self, x):
+        return TrunkFn.apply(x, self, torch.is_grad_enabled(), *self.parameters())
 
 
 class TrunkFn(torch.autograd.Function):
@@ -259,19 +430,19 @@ class ResNet50Trunk(nn.Sequential):
             # out = relu(bn3(r3) + identity): mask from the block output; dz also feeds the identity branch
             dr3, dg, db, dz = c3.bn_bwd(r3, g, ops.MASK_TENSOR, mask_src=out, want_dz=True,
                                         g_scale=g_scale if per_plane else 1.0, g_per_plane=per_plane)
-            grads[c3.bn.weight], grads[c3.bn.bias] = dg, db
+            c3.put_bn_grads(grads, dg, db)
             dv2 = c3.conv_bwd(r3, dr3, grads, need_dx=True)
             dr2, dg, db = c2.bn_bwd(r2, dv2, ops.MASK_RECOMPUTE)
-            grads[c2.bn.weight], grads[c2.bn.bias] = dg, db
+            c2.put_bn_grads(grads, dg, db)
             dv1 = c2.conv_bwd(r2, dr2, grads, need_dx=True)
             dr1, dg, db = c1.bn_bwd(r1, dv1, ops.MASK_RECOMPUTE)
-            grads[c1.bn.weight], grads[c1.bn.bias] = dg, db
+            c1.put_bn_grads(grads, dg, db)
             if down is None:
                 # d(block input) = dz (identity) + conv1's data gradient, summed in the conv epilogue
                 g = c1.conv_bwd(r1, dr1, grads, need_dx=True, dx_out=dz, accumulate=True)
             else:
                 drd, dg, db = down.bn_bwd(rd, dz, ops.MASK_NONE)
-                grads[down.bn.weight], grads[down.bn.bias] = dg, db
+                down.put_bn_grads(grads, dg, db)
                 g = down.conv_bwd(rd, drd, grads, need_dx=True)
                 g = c1.conv_bwd(r1, dr1, grads, need_dx=True, dx_out=g, accumulate=True)
             per_plane = False
@@ -279,6 +450,6 @@ class ResNet50Trunk(nn.Sequential):
         s = recs["stem"]
         dv0 = ops.maxpool3x3s2_bwd(s["y"], g, s["affine"][0], s["affine"][1])
         dr0, dg, db = stem.bn_bwd(s, dv0, ops.MASK_RECOMPUTE)
-        grads[stem.bn.weight], grads[stem.bn.bias] = dg, db
+        stem.put_bn_grads(grads, dg, db)
         stem.conv_bwd(s, dr0, grads, need_dx=False)       # the image itself takes no gradient
         return grads

@@ -24,11 +24,14 @@ import torch.nn as nn
 from . import autograd as AG
 from .decoder import StyleGenerator
 from .discriminator import StyleDiscriminator
-from .encoder import ResNet50Trunk
+from .encoder import GroupedTrunks, ResNet50Trunk
 
 
 class IRFD(nn.Module):
     debug_side_effects = False
+    # Ei, Ee, Ep run the same ResNet-50 on the same image: by default every layer of the three is ONE grouped launch
+    # (encoder.GroupedTrunks); False runs them one after another as the reference does.  Same parameters, same results.
+    group_encoders = True
 
     def __init__(self, max_resolution=256):
         super().__init__()
@@ -72,8 +75,15 @@ class IRFD(nn.Module):
 
         ``swap_type`` / ``noises_*`` are optional hooks for reproducible tests; by default the swap is
         drawn from the host RNG exactly as model.py:98 does and noise is drawn on the device."""
-        fi_s, fe_s, fp_s = self.Ei(x_s), self.Ee(x_s), self.Ep(x_s)
-        fi_t, fe_t, fp_t = self.Ei(x_t), self.Ee(x_t), self.Ep(x_t)
+        if self.group_encoders:
+            enc = self.__dict__.get("_enc_group")
+            if enc is None or enc.trunks != [self.Ei, self.Ee, self.Ep]:
+                enc = self.__dict__["_enc_group"] = GroupedTrunks([self.Ei, self.Ee, self.Ep])
+            fi_s, fe_s, fp_s = enc(x_s).split(2048, dim=1)
+            fi_t, fe_t, fp_t = enc(x_t).split(2048, dim=1)
+        else:
+            fi_s, fe_s, fp_s = self.Ei(x_s), self.Ee(x_s), self.Ep(x_s)
+            fi_t, fe_t, fp_t = self.Ei(x_t), self.Ee(x_t), self.Ep(x_t)
         self._log_feature_stats(fi_s, "Identity features")
         self._log_feature_stats(fe_s, "Emotion features")
         self._log_feature_stats(fp_s, "Pose features")

@@ -501,14 +501,14 @@ def maxpool3x3s2_bwd(x, dy, in_scale=None, in_shift=None):
     return dx
 
 
-def conv2d_dgrad(g, weight_packed_tf, Cin, k, stride, in_hw, config, out=None, accumulate=False):
+def conv2d_dgrad(g, weight_packed_tf, Cin, k, stride, in_hw, config, out=None, accumulate=False, groups=1):
     """Data gradient of a k x k conv: the forward MFMA kernel on ``g`` with transpose-flipped weights
     (stride 2: on the zero-dilated ``g``).  ``in_hw`` = (H, W) of the conv's input."""
     if stride == 2:
         # dx[i] = sum_k gd[i + k' - p] * w[k-1-k'] with gd[2o] = g[o], zeros elsewhere, extended to the input size
         # (an even-sized input has a last row/column no window's stride lattice reaches: it stays zero)
         g = dilate2x(g, in_hw[0], in_hw[1])
-    return conv2d_fused(g, weight_packed_tf, Cin, k, 1, config=config, out=out, accumulate=accumulate)
+    return conv2d_fused(g, weight_packed_tf, Cin, k, 1, config=config, out=out, accumulate=accumulate, groups=groups)
 
 
 # ---- BatchNorm / pooling pieces of the ResNet-50 trunk ----------------------------------------------

@@ -191,3 +191,36 @@ def test_stored_activations_equal_checkpoint_recompute(pkg, dev):
     assert all(torch.equal(a[2][k], b[2][k]) for k in a[2])
     assert all(torch.equal(a[3][k], b[3][k]) for k in a[3]), [k for k in a[3] if not torch.equal(a[3][k], b[3][k])][:4]
     assert int(a[3]["1.num_batches_tracked"]) == 2
+
+
+def test_grouped_trunks_equal_three_separate_trunks(pkg, dev):
+    """``GroupedTrunks`` (Ei, Ee, Ep as one network of grouped launches) vs the three trunks run one after another on
+    the same image: features, every parameter gradient, running statistics and batch counters.  Not bitwise -- a grouped
+    launch may pick another split-K factor, i.e. another summation order -- hence 1e-5 forward / 2e-3 on gradients
+    (ReLU-mask flips, see above)."""
+    enc = importlib.import_module("speak-hack_amd.encoder")
+    x = recipe_input("trg.x", (4, 3, 64, 64), "uniform").to(dev)
+    gfeat = recipe_input("trg.g", (4, 3 * 2048, 1, 1)).to(dev)
+    res = {}
+    for grouped in (False, True):
+        trunks = [_trunk(dev, p)[0].train(True) for p in ("Ei.", "Ee.", "Ep.")]
+        if grouped:
+            y = enc.GroupedTrunks(trunks)(x)
+        else:
+            y = torch.cat([t(x) for t in trunks], dim=1)
+        y.backward(gfeat)
+        res[grouped] = (y.detach(), [{k: p.grad for k, p in t.named_parameters()} for t in trunks],
+                        [{k: v.clone() for k, v in t.state_dict().items() if "running" in k or "num_batches" in k} for t in trunks])
+    a, b = res[False], res[True]
+    assert b[0].shape == (4, 6144, 1, 1) and rel_l2(b[0], a[0]) < 1e-5
+    for q in range(3):
+        assert set(a[1][q]) == set(b[1][q]) and all(v is not None for v in b[1][q].values())
+        cat = lambda d: torch.cat([d[k].double().flatten() for k in sorted(d)])
+        assert rel_l2(cat(b[1][q]), cat(a[1][q])) < 2e-3, q
+        for k in ("0.weight", "7.2.conv3.weight", "5.0.downsample.0.weight", "6.3.bn2.weight", "1.bias"):
+            assert rel_l2(b[1][q][k], a[1][q][k]) < 2e-2, (q, k)
+        for k in a[2][q]:
+            if "num_batches" in k:
+                assert int(a[2][q][k]) == int(b[2][q][k]) == 2, k
+            else:
+                assert rel_l2(b[2][q][k], a[2][q][k]) < 1e-5, (q, k)
