@@ -162,6 +162,10 @@ class _GroupedConvBN:
     def __init__(self, members, shared_input=False):
         self.convs, self.bns = [m.conv for m in members], [m.bn for m in members]
         self.G = len(members)
+        self.uniq = []                       # distinct trunks among the members (members repeat once per image)
+        for m in members:
+            if not any(m is u for u in self.uniq):
+                self.uniq.append(m)
         self.k, self.stride = members[0].k, members[0].stride
         self.shared_input = shared_input
         self.packed = _GroupPacked()
@@ -183,7 +187,8 @@ class _GroupedConvBN:
         if training:
             if bn.momentum is None:
                 raise NotImplementedError("grouped encoders: cumulative-average BatchNorm (momentum=None) is not supported")
-            stats_pool.counters.extend(b.num_batches_tracked for b in self.bns if b.num_batches_tracked is not None)
+            # distinct counters only; the pass bumps them by the number of images it carries
+            stats_pool.counters.extend(b.num_batches_tracked for b in self.bns[:len(self.uniq)] if b.num_batches_tracked is not None)
             fin = ops.bn_finalize(stats, B * Ho * Wo, gamma, beta, rm, rv, bn.momentum, bn.eps, save=keep)
         else:
             fin = ops.bn_finalize(None, 1, gamma, beta, rm, rv, 0.0, bn.eps, save=keep)
@@ -197,14 +202,22 @@ class _GroupedConvBN:
     def second_update(self, rec, counters):
         if not rec.get("training") or "stats" not in rec:
             return
-        counters.extend(b.num_batches_tracked for b in self.bns if b.num_batches_tracked is not None)
+        counters.extend(b.num_batches_tracked for b in self.bns[:len(self.uniq)] if b.num_batches_tracked is not None)
         gamma, beta, rm, rv = self.flat
         ops.bn_finalize(rec["stats"], rec["count"], gamma, beta, rm, rv, rec["momentum"], self.bns[0].eps)
 
+    def _fold(self, t):
+        """Gradient of all groups [G*n, ...] -> per distinct module [T, n, ...]: groups i and i + T (the same trunk on
+        the second image) share their parameters, so their gradients add."""
+        T = len(self.uniq)
+        t = t.view(self.G // T, T, t.shape[0] // self.G, *t.shape[1:])
+        return t[0] if t.shape[0] == 1 else t.sum(0)
+
     def put_bn_grads(self, grads, dg, db):
-        C = self.bns[0].num_features
-        for q, bn in enumerate(self.bns):
-            grads[bn.weight], grads[bn.bias] = dg[q * C:(q + 1) * C], db[q * C:(q + 1) * C]
+        dg, db = self._fold(dg), self._fold(db)
+        for q in range(len(self.uniq)):
+            bn = self.bns[q]
+            grads[bn.weight], grads[bn.bias] = dg[q], db[q]
 
     def bn_bwd(self, rec, g, mask_mode, mask_src=None, want_dz=False, **kw):
         return ops.bn_backward(g, rec["y"], rec["affine"], rec["mean"], rec["invstd"], mask_mode, mask_src,
@@ -217,8 +230,9 @@ class _GroupedConvBN:
         B, _, H, W = x.shape
         dw = ops.conv2d_wgrad(dr, x, Cout, Cin, self.k, self.stride, in_affine=rec["in_affine"], groups=G,
                               shared_input=self.shared_input)
-        for q, c in enumerate(self.convs):
-            grads[c.weight] = dw[q * Cout:(q + 1) * Cout]
+        dw = self._fold(dw)
+        for q in range(len(self.uniq)):
+            grads[self.convs[q].weight] = dw[q]
         if not need_dx:
             return None
         cfg = ops.conv2d_pick_config(self.k, 1, B, Cout, Cin, H, W)
@@ -234,8 +248,13 @@ class GroupedTrunks:
     are gathered into flat tensors with four ``torch.cat`` calls and the running statistics written back with two
     ``torch._foreach_copy_`` calls."""
 
-    def __init__(self, trunks):
+    def __init__(self, trunks, images=1):
+        """``images`` = 2: one pass takes TWO images (``group(x_s, x_t)``): the network then has 2*G groups -- every
+        trunk once per image -- so BatchNorm statistics stay per (trunk, image) exactly as in two separate passes (they
+        are per channel, and the groups are separate channels); parameter gradients of a trunk's two groups add, and the
+        running statistics receive the two momentum updates in the reference's order (x_s, then x_t)."""
         self.trunks = list(trunks)
+        self.images = int(images)
         self._plan = None
         self.recompute = False
 
@@ -257,11 +276,12 @@ class GroupedTrunks:
         for t in self.trunks:
             t._build_plan()
             plans.append(t._plan)
-        stem = _GroupedConvBN([p[0] for p in plans], shared_input=True)
+        rep = self.images
+        stem = _GroupedConvBN([p[0] for p in plans] * rep, shared_input=(rep == 1))
         blocks = []
         for parts in zip(*[p[1] for p in plans]):
-            blocks.append(tuple(_GroupedConvBN([b[i] for b in parts]) if parts[0][i] is not None else None for i in range(4)))
-        self._stats_total = len(self.trunks) * self.trunks[0]._stats_total
+            blocks.append(tuple(_GroupedConvBN([b[i] for b in parts] * rep) if parts[0][i] is not None else None for i in range(4)))
+        self._stats_total = rep * len(self.trunks) * self.trunks[0]._stats_total
         self._plan = (stem, blocks)
         self._members = [stem] + [c for blk in blocks for c in blk if c is not None]
 
@@ -276,11 +296,30 @@ class GroupedTrunks:
             pos += n
         self._flat_running = (flats[2], flats[3])
 
-    def _store_running(self):
+    def _store_running(self, first_image_first=True):
         ms = self._members
         sizes = [bn.num_features for m in ms for bn in m.bns]
-        torch._foreach_copy_([bn.running_mean for m in ms for bn in m.bns], list(self._flat_running[0].split(sizes)))
-        torch._foreach_copy_([bn.running_var for m in ms for bn in m.bns], list(self._flat_running[1].split(sizes)))
+        for k, get in ((0, lambda bn: bn.running_mean), (1, lambda bn: bn.running_var)):
+            parts = list(self._flat_running[k].split(sizes))
+            if self.images == 1:
+                torch._foreach_copy_([get(bn) for m in ms for bn in m.bns], parts)
+                continue
+            # Each group's slice holds (1-m)*r0 + m*mu of ITS image, both computed from the same r0.  Two momentum
+            # updates in sequence (image a, then image b) give (1-m)*[(1-m)*r0 + m*mu_a] + m*mu_b
+            #   = (1-m)*slice_a + slice_b - (1-m)*r0.
+            bufs, a, b, pos = [], [], [], 0
+            for m in ms:
+                T = len(m.uniq)
+                for q in range(T):
+                    bufs.append(get(m.bns[q]))
+                    s_img, t_img = parts[pos + q], parts[pos + T + q]
+                    a.append(s_img if first_image_first else t_img)
+                    b.append(t_img if first_image_first else s_img)
+                pos += m.G
+            keep = 1.0 - ms[0].bns[0].momentum
+            torch._foreach_mul_(bufs, -keep)
+            torch._foreach_add_(bufs, b)
+            torch._foreach_add_(bufs, a, alpha=keep)
 
     def _run(self, x, keep):
         if self._plan is None:
@@ -294,12 +333,16 @@ class GroupedTrunks:
     def _second_bn_update(self, recs):
         self._load_flats()
         ResNet50Trunk._second_bn_update(self, recs)
-        self._store_running()
+        self._store_running(first_image_first=False)     # the checkpoint re-runs the later call (x_t) first
 
     def _backward(self, recs, dfeat):
         return ResNet50Trunk._backward(self, recs, dfeat)
 
-    def __call__(self, x):
+    def __call__(self, *xs):
+        if len(xs) != self.images:
+            raise ValueError(f"GroupedTrunks: expected {self.images} image batch(es), got {len(xs)}")
+        # one image: every group reads the same three channels; two: each group gets its own copy (3 channels, negligible)
+        x = xs[0] if self.images == 1 else torch.cat([x for x in xs for _ in self.trunks], dim=1)
         return TrunkFn.apply(x, self, torch.is_grad_enabled(), *self.parameters())
 
 
@@ -403,7 +446,7 @@ class ResNet50Trunk(nn.Sequential):
                 recs["blocks"].append((r1, r2, r3, rd, out))
             cur = out
         if pool is not None and pool.counters:
-            torch._foreach_add_(pool.counters, 1)                    # 53 one-element kernels -> one fused launch
+            torch._foreach_add_(pool.counters, getattr(self, "images", 1))   # 53 one-element kernels -> one fused launch
         return ops.global_avgpool(cur), recs
 
     def _second_bn_update(self, recs):
@@ -417,7 +460,7 @@ class ResNet50Trunk(nn.Sequential):
             if down is not None:
                 down.second_update(rd, counters)
         if counters:
-            torch._foreach_add_(counters, 1)
+            torch._foreach_add_(counters, getattr(self, "images", 1))
 
     def _backward(self, recs, dfeat):
         """dfeat [B,2048,1,1] -> {parameter: gradient}."""

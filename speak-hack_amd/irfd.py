@@ -78,9 +78,8 @@ class IRFD(nn.Module):
         if self.group_encoders:
             enc = self.__dict__.get("_enc_group")
             if enc is None or enc.trunks != [self.Ei, self.Ee, self.Ep]:
-                enc = self.__dict__["_enc_group"] = GroupedTrunks([self.Ei, self.Ee, self.Ep])
-            fi_s, fe_s, fp_s = enc(x_s).split(2048, dim=1)
-            fi_t, fe_t, fp_t = enc(x_t).split(2048, dim=1)
+                enc = self.__dict__["_enc_group"] = GroupedTrunks([self.Ei, self.Ee, self.Ep], images=2)
+            fi_s, fe_s, fp_s, fi_t, fe_t, fp_t = enc(x_s, x_t).split(2048, dim=1)
         else:
             fi_s, fe_s, fp_s = self.Ei(x_s), self.Ee(x_s), self.Ep(x_s)
             fi_t, fe_t, fp_t = self.Ei(x_t), self.Ee(x_t), self.Ep(x_t)

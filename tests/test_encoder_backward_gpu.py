@@ -224,3 +224,33 @@ def test_grouped_trunks_equal_three_separate_trunks(pkg, dev):
                 assert int(a[2][q][k]) == int(b[2][q][k]) == 2, k
             else:
                 assert rel_l2(b[2][q][k], a[2][q][k]) < 1e-5, (q, k)
+
+
+def test_grouped_trunks_two_images_per_pass(pkg, dev):
+    """``GroupedTrunks(..., images=2)``: Ei/Ee/Ep on x_s AND x_t in one pass of 6-group launches vs six separate trunk
+    calls in the reference's order -- features, summed parameter gradients, running statistics after the four momentum
+    updates (x_s, x_t forward; x_t, x_s checkpoint replay) and the counters."""
+    enc = importlib.import_module("speak-hack_amd.encoder")
+    x_s = recipe_input("trg2.xs", (2, 3, 64, 64), "uniform").to(dev)
+    x_t = recipe_input("trg2.xt", (2, 3, 64, 64), "uniform").to(dev)
+    gfeat = recipe_input("trg2.g", (2, 6 * 2048, 1, 1)).to(dev)
+    res = {}
+    for grouped in (False, True):
+        trunks = [_trunk(dev, p)[0].train(True) for p in ("Ei.", "Ee.", "Ep.")]
+        if grouped:
+            y = enc.GroupedTrunks(trunks, images=2)(x_s, x_t)
+        else:
+            y = torch.cat([t(x_s) for t in trunks] + [t(x_t) for t in trunks], dim=1)
+        y.backward(gfeat)
+        res[grouped] = (y.detach(), [{k: p.grad for k, p in t.named_parameters()} for t in trunks],
+                        [{k: v.clone() for k, v in t.state_dict().items() if "running" in k or "num_batches" in k} for t in trunks])
+    a, b = res[False], res[True]
+    assert b[0].shape == (2, 6 * 2048, 1, 1) and rel_l2(b[0], a[0]) < 1e-5
+    for q in range(3):
+        cat = lambda d: torch.cat([d[k].double().flatten() for k in sorted(d)])
+        assert rel_l2(cat(b[1][q]), cat(a[1][q])) < 2e-3, q
+        for k in a[2][q]:
+            if "num_batches" in k:
+                assert int(a[2][q][k]) == int(b[2][q][k]) == 4, k
+            else:
+                assert rel_l2(b[2][q][k], a[2][q][k]) < 1e-5, (q, k)
