@@ -52,10 +52,14 @@ struct WgradArgs {
 template <int KH, int KW, int S>
 struct WShape {
     static constexpr int TAPS = KH * KW;
-    static constexpr bool ROWPASS = TAPS > 9;               // 7x7: one tap row per workgroup
-    static constexpr int TP = ROWPASS ? KW : TAPS;          // taps per pass (accumulator tiles per wave)
-    static constexpr int CI_T = (S == 2 || KH == 7 || WGRAD_CI32) ? 32 : 64;
-    static constexpr int WCI = CI_T / 32, WPX = 2 / WCI;    // 4 waves = 2 (co) x WCI x WPX
+    // 7x7 (the ResNet stem, Cin = 3): the 32 lanes of the B fragment are (kx, ci) pairs instead of 32 input channels --
+    // 7*3 = 21 of 32 lanes do work, where one-channel-per-lane would use 3 -- and there is one accumulator tile per tap
+    // ROW (ky); needs KW * Cin <= 32.
+    static constexpr bool PACK = KH == 7;
+    static constexpr bool ROWPASS = false;                  // (kept for the launch arithmetic: every kernel is single-pass)
+    static constexpr int TP = PACK ? KH : TAPS;             // accumulator tiles per wave
+    static constexpr int CI_T = PACK ? 4 : ((S == 2 || WGRAD_CI32) ? 32 : 64);
+    static constexpr int WCI = PACK ? 1 : CI_T / 32, WPX = 2 / WCI;    // 4 waves = 2 (co) x WCI x WPX
     static constexpr int CO_T = 64, PIX_T = 64, PAD = (KH - 1) / 2;
     static constexpr int KX = KH == 7 ? 3 : (S == 2 ? 2 : 1);   // plane positions (x256) a thread stages
 };
@@ -171,7 +175,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
         if (tile + (int)gridDim.z < p.n_tiles) SPK_WG_PREFETCH(tile + (int)gridDim.z);
         // ---- k-steps over this wave's pixel range: A read once per step, reused by every tap ----
         const float* ga = g_s + (wco * 32 + l32) * GPITCH;
-        const float* xb = x_s + (wci * 32 + l32) * XPITCH;
+        // B-fragment row of this lane: its input channel, or (PACK) its (kx, ci) pair: channel row + kx columns
+        const float* xb = SH::PACK ? x_s + (l32 % nci) * XPITCH + min(l32 / nci, KW - 1)
+                                   : x_s + (wci * 32 + l32) * XPITCH;
         constexpr int STEPS = PIX_T / 2 / SH::WPX;
         // Fragments are read one k-step ahead of the MFMAs that use them (two register sets, static indices after full
         // unrolling; sched_group_barrier pins the ds_read / MFMA interleave): with 144 accumulator registers the kernel
@@ -185,8 +191,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
         fa[slot_] = ga[pix];                                                                                \
         const float* xp = xb + tb * PLANE + (py * S) * PW + px * S;                                         \
         _Pragma("unroll") for (int t = 0; t < TP; ++t) {                                                    \
-            const int tap = tap0 + t;                         /* tap0 is 0 unless ROWPASS */                \
-            const int ky = SH::ROWPASS ? pass : tap / KW, kx = SH::ROWPASS ? t : tap % KW;                  \
+            const int tap = tap0 + t;                                                                       \
+            const int ky = SH::PACK ? t : tap / KW, kx = SH::PACK ? 0 : tap % KW;   /* PACK: kx sits in the lane */ \
             fb[slot_][t] = xp[ky * PW + kx];                                                                \
         }                                                                                                   \
     }
@@ -210,13 +216,17 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     // ---- partial block -> slab [slab][co][tap][ci] (ci contiguous: 128-B stores per half wave) ----
     const int slab = blockIdx.z * SH::WPX + wpx;
     float* out = p.slabs + (size_t)slab * p.Cy * TAPS * p.Cin;
-    const int ci = ci0 + wci * 32 + l32;
+    // D column of this lane: an input channel, or (PACK) the (kx, ci) pair l32 = kx * nci + ci
+    const int ci = SH::PACK ? l32 % nci : ci0 + wci * 32 + l32;
+    const int kx_l = SH::PACK ? l32 / nci : 0;
+    const bool col_ok = SH::PACK ? l32 < KW * nci : ci < p.Cin;
 #pragma unroll
     for (int t = 0; t < TP; ++t)
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int co = co0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            if (co < co_end && ci < p.Cin) out[((size_t)co * TAPS + tap0 + t) * p.Cin + ci] = acc[t][r];
+            const int tap = SH::PACK ? t * KW + kx_l : tap0 + t;
+            if (co < co_end && col_ok) out[((size_t)co * TAPS + tap) * p.Cin + ci] = acc[t][r];
         }
 }
 
@@ -281,6 +291,7 @@ template <int KH, int KW, int S, int MODE>
 int run_wgrad(const spk_wgrad_desc* d, hipStream_t stream) {
     using SH = WShape<KH, KW, S>;
     const int G = d->groups > 1 ? d->groups : 1;
+    SPK_REQUIRE(!SH::PACK || KW * d->Cin <= 32, "wgrad: the %dx%d kernel packs (kx, ci) into 32 lanes: Cin <= %d", KH, KW, 32 / KW);
     SPK_REQUIRE(G == 1 || d->Cout % SH::CO_T == 0, "wgrad: grouped launches need Cout (per group) to be a multiple of %d", SH::CO_T);
     const WGeom g = wgeom<KH, KW, S>(d->B, d->Cin, G * d->Cout, d->H, d->W, d->splits);
     SPK_REQUIRE(g.lds_bytes <= 160 * 1024, "wgrad: input tile does not fit LDS");
