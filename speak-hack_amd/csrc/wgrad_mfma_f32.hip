@@ -61,7 +61,13 @@ struct WShape {
     static constexpr int CI_T = PACK ? 4 : ((S == 2 || WGRAD_CI32) ? 32 : 64);
     static constexpr int WCI = PACK ? 1 : CI_T / 32, WPX = 2 / WCI;    // 4 waves = 2 (co) x WCI x WPX
     static constexpr int CO_T = 64, PIX_T = 64, PAD = (KH - 1) / 2;
-    static constexpr int KX = KH == 7 ? 3 : (S == 2 ? 2 : 1);   // plane positions (x256) a thread stages
+    // Staging of the input tile: a thread owns KX plane positions and, of the CI_T channels, one of CS slices -- with
+    // CS = 2 (the 64-channel 3x3 stride-1 form, whose tile has <= 128 positions) all 256 threads work on 32 channels
+    // each instead of half of them on 64.
+    static constexpr int CS = (!PACK && S == 1 && CI_T == 64) ? 2 : 1;
+    static constexpr int NPT = 256 / CS;                        // threads per channel slice = positions per round
+    static constexpr int CPT = CI_T / CS;                       // channels a thread stages
+    static constexpr int KX = KH == 7 ? 3 : (S == 2 ? 2 : 1);   // plane positions (x NPT) a thread stages
 };
 
 template <int KH, int KW, int S, int MODE>
@@ -69,10 +75,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     using SH = WShape<KH, KW, S>;
     constexpr int TAPS = SH::TAPS, TP = SH::TP, CI_T = SH::CI_T, CO_T = SH::CO_T, PIX_T = SH::PIX_T, PAD = SH::PAD;
     constexpr bool AFF = MODE == WG_AFFINE_RELU;
-    constexpr int KX = SH::KX, NG = CO_T * PIX_T / 256;
+    constexpr int KX = SH::KX, NG = CO_T * PIX_T / 256, NPT = SH::NPT, CPT = SH::CPT;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
+    const int cb = (tid / NPT) * CPT;                   // first channel (within the block) this thread stages
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l32 = lane & 31;
     const int wco = wave & 1, wci = (wave >> 1) % SH::WCI, wpx = (wave >> 1) / SH::WCI;
@@ -104,7 +111,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     int xs_rem[KX], xs_r[KX], xs_c[KX], xs_tb[KX];
 #pragma unroll
     for (int k = 0; k < KX; ++k) {
-        const int e = tid + 256 * k;
+        const int e = (tid % NPT) + NPT * k;
         xs_rem[k] = -1; xs_r[k] = 0; xs_c[k] = 0; xs_tb[k] = 0;
         if (e < TB * PLANE) {
             const int tb = e / PLANE, pidx = e - tb * PLANE;
@@ -113,7 +120,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     }
 
     // prefetch registers: the next tile's global loads are in flight during the current tile's MFMAs
-    float xg[KX * CI_T], gg[NG];
+    float xg[KX * CPT], gg[NG];
     unsigned xok = 0;   // bit k: plane position k of the prefetched tile is inside the image
     unsigned gok = 0;   // bit i: gradient element i of the prefetched tile is inside the tensor
 
@@ -141,8 +148,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
             if (ok) xok |= 1u << k;                                                                         \
             const float* src = p.x + ((size_t)(ok ? b : 0) * p.Cx + cx0 + ci0) * src_plane +                \
                                (ok ? (size_t)uy * p.Ws + ux : 0);                                           \
-            _Pragma("unroll") for (int ci = 0; ci < CI_T; ++ci)                                             \
-                xg[k * CI_T + ci] = src[(size_t)(ci < nci ? ci : 0) * src_plane];                           \
+            _Pragma("unroll") for (int ci = 0; ci < CPT; ++ci)                                              \
+                xg[k * CPT + ci] = src[(size_t)(cb + ci < nci ? cb + ci : 0) * src_plane];                  \
         }                                                                                                   \
     }
 
@@ -156,11 +163,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
             if (xs_rem[k] >= 0) {                                                                           \
                 const bool ok = (xok >> k) & 1u;                                                            \
                 float* dst = x_s + xs_rem[k];                                                               \
-                _Pragma("unroll") for (int ci = 0; ci < CI_T; ++ci) {                                       \
-                    float v = xg[k * CI_T + ci];                                                            \
-                    if (AFF) v = fmaxf(v * p.in_scale[cx0 + ci0 + (ci < nci ? ci : 0)] +                    \
-                                       p.in_shift[cx0 + ci0 + (ci < nci ? ci : 0)], 0.f);                   \
-                    dst[ci * XPITCH] = (ok && ci < nci) ? v : 0.f;                                          \
+                _Pragma("unroll") for (int ci = 0; ci < CPT; ++ci) {                                        \
+                    float v = xg[k * CPT + ci];                                                             \
+                    const int cc = cb + ci;                                                                 \
+                    if (AFF) v = fmaxf(v * p.in_scale[cx0 + ci0 + (cc < nci ? cc : 0)] +                    \
+                                       p.in_shift[cx0 + ci0 + (cc < nci ? cc : 0)], 0.f);                   \
+                    dst[cc * XPITCH] = (ok && cc < nci) ? v : 0.f;                                          \
                 }                                                                                           \
             }                                                                                               \
         }                                                                                                   \
@@ -266,6 +274,7 @@ WGeom wgeom(int B, int Cin, int Cout, int H, int W, int want_splits) {
     using SH = WShape<KH, KW, S>;
     WGeom g;
     g.TW = std::min(32, spk::pow2_ceil(W));
+    if (SH::CS > 1 && H >= 4) g.TW = std::min(g.TW, 16);     // 16x4 tiles: 108 staged positions (<= 128) instead of 136
     g.TH = std::min(SH::PIX_T / g.TW, spk::pow2_ceil(H));
     g.TB = SH::PIX_T / (g.TW * g.TH);
     // keep the staged input tile within LDS: shrink the image group first, then the rows
@@ -274,8 +283,8 @@ WGeom wgeom(int B, int Cin, int Cout, int H, int W, int want_splits) {
         return (SH::CO_T * (SH::PIX_T + 1) + SH::CI_T * ((g.TB * plane) | 1)) * sizeof(float);
     };
     auto plane_elems = [&]() { return g.TB * ((g.TH - 1) * S + KH) * ((g.TW - 1) * S + KW); };
-    while ((lds() > 100 * 1024 || plane_elems() > 256 * SH::KX) && g.TB > 1) g.TB >>= 1;   // idle pixel groups
-    while (plane_elems() > 256 * SH::KX && g.TH > 1) g.TH >>= 1;
+    while ((lds() > 100 * 1024 || plane_elems() > SH::NPT * SH::KX) && g.TB > 1) g.TB >>= 1;   // idle pixel groups
+    while (plane_elems() > SH::NPT * SH::KX && g.TH > 1) g.TH >>= 1;
     g.lds_bytes = lds();
     g.tiles_x = spk::ceil_div(W, g.TW);
     g.tiles_y = spk::ceil_div(H, g.TH);
