@@ -87,6 +87,8 @@ def main():
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
+                    "rehearse the multi-rank path on a box with fewer GPUs than ranks, together with SPK_BENCH_ONE_DEVICE=1)")
     ap.add_argument("--no-graph", action="store_true", help="launch the step's kernels one by one instead of replaying "
                     "the hipGraph captured from them")
     args = ap.parse_args()
@@ -98,13 +100,18 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} needs torch.distributed.run with {args.gpus} ranks (WORLD_SIZE={world})")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a HIP device (no CPU fallback)")
+    if os.environ.get("SPK_BENCH_ONE_DEVICE") == "1":      # rehearsal: every rank on GPU 0
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(args.backend)
 
     pkg = importlib.import_module("speak-hack_amd")
     pkg._lib.lib()
