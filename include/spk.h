@@ -281,6 +281,17 @@ int spk_global_avgpool_fwd(const float* x, float* y, int64_t planes, int64_t HW,
  *   demodulation), O <= 4. */
 int spk_modconv_demod(const float* w, const float* s, float* d, int B, int Cin, int Cout, int taps, float scale, float eps,
                       void* stream);
+/* the same for several layers in one launch (a decoder step's 13 demodulation vectors depend only on its modulations);
+ * `groups` is a HOST array of n_groups <= SPK_DEMOD_MAX_GROUPS descriptors. */
+#define SPK_DEMOD_MAX_GROUPS 16
+typedef struct spk_demod_group {
+    const float* w;   /* [Cout, Cin, taps] */
+    const float* s;   /* [B, Cin] */
+    float* d;         /* [B, Cout] */
+    int32_t Cin, Cout, taps;
+    float scale;
+} spk_demod_group;
+int spk_modconv_demod_grouped(const spk_demod_group* groups, int n_groups, int B, float eps, void* stream);
 int spk_upfirdn2d_fwd(const float* x, float* y, const float* filter_host, int k, int64_t planes, int H, int W, int up, int down,
                       int pad0, int pad1, float gain, void* stream);
 int spk_conv1x1_small_mod_fwd(const float* x, const float* w, const float* mod, const float* bias, float* y, int B, int C, int O,

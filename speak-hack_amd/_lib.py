@@ -40,6 +40,7 @@ CONV_UP_FIR1331 = 512
 
 
 FC_MAX_GROUPS = 16
+DEMOD_MAX_GROUPS = 16
 
 
 class FcGroup(C.Structure):
@@ -47,6 +48,12 @@ class FcGroup(C.Structure):
     _fields_ = [("x", C.c_void_p), ("x_stride", C.c_int64), ("w", C.c_void_p), ("bias", C.c_void_p), ("out", C.c_void_p),
                 ("out_stride", C.c_int64), ("I", C.c_int32), ("O", C.c_int32), ("wmul", C.c_float), ("bmul", C.c_float),
                 ("slope", C.c_float), ("reserved", C.c_int32)]
+
+
+class DemodGroup(C.Structure):
+    """``spk_demod_group`` (include/spk.h)."""
+    _fields_ = [("w", C.c_void_p), ("s", C.c_void_p), ("d", C.c_void_p), ("Cin", C.c_int32), ("Cout", C.c_int32),
+                ("taps", C.c_int32), ("scale", C.c_float)]
 
 
 class WgradDesc(C.Structure):
@@ -62,6 +69,7 @@ class WgradDesc(C.Structure):
 _PROTOTYPES = {
     "spk_modconv_demod": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float,
                                     C.c_void_p]),
+    "spk_modconv_demod_grouped": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "spk_upfirdn2d_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int,
                                     C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "spk_conv1x1_small_mod_fwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_float, C.c_void_p]),

@@ -33,6 +33,39 @@ __global__ __launch_bounds__(256) void demod_kernel(const float* __restrict__ w,
     }
 }
 
+// the demodulation vectors of several layers in one launch (they all depend only on the step's modulations)
+struct DemodGroups {
+    spk_demod_group g[SPK_DEMOD_MAX_GROUPS];
+    int row_start[SPK_DEMOD_MAX_GROUPS + 1];   // in units of 4-output-channel blocks
+    int n;
+};
+
+__global__ __launch_bounds__(256) void demod_grouped_kernel(const DemodGroups a, int B, float eps) {
+    int gi = 0;
+    while (gi + 1 < a.n && (int)blockIdx.x >= a.row_start[gi + 1]) ++gi;
+    const spk_demod_group& q = a.g[gi];
+    const int co = ((int)blockIdx.x - a.row_start[gi]) * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (co >= q.Cout) return;
+    const float* wr = q.w + (size_t)co * q.Cin * q.taps;
+    const float scale2 = q.scale * q.scale;
+    for (int b0 = 0; b0 < B; b0 += 8) {
+        float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        for (int ci = lane; ci < q.Cin; ci += 64) {
+            float wsq = 0.f;
+            for (int k = 0; k < q.taps; ++k) { const float v = wr[(size_t)ci * q.taps + k]; wsq += v * v; }
+#pragma unroll
+            for (int b = 0; b < 8; ++b)
+                if (b0 + b < B) { const float sv = q.s[(size_t)(b0 + b) * q.Cin + ci]; acc[b] += sv * sv * wsq; }
+        }
+#pragma unroll
+        for (int b = 0; b < 8; ++b) {
+#pragma unroll
+            for (int off = 32; off >= 1; off >>= 1) acc[b] += __shfl_xor(acc[b], off);
+            if (lane == 0 && b0 + b < B) q.d[(size_t)(b0 + b) * q.Cout + co] = rsqrtf(acc[b] * scale2 + eps);
+        }
+    }
+}
+
 struct Fir2 { float f[49]; int k; };
 
 // out[oy,ox] = gain * sum_{ky,kx} f[k-1-ky][k-1-kx] * xu[oy*down + ky - pad0][ox*down + kx - pad0],
@@ -71,6 +104,22 @@ int spk_modconv_demod(const float* w, const float* s, float* d, int B, int Cin, 
     hipLaunchKernelGGL(demod_kernel, dim3((unsigned)spk::ceil_div(Cout, 4)), dim3(256), 0, (hipStream_t)stream, w, s, d, B, Cin, Cout,
                        taps, scale * scale, eps);
     return spk::check_launch("demod_kernel");
+}
+
+int spk_modconv_demod_grouped(const spk_demod_group* groups, int n_groups, int B, float eps, void* stream) {
+    SPK_REQUIRE(groups && n_groups > 0 && n_groups <= SPK_DEMOD_MAX_GROUPS && B > 0, "modconv_demod_grouped: bad arguments (1..%d groups)",
+                SPK_DEMOD_MAX_GROUPS);
+    DemodGroups a;
+    a.n = n_groups;
+    a.row_start[0] = 0;
+    for (int i = 0; i < n_groups; ++i) {
+        const spk_demod_group& q = groups[i];
+        SPK_REQUIRE(q.w && q.s && q.d && q.Cin > 0 && q.Cout > 0 && q.taps > 0, "modconv_demod_grouped: group %d: bad arguments", i);
+        a.g[i] = q;
+        a.row_start[i + 1] = a.row_start[i] + spk::ceil_div(q.Cout, 4);
+    }
+    hipLaunchKernelGGL(demod_grouped_kernel, dim3((unsigned)a.row_start[n_groups]), dim3(256), 0, (hipStream_t)stream, a, B, eps);
+    return spk::check_launch("demod_grouped_kernel");
 }
 
 int spk_upfirdn2d_fwd(const float* x, float* y, const float* filter_host, int k, int64_t planes, int H, int W, int up, int down,

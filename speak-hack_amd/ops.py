@@ -373,6 +373,22 @@ def modconv_demod(weight, s, scale, eps=1e-8):
     return d
 
 
+def modconv_demod_grouped(items, eps=1e-8):
+    """One launch for up to 16 layers' demodulation vectors.  ``items``: (weight [Cout,Cin,k,k], s [B,Cin], scale)."""
+    items = list(items)
+    groups, outs = (L.DemodGroup * len(items))(), []
+    B = items[0][1].shape[0]
+    for q, (weight, s, scale) in zip(groups, items):
+        Cout, Cin, kh, kw = weight.shape
+        d = torch.empty((B, Cout), device=s.device, dtype=torch.float32)
+        outs.append(d)
+        q.w, q.s, q.d = L.dptr(weight, "weight"), L.dptr(s, "s"), d.data_ptr()
+        q.Cin, q.Cout, q.taps, q.scale = Cin, Cout, kh * kw, float(scale)
+    L.check(L.lib().spk_modconv_demod_grouped(C.cast(groups, C.c_void_p), len(items), B, float(eps), L.stream_ptr()),
+            "spk_modconv_demod_grouped")
+    return outs
+
+
 def upfirdn2d(x, filt2d, up=1, down=1, pad=(0, 0), gain=1.0):
     """upfirdn2d of the StyleGAN2 reference implementation (zero-insert, pad/crop, flipped-FIR, decimate)."""
     B, Cc, H, W = x.shape

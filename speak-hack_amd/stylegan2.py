@@ -68,16 +68,16 @@ class ModulatedConv2d(nn.Module):
         self.modulation = EqualLinear(style_dim, in_channel, bias_init=1.0)
         self._pk = ops.PackedConvWeight()
 
-    def forward(self, x, style, bias=None, noise_w=None, noise=None, lrelu=None, act_gain=1.0, upsample=False, s=None):
-        """``s`` (optional): the modulation ``self.modulation(style)`` computed elsewhere (grouped launch)."""
+    def forward(self, x, style, bias=None, noise_w=None, noise=None, lrelu=None, act_gain=1.0, upsample=False, s=None, d=None):
+        """``s`` / ``d`` (optional): the modulation ``self.modulation(style)`` and the demodulation vector computed
+        elsewhere (grouped launches)."""
         if s is None:
             s = self.modulation(style)
         if self.kernel_size == 1 and self.out_channel <= 4 and not self.demodulate:
             return AG.mod_to_rgb(x.contiguous(), self.weight, s.contiguous(), bias, self.scale)
         if self.kernel_size != 3:
             raise NotImplementedError("ModulatedConv2d: 3x3 (styled convs) and 1x1 toRGB are on the HIP path")
-        d = None
-        if self.demodulate:
+        if self.demodulate and d is None:
             if torch.is_grad_enabled() and (s.requires_grad or self.weight.requires_grad):
                 # training: d as a differentiable [B,Cout] expression of (w, s) -- a [B,Cin] x [Cin,Cout] product
                 w2 = self.weight.pow(2).sum((2, 3))
@@ -112,7 +112,7 @@ class StyledConv(nn.Module):
         self.noise = NoiseInjection()
         self.activate = FusedLeakyReLU(out_channel)
 
-    def forward(self, x, style, noise=None, s=None):
+    def forward(self, x, style, noise=None, s=None, d=None):
         B, _, H, W = x.shape
         if self.upsample:
             H, W = 2 * H, 2 * W
@@ -121,7 +121,7 @@ class StyledConv(nn.Module):
         nw = self.noise.weight.expand(self.conv.out_channel).contiguous()
         # conv*demod + noise_w*noise + bias -> lrelu(0.2) * sqrt2: one launch
         return self.conv(x, style, bias=self.activate.bias, noise_w=nw, noise=noise.contiguous(), lrelu=0.2, act_gain=SQRT2,
-                         upsample=self.upsample, s=s)
+                         upsample=self.upsample, s=s, d=d)
 
 
 class ToRGB(nn.Module):
@@ -186,12 +186,18 @@ class StyleGAN2Generator(nn.Module):
             ss = []
             for k in range(0, len(mods), ops.L.FC_MAX_GROUPS):
                 ss += ops.fc_grouped((w, m.weight, m.bias, m.scale, m.lr_mul, 1.0) for m in mods[k:k + ops.L.FC_MAX_GROUPS])
-        sit = iter(ss)
+        # ... and the demodulation vectors of the 13 styled convs only on those modulations: one more grouped launch
+        styled = [m for m in layers if isinstance(m, StyledConv)]
+        dd = [None] * len(styled)
+        if not train and len(styled) <= ops.L.DEMOD_MAX_GROUPS:
+            s_of = {id(m): sv for m, sv in zip(layers, ss)}
+            dd = ops.modconv_demod_grouped((m.conv.weight, s_of[id(m)], m.conv.scale) for m in styled)
+        sit, dit = iter(ss), iter(dd)
         out = self.input.input.expand(B, -1, -1, -1).contiguous()
-        out = self.conv1(out, w, nxt(), s=next(sit))
+        out = self.conv1(out, w, nxt(), s=next(sit), d=next(dit))
         skip = self.to_rgb1(out, w, s=next(sit))
         for i, rgb in enumerate(self.to_rgbs):
-            out = self.convs[2 * i](out, w, nxt(), s=next(sit))
-            out = self.convs[2 * i + 1](out, w, nxt(), s=next(sit))
+            out = self.convs[2 * i](out, w, nxt(), s=next(sit), d=next(dit))
+            out = self.convs[2 * i + 1](out, w, nxt(), s=next(sit), d=next(dit))
             skip = rgb(out, w, skip, s=next(sit))
         return skip

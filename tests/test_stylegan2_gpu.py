@@ -66,6 +66,24 @@ def test_modulated_conv3x3(sg2, dev, B, Cin, Cout, H, demodulate):
     assert rel_l2(y, ref) < 2e-5
 
 
+@pytest.mark.parametrize("B", [1, 3, 8, 11])
+def test_demod_grouped_launch(ops, dev, B):
+    """All layers' demodulation vectors in one launch: rsqrt(scale^2 sum_{ci,k} (w s)^2 + eps) per (batch, cout),
+    ragged channel counts (Cout not a multiple of 4, Cin not of 64), 3x3 and 1x1 taps, batch beyond one register pass."""
+    shapes = [(24, 16, 3), (512, 512, 3), (5, 70, 1), (64, 128, 3), (33, 9, 3)]
+    items = []
+    for i, (Cout, Cin, k) in enumerate(shapes):
+        w = recipe_tensor(f"dg.{i}.w", (Cout, Cin, k, k), 1.0)
+        s = 1.0 + recipe_tensor(f"dg.{i}.s.{B}", (B, Cin), 0.5)
+        items.append((w, s, 1 / (Cin * k * k) ** 0.5))
+    got = ops.modconv_demod_grouped([(w.to(dev), s.to(dev), sc) for w, s, sc in items])
+    for (w, s, sc), d in zip(items, got):
+        ww = (sc * w.double()[None] * s.double()[:, None, :, None, None])
+        ref = torch.rsqrt(ww.pow(2).sum((2, 3, 4)) + 1e-8)
+        assert d.shape == ref.shape and rel_l2(d, ref) < 2e-6
+        assert rel_l2(ops.modconv_demod(w.to(dev), s.to(dev), sc), ref) < 2e-6
+
+
 @pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 16, 24, 8, 8), (1, 6, 10, 5, 7), (3, 64, 32, 16, 16), (9, 12, 8, 3, 4), (8, 128, 64, 32, 32)])
 def test_modulated_conv_fused_upfirdn(sg2, dev, B, Cin, Cout, H, W):
     """upfirdn2d(up=2, [1,3,3,1]) folded into the modulated conv's input staging (SPK_CONV_UP_FIR1331) vs
