@@ -72,7 +72,7 @@ typedef struct spk_conv2d_desc {
     const float* style;      /* row b at style + b*style_stride: [s0(Cout) | s1(Cout)] or NULL */
     const float* in_scale;   /* [Cin] (SPK_CONV_IN_AFFINE_RELU) or NULL */
     const float* in_shift;   /* [Cin] */
-    double*      stats;      /* [2*Cout] (SPK_EPI_STATS) or NULL; caller zeroes it */
+    double*      stats;      /* [stats_slots][2*Cout] (SPK_EPI_STATS) or NULL; caller zeroes it */
     float*       y;          /* [B,Cout,H,W] */
     float*       y_pre;      /* [B,Cout,H,W] or NULL: the value before the style stage (after LeakyReLU), kept
                               * for the backward pass (sign = LeakyReLU mask, value = d style / d s0) */
@@ -102,6 +102,11 @@ typedef struct spk_conv2d_desc {
      * Allowed flags: SPK_EPI_BIAS | LRELU | ACCUM | STATS, SPK_CONV_IN_AFFINE_RELU (in_scale / in_shift per x channel). */
     int32_t groups;
     int32_t group_in_stride;
+    /* SPK_EPI_STATS: `stats` holds stats_slots (a power of two; 0 = 1) copies of the [2*groups*Cout] sums and every
+     * workgroup adds into copy (its index % stats_slots); spk_bn_finalize adds the copies up.  Same-address fp64
+     * atomics serialise at ~0.3 us each on MI355X (measured: the 1024 pixel tiles of the trunk's 128^2 stem spent
+     * 500 us queueing on one copy), so high-resolution layers want 16-32 copies. */
+    int32_t stats_slots;
 } spk_conv2d_desc;
 
 int spk_conv2d_num_configs(void);
@@ -236,8 +241,9 @@ int spk_upsample2x_bilinear_fwd(const float* x, float* y, int64_t planes, int Hi
  *   shift = beta - mean*scale; and (momentum > 0) updates running_mean / running_var (unbiased var) as
  *   nn.BatchNorm2d does in training mode.  With stats = NULL (eval mode) the running statistics are used.
  *   save_mean / save_invstd ([C], may be NULL) keep the batch statistics for the backward pass.
+ *   stats = [stats_slots][2C] (spk_conv2d_desc.stats_slots; 0 = 1): the copies are added here.
  * replaces: the statistics half of F.batch_norm for every bn1/bn2/bn3/downsample.1 of the trunk. */
-int spk_bn_finalize(const double* stats, int64_t count, const float* gamma, const float* beta, float* running_mean,
+int spk_bn_finalize(const double* stats, int stats_slots, int64_t count, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, float momentum, float eps, float* scale, float* shift, float* save_mean,
                     float* save_invstd, int C, void* stream);
 /* y = [relu]( a*sa[c] + ba[c] + (b ? b*sb[c] + bb[c] : 0) ): BatchNorm apply (+ residual add) (+ ReLU).

@@ -32,7 +32,7 @@ class Conv2dDesc(C.Structure):
                 ("out_scale", C.c_float), ("config", C.c_int32), ("ksplit", C.c_int32),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
                 ("out_scale_bc", C.c_void_p), ("act_gain", C.c_float),
-                ("groups", C.c_int32), ("group_in_stride", C.c_int32)]
+                ("groups", C.c_int32), ("group_in_stride", C.c_int32), ("stats_slots", C.c_int32)]
 
 
 CONV_IN_BATCH_SCALE = 256
@@ -109,7 +109,7 @@ _PROTOTYPES = {
     "spk_conv2d_pack_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_void_p]),
     "spk_conv2d_fwd": (C.c_int, [C.POINTER(Conv2dDesc), C.c_void_p]),
-    "spk_bn_finalize": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
+    "spk_bn_finalize": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
                                   C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
     "spk_bn_add_relu_fwd": (C.c_int, [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_int64, C.c_int, C.c_void_p]),
     "spk_maxpool3x3s2_fwd": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p]),

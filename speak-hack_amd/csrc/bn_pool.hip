@@ -10,7 +10,7 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ stats, long long count,
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ stats, int slots, long long count,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          float* running_mean, float* running_var, float momentum,
                                                          float eps, float* __restrict__ scale, float* __restrict__ shift,
@@ -19,8 +19,13 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
     if (c >= C) return;
     float mean, var;
     if (stats) {
-        const double m = stats[c] / (double)count;
-        double v = stats[C + c] / (double)count - m * m;
+        double s1 = 0.0, s2 = 0.0;
+        for (int k = 0; k < slots; ++k) {                     // the conv epilogue spreads its atomics over `slots` copies
+            s1 += stats[(size_t)k * 2 * C + c];
+            s2 += stats[(size_t)k * 2 * C + C + c];
+        }
+        const double m = s1 / (double)count;
+        double v = s2 / (double)count - m * m;
         v = v > 0.0 ? v : 0.0;
         mean = (float)m;
         var = (float)v;
@@ -247,14 +252,15 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_bwd_kernel(const float* __re
 
 extern "C" {
 
-int spk_bn_finalize(const double* stats, int64_t count, const float* gamma, const float* beta, float* running_mean,
+int spk_bn_finalize(const double* stats, int stats_slots, int64_t count, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, float momentum, float eps, float* scale, float* shift, float* save_mean,
                     float* save_invstd, int C, void* stream) {
     SPK_REQUIRE(scale && shift && C > 0, "bn_finalize: bad arguments");
     SPK_REQUIRE(stats || (running_mean && running_var), "bn_finalize: need batch sums or running statistics");
     SPK_REQUIRE(!stats || count > 0, "bn_finalize: element count must be positive");
+    SPK_REQUIRE(stats_slots >= 0 && stats_slots <= 1024, "bn_finalize: bad stats_slots %d", stats_slots);
     hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)spk::ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, stats,
-                       (long long)count, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, save_mean,
+                       stats_slots > 1 ? stats_slots : 1, (long long)count, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, save_mean,
                        save_invstd, C);
     return spk::check_launch("bn_finalize_kernel");
 }

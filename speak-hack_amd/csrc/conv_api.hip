@@ -312,6 +312,8 @@ int spk_conv2d_fwd(const spk_conv2d_desc* d, void* stream) {
     SPK_REQUIRE(!(d->flags & SPK_EPI_NOISE) || (d->noise && d->noise_w), "conv2d: SPK_EPI_NOISE without noise");
     SPK_REQUIRE(!(d->flags & SPK_EPI_STYLE) || d->style, "conv2d: SPK_EPI_STYLE without style");
     SPK_REQUIRE(!(d->flags & SPK_EPI_STATS) || d->stats, "conv2d: SPK_EPI_STATS without stats");
+    SPK_REQUIRE(d->stats_slots >= 0 && d->stats_slots <= 1024 && (d->stats_slots & (d->stats_slots - 1)) == 0,
+                "conv2d: stats_slots must be 0 or a power of two <= 1024 (got %d)", d->stats_slots);
     SPK_REQUIRE(!aff || (d->in_scale && d->in_shift), "conv2d: IN_AFFINE_RELU without in_scale/in_shift");
     SPK_REQUIRE((long long)d->B * d->Cout * d->H * d->W < (1ll << 40), "conv2d: tensor too large");
     if (d->groups > 1) {

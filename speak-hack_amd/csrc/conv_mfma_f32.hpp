@@ -55,7 +55,8 @@ struct ConvArgs {
     const float* in_scale;   // MODE_AFFINE_RELU: per input channel; MODE_BATCH_SCALE: [B,Cin] modulation
     const float* out_scale_bc;  // optional [B,Cout] factor applied right after the contraction (demodulation)
     const float* in_shift;
-    double* stats;           // [2*Cout] sum / sum of squares of y (SPK_EPI_STATS)
+    double* stats;           // [stats_mask+1][2*Cy] sum / sum of squares of y (SPK_EPI_STATS)
+    int stats_mask;          // copies - 1 (a power of two): workgroup i adds into copy i & stats_mask
     float* y;                // output, or the split-K workspace [ksplit][B][Cout][H][W]
     float* y_pre;            // optional: value before the style stage (kept for backward)
     int B, Cin, Cout, H, W;  // output spatial size
@@ -544,8 +545,9 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
                     ssq += __shfl_xor(ssq, off);
                 }
                 if (l32 == 0 && cv) {
-                    atomicAdd(p.stats + cg, (double)ssum);
-                    atomicAdd(p.stats + p.Cy + cg, (double)ssq);
+                    double* sp = p.stats + (size_t)((int)blockIdx.x & p.stats_mask) * 2 * p.Cy;
+                    atomicAdd(sp + cg, (double)ssum);
+                    atomicAdd(sp + p.Cy + cg, (double)ssq);
                 }
             }
         }
@@ -609,7 +611,7 @@ template <class C, int KH, int KW, int S, int MODE>
 int run(const spk_conv2d_desc* d, hipStream_t stream) {
     ConvArgs a;
     a.x = d->x; a.wp = d->w_packed; a.bias = d->bias; a.noise_w = d->noise_w; a.noise = d->noise;
-    a.style = d->style; a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.stats = d->stats; a.y = d->y; a.y_pre = d->y_pre; a.out_scale_bc = d->out_scale_bc;
+    a.style = d->style; a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.stats = d->stats; a.stats_mask = d->stats_slots > 1 ? d->stats_slots - 1 : 0; a.y = d->y; a.y_pre = d->y_pre; a.out_scale_bc = d->out_scale_bc;
     a.B = d->B; a.Cin = d->Cin; a.Cout = d->Cout; a.H = d->H; a.W = d->W; a.Hs = d->Hin; a.Ws = d->Win;
     a.G = d->groups > 1 ? d->groups : 1;
     a.gin = a.G > 1 ? d->group_in_stride : d->Cin;

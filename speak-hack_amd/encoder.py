@@ -67,7 +67,7 @@ class _ConvBN:
         Cout = conv.out_channels
         Ho, Wo = ops.conv_out_size(H, self.k, self.stride), ops.conv_out_size(W, self.k, self.stride)
         cfg = ops.conv2d_pick_config(self.k, self.stride, B, Cin, Cout, Ho, Wo)
-        stats = stats_pool.take(2 * Cout) if training else None
+        stats = stats_pool.take(ops.stats_slots(B, Ho, Wo) * 2 * Cout) if training else None
         y = ops.conv2d_fused(x, self.packed.get(conv.weight, cfg), Cout, self.k, self.stride, in_affine=in_affine,
                              stats=stats, config=cfg)
         if training:
@@ -122,14 +122,22 @@ class _ConvBN:
 
 
 class _StatsPool:
-    """One zeroed fp64 buffer per forward, sliced per BatchNorm (a single memset instead of 53)."""
+    """Zeroed fp64 pages per forward, sliced per BatchNorm (a few memsets instead of 53).  ``total`` = the sums of one
+    copy of every BatchNorm; the high-resolution layers take several copies (``ops.stats_slots``), so the pool grows by
+    pages when the first one is used up."""
+
+    PAGE = 1 << 19               # doubles (4 MiB)
 
     def __init__(self, device, total):
-        self.buf = torch.zeros(total, device=device, dtype=torch.float64)
+        self.device = device
+        self.buf = torch.zeros(max(total, self.PAGE), device=device, dtype=torch.float64)
         self.pos = 0
         self.counters = []       # num_batches_tracked buffers of the BatchNorms this pass went through
 
     def take(self, n):
+        if self.pos + n > self.buf.numel():
+            self.buf = torch.zeros(max(n, self.PAGE), device=self.device, dtype=torch.float64)
+            self.pos = 0
         out = self.buf[self.pos:self.pos + n]
         self.pos += n
         return out
@@ -180,7 +188,7 @@ class _GroupedConvBN:
         Cin, Cout = conv.in_channels, conv.out_channels
         Ho, Wo = ops.conv_out_size(H, self.k, self.stride), ops.conv_out_size(W, self.k, self.stride)
         cfg = ops.conv2d_pick_config(self.k, self.stride, B, Cin, Cout, Ho, Wo)
-        stats = stats_pool.take(2 * G * Cout) if training else None
+        stats = stats_pool.take(ops.stats_slots(B, Ho, Wo) * 2 * G * Cout) if training else None
         y = ops.conv2d_fused(x, self.packed.get(self._weights(), cfg), Cout, self.k, self.stride, in_affine=in_affine,
                              stats=stats, config=cfg, groups=G, shared_input=self.shared_input)
         gamma, beta, rm, rv = self.flat

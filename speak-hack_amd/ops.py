@@ -139,9 +139,13 @@ def conv2d_fused(x, w_packed, Cout: int, k: int = 3, stride: int = 1, *, bias=No
         flags |= L.CONV_IN_BATCH_SCALE
     if demod is not None and tuple(demod.shape) != (B, Cout):
         raise L.SpkError("conv2d_fused: demod must be [B,Cout]")
+    slots = 0
     if stats is not None:
-        if stats.dtype != torch.float64 or stats.numel() != 2 * G * Cout or not stats.is_cuda:
-            raise L.SpkError("conv2d_fused: stats must be a float64 HIP tensor of 2*groups*Cout elements")
+        slots = stats.numel() // (2 * G * Cout)
+        if (stats.dtype != torch.float64 or not stats.is_cuda or not stats.is_contiguous() or slots < 1 or slots & (slots - 1)
+                or stats.numel() != slots * 2 * G * Cout):
+            raise L.SpkError("conv2d_fused: stats must be a contiguous float64 HIP tensor of slots*2*groups*Cout elements, "
+                             "slots a power of two (see stats_slots)")
         flags |= L.EPI_STATS
     if config < 0:
         config = conv2d_pick_config(k, stride, B, Cin, Cout, H, W)
@@ -164,7 +168,7 @@ def conv2d_fused(x, w_packed, Cout: int, k: int = 3, stride: int = 1, *, bias=No
                      lrelu_slope=float(lrelu_slope if lrelu_slope is not None else 1.0), out_scale=float(out_scale),
                      config=int(config), ksplit=int(ksplit), workspace=ws.data_ptr() if ws is not None else None,
                      workspace_bytes=ws.numel() * 4 if ws is not None else 0, groups=G,
-                     group_in_stride=0 if (shared_input or G == 1) else Cin)
+                     group_in_stride=0 if (shared_input or G == 1) else Cin, stats_slots=slots)
     if CONV_SKIP:           # measurement aid (bench.py): everything but the conv launch itself
         return out
     if CONV_EVENTS is not None:
@@ -531,17 +535,32 @@ def conv2d_dgrad(g, weight_packed_tf, Cin, k, stride, in_hw, config, out=None, a
 
 
 # ---- BatchNorm / pooling pieces of the ResNet-50 trunk ----------------------------------------------
+def stats_slots(B, H, W):
+    """Copies of the BatchNorm sums a conv epilogue should spread its atomics over (``spk_conv2d_desc.stats_slots``):
+    about one per 8 pixel tiles of 128, between 1 and 32 -- same-address fp64 atomics serialise at ~0.3 us each."""
+    tiles = (B * H * W + 127) // 128
+    s = 1
+    while s < 32 and s * 16 <= tiles:
+        s *= 2
+    return s
+
+
 def bn_finalize(stats, count, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, save=False):
-    """Batch sums (fp64 [2C], from a conv epilogue) -> the per-channel affine (scale, shift) its consumer
+    """Batch sums (fp64 [slots][2C], from a conv epilogue) -> the per-channel affine (scale, shift) its consumer
     applies; updates running statistics when momentum > 0.  ``stats=None``: eval mode (running statistics).
     With ``save`` also returns (mean, invstd) for the backward pass."""
     Cc = gamma.numel()
+    slots = 0
+    if stats is not None:
+        slots = stats.numel() // (2 * Cc)
+        if slots < 1 or stats.numel() != slots * 2 * Cc:
+            raise L.SpkError("bn_finalize: stats must hold slots*2*C sums")
     dev = gamma.device
     scale = torch.empty(Cc, device=dev, dtype=torch.float32)
     shift = torch.empty(Cc, device=dev, dtype=torch.float32)
     mean = torch.empty(Cc, device=dev, dtype=torch.float32) if save else None
     invstd = torch.empty(Cc, device=dev, dtype=torch.float32) if save else None
-    L.check(L.lib().spk_bn_finalize(stats.data_ptr() if stats is not None else None, int(count), L.dptr(gamma, "gamma"),
+    L.check(L.lib().spk_bn_finalize(stats.data_ptr() if stats is not None else None, slots, int(count), L.dptr(gamma, "gamma"),
                                     L.dptr(beta, "beta"), L.dptr(running_mean, "running_mean"),
                                     L.dptr(running_var, "running_var"), float(momentum), float(eps), L.dptr(scale),
                                     L.dptr(shift), L.dptr(mean), L.dptr(invstd), Cc, L.stream_ptr()), "spk_bn_finalize")

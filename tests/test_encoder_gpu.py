@@ -79,6 +79,38 @@ def test_conv2d_folded_bn_relu_input_and_statistics(pkg, dev, k, stride):
         assert rel_l2(stats[Cout:], (ref.double() ** 2).sum((0, 2, 3))) < 1e-6
 
 
+@pytest.mark.parametrize("slots,groups", [(4, 1), (16, 1), (8, 3)])
+def test_conv2d_statistics_spread_over_slots(pkg, dev, slots, groups):
+    """``stats_slots`` copies of the sums (one per workgroup index % slots): their total, and the affine
+    ``bn_finalize`` makes of them, equal the single-copy result; ragged tiles, ordinary and grouped launches."""
+    B, Cin, Cout, H, W = 5, 20, 40, 30, 22
+    tag = f"c2slots.{slots}.{groups}"
+    x = recipe_input(tag + ".x", (B, groups * Cin, H, W))
+    ws = [recipe_tensor(tag + f".weight{g}", (Cout, Cin, 3, 3)) for g in range(groups)]
+    ref = torch.cat([F.conv2d(x[:, g * Cin:(g + 1) * Cin], ws[g], padding=1) for g in range(groups)], 1)
+    cfg = pkg.ops.conv2d_pick_config(3, 1, B, Cin, Cout, H, W)
+    wp = torch.cat([pkg.ops.pack_conv_weight(w.to(dev), cfg) for w in ws])
+    Cy = groups * Cout
+    stats = torch.zeros(slots * 2 * Cy, device=dev, dtype=torch.float64)
+    y = pkg.ops.conv2d_fused(x.to(dev), wp, Cout, 3, 1, stats=stats, config=cfg, groups=groups)
+    assert rel_l2(y, ref) < TOL_OP
+    per = stats.view(slots, 2, Cy)
+    assert int((per.abs().sum((1, 2)) > 0).sum()) > 1                     # more than one copy was written
+    assert rel_l2(per.sum(0)[0], ref.double().sum((0, 2, 3))) < 1e-6
+    assert rel_l2(per.sum(0)[1], (ref.double() ** 2).sum((0, 2, 3))) < 1e-6
+    g, be = 1.0 + recipe_tensor(tag + ".g", (Cy,), 0.2), recipe_tensor(tag + ".b", (Cy,), 0.2)
+    rm, rv = torch.zeros(Cy), torch.ones(Cy)
+    want = F.batch_norm(ref, rm.clone(), rv.clone(), g, be, True, 0.1, 1e-5)
+    rm_d, rv_d = rm.to(dev), rv.to(dev)
+    sc, sh = pkg.ops.bn_finalize(stats, B * H * W, g.to(dev), be.to(dev), rm_d, rv_d, 0.1, 1e-5)
+    assert rel_l2(y * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1), want) < TOL_OP
+    F.batch_norm(ref, rm, rv, g, be, True, 0.1, 1e-5)
+    assert rel_l2(rm_d, rm) < 1e-5 and rel_l2(rv_d, rv) < 1e-5
+    with pytest.raises(pkg._lib.SpkError):
+        pkg.ops.conv2d_fused(x.to(dev), wp, Cout, 3, 1, stats=torch.zeros(3 * 2 * Cy, device=dev, dtype=torch.float64),
+                             config=cfg, groups=groups)
+
+
 def test_bn_finalize_train_and_eval(pkg, dev):
     C, B, H = 37, 4, 9
     y = recipe_input("bnf.y", (B, C, H, H)) * 2.0 + 0.7
