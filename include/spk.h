@@ -102,14 +102,18 @@ typedef struct spk_conv2d_desc {
      * Allowed flags: SPK_EPI_BIAS | LRELU | ACCUM | STATS, SPK_CONV_IN_AFFINE_RELU (in_scale / in_shift per x channel). */
     int32_t groups;
     int32_t group_in_stride;
-    /* SPK_EPI_STATS: `stats` holds stats_slots (a power of two; 0 = 1) copies of the [2*groups*Cout] sums and every
-     * workgroup adds into copy (its index % stats_slots); spk_bn_finalize adds the copies up.  Same-address fp64
-     * atomics serialise at ~0.3 us each on MI355X (measured: the 1024 pixel tiles of the trunk's 128^2 stem spent
-     * 500 us queueing on one copy), so high-resolution layers want 16-32 copies. */
+    /* SPK_EPI_STATS: `stats` holds stats_slots (0 = 1) copies of the [2*groups*Cout] sums; the workgroups of pixel
+     * tile i add into copy i % stats_slots and spk_bn_finalize adds the copies up.  fp64 atomics are what this
+     * epilogue costs on MI355X: same-address ones serialise at ~0.3 us each (the 512 pixel tiles of the trunk's 128^2
+     * stem spent 500 us queueing on one copy) and ~10-20 per ns is all the chip retires.  With stats_slots >=
+     * spk_conv2d_stats_slots(...) every pixel tile owns its copy and the sums are plain stores (no atomics at all):
+     * the setting for high-resolution layers.  The caller zeroes all copies either way. */
     int32_t stats_slots;
 } spk_conv2d_desc;
 
 int spk_conv2d_num_configs(void);
+/* pixel tiles of the launch (its gridDim.x): the stats_slots value from which every tile owns its copy; -1 = unsupported */
+int spk_conv2d_stats_slots(int config, int kh, int kw, int stride, int B, int Cin, int Cout, int H, int W);
 /* whether tile config `config` is built for this kernel size / stride */
 int spk_conv2d_config_valid(int config, int kh, int kw, int stride);
 /* tile config chosen by the heuristic for this problem (what `config = -1` resolves to); H, W = output size */

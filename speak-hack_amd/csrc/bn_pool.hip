@@ -15,15 +15,27 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
                                                          float* running_mean, float* running_var, float momentum,
                                                          float eps, float* __restrict__ scale, float* __restrict__ shift,
                                                          float* save_mean, float* save_invstd, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    float mean, var;
+    // 64 channels per workgroup; the `slots` copies of the sums (one per pixel tile of the producing conv) are shared
+    // out over the 4 waves and meet in LDS
+    __shared__ double part[2][4][64];
+    const int cl = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const int c = blockIdx.x * 64 + cl;
     if (stats) {
         double s1 = 0.0, s2 = 0.0;
-        for (int k = 0; k < slots; ++k) {                     // the conv epilogue spreads its atomics over `slots` copies
-            s1 += stats[(size_t)k * 2 * C + c];
-            s2 += stats[(size_t)k * 2 * C + C + c];
-        }
+        if (c < C)
+            for (int k = q; k < slots; k += 4) {
+                s1 += stats[(size_t)k * 2 * C + c];
+                s2 += stats[(size_t)k * 2 * C + C + c];
+            }
+        part[0][q][cl] = s1;
+        part[1][q][cl] = s2;
+        __syncthreads();
+    }
+    if (c >= C || q != 0) return;
+    float mean, var;
+    if (stats) {
+        const double s1 = (part[0][0][cl] + part[0][1][cl]) + (part[0][2][cl] + part[0][3][cl]);
+        const double s2 = (part[1][0][cl] + part[1][1][cl]) + (part[1][2][cl] + part[1][3][cl]);
         const double m = s1 / (double)count;
         double v = s2 / (double)count - m * m;
         v = v > 0.0 ? v : 0.0;
@@ -258,8 +270,8 @@ int spk_bn_finalize(const double* stats, int stats_slots, int64_t count, const f
     SPK_REQUIRE(scale && shift && C > 0, "bn_finalize: bad arguments");
     SPK_REQUIRE(stats || (running_mean && running_var), "bn_finalize: need batch sums or running statistics");
     SPK_REQUIRE(!stats || count > 0, "bn_finalize: element count must be positive");
-    SPK_REQUIRE(stats_slots >= 0 && stats_slots <= 1024, "bn_finalize: bad stats_slots %d", stats_slots);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)spk::ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, stats,
+    SPK_REQUIRE(stats_slots >= 0 && stats_slots <= 65536, "bn_finalize: bad stats_slots %d", stats_slots);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)spk::ceil_div(C, 64)), dim3(256), 0, (hipStream_t)stream, stats,
                        stats_slots > 1 ? stats_slots : 1, (long long)count, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, save_mean,
                        save_invstd, C);
     return spk::check_launch("bn_finalize_kernel");

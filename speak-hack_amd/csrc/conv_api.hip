@@ -272,6 +272,14 @@ int64_t spk_conv2d_workspace_bytes_grouped(int config, int ksplit, int kh, int k
     return ks > 1 ? (int64_t)ks * B * groups * Cout * H * W * (int64_t)sizeof(float) : 0;
 }
 
+int spk_conv2d_stats_slots(int config, int kh, int kw, int stride, int B, int Cin, int Cout, int H, int W) {
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || !supported_kernel(kh, kw, stride)) return -1;
+    if (config < 0) config = pick_config(kh, stride, B, Cin, Cout, H, W);
+    const Geometry g = geometry_any(kh, stride, config, B, Cin, Cout, H, W);
+    if (!g.ok) return -1;
+    return g.tiles_x * g.tiles_y * g.tiles_b;            // = gridDim.x of the launch
+}
+
 int64_t spk_conv2d_workspace_bytes(int config, int ksplit, int kh, int kw, int stride, int B, int Cin, int Cout,
                                    int H, int W) {
     return spk_conv2d_workspace_bytes_grouped(config, ksplit, kh, kw, stride, B, Cin, Cout, H, W, 1);
@@ -312,8 +320,7 @@ int spk_conv2d_fwd(const spk_conv2d_desc* d, void* stream) {
     SPK_REQUIRE(!(d->flags & SPK_EPI_NOISE) || (d->noise && d->noise_w), "conv2d: SPK_EPI_NOISE without noise");
     SPK_REQUIRE(!(d->flags & SPK_EPI_STYLE) || d->style, "conv2d: SPK_EPI_STYLE without style");
     SPK_REQUIRE(!(d->flags & SPK_EPI_STATS) || d->stats, "conv2d: SPK_EPI_STATS without stats");
-    SPK_REQUIRE(d->stats_slots >= 0 && d->stats_slots <= 1024 && (d->stats_slots & (d->stats_slots - 1)) == 0,
-                "conv2d: stats_slots must be 0 or a power of two <= 1024 (got %d)", d->stats_slots);
+    SPK_REQUIRE(d->stats_slots >= 0 && d->stats_slots <= 65536, "conv2d: stats_slots must be in [0, 65536] (got %d)", d->stats_slots);
     SPK_REQUIRE(!aff || (d->in_scale && d->in_shift), "conv2d: IN_AFFINE_RELU without in_scale/in_shift");
     SPK_REQUIRE((long long)d->B * d->Cout * d->H * d->W < (1ll << 40), "conv2d: tensor too large");
     if (d->groups > 1) {

@@ -55,8 +55,8 @@ struct ConvArgs {
     const float* in_scale;   // MODE_AFFINE_RELU: per input channel; MODE_BATCH_SCALE: [B,Cin] modulation
     const float* out_scale_bc;  // optional [B,Cout] factor applied right after the contraction (demodulation)
     const float* in_shift;
-    double* stats;           // [stats_mask+1][2*Cy] sum / sum of squares of y (SPK_EPI_STATS)
-    int stats_mask;          // copies - 1 (a power of two): workgroup i adds into copy i & stats_mask
+    double* stats;           // [stats_slots][2*Cy] sum / sum of squares of y (SPK_EPI_STATS)
+    int stats_slots;         // copies: workgroup (pixel tile) i adds into copy i % stats_slots; >= gridDim.x: plain stores
     float* y;                // output, or the split-K workspace [ksplit][B][Cout][H][W]
     float* y_pre;            // optional: value before the style stage (kept for backward)
     int B, Cin, Cout, H, W;  // output spatial size
@@ -506,6 +506,10 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
         nz[n] = (f_noise && pv[n] && !split) ? p.noise[(size_t)b * HW + pix] : 0.f;
         st[n] = (f_style && pv[n]) ? p.style + (size_t)b * p.style_stride : nullptr;
     }
+    // BatchNorm sums: the waves' per-channel partial sums meet in LDS (the ring is idle by now), so that a workgroup
+    // issues ONE add per channel and moment -- fp64 atomics are what limits this epilogue (~10-20 per ns chip-wide)
+    float* const red = smem;                              // [WN][CO_T][2]
+    if (f_stats) __syncthreads();                         // every wave is done reading the ring
 #pragma unroll
     for (int m = 0; m < C::MT; ++m) {
 #pragma unroll
@@ -544,11 +548,32 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
                     ssum += __shfl_xor(ssum, off);
                     ssq += __shfl_xor(ssq, off);
                 }
-                if (l32 == 0 && cv) {
-                    double* sp = p.stats + (size_t)((int)blockIdx.x & p.stats_mask) * 2 * p.Cy;
-                    atomicAdd(sp + cg, (double)ssum);
-                    atomicAdd(sp + p.Cy + cg, (double)ssq);
+                if (l32 == 0) {
+                    float* rp = red + (wn * C::CO_T + (co - co_tile0)) * 2;
+                    rp[0] = ssum;
+                    rp[1] = ssq;
                 }
+            }
+        }
+    }
+    if (f_stats) {
+        __syncthreads();
+        const int co = co_tile0 + tid;
+        if (tid < C::CO_T && co < p.Cout) {
+            double s = 0.0, q = 0.0;
+#pragma unroll
+            for (int w = 0; w < C::WN; ++w) {
+                s += (double)red[(w * C::CO_T + tid) * 2];
+                q += (double)red[(w * C::CO_T + tid) * 2 + 1];
+            }
+            const int cg = grp * p.Cout + co;
+            double* sp = p.stats + (size_t)((int)blockIdx.x % p.stats_slots) * 2 * p.Cy;
+            if (p.stats_slots >= (int)gridDim.x) {        // this pixel tile owns its copy (the caller zeroed it)
+                sp[cg] = s;
+                sp[p.Cy + cg] = q;
+            } else {
+                atomicAdd(sp + cg, s);
+                atomicAdd(sp + p.Cy + cg, q);
             }
         }
     }
@@ -611,7 +636,7 @@ template <class C, int KH, int KW, int S, int MODE>
 int run(const spk_conv2d_desc* d, hipStream_t stream) {
     ConvArgs a;
     a.x = d->x; a.wp = d->w_packed; a.bias = d->bias; a.noise_w = d->noise_w; a.noise = d->noise;
-    a.style = d->style; a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.stats = d->stats; a.stats_mask = d->stats_slots > 1 ? d->stats_slots - 1 : 0; a.y = d->y; a.y_pre = d->y_pre; a.out_scale_bc = d->out_scale_bc;
+    a.style = d->style; a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.stats = d->stats; a.stats_slots = d->stats_slots > 1 ? d->stats_slots : 1; a.y = d->y; a.y_pre = d->y_pre; a.out_scale_bc = d->out_scale_bc;
     a.B = d->B; a.Cin = d->Cin; a.Cout = d->Cout; a.H = d->H; a.W = d->W; a.Hs = d->Hin; a.Ws = d->Win;
     a.G = d->groups > 1 ? d->groups : 1;
     a.gin = a.G > 1 ? d->group_in_stride : d->Cin;

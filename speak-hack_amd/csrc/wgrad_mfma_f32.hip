@@ -79,8 +79,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
-    const int cb = (tid / NPT) * CPT;                   // first channel (within the block) this thread stages
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    // first channel (within the block) this thread stages: NPT is a multiple of 64, so it is the same for a whole wave --
+    // kept in an SGPR, the BatchNorm scale / shift of the staged channels are scalar loads (as per-lane loads they were
+    // 2 * CPT vector loads per tile on the serial store phase)
+    static_assert(NPT % 64 == 0, "a wave stages one channel slice");
+    const int cb = (wave / (NPT / 64)) * CPT;
     const int half = lane >> 5, l32 = lane & 31;
     const int wco = wave & 1, wci = (wave >> 1) % SH::WCI, wpx = (wave >> 1) / SH::WCI;
 

@@ -67,7 +67,7 @@ class _ConvBN:
         Cout = conv.out_channels
         Ho, Wo = ops.conv_out_size(H, self.k, self.stride), ops.conv_out_size(W, self.k, self.stride)
         cfg = ops.conv2d_pick_config(self.k, self.stride, B, Cin, Cout, Ho, Wo)
-        stats = stats_pool.take(ops.stats_slots(B, Ho, Wo) * 2 * Cout) if training else None
+        stats = stats_pool.take(ops.stats_slots(cfg, self.k, self.stride, B, Cin, Cout, Ho, Wo) * 2 * Cout) if training else None
         y = ops.conv2d_fused(x, self.packed.get(conv.weight, cfg), Cout, self.k, self.stride, in_affine=in_affine,
                              stats=stats, config=cfg)
         if training:
@@ -116,7 +116,8 @@ class _ConvBN:
         grads[conv.weight] = ops.conv2d_wgrad(dr, x, Cout, Cin, self.k, self.stride, in_affine=rec["in_affine"])
         if not need_dx:
             return None
-        cfg = ops.conv2d_pick_config(self.k, 1, B, Cout, Cin, H, W)
+        hw = dr.shape[-2:] if ops.dgrad_at_output_size(self.k, self.stride, dx_out, accumulate) else (H, W)
+        cfg = ops.conv2d_pick_config(self.k, 1, B, Cout, Cin, *hw)
         return ops.conv2d_dgrad(dr, self.packed.get(conv.weight, cfg, transpose_flip=True), Cin, self.k, self.stride,
                                 (H, W), cfg, out=dx_out, accumulate=accumulate)
 
@@ -126,7 +127,7 @@ class _StatsPool:
     copy of every BatchNorm; the high-resolution layers take several copies (``ops.stats_slots``), so the pool grows by
     pages when the first one is used up."""
 
-    PAGE = 1 << 19               # doubles (4 MiB)
+    PAGE = 1 << 21               # doubles (16 MiB)
 
     def __init__(self, device, total):
         self.device = device
@@ -188,7 +189,7 @@ class _GroupedConvBN:
         Cin, Cout = conv.in_channels, conv.out_channels
         Ho, Wo = ops.conv_out_size(H, self.k, self.stride), ops.conv_out_size(W, self.k, self.stride)
         cfg = ops.conv2d_pick_config(self.k, self.stride, B, Cin, Cout, Ho, Wo)
-        stats = stats_pool.take(ops.stats_slots(B, Ho, Wo) * 2 * G * Cout) if training else None
+        stats = stats_pool.take(ops.stats_slots(cfg, self.k, self.stride, B, Cin, Cout, Ho, Wo) * 2 * G * Cout) if training else None
         y = ops.conv2d_fused(x, self.packed.get(self._weights(), cfg), Cout, self.k, self.stride, in_affine=in_affine,
                              stats=stats, config=cfg, groups=G, shared_input=self.shared_input)
         gamma, beta, rm, rv = self.flat
@@ -243,7 +244,8 @@ class _GroupedConvBN:
             grads[self.convs[q].weight] = dw[q]
         if not need_dx:
             return None
-        cfg = ops.conv2d_pick_config(self.k, 1, B, Cout, Cin, H, W)
+        hw = dr.shape[-2:] if ops.dgrad_at_output_size(self.k, self.stride, dx_out, accumulate) else (H, W)
+        cfg = ops.conv2d_pick_config(self.k, 1, B, Cout, Cin, *hw)
         return ops.conv2d_dgrad(dr, self.packed.get(self._weights(), cfg, transpose_flip=True), Cin, self.k, self.stride,
                                 (H, W), cfg, out=dx_out, accumulate=accumulate, groups=G)
 

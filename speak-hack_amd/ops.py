@@ -142,10 +142,10 @@ def conv2d_fused(x, w_packed, Cout: int, k: int = 3, stride: int = 1, *, bias=No
     slots = 0
     if stats is not None:
         slots = stats.numel() // (2 * G * Cout)
-        if (stats.dtype != torch.float64 or not stats.is_cuda or not stats.is_contiguous() or slots < 1 or slots & (slots - 1)
+        if (stats.dtype != torch.float64 or not stats.is_cuda or not stats.is_contiguous() or slots < 1
                 or stats.numel() != slots * 2 * G * Cout):
-            raise L.SpkError("conv2d_fused: stats must be a contiguous float64 HIP tensor of slots*2*groups*Cout elements, "
-                             "slots a power of two (see stats_slots)")
+            raise L.SpkError("conv2d_fused: stats must be a contiguous float64 HIP tensor of slots*2*groups*Cout elements "
+                             "(see stats_slots)")
         flags |= L.EPI_STATS
     if config < 0:
         config = conv2d_pick_config(k, stride, B, Cin, Cout, H, W)
@@ -524,9 +524,19 @@ def maxpool3x3s2_bwd(x, dy, in_scale=None, in_shift=None):
     return dx
 
 
+def dgrad_at_output_size(k, stride, out=None, accumulate=False):
+    """Whether ``conv2d_dgrad`` contracts at the conv's OUTPUT size (then ``config`` must be picked for that size)."""
+    return k == 1 and stride == 2 and out is None and not accumulate
+
+
 def conv2d_dgrad(g, weight_packed_tf, Cin, k, stride, in_hw, config, out=None, accumulate=False, groups=1):
     """Data gradient of a k x k conv: the forward MFMA kernel on ``g`` with transpose-flipped weights
-    (stride 2: on the zero-dilated ``g``).  ``in_hw`` = (H, W) of the conv's input."""
+    (stride 2: on the zero-dilated ``g``; a strided 1x1 without a destination: at the output size, dilated
+    afterwards -- a quarter of the contraction).  ``in_hw`` = (H, W) of the conv's input."""
+    if dgrad_at_output_size(k, stride, out, accumulate):
+        # a strided 1x1 reads only the even input pixels: dx = dilate(W^T g), the contraction at the OUTPUT size
+        t = conv2d_fused(g, weight_packed_tf, Cin, 1, 1, config=config, groups=groups)
+        return dilate2x(t, in_hw[0], in_hw[1])
     if stride == 2:
         # dx[i] = sum_k gd[i + k' - p] * w[k-1-k'] with gd[2o] = g[o], zeros elsewhere, extended to the input size
         # (an even-sized input has a last row/column no window's stride lattice reaches: it stays zero)
@@ -535,14 +545,13 @@ def conv2d_dgrad(g, weight_packed_tf, Cin, k, stride, in_hw, config, out=None, a
 
 
 # ---- BatchNorm / pooling pieces of the ResNet-50 trunk ----------------------------------------------
-def stats_slots(B, H, W):
-    """Copies of the BatchNorm sums a conv epilogue should spread its atomics over (``spk_conv2d_desc.stats_slots``):
-    about one per 8 pixel tiles of 128, between 1 and 32 -- same-address fp64 atomics serialise at ~0.3 us each."""
-    tiles = (B * H * W + 127) // 128
-    s = 1
-    while s < 32 and s * 16 <= tiles:
-        s *= 2
-    return s
+def stats_slots(config, k, stride, B, Cin, Cout, H, W):
+    """Copies of the BatchNorm sums for a conv launch (``spk_conv2d_desc.stats_slots``): one per pixel tile, so that the
+    epilogue stores its sums instead of queueing fp64 atomics (H, W = output size)."""
+    n = L.lib().spk_conv2d_stats_slots(int(config), k, k, stride, B, Cin, Cout, H, W)
+    if n < 1:
+        raise L.SpkError(f"stats_slots: config {config} cannot host k={k} s={stride} shape {(B, Cin, Cout, H, W)}")
+    return n
 
 
 def bn_finalize(stats, count, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, save=False):

@@ -85,16 +85,22 @@ def test_bn_relu_backward_three_mask_modes(pkg, dev):
 
 @pytest.mark.parametrize("k,Hin", [(3, 16), (3, 15), (1, 16), (1, 13)])
 def test_stride2_data_gradient_by_dilation(pkg, dev, k, Hin):
+    """3x3: the stride-1 kernel on the zero-dilated gradient; 1x1 into a fresh tensor: W^T g at the output size, dilated
+    afterwards; 1x1 accumulating into the residual sum: the dilated form again."""
     B, Cin, Cout = 2, 24, 40
     x = recipe_input(f"s2.x.{k}.{Hin}", (B, Cin, Hin, Hin)).requires_grad_(True)
     w = recipe_tensor(f"s2.w.{k}", (Cout, Cin, k, k))
     y = F.conv2d(x, w, stride=2, padding=(k - 1) // 2)
     g = recipe_input(f"s2.g.{k}.{Hin}", y.shape)
     y.backward(g)
-    cfg = pkg.ops.conv2d_pick_config(k, 1, B, Cout, Cin, Hin, Hin)
+    hd = y.shape[-1] if pkg.ops.dgrad_at_output_size(k, 2) else Hin
+    assert pkg.ops.dgrad_at_output_size(k, 2) == (k == 1)
+    cfg = pkg.ops.conv2d_pick_config(k, 1, B, Cout, Cin, hd, hd)
     wp = pkg.ops.pack_conv_weight(w.to(dev), cfg, transpose_flip=True)
     dx = pkg.ops.conv2d_dgrad(g.to(dev), wp, Cin, k, 2, (Hin, Hin), cfg)
-    assert rel_l2(dx, x.grad) < TOL
+    assert dx.shape == x.shape and rel_l2(dx, x.grad) < TOL
+    cfg = pkg.ops.conv2d_pick_config(k, 1, B, Cout, Cin, Hin, Hin)
+    wp = pkg.ops.pack_conv_weight(w.to(dev), cfg, transpose_flip=True)
     # accumulate into an existing gradient (the residual sum)
     base = recipe_input("s2.base", x.shape).to(dev)
     dx2 = pkg.ops.conv2d_dgrad(g.to(dev), wp, Cin, k, 2, (Hin, Hin), cfg, out=base.clone(), accumulate=True)

@@ -79,10 +79,11 @@ def test_conv2d_folded_bn_relu_input_and_statistics(pkg, dev, k, stride):
         assert rel_l2(stats[Cout:], (ref.double() ** 2).sum((0, 2, 3))) < 1e-6
 
 
-@pytest.mark.parametrize("slots,groups", [(4, 1), (16, 1), (8, 3)])
+@pytest.mark.parametrize("slots,groups", [(4, 1), (16, 1), (8, 3), (3, 1), (0, 1), (0, 3)])
 def test_conv2d_statistics_spread_over_slots(pkg, dev, slots, groups):
-    """``stats_slots`` copies of the sums (one per workgroup index % slots): their total, and the affine
-    ``bn_finalize`` makes of them, equal the single-copy result; ragged tiles, ordinary and grouped launches."""
+    """``stats_slots`` copies of the sums (pixel tile i -> copy i % slots; 0 here = one copy per tile, the plain-store
+    form): their total, and the affine ``bn_finalize`` makes of them, equal the single-copy result; ragged tiles,
+    ordinary and grouped launches."""
     B, Cin, Cout, H, W = 5, 20, 40, 30, 22
     tag = f"c2slots.{slots}.{groups}"
     x = recipe_input(tag + ".x", (B, groups * Cin, H, W))
@@ -91,6 +92,9 @@ def test_conv2d_statistics_spread_over_slots(pkg, dev, slots, groups):
     cfg = pkg.ops.conv2d_pick_config(3, 1, B, Cin, Cout, H, W)
     wp = torch.cat([pkg.ops.pack_conv_weight(w.to(dev), cfg) for w in ws])
     Cy = groups * Cout
+    if slots == 0:              # one copy per pixel tile: plain stores, no atomics
+        slots = pkg.ops.stats_slots(cfg, 3, 1, B, Cin, Cout, H, W)
+        assert slots > 4
     stats = torch.zeros(slots * 2 * Cy, device=dev, dtype=torch.float64)
     y = pkg.ops.conv2d_fused(x.to(dev), wp, Cout, 3, 1, stats=stats, config=cfg, groups=groups)
     assert rel_l2(y, ref) < TOL_OP
@@ -107,7 +111,7 @@ def test_conv2d_statistics_spread_over_slots(pkg, dev, slots, groups):
     F.batch_norm(ref, rm, rv, g, be, True, 0.1, 1e-5)
     assert rel_l2(rm_d, rm) < 1e-5 and rel_l2(rv_d, rv) < 1e-5
     with pytest.raises(pkg._lib.SpkError):
-        pkg.ops.conv2d_fused(x.to(dev), wp, Cout, 3, 1, stats=torch.zeros(3 * 2 * Cy, device=dev, dtype=torch.float64),
+        pkg.ops.conv2d_fused(x.to(dev), wp, Cout, 3, 1, stats=torch.zeros(3 * 2 * Cy + 1, device=dev, dtype=torch.float64),
                              config=cfg, groups=groups)
 
 

@@ -59,7 +59,7 @@ def main():
         cfg = ops.conv2d_pick_config(k, s, B, Cin, Cout, Ho, Ho)
         wp = torch.cat([ops.pack_conv_weight(w, cfg) for w in ws])
         aff = None if first else (torch.rand(G * Cin, device=dev) + 0.5, torch.randn(G * Cin, device=dev) * 0.1)
-        stats = torch.zeros(ops.stats_slots(B, Ho, Ho) * 2 * G * Cout, device=dev, dtype=torch.float64)
+        stats = torch.zeros(ops.stats_slots(cfg, k, s, B, Cin, Cout, Ho, Ho) * 2 * G * Cout, device=dev, dtype=torch.float64)
         flops = 2.0 * k * k * Cin * Cout * Ho * Ho * B * G
         t_f = timeit(lambda: ops.conv2d_fused(x, wp, Cout, k, s, in_affine=aff, stats=stats, config=cfg, groups=G,
                                               shared_input=first))
@@ -68,7 +68,8 @@ def main():
         if first:
             t_d = 0.0
         else:
-            cfd = ops.conv2d_pick_config(k, 1, B, Cout, Cin, H, H)
+            hd = Ho if ops.dgrad_at_output_size(k, s) else H
+            cfd = ops.conv2d_pick_config(k, 1, B, Cout, Cin, hd, hd)
             wt = torch.cat([ops.pack_conv_weight(w, cfd, True) for w in ws])
             t_d = timeit(lambda: ops.conv2d_dgrad(g, wt, Cin, k, s, (H, H), cfd, groups=G))
         tf = lambda t: flops / (t * 1e-3) / 1e12 if t else 0.0
