@@ -245,9 +245,11 @@ int spk_upsample2x_bilinear_fwd(const float* x, float* y, int64_t planes, int Hi
  *   shift = beta - mean*scale; and (momentum > 0) updates running_mean / running_var (unbiased var) as
  *   nn.BatchNorm2d does in training mode.  With stats = NULL (eval mode) the running statistics are used.
  *   save_mean / save_invstd ([C], may be NULL) keep the batch statistics for the backward pass.
- *   stats = [stats_slots][2C] (spk_conv2d_desc.stats_slots; 0 = 1): the copies are added here.
+ *   stats = [stats_slots][2C] (spk_conv2d_desc.stats_slots; 0 = 1): the copies are added here, and with more than one
+ *   copy the totals are written back to copy 0 (so a second finalize of the same sums -- the replayed running-statistics
+ *   update of a pass that ran twice -- passes stats_slots = 1).
  * replaces: the statistics half of F.batch_norm for every bn1/bn2/bn3/downsample.1 of the trunk. */
-int spk_bn_finalize(const double* stats, int stats_slots, int64_t count, const float* gamma, const float* beta, float* running_mean,
+int spk_bn_finalize(double* stats, int stats_slots, int64_t count, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, float momentum, float eps, float* scale, float* shift, float* save_mean,
                     float* save_invstd, int C, void* stream);
 /* y = [relu]( a*sa[c] + ba[c] + (b ? b*sb[c] + bb[c] : 0) ): BatchNorm apply (+ residual add) (+ ReLU).

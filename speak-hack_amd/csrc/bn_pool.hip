@@ -10,20 +10,20 @@
 
 namespace {
 
-__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restrict__ stats, int slots, long long count,
+__global__ __launch_bounds__(256) void bn_finalize_kernel(double* __restrict__ stats, int slots, long long count,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          float* running_mean, float* running_var, float momentum,
                                                          float eps, float* __restrict__ scale, float* __restrict__ shift,
                                                          float* save_mean, float* save_invstd, int C) {
-    // 64 channels per workgroup; the `slots` copies of the sums (one per pixel tile of the producing conv) are shared
-    // out over the 4 waves and meet in LDS
-    __shared__ double part[2][4][64];
-    const int cl = threadIdx.x & 63, q = threadIdx.x >> 6;
-    const int c = blockIdx.x * 64 + cl;
+    // 16 channels per workgroup (128-byte rows); the `slots` copies of the sums (one per pixel tile of the producing
+    // conv) are shared out over 16 thread groups and meet in LDS
+    __shared__ double part[2][16][17];
+    const int cl = threadIdx.x & 15, q = threadIdx.x >> 4;
+    const int c = blockIdx.x * 16 + cl;
     if (stats) {
         double s1 = 0.0, s2 = 0.0;
         if (c < C)
-            for (int k = q; k < slots; k += 4) {
+            for (int k = q; k < slots; k += 16) {
                 s1 += stats[(size_t)k * 2 * C + c];
                 s2 += stats[(size_t)k * 2 * C + C + c];
             }
@@ -34,8 +34,16 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(const double* __restri
     if (c >= C || q != 0) return;
     float mean, var;
     if (stats) {
-        const double s1 = (part[0][0][cl] + part[0][1][cl]) + (part[0][2][cl] + part[0][3][cl]);
-        const double s2 = (part[1][0][cl] + part[1][1][cl]) + (part[1][2][cl] + part[1][3][cl]);
+        double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            s1 += part[0][k][cl];
+            s2 += part[1][k][cl];
+        }
+        if (slots > 1) {                 // copy 0 now holds the totals: a later finalize of the same sums passes 1 copy
+            stats[c] = s1;
+            stats[C + c] = s2;
+        }
         const double m = s1 / (double)count;
         double v = s2 / (double)count - m * m;
         v = v > 0.0 ? v : 0.0;
@@ -264,14 +272,14 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_bwd_kernel(const float* __re
 
 extern "C" {
 
-int spk_bn_finalize(const double* stats, int stats_slots, int64_t count, const float* gamma, const float* beta, float* running_mean,
+int spk_bn_finalize(double* stats, int stats_slots, int64_t count, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, float momentum, float eps, float* scale, float* shift, float* save_mean,
                     float* save_invstd, int C, void* stream) {
     SPK_REQUIRE(scale && shift && C > 0, "bn_finalize: bad arguments");
     SPK_REQUIRE(stats || (running_mean && running_var), "bn_finalize: need batch sums or running statistics");
     SPK_REQUIRE(!stats || count > 0, "bn_finalize: element count must be positive");
     SPK_REQUIRE(stats_slots >= 0 && stats_slots <= 65536, "bn_finalize: bad stats_slots %d", stats_slots);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)spk::ceil_div(C, 64)), dim3(256), 0, (hipStream_t)stream, stats,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((unsigned)spk::ceil_div(C, 16)), dim3(256), 0, (hipStream_t)stream, stats,
                        stats_slots > 1 ? stats_slots : 1, (long long)count, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, save_mean,
                        save_invstd, C);
     return spk::check_launch("bn_finalize_kernel");

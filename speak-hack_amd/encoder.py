@@ -85,7 +85,7 @@ class _ConvBN:
         if keep:
             rec.update(x=x, in_affine=in_affine, mean=fin[2], invstd=fin[3], training=training)
             if training:
-                rec.update(stats=stats, count=B * Ho * Wo, momentum=momentum)
+                rec.update(stats=stats[:2 * Cout], count=B * Ho * Wo, momentum=momentum)   # copy 0 = the totals now
         return rec
 
     def second_update(self, rec, counters):
@@ -205,7 +205,7 @@ class _GroupedConvBN:
         if keep:
             rec.update(x=x, in_affine=in_affine, mean=fin[2], invstd=fin[3], training=training)
             if training:
-                rec.update(stats=stats, count=B * Ho * Wo, momentum=bn.momentum)
+                rec.update(stats=stats[:2 * G * Cout], count=B * Ho * Wo, momentum=bn.momentum)   # copy 0 = the totals now
         return rec
 
     def second_update(self, rec, counters):

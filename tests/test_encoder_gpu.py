@@ -110,6 +110,11 @@ def test_conv2d_statistics_spread_over_slots(pkg, dev, slots, groups):
     assert rel_l2(y * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1), want) < TOL_OP
     F.batch_norm(ref, rm, rv, g, be, True, 0.1, 1e-5)
     assert rel_l2(rm_d, rm) < 1e-5 and rel_l2(rv_d, rv) < 1e-5
+    # the totals are in copy 0 now: the replayed update of a pass that ran twice reads one copy
+    sc2, sh2 = pkg.ops.bn_finalize(stats[:2 * Cy], B * H * W, g.to(dev), be.to(dev), rm_d, rv_d, 0.1, 1e-5)
+    assert torch.equal(sc2, sc) and torch.equal(sh2, sh)
+    F.batch_norm(ref, rm, rv, g, be, True, 0.1, 1e-5)
+    assert rel_l2(rm_d, rm) < 1e-5 and rel_l2(rv_d, rv) < 1e-5
     with pytest.raises(pkg._lib.SpkError):
         pkg.ops.conv2d_fused(x.to(dev), wp, Cout, 3, 1, stats=torch.zeros(3 * 2 * Cy + 1, device=dev, dtype=torch.float64),
                              config=cfg, groups=groups)
