@@ -232,39 +232,60 @@ __global__ __launch_bounds__(256) void dilate2x_kernel(const float* __restrict__
 }
 
 // adjoint of maxpool3x3s2 (input optionally max(x*s+b,0) on the fly): every input pixel collects dy from the
-// <= 4 windows in which it is the (first, row-major) maximum -- torch's tie rule.
+// <= 4 windows in which it is the (first, row-major) maximum -- torch's tie rule.  A workgroup owns 32x32 input pixels
+// of one plane: it first finds the argmax of the 17x17 windows that touch them (once each, code ky*3+kx in LDS; a
+// per-pixel search would redo every window four times), then every pixel looks its windows up.
 __global__ __launch_bounds__(256) void maxpool3x3s2_bwd_kernel(const float* __restrict__ x, const float* __restrict__ sc,
                                                               const float* __restrict__ sh, const float* __restrict__ dy,
                                                               float* __restrict__ dx, int C, int Hin, int Win, int Ho, int Wo,
-                                                              long long total) {
-    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-        const int ix = (int)(idx % Win), iy = (int)((idx / Win) % Hin);
-        const long long plane = idx / ((long long)Win * Hin);
-        const int c = (int)(plane % C);
-        const float s = sc ? sc[c] : 1.f, o = sc ? sh[c] : 0.f;
-        const float* xp = x + plane * Hin * Win;
-        const float* gp = dy + plane * Ho * Wo;
-        float acc = 0.f;
-        for (int oy = max((iy - 1 + 1) / 2, 0); oy <= min((iy + 1) / 2, Ho - 1); ++oy) {
-            for (int ox = max((ix - 1 + 1) / 2, 0); ox <= min((ix + 1) / 2, Wo - 1); ++ox) {
-                // argmax of window (oy, ox), first maximum in row-major order
-                float m = -INFINITY;
-                int my = -1, mx = -1;
-                for (int ky = 0; ky < 3; ++ky) {
-                    const int yy = oy * 2 + ky - 1;
-                    if (yy < 0 || yy >= Hin) continue;
-                    for (int kx = 0; kx < 3; ++kx) {
-                        const int xx = ox * 2 + kx - 1;
-                        if (xx < 0 || xx >= Win) continue;
-                        float v = xp[yy * Win + xx];
-                        if (sc) v = fmaxf(v * s + o, 0.f);
-                        if (v > m) { m = v; my = yy; mx = xx; }
-                    }
+                                                              int tiles_x, int tiles_y) {
+    constexpr int TO = 16, TW = TO + 1;            // windows per tile side (+1: the odd last row / column reaches the next)
+    __shared__ unsigned char code[TW * TW];
+    int bx = blockIdx.x;
+    const int tx = bx % tiles_x; bx /= tiles_x;
+    const int ty = bx % tiles_y;
+    const long long plane = bx / tiles_y;
+    const int oy0 = ty * TO, ox0 = tx * TO;
+    const int c = (int)(plane % C);
+    const float s = sc ? sc[c] : 1.f, o = sc ? sh[c] : 0.f;
+    const float* xp = x + plane * Hin * Win;
+    const float* gp = dy + plane * Ho * Wo;
+    for (int w = threadIdx.x; w < TW * TW; w += 256) {
+        const int oy = oy0 + w / TW, ox = ox0 + w % TW;
+        int best = 255;
+        if (oy < Ho && ox < Wo) {
+            float m = -INFINITY;
+#pragma unroll
+            for (int ky = 0; ky < 3; ++ky) {
+                const int yy = oy * 2 + ky - 1;
+#pragma unroll
+                for (int kx = 0; kx < 3; ++kx) {
+                    const int xx = ox * 2 + kx - 1;
+                    if (yy < 0 || yy >= Hin || xx < 0 || xx >= Win) continue;
+                    float v = xp[yy * Win + xx];
+                    if (sc) v = fmaxf(v * s + o, 0.f);
+                    if (v > m) { m = v; best = ky * 3 + kx; }
                 }
-                if (my == iy && mx == ix) acc += gp[oy * Wo + ox];
             }
         }
-        dx[idx] = acc;
+        code[w] = (unsigned char)best;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int e = threadIdx.x + 256 * i;
+        const int ly = e >> 5, lx = e & 31;
+        const int iy = 2 * oy0 + ly, ix = 2 * ox0 + lx;
+        if (iy >= Hin || ix >= Win) continue;
+        float acc = 0.f;
+        for (int wy = ly >> 1; wy <= (ly + 1) >> 1; ++wy) {
+            const int ky = ly - 2 * wy + 1;
+            for (int wx = lx >> 1; wx <= (lx + 1) >> 1; ++wx) {
+                const int kx = lx - 2 * wx + 1;
+                if (code[wy * TW + wx] == ky * 3 + kx) acc += gp[(oy0 + wy) * Wo + ox0 + wx];   // 255 = no such window
+            }
+        }
+        dx[plane * Hin * Win + (long long)iy * Win + ix] = acc;
     }
 }
 
@@ -351,9 +372,11 @@ int spk_maxpool3x3s2_bwd(const float* x, const float* in_scale, const float* in_
     SPK_REQUIRE(x && dy && dx && B > 0 && C > 0 && Hin > 0 && Win > 0, "maxpool_bwd: bad arguments");
     SPK_REQUIRE(!in_scale == !in_shift, "maxpool_bwd: in_scale and in_shift go together");
     const int Ho = (Hin - 1) / 2 + 1, Wo = (Win - 1) / 2 + 1;
-    const long long total = (long long)B * C * Hin * Win;
-    hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, dim3((unsigned)std::min((total + 255) / 256, 256ll * 16)), dim3(256), 0,
-                       (hipStream_t)stream, x, in_scale, in_shift, dy, dx, C, Hin, Win, Ho, Wo, total);
+    const int tiles_x = spk::ceil_div(Win, 32), tiles_y = spk::ceil_div(Hin, 32);
+    const long long blocks = (long long)B * C * tiles_x * tiles_y;
+    SPK_REQUIRE(blocks < (1ll << 31), "maxpool_bwd: too many tiles");
+    hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, x, in_scale,
+                       in_shift, dy, dx, C, Hin, Win, Ho, Wo, tiles_x, tiles_y);
     return spk::check_launch("maxpool3x3s2_bwd_kernel");
 }
 

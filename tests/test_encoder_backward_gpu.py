@@ -108,7 +108,8 @@ def test_stride2_data_gradient_by_dilation(pkg, dev, k, Hin):
 
 
 def test_maxpool_adjoint_with_folded_affine(pkg, dev):
-    for shape in [(2, 5, 12, 12), (1, 3, 9, 11), (1, 2, 2, 2)]:
+    # several 32x32 tiles per plane, ragged edges, odd / even sizes; the ReLU zeros make ties the common case
+    for shape in [(2, 5, 12, 12), (1, 3, 9, 11), (1, 2, 2, 2), (2, 3, 70, 45), (1, 2, 64, 64), (1, 1, 33, 65), (1, 2, 1, 7)]:
         x = recipe_input(f"mpb.x.{shape}", shape).requires_grad_(True)
         s, o = 1.0 + recipe_tensor("mpb.s", (shape[1],), 0.3), recipe_tensor("mpb.o", (shape[1],), 0.3)
         v = F.relu(x * s.view(1, -1, 1, 1) + o.view(1, -1, 1, 1))
@@ -118,6 +119,10 @@ def test_maxpool_adjoint_with_folded_affine(pkg, dev):
         y.backward(g)
         dv = pkg.ops.maxpool3x3s2_bwd(x.detach().to(dev), g.to(dev), s.to(dev), o.to(dev))
         assert rel_l2(dv, v.grad) < 1e-6
+        # without the folded affine: the plain pool's adjoint
+        x2 = x.detach().clone().requires_grad_(True)
+        F.max_pool2d(x2, 3, 2, 1).backward(g)
+        assert rel_l2(pkg.ops.maxpool3x3s2_bwd(x2.detach().to(dev), g.to(dev)), x2.grad) < 1e-6
 
 
 def _trunk(dev, prefix):
