@@ -42,6 +42,12 @@ extern "C" {
 #define SPK_CONV_IN_AFFINE_RELU 128u /* x' = max(x*in_scale[ci] + in_shift[ci], 0) applied while staging */
 #define SPK_CONV_IN_BATCH_SCALE 256u /* x' = x * in_scale[b*Cin + ci] applied while staging (weight modulation); may be
                                       * combined with SPK_CONV_UPSAMPLE2X (configs 4-7) */
+#define SPK_CONV_DGRAD_S2 1024u  /* kh = kw = 3, stride = 2: run the DATA GRADIENT of that conv instead: x = the output-side
+                                  * gradient [B,Cin,Hin,Win], y = the input-side gradient [B,Cout,H,W] (H in {2Hin-1, 2Hin});
+                                  * w_packed from spk_conv2d_pack_weights(w[Cin][Cout][3][3], transpose_flip = 2) for a
+                                  * tile config in 0-3 (spk_conv2d_pick_config(2, 2, 1, B, Cin, 4*Cout, Hin, Win));
+                                  * SPK_EPI_ACCUM is the only other flag.  Computed by output parity -- dx[2m+py, 2n+px]
+                                  * needs 1/2/2/4 of the 9 taps -- as four 2x2 kernels in one launch, stored interleaved. */
 #define SPK_CONV_UP_FIR1331 512u     /* with UPSAMPLE2X: the x2 interpolation is upfirdn2d(up=2, FIR [1,3,3,1], pad (2,1)) --
                                       * the same (.75,.25) taps as bilinear, but neighbours outside the image are zero */
 
@@ -130,8 +136,11 @@ int64_t spk_conv2d_workspace_bytes(int config, int ksplit, int kh, int kw, int s
 int64_t spk_conv2d_workspace_bytes_grouped(int config, int ksplit, int kh, int kw, int stride, int B, int Cin, int Cout,
                                            int H, int W, int groups);
 /* w[Cout,Cin,kh,kw] -> packed [co_tile][ci_chunk][tap][ci][co] (zero padded).
- * transpose_flip != 0 packs the data-gradient operator instead: w'[ci,co,ky,kx] = w[co,ci,kh-1-ky,kw-1-kx]
+ * transpose_flip = 1 packs the data-gradient operator instead: w'[ci,co,ky,kx] = w[co,ci,kh-1-ky,kw-1-kx]
  * (then the packed image is that of a [Cin,Cout,kh,kw] weight).
+ * transpose_flip = 2 (kh = kw = 3): the four output-parity 2x2 kernels of the STRIDE-2 data gradient
+ * (SPK_CONV_DGRAD_S2), the image of a [4*Cin, Cout, 2, 2] weight: spk_conv2d_packed_floats(config, 2, 2, Cout, 4*Cin)
+ * floats, config in 0-3.  2x2 is accepted by the size / config queries for that purpose only.
  * replaces: nothing in the reference (layout change private to this library). */
 int spk_conv2d_pack_weights(const float* w, float* w_packed, int kh, int kw, int Cin, int Cout, int config,
                             int transpose_flip, void* stream);

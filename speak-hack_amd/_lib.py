@@ -37,6 +37,7 @@ class Conv2dDesc(C.Structure):
 
 CONV_IN_BATCH_SCALE = 256
 CONV_UP_FIR1331 = 512
+CONV_DGRAD_S2 = 1024
 
 
 FC_MAX_GROUPS = 16

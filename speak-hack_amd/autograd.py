@@ -184,9 +184,8 @@ def _conv_plain(x, weight, k, stride):
 def _conv_dgrad(dt, weight, k, stride, in_hw):
     B, Cout = dt.shape[:2]
     Cin = weight.shape[1]
-    hw = dt.shape[-2:] if ops.dgrad_at_output_size(k, stride) else in_hw
-    cfg = ops.conv2d_pick_config(k, 1, B, Cout, Cin, hw[0], hw[1])
-    return ops.conv2d_dgrad(dt, ops.pack_conv_weight(weight, cfg, transpose_flip=True), Cin, k, stride, in_hw, cfg)
+    cfg, tf = ops.dgrad_plan(k, stride, B, Cout, Cin, in_hw, dt.shape[-2:])
+    return ops.conv2d_dgrad(dt, ops.pack_conv_weight(weight, cfg, transpose_flip=tf), Cin, k, stride, in_hw, cfg)
 
 
 class ConvDgradFn(torch.autograd.Function):

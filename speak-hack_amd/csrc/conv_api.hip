@@ -161,8 +161,17 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
     const int co = cot * CO_T + co_in, cig = chunk * CI_T + ci;
     float v = 0.f;
     if (co < opCout && cig < opCin) {
-        if (!tf) v = w[((size_t)co * Cin_orig + cig) * taps + tap];
-        else     v = w[((size_t)cig * Cin_orig + co) * taps + (taps - 1 - tap)];
+        if (tf == 0) v = w[((size_t)co * Cin_orig + cig) * taps + tap];
+        else if (tf == 1) v = w[((size_t)cig * Cin_orig + co) * taps + (taps - 1 - tap)];
+        else {
+            // parity kernels of the 3x3 stride-2 pad-1 data gradient (taps = 4 here, w is [Cout][Cin][3][3]): output
+            // channel co = q*Cin + ci, q = (py, px); window position (a, b) = gradient pixel (m+a, n+b) for the input
+            // pixel (2m+py, 2n+px).  Even coordinate: only a = 0 reaches it, through tap 1; odd: a = 0 through tap 2,
+            // a = 1 through tap 0.
+            const int q = co / Cin_orig, ci_o = co - q * Cin_orig, a = tap >> 1, b = tap & 1;
+            const int ky = (q >> 1) ? (a ? 0 : 2) : (a ? -1 : 1), kx = (q & 1) ? (b ? 0 : 2) : (b ? -1 : 1);
+            if (ky >= 0 && kx >= 0) v = w[(((size_t)cig * Cin_orig + ci_o) * 3 + ky) * 3 + kx];
+        }
     }
     wp[idx] = v;
 }
@@ -175,12 +184,14 @@ static const CfgDims kDims[kNumConfigs] = {
     {Cfg9::CO_T, Cfg9::CI_T, Cfg9::PIX_T},   {Cfg10::CO_T, Cfg10::CI_T, Cfg10::PIX_T}, {Cfg11::CO_T, Cfg11::CI_T, Cfg11::PIX_T}};
 
 static bool supported_kernel(int kh, int kw, int stride) {
+    if (kh == 2 && kw == 2) return stride == 1;   // the parity form of the 3x3 stride-2 data gradient (SPK_CONV_DGRAD_S2)
     return kh == kw && (kh == 1 || kh == 3 || kh == 7) && (stride == 1 || stride == 2) && !(kh == 7 && stride == 1);
 }
 
 static bool config_valid(int cfg, int kh, int kw, int stride) {
     if (!supported_kernel(kh, kw, stride) || cfg < 0 || cfg >= kNumConfigs) return false;
     if (kh == 1) return cfg >= 8;
+    if (kh == 2) return cfg <= 3;
     if (kh == 3 && stride == 1) return cfg <= 7;
     return cfg >= 4 && cfg <= 7;  // 3x3 s2, 7x7 s2
 }
@@ -207,6 +218,7 @@ static Geometry geometry_any(int kh, int stride, int cfg, int B, int Cin, int Co
     Geometry g;
     if (!config_valid(cfg, kh, kh, stride)) { g.ok = false; return g; }
     if (kh == 1) return stride == 1 ? geom_k<1, 1>(cfg, B, Cin, Cout, H, W) : geom_k<1, 2>(cfg, B, Cin, Cout, H, W);
+    if (kh == 2) return geom_k<2, 1>(cfg, B, Cin, Cout, H, W);
     if (kh == 3) return stride == 1 ? geom_k<3, 1>(cfg, B, Cin, Cout, H, W) : geom_k<3, 2>(cfg, B, Cin, Cout, H, W);
     return geom_k<7, 2>(cfg, B, Cin, Cout, H, W);
 }
@@ -217,8 +229,8 @@ static Geometry geometry_any(int kh, int stride, int cfg, int B, int Cin, int Co
 static int pick_config(int kh, int stride, int B, int Cin, int Cout, int H, int W) {
     const long long pixels = (long long)B * H * W;
     const int shape = Cout <= 32 ? 3 : (Cout <= 64 ? (pixels >= 64 * 1024 ? 1 : 2) : (pixels >= 2048 ? 0 : 2));
-    const int base = kh == 1 ? 8 : 4;            // 1x1 -> ids 8-11; everything else prefers ids 4-7
-    const int lo = kh == 1 ? 8 : (kh == 3 && stride == 1 ? 0 : 4), hi = kh == 1 ? 11 : 7;
+    const int base = kh == 1 ? 8 : (kh == 2 ? 0 : 4);   // 1x1 -> ids 8-11, 2x2 -> 0-3; everything else prefers ids 4-7
+    const int lo = kh == 1 ? 8 : ((kh == 3 && stride == 1) || kh == 2 ? 0 : 4), hi = kh == 1 ? 11 : (kh == 2 ? 3 : 7);
     const int want = base + shape;
     if (geometry_any(kh, stride, want, B, Cin, Cout, H, W).ok) return want;
     static const int alt[4][3] = {{2, 3, 1}, {2, 3, 0}, {3, 0, 1}, {2, 0, 1}};
@@ -290,14 +302,17 @@ int spk_conv2d_pack_weights(const float* w, float* w_packed, int kh, int kw, int
     SPK_REQUIRE(w && w_packed, "pack_weights: null pointer");
     SPK_REQUIRE(config >= 0 && config < kNumConfigs, "pack_weights: bad config %d", config);
     SPK_REQUIRE(Cin > 0 && Cout > 0 && kh > 0 && kw > 0, "pack_weights: bad shape");
+    SPK_REQUIRE(transpose_flip >= 0 && transpose_flip <= 2, "pack_weights: transpose_flip is 0, 1 or 2");
+    SPK_REQUIRE(transpose_flip != 2 || (kh == 3 && kw == 3), "pack_weights: the stride-2 data-gradient form packs a 3x3 kernel");
     const CfgDims& c = kDims[config];
-    const int opCin = transpose_flip ? Cout : Cin, opCout = transpose_flip ? Cin : Cout;
+    const int opCin = transpose_flip ? Cout : Cin, opCout = transpose_flip == 2 ? 4 * Cin : (transpose_flip ? Cin : Cout);
+    const int taps = transpose_flip == 2 ? 4 : kh * kw;
     const int n_chunks = spk::ceil_div(opCin, c.ci_t);
-    const long long total = (long long)spk::ceil_div(opCout, c.co_t) * n_chunks * kh * kw * c.ci_t * c.co_t;
+    const long long total = (long long)spk::ceil_div(opCout, c.co_t) * n_chunks * taps * c.ci_t * c.co_t;
     const int threads = 256;
     hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((total + threads - 1) / threads)), dim3(threads), 0,
-                       (hipStream_t)stream, w, w_packed, kh * kw, Cin, opCin, opCout, c.co_t, c.ci_t, n_chunks,
-                       transpose_flip ? 1 : 0, total);
+                       (hipStream_t)stream, w, w_packed, taps, Cin, opCin, opCout, c.co_t, c.ci_t, n_chunks,
+                       transpose_flip, total);
     return spk::check_launch("pack_weights_kernel");
 }
 
@@ -305,7 +320,24 @@ int spk_conv2d_fwd(const spk_conv2d_desc* d, void* stream) {
     SPK_REQUIRE(d, "conv2d: null descriptor");
     SPK_REQUIRE(d->x && d->w_packed && d->y, "conv2d: null tensor pointer");
     SPK_REQUIRE(d->B > 0 && d->Cin > 0 && d->Cout > 0 && d->H > 0 && d->W > 0 && d->Hin > 0 && d->Win > 0, "conv2d: bad shape");
-    SPK_REQUIRE(supported_kernel(d->kh, d->kw, d->stride), "conv2d: unsupported kernel %dx%d stride %d", d->kh, d->kw, d->stride);
+    SPK_REQUIRE(supported_kernel(d->kh, d->kw, d->stride) && d->kh != 2, "conv2d: unsupported kernel %dx%d stride %d", d->kh, d->kw, d->stride);
+    if (d->flags & SPK_CONV_DGRAD_S2) {
+        // data gradient of a 3x3 stride-2 pad-1 conv: x = the output-side gradient [B, Cin, Hin, Win], y = the input-side
+        // gradient [B, Cout, H, W]; run as the four output-parity classes (2x2 kernels, 4*Cout channels, interleaved stores)
+        SPK_REQUIRE(d->kh == 3 && d->kw == 3 && d->stride == 2, "conv2d: DGRAD_S2 is the data gradient of a 3x3 stride-2 conv");
+        SPK_REQUIRE(!(d->flags & ~(SPK_CONV_DGRAD_S2 | SPK_EPI_ACCUM)) && !d->out_scale_bc && !d->y_pre,
+                    "conv2d: DGRAD_S2 takes SPK_EPI_ACCUM only");
+        SPK_REQUIRE((d->H == 2 * d->Hin || d->H == 2 * d->Hin - 1) && (d->W == 2 * d->Win || d->W == 2 * d->Win - 1),
+                    "conv2d: DGRAD_S2 output %dx%d is not the input size of a stride-2 conv with output %dx%d", d->H, d->W, d->Hin, d->Win);
+        SPK_REQUIRE(d->groups <= 1 || d->group_in_stride >= d->Cin, "conv2d: DGRAD_S2 groups read disjoint channels");
+        SPK_REQUIRE((long long)d->B * d->Cout * d->H * d->W < (1ll << 40), "conv2d: tensor too large");
+        spk_conv2d_desc dd = *d;
+        dd.kh = dd.kw = 2; dd.stride = 1; dd.Cout = 4 * d->Cout; dd.H = d->Hin; dd.W = d->Win; dd.ksplit = 1;
+        dd.flags = d->flags & SPK_EPI_ACCUM; dd.out_scale = d->out_scale;
+        if (dd.config < 0) dd.config = pick_config(2, 1, dd.B, dd.Cin, dd.Cout, dd.H, dd.W);
+        SPK_REQUIRE(config_valid(dd.config, 2, 2, 1), "conv2d: DGRAD_S2 runs tile configs 0-3 (got %d)", dd.config);
+        return run_2x2_parity(dd.config, &dd, d->H, d->W, (hipStream_t)stream);
+    }
     const bool ups = d->flags & SPK_CONV_UPSAMPLE2X, aff = d->flags & SPK_CONV_IN_AFFINE_RELU;
     const bool bsc = d->flags & SPK_CONV_IN_BATCH_SCALE;
     SPK_REQUIRE(!aff || (!ups && !bsc), "conv2d: IN_AFFINE_RELU excludes UPSAMPLE2X and IN_BATCH_SCALE");

@@ -1,4 +1,4 @@
-// 2-D convolution (KHxKW in {1x1, 3x3, 7x7}, stride 1 or 2, zero pad (K-1)/2) as an LDS-staged implicit
+// 2-D convolution (KHxKW in {1x1, 3x3, 7x7}, stride 1 or 2, zero pad (K-1)/2; 2x2 = window rows y, y+1, see the epilogue) as an LDS-staged implicit
 // GEMM on the gfx950 f32 MFMA pipe.  One kernel template serves the StyleGAN decoder (3x3 s1 with the
 // bilinear x2 upsampling folded into staging and the bias/noise/LeakyReLU/style epilogue) and the
 // ResNet-50 trunk (1x1 / 3x3 / 7x7, stride 1/2, the producer's BatchNorm+ReLU folded into staging as a
@@ -74,6 +74,7 @@ struct ConvArgs {
     // input); y, bias, stats, ... have Cy = G*Cout channels; blockIdx.y = g * co_tiles_g + co tile.  G = 1: Cx = gin =
     // Cin, Cy = Cout.
     int G, Cx, Cy, gin, co_tiles_g;
+    int Hd, Wd;              // 2x2 (parity) kernels: spatial size of the interleaved destination
 };
 
 template <int WM_, int WN_, int MT_, int NT_, int CIT_>
@@ -482,6 +483,10 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
 #undef SPK_LOAD_W
 
     // ---- epilogue ----
+    // 2x2 kernels exist for one purpose, the data gradient of a 3x3 stride-2 conv by output parity: the Cout channels
+    // are 4 classes q = (py, px) of Cout/4 channels (class-major), and channel (q, c) at window (y, x) is the gradient
+    // at pixel (2y+py, 2x+px) of channel c in a [B, G*Cout/4, Hd, Wd] tensor
+    constexpr bool UNSH = KH == 2;
     const bool split = gridDim.z > 1;
     const bool f_bias = p.flags & SPK_EPI_BIAS, f_noise = p.flags & SPK_EPI_NOISE;
     const bool f_lrelu = p.flags & SPK_EPI_LRELU, f_style = p.flags & SPK_EPI_STYLE;
@@ -491,7 +496,7 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
     // per pixel group: validity, output offset, noise value, style row
     bool pv[C::NT];
     size_t poff[C::NT];
-    int pb[C::NT];
+    int pb[C::NT], uy2[C::NT], ux2[C::NT];
     float nz[C::NT];
     const float* st[C::NT];
 #pragma unroll
@@ -503,6 +508,8 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
         const size_t pix = (size_t)yy * p.W + xx;
         poff[n] = pv[n] ? (size_t)b * p.Cy * HW + pix : 0;
         pb[n] = pv[n] ? b : 0;
+        uy2[n] = 2 * yy;
+        ux2[n] = 2 * xx;
         nz[n] = (f_noise && pv[n] && !split) ? p.noise[(size_t)b * HW + pix] : 0.f;
         st[n] = (f_style && pv[n]) ? p.style + (size_t)b * p.style_stride : nullptr;
     }
@@ -525,6 +532,12 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
                 for (int n = 0; n < C::NT; ++n) {
                     if (!pv[n]) continue;
                     float* dst = ybase + poff[n] + (size_t)cg * HW;
+                    if constexpr (UNSH) {
+                        const int c4 = p.Cout >> 2, q = co / c4;
+                        const int Y = uy2[n] + (q >> 1), X = ux2[n] + (q & 1);
+                        if (Y >= p.Hd || X >= p.Wd) continue;
+                        dst = p.y + (((size_t)pb[n] * (p.G * c4) + grp * c4 + (co - q * c4)) * p.Hd + Y) * p.Wd + X;
+                    }
                     if (split) {  // raw partial sums; splitk_epilogue_kernel finishes
                         *dst = acc[m][n][r];
                         continue;
@@ -633,8 +646,9 @@ int launch_splitk_epilogue(const ConvArgs& a, const float* ws, int ksplit, hipSt
 
 // Fill ConvArgs from the public descriptor, pick geometry / split-K, launch (and the split-K epilogue).
 template <class C, int KH, int KW, int S, int MODE>
-int run(const spk_conv2d_desc* d, hipStream_t stream) {
+int run(const spk_conv2d_desc* d, hipStream_t stream, int Hd = 0, int Wd = 0) {
     ConvArgs a;
+    a.Hd = Hd; a.Wd = Wd;
     a.x = d->x; a.wp = d->w_packed; a.bias = d->bias; a.noise_w = d->noise_w; a.noise = d->noise;
     a.style = d->style; a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.stats = d->stats; a.stats_slots = d->stats_slots > 1 ? d->stats_slots : 1; a.y = d->y; a.y_pre = d->y_pre; a.out_scale_bc = d->out_scale_bc;
     a.B = d->B; a.Cin = d->Cin; a.Cout = d->Cout; a.H = d->H; a.W = d->W; a.Hs = d->Hin; a.Ws = d->Win;
@@ -707,5 +721,6 @@ int run_3x3s1_a(int cfg, int mode, const spk_conv2d_desc* d, hipStream_t s);  //
 int run_3x3s1_b(int cfg, int mode, const spk_conv2d_desc* d, hipStream_t s);  // ids 4-7
 int run_3x3s2_7x7s2(int kh, int cfg, int mode, const spk_conv2d_desc* d, hipStream_t s);  // ids 4-7
 int run_1x1(int stride, int cfg, int mode, const spk_conv2d_desc* d, hipStream_t s);      // ids 8-11
+int run_2x2_parity(int cfg, const spk_conv2d_desc* d, int Hd, int Wd, hipStream_t s);     // ids 0-3
 
 }  // namespace spkconv

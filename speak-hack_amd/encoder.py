@@ -116,9 +116,8 @@ class _ConvBN:
         grads[conv.weight] = ops.conv2d_wgrad(dr, x, Cout, Cin, self.k, self.stride, in_affine=rec["in_affine"])
         if not need_dx:
             return None
-        hw = dr.shape[-2:] if ops.dgrad_at_output_size(self.k, self.stride, dx_out, accumulate) else (H, W)
-        cfg = ops.conv2d_pick_config(self.k, 1, B, Cout, Cin, *hw)
-        return ops.conv2d_dgrad(dr, self.packed.get(conv.weight, cfg, transpose_flip=True), Cin, self.k, self.stride,
+        cfg, tf = ops.dgrad_plan(self.k, self.stride, B, Cout, Cin, (H, W), dr.shape[-2:], dx_out, accumulate)
+        return ops.conv2d_dgrad(dr, self.packed.get(conv.weight, cfg, transpose_flip=tf), Cin, self.k, self.stride,
                                 (H, W), cfg, out=dx_out, accumulate=accumulate)
 
 
@@ -244,9 +243,8 @@ class _GroupedConvBN:
             grads[self.convs[q].weight] = dw[q]
         if not need_dx:
             return None
-        hw = dr.shape[-2:] if ops.dgrad_at_output_size(self.k, self.stride, dx_out, accumulate) else (H, W)
-        cfg = ops.conv2d_pick_config(self.k, 1, B, Cout, Cin, *hw)
-        return ops.conv2d_dgrad(dr, self.packed.get(self._weights(), cfg, transpose_flip=True), Cin, self.k, self.stride,
+        cfg, tf = ops.dgrad_plan(self.k, self.stride, B, Cout, Cin, (H, W), dr.shape[-2:], dx_out, accumulate)
+        return ops.conv2d_dgrad(dr, self.packed.get(self._weights(), cfg, transpose_flip=tf), Cin, self.k, self.stride,
                                 (H, W), cfg, out=dx_out, accumulate=accumulate, groups=G)
 
 

@@ -58,14 +58,20 @@ def conv2d_config_info(config: int):
     return co.value, ci.value, px.value
 
 
-def pack_conv_weight(weight: torch.Tensor, config: int, transpose_flip: bool = False) -> torch.Tensor:
+def pack_conv_weight(weight: torch.Tensor, config: int, transpose_flip=False) -> torch.Tensor:
+    """``transpose_flip``: False = the forward operator; True (1) = the data-gradient operator of a stride-1 conv (run
+    by the forward kernel); 2 = the four output-parity 2x2 kernels of a 3x3 STRIDE-2 conv's data gradient."""
     Cout, Cin, kh, kw = weight.shape
-    n = L.lib().spk_conv2d_packed_floats(config, kh, kw, Cout if transpose_flip else Cin, Cin if transpose_flip else Cout)
+    tf = int(transpose_flip)
+    if tf == 2:
+        n = L.lib().spk_conv2d_packed_floats(config, 2, 2, Cout, 4 * Cin)
+    else:
+        n = L.lib().spk_conv2d_packed_floats(config, kh, kw, Cout if tf else Cin, Cin if tf else Cout)
     if n <= 0:
         raise L.SpkError("spk_conv2d_packed_floats: bad arguments")
     out = torch.empty(n, device=weight.device, dtype=torch.float32)
     L.check(L.lib().spk_conv2d_pack_weights(L.dptr(weight.contiguous(), "weight"), L.dptr(out), kh, kw, Cin, Cout,
-                                            config, 1 if transpose_flip else 0, L.stream_ptr()),
+                                            config, tf, L.stream_ptr()),
             "spk_conv2d_pack_weights")
     return out
 
@@ -526,13 +532,45 @@ def maxpool3x3s2_bwd(x, dy, in_scale=None, in_shift=None):
 
 def dgrad_at_output_size(k, stride, out=None, accumulate=False):
     """Whether ``conv2d_dgrad`` contracts at the conv's OUTPUT size (then ``config`` must be picked for that size)."""
-    return k == 1 and stride == 2 and out is None and not accumulate
+    return stride == 2 and (k == 3 or (k == 1 and out is None and not accumulate))
+
+
+def dgrad_plan(k, stride, B, Cout, Cin, in_hw, g_hw, out=None, accumulate=False):
+    """-> (tile config, ``transpose_flip`` mode of ``pack_conv_weight``) for ``conv2d_dgrad`` of this conv."""
+    if k == 3 and stride == 2:       # four output-parity 2x2 kernels over the gradient's own pixels
+        return conv2d_pick_config(2, 1, B, Cout, 4 * Cin, g_hw[0], g_hw[1]), 2
+    hw = g_hw if dgrad_at_output_size(k, stride, out, accumulate) else in_hw
+    return conv2d_pick_config(k, 1, B, Cout, Cin, hw[0], hw[1]), 1
+
+
+def _dgrad_s2_parity(g, weight_packed, Cin, in_hw, config, out, accumulate, groups):
+    B, Cg, Hg, Wg = g.shape
+    G = int(groups)
+    if Cg % G:
+        raise L.SpkError(f"conv2d_dgrad: {Cg} gradient channels do not split into {G} groups")
+    H, W = in_hw
+    if out is None:
+        out = torch.empty((B, G * Cin, H, W), device=g.device, dtype=torch.float32)
+    elif tuple(out.shape) != (B, G * Cin, H, W) or not out.is_contiguous():
+        raise L.SpkError("conv2d_dgrad: out must be a contiguous [B, groups*Cin, H, W] tensor")
+    d = L.Conv2dDesc(x=L.dptr(g, "g"), w_packed=L.dptr(weight_packed, "w_packed"), y=L.dptr(out, "out"), B=B, Cin=Cg // G,
+                     Cout=Cin, H=H, W=W, Hin=Hg, Win=Wg, kh=3, kw=3, stride=2,
+                     flags=L.CONV_DGRAD_S2 | (L.EPI_ACCUM if accumulate else 0), lrelu_slope=1.0, out_scale=1.0,
+                     config=int(config), ksplit=1, groups=G, group_in_stride=0 if G == 1 else Cg // G)
+    if CONV_SKIP:
+        return out
+    L.check(L.lib().spk_conv2d_fwd(C.byref(d), L.stream_ptr()), "spk_conv2d_fwd")
+    return out
 
 
 def conv2d_dgrad(g, weight_packed_tf, Cin, k, stride, in_hw, config, out=None, accumulate=False, groups=1):
-    """Data gradient of a k x k conv: the forward MFMA kernel on ``g`` with transpose-flipped weights
-    (stride 2: on the zero-dilated ``g``; a strided 1x1 without a destination: at the output size, dilated
-    afterwards -- a quarter of the contraction).  ``in_hw`` = (H, W) of the conv's input."""
+    """Data gradient of a k x k conv.  Stride 1: the forward MFMA kernel on ``g`` with transpose-flipped weights.
+    3x3 stride 2: by output parity (``SPK_CONV_DGRAD_S2``: dx[2m+py, 2n+px] needs 1/2/2/4 of the 9 taps; four 2x2
+    kernels in one launch over the gradient's own pixels, stored interleaved).  1x1 stride 2 without a destination: at
+    the output size, dilated afterwards; into a destination: on the zero-dilated ``g``.  ``in_hw`` = (H, W) of the
+    conv's input; ``config`` / the packing of ``weight_packed_tf`` from ``dgrad_plan``."""
+    if k == 3 and stride == 2:
+        return _dgrad_s2_parity(g, weight_packed_tf, Cin, in_hw, config, out, accumulate, groups)
     if dgrad_at_output_size(k, stride, out, accumulate):
         # a strided 1x1 reads only the even input pixels: dx = dilate(W^T g), the contraction at the OUTPUT size
         t = conv2d_fused(g, weight_packed_tf, Cin, 1, 1, config=config, groups=groups)

@@ -83,28 +83,58 @@ def test_bn_relu_backward_three_mask_modes(pkg, dev):
     assert rel_l2(res[0], r.grad) < TOL and rel_l2(res[1], gamma.grad) < TOL and rel_l2(res[2], beta.grad) < TOL
 
 
-@pytest.mark.parametrize("k,Hin", [(3, 16), (3, 15), (1, 16), (1, 13)])
-def test_stride2_data_gradient_by_dilation(pkg, dev, k, Hin):
-    """3x3: the stride-1 kernel on the zero-dilated gradient; 1x1 into a fresh tensor: W^T g at the output size, dilated
-    afterwards; 1x1 accumulating into the residual sum: the dilated form again."""
+@pytest.mark.parametrize("k,Hin,Win", [(3, 16, 16), (3, 15, 15), (3, 22, 37), (3, 3, 5), (1, 16, 16), (1, 13, 13), (1, 8, 21)])
+def test_stride2_data_gradient(pkg, dev, k, Hin, Win):
+    """3x3: by output parity (four 2x2 kernels over the gradient's own pixels, interleaved stores: SPK_CONV_DGRAD_S2);
+    1x1 into a fresh tensor: W^T g at the output size, dilated afterwards; 1x1 accumulating into the residual sum: the
+    stride-1 kernel on the zero-dilated gradient.  Even / odd / non-square sizes, ragged channel counts."""
     B, Cin, Cout = 2, 24, 40
-    x = recipe_input(f"s2.x.{k}.{Hin}", (B, Cin, Hin, Hin)).requires_grad_(True)
+    x = recipe_input(f"s2.x.{k}.{Hin}.{Win}", (B, Cin, Hin, Win)).requires_grad_(True)
     w = recipe_tensor(f"s2.w.{k}", (Cout, Cin, k, k))
     y = F.conv2d(x, w, stride=2, padding=(k - 1) // 2)
-    g = recipe_input(f"s2.g.{k}.{Hin}", y.shape)
+    g = recipe_input(f"s2.g.{k}.{Hin}.{Win}", y.shape)
     y.backward(g)
-    hd = y.shape[-1] if pkg.ops.dgrad_at_output_size(k, 2) else Hin
-    assert pkg.ops.dgrad_at_output_size(k, 2) == (k == 1)
-    cfg = pkg.ops.conv2d_pick_config(k, 1, B, Cout, Cin, hd, hd)
-    wp = pkg.ops.pack_conv_weight(w.to(dev), cfg, transpose_flip=True)
-    dx = pkg.ops.conv2d_dgrad(g.to(dev), wp, Cin, k, 2, (Hin, Hin), cfg)
-    assert dx.shape == x.shape and rel_l2(dx, x.grad) < TOL
-    cfg = pkg.ops.conv2d_pick_config(k, 1, B, Cout, Cin, Hin, Hin)
-    wp = pkg.ops.pack_conv_weight(w.to(dev), cfg, transpose_flip=True)
-    # accumulate into an existing gradient (the residual sum)
-    base = recipe_input("s2.base", x.shape).to(dev)
-    dx2 = pkg.ops.conv2d_dgrad(g.to(dev), wp, Cin, k, 2, (Hin, Hin), cfg, out=base.clone(), accumulate=True)
+    base = recipe_input(f"s2.base.{Hin}.{Win}", x.shape).to(dev)
+    for out, acc in ((None, False), (base.clone(), True), (torch.full_like(base, 7.0), False)):
+        cfg, tf = pkg.ops.dgrad_plan(k, 2, B, Cout, Cin, (Hin, Win), y.shape[-2:], out, acc)
+        assert tf == (2 if k == 3 else 1)
+        wp = pkg.ops.pack_conv_weight(w.to(dev), cfg, transpose_flip=tf)
+        dx = pkg.ops.conv2d_dgrad(g.to(dev), wp, Cin, k, 2, (Hin, Win), cfg, out=out, accumulate=acc)
+        assert dx.shape == x.shape and rel_l2(dx, (base.cpu() + x.grad) if acc else x.grad) < TOL
+        assert out is None or dx.data_ptr() == out.data_ptr()
+    if k == 3:                 # every tile config built for the parity form
+        for cfg in range(4):
+            if not pkg.ops.conv2d_config_fits(cfg, 2, 1, B, Cout, 4 * Cin, *y.shape[-2:]):
+                continue
+            wp = pkg.ops.pack_conv_weight(w.to(dev), cfg, transpose_flip=2)
+            assert rel_l2(pkg.ops.conv2d_dgrad(g.to(dev), wp, Cin, 3, 2, (Hin, Win), cfg), x.grad) < TOL, cfg
+
+
+@pytest.mark.parametrize("groups,B,Cin,Cout,Hin", [(3, 2, 16, 64, 12), (6, 1, 64, 64, 9), (2, 3, 20, 24, 14)])
+def test_stride2_data_gradient_grouped(pkg, dev, groups, B, Cin, Cout, Hin):
+    """The grouped form (the three encoders' conv2 of layer2-4 in one launch), fresh and accumulating."""
+    x = recipe_input(f"s2g.x.{groups}.{Hin}", (B, groups * Cin, Hin, Hin)).requires_grad_(True)
+    ws = [recipe_tensor(f"s2g.w.{groups}.{q}", (Cout, Cin, 3, 3)) for q in range(groups)]
+    y = torch.cat([F.conv2d(x[:, q * Cin:(q + 1) * Cin], ws[q], stride=2, padding=1) for q in range(groups)], 1)
+    g = recipe_input(f"s2g.g.{groups}.{Hin}", y.shape)
+    y.backward(g)
+    cfg, tf = pkg.ops.dgrad_plan(3, 2, B, Cout, Cin, (Hin, Hin), y.shape[-2:])
+    wp = torch.cat([pkg.ops.pack_conv_weight(w.to(dev), cfg, transpose_flip=tf) for w in ws])
+    dx = pkg.ops.conv2d_dgrad(g.to(dev), wp, Cin, 3, 2, (Hin, Hin), cfg, groups=groups)
+    assert rel_l2(dx, x.grad) < TOL
+    base = recipe_input(f"s2g.base.{groups}", x.shape).to(dev)
+    dx2 = pkg.ops.conv2d_dgrad(g.to(dev), wp, Cin, 3, 2, (Hin, Hin), cfg, out=base.clone(), accumulate=True, groups=groups)
     assert rel_l2(dx2, base.cpu() + x.grad) < TOL
+
+
+def test_stride2_data_gradient_flag_is_validated(pkg, dev):
+    L = pkg._lib
+    g = torch.zeros(1, 8, 4, 4, device=dev)
+    wp = pkg.ops.pack_conv_weight(torch.zeros(8, 4, 3, 3, device=dev), 0, transpose_flip=2)
+    with pytest.raises(L.SpkError):          # 9x9 is not the input size of a stride-2 conv with a 4x4 output
+        pkg.ops.conv2d_dgrad(g, wp, 4, 3, 2, (9, 9), 0)
+    with pytest.raises(L.SpkError):          # tile configs 0-3 only
+        pkg.ops.conv2d_dgrad(g, wp, 4, 3, 2, (8, 8), 5)
 
 
 def test_maxpool_adjoint_with_folded_affine(pkg, dev):

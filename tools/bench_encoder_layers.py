@@ -68,9 +68,8 @@ def main():
         if first:
             t_d = 0.0
         else:
-            hd = Ho if ops.dgrad_at_output_size(k, s) else H
-            cfd = ops.conv2d_pick_config(k, 1, B, Cout, Cin, hd, hd)
-            wt = torch.cat([ops.pack_conv_weight(w, cfd, True) for w in ws])
+            cfd, tf = ops.dgrad_plan(k, s, B, Cout, Cin, (H, H), (Ho, Ho))
+            wt = torch.cat([ops.pack_conv_weight(w, cfd, tf) for w in ws])
             t_d = timeit(lambda: ops.conv2d_dgrad(g, wt, Cin, k, s, (H, H), cfd, groups=G))
         tf = lambda t: flops / (t * 1e-3) / 1e12 if t else 0.0
         print(f"{Cin:5d} {Cout:5d} {k} {s} {H:4d} {n:2d} | {t_f * 1e3:8.1f} {tf(t_f):6.1f} | {t_d * 1e3:8.1f} {tf(t_d):6.1f} | "
