@@ -70,8 +70,13 @@ struct WShape {
     static constexpr int KX = KH == 7 ? 3 : (S == 2 ? 2 : 1);   // plane positions (x NPT) a thread stages
 };
 
-template <int KH, int KW, int S, int MODE>
-__global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
+// GEO = 0: the pixel-tile shape (TW x TH x TB) comes from the arguments.  GEO = 1: fixed 16 x 4 x 1 -- the shape of every
+// layer whose plane is at least 16 x 4.  With the shape known at compile time the LDS offsets of the 32 k-steps are
+// immediates instead of ~100 hoisted address registers, the kernel fits 256 registers and TWO workgroups share a CU
+// (one covers the other's staging phase; with runtime geometry the compiler needs 402 registers: one wave per SIMD,
+// and the MFMA pipe idles through every store / barrier phase).
+template <int KH, int KW, int S, int MODE, int GEO>
+__global__ __launch_bounds__(256, GEO ? 2 : 1) void wgrad_kernel(const WgradArgs p) {
     using SH = WShape<KH, KW, S>;
     constexpr int TAPS = SH::TAPS, TP = SH::TP, CI_T = SH::CI_T, CO_T = SH::CO_T, PIX_T = SH::PIX_T, PAD = SH::PAD;
     constexpr bool AFF = MODE == WG_AFFINE_RELU;
@@ -88,7 +93,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     const int half = lane >> 5, l32 = lane & 31;
     const int wco = wave & 1, wci = (wave >> 1) % SH::WCI, wpx = (wave >> 1) / SH::WCI;
 
-    const int TW = 1 << p.lgTW, TH = 1 << p.lgTH, TB = 1 << p.lgTB;
+    const int lgTW = GEO ? 4 : p.lgTW, lgTH = GEO ? 2 : p.lgTH, lgTB = GEO ? 0 : p.lgTB;
+    const int TW = 1 << lgTW, TH = 1 << lgTH, TB = 1 << lgTB;
     const int PW = (TW - 1) * S + KW, PH = (TH - 1) * S + KH, PLANE = PH * PW;
     const int GPITCH = PIX_T + 1, XPITCH = (TB * PLANE) | 1;
     float* const g_s = smem;
@@ -133,12 +139,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
         int bx_ = (tile_);                                                                                  \
         const int tx_ = bx_ % p.tiles_x; bx_ /= p.tiles_x;                                                  \
         const int ty_ = bx_ % p.tiles_y;                                                                    \
-        const int b0_ = (bx_ / p.tiles_y) << p.lgTB, y0_ = ty_ << p.lgTH, x0_ = tx_ << p.lgTW;              \
+        const int b0_ = (bx_ / p.tiles_y) << lgTB, y0_ = ty_ << lgTH, x0_ = tx_ << lgTW;                    \
         gok = 0;                                                                                            \
         _Pragma("unroll") for (int i = 0; i < NG; ++i) {                                                    \
             const int e = tid + 256 * i;                                                                    \
             const int co = e / PIX_T, pix = e % PIX_T;                                                      \
-            const int px = pix & (TW - 1), py = (pix >> p.lgTW) & (TH - 1), tb = pix >> (p.lgTW + p.lgTH);  \
+            const int px = pix & (TW - 1), py = (pix >> lgTW) & (TH - 1), tb = pix >> (lgTW + lgTH);        \
             const int b = b0_ + tb, yy = y0_ + py, xx = x0_ + px;                                           \
             const bool ok = tb < TB && b < p.B && yy < p.H && xx < p.W && co0 + co < co_end;                \
             const size_t off = ok ? ((size_t)b * p.Cy + co0 + co) * HW + (size_t)yy * p.W + xx : 0;         \
@@ -179,12 +185,24 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
     }
 
     int tile = blockIdx.z;
+#ifdef WGRAD_LAB
+    long long lab_t[5] = {0, 0, 0, 0, 0};
+    long long lab_a = __builtin_readcyclecounter();
+    const long long lab_begin = lab_a;
+#define LAB_MARK(i_) { const long long n_ = __builtin_readcyclecounter(); lab_t[i_] += n_ - lab_a; lab_a = n_; }
+#else
+#define LAB_MARK(i_)
+#endif
     if (tile < p.n_tiles) SPK_WG_PREFETCH(tile);
+    LAB_MARK(0)
     for (; tile < p.n_tiles; tile += gridDim.z) {
         __syncthreads();          // previous tile fully consumed
+        LAB_MARK(1)
         SPK_WG_STORE();
         __syncthreads();
+        LAB_MARK(2)
         if (tile + (int)gridDim.z < p.n_tiles) SPK_WG_PREFETCH(tile + (int)gridDim.z);
+        LAB_MARK(3)
         // ---- k-steps over this wave's pixel range: A read once per step, reused by every tap ----
         const float* ga = g_s + (wco * 32 + l32) * GPITCH;
         // B-fragment row of this lane: its input channel, or (PACK) its (kx, ci) pair: channel row + kx columns
@@ -198,8 +216,8 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
 #define SPK_WG_FRAG(st_, slot_)                                                                             \
     {                                                                                                       \
         const int pix = wpx * (PIX_T / SH::WPX) + 2 * (st_) + half;                                         \
-        const int px = pix & (TW - 1), py = (pix >> p.lgTW) & (TH - 1);                                     \
-        const int tb = min(pix >> (p.lgTW + p.lgTH), TB - 1);   /* idle pixel groups hold zeros in g_s */   \
+        const int px = pix & (TW - 1), py = (pix >> lgTW) & (TH - 1);                                       \
+        const int tb = min(pix >> (lgTW + lgTH), TB - 1);       /* idle pixel groups hold zeros in g_s */   \
         fa[slot_] = ga[pix];                                                                                \
         const float* xp = xb + tb * PLANE + (py * S) * PW + px * S;                                         \
         _Pragma("unroll") for (int t = 0; t < TP; ++t) {                                                    \
@@ -221,7 +239,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs p) {
             __builtin_amdgcn_sched_group_barrier(0x8, TP, 0);
         });
 #undef SPK_WG_FRAG
+        LAB_MARK(4)
     }
+#ifdef WGRAD_LAB
+    if (KH == 3 && blockIdx.x == 1 && blockIdx.y == 0 && blockIdx.z == 3 && (tid & 63) == 0)
+        printf("GEO %d wave %d: first-prefetch %lld  barrier-wait %lld  store+barrier %lld  prefetch-issue %lld  mfma %lld  total %lld (tiles %d)\n",
+               GEO, wave, lab_t[0], lab_t[1], lab_t[2], lab_t[3], lab_t[4], (long long)__builtin_readcyclecounter() - lab_begin,
+               (p.n_tiles - (int)blockIdx.z + (int)gridDim.z - 1) / (int)gridDim.z);
+#endif
 #undef SPK_WG_PREFETCH
 #undef SPK_WG_STORE
 
@@ -319,7 +344,13 @@ int run_wgrad(const spk_wgrad_desc* d, hipStream_t stream) {
     a.Cy = G * d->Cout;
     a.lgTW = spk::ilog2(g.TW); a.lgTH = spk::ilog2(g.TH); a.lgTB = spk::ilog2(g.TB);
     a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y; a.n_tiles = g.n_tiles;
-    auto kern = &wgrad_kernel<KH, KW, S, MODE>;
+    // the compile-time tile shape (two workgroups per CU) wherever the geometry picked it
+    // (measured, profiles/r01_k_wgrad_phases.txt: +8% on the trunk's BatchNorm-folded layers, whose store phase carries
+    // the affine; -4% on the decoder's plain layers, which stay on the one-wave form)
+    constexpr bool HAS_FIXED = KH == 3 && S == 1 && MODE == WG_AFFINE_RELU;
+    static const bool allow_fixed = [] { const char* e = getenv("SPK_WGRAD_FIXED"); return !e || atoi(e) != 0; }();
+    const bool fixed = HAS_FIXED && allow_fixed && g.TW == 16 && g.TH == 4 && g.TB == 1;
+    auto kern = fixed ? &wgrad_kernel<KH, KW, S, MODE, HAS_FIXED ? 1 : 0> : &wgrad_kernel<KH, KW, S, MODE, 0>;
     if (g.lds_bytes > 64 * 1024) {
         static bool raised = false;
         if (!raised) {
