@@ -129,6 +129,10 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
     constexpr int NSLOT = SH::NSLOT, W_FLOATS = SH::W_FLOATS, WV = SH::WV, PAD = SH::PAD;
     static_assert(!UPS || S == 1, "upsample folding needs stride 1");
     extern __shared__ __attribute__((aligned(16))) float smem[];
+#ifdef SPK_LAB_CLOCK   // core clock under this kernel's load: shader cycles (s_memtime) per 100 MHz tick (s_memrealtime)
+    const long long lab_c0 = __builtin_readcyclecounter();
+    const unsigned long long lab_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -590,6 +594,14 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
             }
         }
     }
+#ifdef SPK_LAB_CLOCK
+    if (KH == 3 && threadIdx.x == 0 && blockIdx.y == 0 && blockIdx.z == 0 && (blockIdx.x == 0 || blockIdx.x == gridDim.x / 2)) {
+        const long long c = __builtin_readcyclecounter() - lab_c0;
+        const unsigned long long r = __builtin_amdgcn_s_memrealtime() - lab_r0;
+        printf("conv clock: wg %u of %u (Cin %d, %dx%d): %lld cycles in %llu ticks of 10 ns = %.0f MHz\n", blockIdx.x, gridDim.x, p.Cin,
+               p.H, p.W, c, r, r ? (double)c / (double)r * 100.0 : 0.0);
+    }
+#endif
 }
 
 // ---- host side -------------------------------------------------------------------------------------

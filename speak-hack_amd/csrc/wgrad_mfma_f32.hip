@@ -189,6 +189,7 @@ __global__ __launch_bounds__(256, GEO ? 2 : 1) void wgrad_kernel(const WgradArgs
     long long lab_t[5] = {0, 0, 0, 0, 0};
     long long lab_a = __builtin_readcyclecounter();
     const long long lab_begin = lab_a;
+    const unsigned long long lab_r0 = __builtin_amdgcn_s_memrealtime();
 #define LAB_MARK(i_) { const long long n_ = __builtin_readcyclecounter(); lab_t[i_] += n_ - lab_a; lab_a = n_; }
 #else
 #define LAB_MARK(i_)
@@ -243,9 +244,10 @@ __global__ __launch_bounds__(256, GEO ? 2 : 1) void wgrad_kernel(const WgradArgs
     }
 #ifdef WGRAD_LAB
     if (KH == 3 && blockIdx.x == 1 && blockIdx.y == 0 && blockIdx.z == 3 && (tid & 63) == 0)
-        printf("GEO %d wave %d: first-prefetch %lld  barrier-wait %lld  store+barrier %lld  prefetch-issue %lld  mfma %lld  total %lld (tiles %d)\n",
+        printf("GEO %d wave %d: first-prefetch %lld  barrier-wait %lld  store+barrier %lld  prefetch-issue %lld  mfma %lld  total %lld (tiles %d) in %llu ticks of 10 ns\n",
                GEO, wave, lab_t[0], lab_t[1], lab_t[2], lab_t[3], lab_t[4], (long long)__builtin_readcyclecounter() - lab_begin,
-               (p.n_tiles - (int)blockIdx.z + (int)gridDim.z - 1) / (int)gridDim.z);
+               (p.n_tiles - (int)blockIdx.z + (int)gridDim.z - 1) / (int)gridDim.z,
+               (unsigned long long)(__builtin_amdgcn_s_memrealtime() - lab_r0));
 #endif
 #undef SPK_WG_PREFETCH
 #undef SPK_WG_STORE
