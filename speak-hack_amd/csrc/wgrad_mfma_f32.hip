@@ -269,6 +269,165 @@ __global__ __launch_bounds__(256, GEO ? 2 : 1) void wgrad_kernel(const WgradArgs
         }
 }
 
+// ---- 3x3 stride-1 weight gradient, staging interleaved with the MFMAs ------------------------------------------------
+// Same block (64co x 64ci x 9 taps, 4 waves, 16x4-pixel tiles) and the same arithmetic order as wgrad_kernel<3,3,1>, but
+// the LDS tile is double-buffered and the next tile's staging rides in the shadow of this tile's MFMAs: k-steps 0-15
+// issue its 48 global loads per thread (3 per step), k-steps 16-31 store them to the other buffer (3 per step), and one
+// barrier ends the tile.  In the serial form a tile cost 18.6K cycles of MFMA + 8.6K of load issue, LDS stores and two
+// barriers (profiles/r01_m_core_clock_under_load.txt).  The tile shape is a compile-time constant, so every LDS offset is
+// an immediate and a staging piece is a clamp, a load or store and a select -- the per-piece index arithmetic is what
+// made an earlier pipelined attempt slower than the serial kernel.
+constexpr int WP_TW = 16, WP_PW = WP_TW + 2, WP_PLANE = 6 * WP_PW, WP_GPITCH = 65, WP_XPITCH = WP_PLANE | 1;
+constexpr int WP_BUF = 64 * WP_GPITCH + 64 * WP_XPITCH + 4;      // floats per buffer (+ a dump slot for idle lanes)
+
+__global__ __launch_bounds__(256) void wgrad3x3_pipe_kernel(const WgradArgs p) {
+    constexpr int TAPS = 9, CI_T = 64, CO_T = 64, TW = WP_TW, PW = WP_PW, PLANE = WP_PLANE;
+    constexpr int GPITCH = WP_GPITCH, XPITCH = WP_XPITCH, BUF = WP_BUF;
+    constexpr int NGL = 16, NXL = 32, STEPS = 32, PPS = (NGL + NXL) / (STEPS / 2);   // 3 staging pieces per k-step
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l32 = lane & 31;
+    const int wco = wave & 1, wci = wave >> 1;
+
+    const int co0 = blockIdx.x * CO_T;
+    const int grp = co0 / p.Cout;
+    const int co_end = (grp + 1) * p.Cout;
+    const int cx0 = grp * p.gin;
+    const int ci0 = blockIdx.y * CI_T;
+    const int nci = min(CI_T, p.Cin - ci0);
+    const size_t HW = (size_t)p.H * p.W, src_plane = (size_t)p.Hs * p.Ws;
+
+    // staging roles.  Gradient tile: thread -> pixel tid % 64, output channels tid / 64 + 4 i.  Input tile: thread -> plane
+    // position tid % 128 (108 of them exist), channels 32 (tid / 128) + i (a wave-uniform slice).
+    const int gpix = tid & 63, gpx = gpix & (TW - 1), gpy = gpix >> 4, gco = wave;
+    const int xpos = tid & 127, cbw = (wave >> 1) * NXL;
+    const bool xpos_ok = xpos < PLANE;
+    const int xr = xpos / PW, xc = xpos - xr * PW;
+    const int g_dst = gco * GPITCH + gpix;                                      // + 4 i GPITCH
+    const int x_dst = xpos_ok ? CO_T * GPITCH + cbw * XPITCH + xpos : BUF - 1;  // + i XPITCH (idle lanes: the dump slot)
+    const int x_dst_step = xpos_ok ? XPITCH : 0;
+
+    f32x16 acc[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    float gg[NGL], xg[NXL];
+    bool g_ok = false, x_ok = false;          // the tile being staged: this thread's pixel / plane position is inside the image
+    const float* g_ptr = p.g;                 // ... and the address of its element in channel 0 of the block
+    const float* x_ptr = p.x;
+
+    // tile -> pointers and validity of this thread's elements (elements outside the image read the tensor's first float)
+    auto aim = [&](int tile) {
+        const int tx = tile % p.tiles_x;
+        const int q = tile / p.tiles_x;
+        const int ty = q % p.tiles_y, b = q / p.tiles_y;
+        const int yy = ty * 4 + gpy, xx = tx * TW + gpx;
+        g_ok = yy < p.H && xx < p.W;
+        g_ptr = p.g + (g_ok ? (size_t)b * p.Cy * HW + (size_t)yy * p.W + xx : 0);
+        const int uy = ty * 4 + xr - 1, ux = tx * TW + xc - 1;
+        x_ok = xpos_ok && uy >= 0 && uy < p.Hs && ux >= 0 && ux < p.Ws;
+        x_ptr = p.x + (x_ok ? ((size_t)b * p.Cx + cx0 + ci0) * src_plane + (size_t)uy * p.Ws + ux : 0);
+    };
+    // staging pieces (j static): 0..15 the gradient element j, 16..47 the input channel j - 16
+    auto load_piece = [&](auto j_) {
+        constexpr int j = decltype(j_)::value;
+        if constexpr (j < NGL) {
+            const int c = min(co0 + gco + 4 * j, co_end - 1);      // rows past the group's last channel: clamped (see the store)
+            gg[j] = g_ptr[g_ok ? (size_t)c * HW : 0];
+        } else {
+            const int c = min(cbw + (j - NGL), nci - 1);
+            xg[j - NGL] = x_ptr[x_ok ? (size_t)c * src_plane : 0];
+        }
+    };
+    auto store_piece = [&](float* buf, auto j_) {
+        constexpr int j = decltype(j_)::value;
+        if constexpr (j < NGL) {
+            // only the PIXEL axis (the contraction) needs zeros; rows of channels past the block's last one hold the
+            // clamped row's values and feed accumulator rows / columns the epilogue never writes (a uniform test here
+            // would also split the loop body into branches)
+            buf[g_dst + 4 * j * GPITCH] = g_ok ? gg[j] : 0.f;
+        } else {
+            buf[x_dst + (j - NGL) * x_dst_step] = x_ok ? xg[j - NGL] : 0.f;
+        }
+    };
+
+    int tile = blockIdx.z;
+    int cur = 0;
+    if (tile < p.n_tiles) {                  // first tile: staged the serial way
+        aim(tile);
+        wg_static_for<0, NGL + NXL>([&](auto j_) { load_piece(j_); });
+        wg_static_for<0, NGL + NXL>([&](auto j_) { store_piece(smem, j_); });
+    }
+    __syncthreads();
+
+    // one tile's 32 k-steps out of buffer `cur`; PIPE: the next tile is staged into the other buffer on the way
+    auto run_tile = [&](auto pipe_) {
+        constexpr bool PIPE = decltype(pipe_)::value;
+        const float* cbuf = smem + cur * BUF;
+        float* nbuf = smem + (cur ^ 1) * BUF;
+        const float* ga = cbuf + (wco * 32 + l32) * GPITCH + half;              // pixel 2 st + half of this lane's channel row
+        const float* xb = cbuf + CO_T * GPITCH + (wci * 32 + l32) * XPITCH + half;
+        float fa[2], fb[2][TAPS];
+#define SPK_WP_FRAG(st_, slot_)                                                                               \
+    {                                                                                                         \
+        constexpr int px_ = (2 * (st_)) & (TW - 1), py_ = (2 * (st_)) >> 4;                                   \
+        fa[slot_] = ga[2 * (st_)];                                                                            \
+        _Pragma("unroll") for (int t = 0; t < TAPS; ++t) fb[slot_][t] = xb[(py_ + t / 3) * PW + px_ + t % 3];  \
+    }
+        SPK_WP_FRAG(0, 0);
+        wg_static_for<0, STEPS>([&](auto s_) {
+            constexpr int st = decltype(s_)::value;
+            if constexpr (st + 1 < STEPS) SPK_WP_FRAG(st + 1, (st + 1) & 1);
+            if constexpr (PIPE && st < STEPS / 2)
+                wg_static_for<PPS * st, PPS * st + PPS>([&](auto j_) { load_piece(j_); });
+            if constexpr (PIPE && st >= STEPS / 2)
+                wg_static_for<PPS * (st - STEPS / 2), PPS * (st - STEPS / 2) + PPS>([&](auto j_) { store_piece(nbuf, j_); });
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[st & 1], fb[st & 1][t], acc[t], 0, 0, 0);
+            // order: next step's fragments, then the MFMAs with one staging access behind every third
+            if constexpr (st + 1 < STEPS) __builtin_amdgcn_sched_group_barrier(0x100, TAPS + 1, 0);
+            if constexpr (PIPE) {
+#pragma unroll
+                for (int k = 0; k < PPS; ++k) {
+                    __builtin_amdgcn_sched_group_barrier(0x8, TAPS / PPS, 0);
+                    __builtin_amdgcn_sched_group_barrier(st < STEPS / 2 ? 0x20 : 0x200, 1, 0);
+                }
+            } else {
+                __builtin_amdgcn_sched_group_barrier(0x8, TAPS, 0);
+            }
+        });
+#undef SPK_WP_FRAG
+    };
+
+    for (; tile < p.n_tiles; tile += gridDim.z) {
+        const int next = tile + (int)gridDim.z;
+        if (next < p.n_tiles) {               // uniform
+            aim(next);
+            run_tile(std::true_type{});
+        } else {
+            run_tile(std::false_type{});
+        }
+        __syncthreads();                      // every wave is done with `cur`, and the other buffer is complete
+        cur ^= 1;
+    }
+
+    // ---- partial block -> slab [slab][co][tap][ci] (ci contiguous: 128-B stores per half wave) ----
+    float* out = p.slabs + (size_t)blockIdx.z * p.Cy * TAPS * p.Cin;
+    const int ci = ci0 + wci * 32 + l32;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (co < co_end && ci < p.Cin) out[((size_t)co * TAPS + t) * p.Cin + ci] = acc[t][r];
+        }
+}
+
 // dW[co][ci][tap] (+)= scale * sum_slab slabs[slab][co][tap][ci]   (fixed order)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw,
                                                           int n_slabs, int Cout, int Cin, int taps, float scale,
@@ -352,6 +511,24 @@ int run_wgrad(const spk_wgrad_desc* d, hipStream_t stream) {
     constexpr bool HAS_FIXED = KH == 3 && S == 1 && MODE == WG_AFFINE_RELU;
     static const bool allow_fixed = [] { const char* e = getenv("SPK_WGRAD_FIXED"); return !e || atoi(e) != 0; }();
     const bool fixed = HAS_FIXED && allow_fixed && g.TW == 16 && g.TH == 4 && g.TB == 1;
+    // plain 3x3 stride-1 layers on that tile shape: the form whose staging is interleaved with the MFMAs
+    static const bool allow_pipe = [] { const char* e = getenv("SPK_WGRAD_PIPE"); return !e || atoi(e) != 0; }();
+    if (KH == 3 && S == 1 && MODE == WG_PLAIN && allow_pipe && g.TW == 16 && g.TH == 4 && g.TB == 1) {
+        static bool pipe_raised = false;
+        if (!pipe_raised) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_pipe_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return spk::fail(SPK_ELAUNCH, "hipFuncSetAttribute(LDS): %s", hipGetErrorString(e));
+            pipe_raised = true;
+        }
+        dim3 pgrid((unsigned)spk::ceil_div(G * d->Cout, SH::CO_T), (unsigned)spk::ceil_div(d->Cin, SH::CI_T), (unsigned)g.splits);
+        hipLaunchKernelGGL(wgrad3x3_pipe_kernel, pgrid, dim3(256), 2 * WP_BUF * sizeof(float), stream, a);
+        int prc = spk::check_launch("wgrad3x3_pipe_kernel");
+        if (prc != SPK_OK) return prc;
+        const unsigned pblocks = (unsigned)std::min<size_t>((slab_floats + 255) / 256, 2048);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(pblocks), dim3(256), 0, stream, a.slabs, d->dw, g.n_slabs, G * d->Cout,
+                           d->Cin, SH::TAPS, d->scale, d->accumulate ? 1 : 0);
+        return spk::check_launch("wgrad_reduce_kernel");
+    }
     auto kern = fixed ? &wgrad_kernel<KH, KW, S, MODE, HAS_FIXED ? 1 : 0> : &wgrad_kernel<KH, KW, S, MODE, 0>;
     if (g.lds_bytes > 64 * 1024) {
         static bool raised = false;
