@@ -228,7 +228,9 @@ static Geometry geometry_any(int kh, int stride, int cfg, int B, int Cin, int Co
 // epilogues; the wide-pixel tile for Cout <= 64; the small tile when the whole problem is small.
 static int pick_config(int kh, int stride, int B, int Cin, int Cout, int H, int W) {
     const long long pixels = (long long)B * H * W;
-    const int shape = Cout <= 32 ? 3 : (Cout <= 64 ? (pixels >= 64 * 1024 ? 1 : 2) : (pixels >= 2048 ? 0 : 2));
+    // (128 -> 128 at 128^2: the wide-pixel tile measured 335 us against 350 for the square one; with Cin = 256 the square wins)
+    const bool wide = Cout <= 64 ? pixels >= 64 * 1024 : (Cout <= 128 && Cin <= 128 && kh == 3 && stride == 1 && pixels >= 128 * 1024);
+    const int shape = Cout <= 32 ? 3 : (wide ? 1 : (Cout <= 64 ? 2 : (pixels >= 2048 ? 0 : 2)));
     const int base = kh == 1 ? 8 : (kh == 2 ? 0 : 4);   // 1x1 -> ids 8-11, 2x2 -> 0-3; everything else prefers ids 4-7
     const int lo = kh == 1 ? 8 : ((kh == 3 && stride == 1) || kh == 2 ? 0 : 4), hi = kh == 1 ? 11 : (kh == 2 ? 3 : 7);
     const int want = base + shape;
