@@ -7,12 +7,15 @@ mini-batch is sharded by rank (no data-path collective in forward), and the ONE 
 training iteration -- summing parameter gradients over ranks -- is done here:
 
 * parameters are grouped, in reverse registration order (~ the order autograd finishes them: toRGB
-  first, mapping last), into flat fp32 buckets; each ``param.grad`` is a *view* into its bucket, so
-  backward kernels accumulate straight into the communication buffer (no pack/unpack copies);
-* a post-accumulate hook per parameter counts arrivals; when a bucket is complete its all-reduce is
-  launched asynchronously -- on GPU that is RCCL over xGMI on its own stream, overlapping the rest of
-  backward (the big low-resolution 512x512x3x3 weight gradients, 9.4 MB each, arrive last and are the
-  only exposed part);
+  first, mapping last), into flat fp32 buckets;
+* ``zero_grad()`` drops the gradients (``p.grad = None``), so backward's first -- here only -- gradient of a
+  parameter is simply adopted by autograd: no zero-fill of 386 MB and no ``grad += g`` kernel per parameter
+  (630 launches, 2 ms of the generator step when the gradients lived inside pre-zeroed buckets);
+* a post-accumulate hook per parameter counts arrivals; when a bucket is complete its gradients are gathered into
+  the flat buffer by ONE multi-tensor copy, ``param.grad`` is re-pointed at its slice of the buffer, and the
+  all-reduce is launched asynchronously -- on GPU that is RCCL over xGMI on its own stream, overlapping the rest
+  of backward (the big low-resolution 512x512x3x3 weight gradients, 9.4 MB each, arrive last and are the only
+  exposed part).  With one rank there is nothing to exchange and nothing is copied;
 * ``finish()`` waits for the outstanding collectives (stream-side on GPU) and leaves ``1/world``-scaled
   sums in place, exactly what DDP's gradient averaging leaves.
 
@@ -40,7 +43,7 @@ class GradBucketReducer:
             raise ValueError("GradBucketReducer: no trainable parameters")
         self.params = list(reversed(plist))
         dev, dtype = self.params[0].device, self.params[0].dtype
-        # ---- assign parameters to buckets and carve grad views out of flat buffers ----
+        # ---- assign parameters to buckets ----
         self.buckets: List[dict] = []
         cur, cur_bytes = [], 0
         for p in self.params:
@@ -57,15 +60,19 @@ class GradBucketReducer:
         self._handles = []
         self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(bi))
                        for bi, b in enumerate(self.buckets) for p in b["params"]]
+        self.zero_grad()
 
     def _seal(self, plist, dev, dtype):
         total = sum(p.numel() for p in plist)
-        flat = torch.zeros(total, device=dev, dtype=dtype)
-        off = 0
-        for p in plist:
-            p.grad = flat[off:off + p.numel()].view_as(p)      # gradients accumulate into the bucket
-            off += p.numel()
-        self.buckets.append({"params": plist, "flat": flat, "pending": len(plist), "n": len(plist)})
+        flat = views = None
+        if self.world > 1:                     # the communication buffer and each parameter's slice of it
+            flat = torch.zeros(total, device=dev, dtype=dtype)
+            views, off = [], 0
+            for p in plist:
+                views.append(flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+        self.buckets.append({"params": plist, "flat": flat, "views": views, "numel": total, "pending": len(plist),
+                             "n": len(plist)})
 
     def _make_hook(self, bi):
         def hook(param):
@@ -78,15 +85,30 @@ class GradBucketReducer:
     def _launch(self, b):
         if self.world == 1:
             return
-        if self.average:
-            b["flat"].div_(self.world)
+        have_v, have_g, missing = [], [], []
+        for p, v in zip(b["params"], b["views"]):
+            if p.grad is None:
+                missing.append(v)              # no gradient this step: contributes zeros
+            elif p.grad.data_ptr() != v.data_ptr():
+                have_v.append(v)
+                have_g.append(p.grad)
+        with torch.no_grad():
+            if missing:
+                torch._foreach_zero_(missing)
+            if have_v:
+                torch._foreach_copy_(have_v, have_g)
+            for p, v in zip(b["params"], b["views"]):
+                p.grad = v                     # the optimizer reads the reduced values in place
+            if self.average:
+                b["flat"].div_(self.world)
         self._handles.append(dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     # ---- step protocol -------------------------------------------------------------------------
     def zero_grad(self):
-        """Zero the buckets in place (keeps the grad views; do not call ``module.zero_grad(set_to_none=True)``)."""
+        """Drop the gradients (``set_to_none``) and re-arm the buckets."""
         for b in self.buckets:
-            b["flat"].zero_()
+            for p in b["params"]:
+                p.grad = None
             b["pending"] = b["n"]
         self._handles = []
 
@@ -101,20 +123,33 @@ class GradBucketReducer:
             h.wait()
         self._handles = []
 
+    def _grads(self):
+        return [p.grad for p in self.params if p.grad is not None]
+
     def grad_norm(self) -> torch.Tensor:
         """Global L2 norm of the (already synchronised, hence rank-identical) gradients -- what
         ``clip_grad_norm_`` (train.py:207-208) needs; no further collective."""
-        return torch.sqrt(sum((b["flat"].double() ** 2).sum() for b in self.buckets)).float()
+        if self.world > 1:
+            return torch.sqrt(sum((b["flat"].double() ** 2).sum() for b in self.buckets)).float()
+        grads = self._grads()
+        if not grads:
+            return torch.zeros((), device=self.params[0].device)
+        return torch.linalg.vector_norm(torch.stack(torch._foreach_norm(grads)).double()).float()
 
     def clip_(self, max_norm: float) -> torch.Tensor:
         total = self.grad_norm()
         coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
-        for b in self.buckets:
-            b["flat"].mul_(coef)
+        if self.world > 1:
+            for b in self.buckets:
+                b["flat"].mul_(coef)
+        else:
+            grads = self._grads()
+            if grads:
+                torch._foreach_mul_(grads, coef)
         return total
 
     def bytes_per_step(self) -> int:
-        return sum(b["flat"].numel() * b["flat"].element_size() for b in self.buckets)
+        return sum(b["numel"] * p.element_size() for b in self.buckets for p in b["params"][:1])
 
     def remove(self):
         for h in self._hooks:

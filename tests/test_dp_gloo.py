@@ -91,5 +91,13 @@ def test_single_process_reducer_is_a_noop_exchange():
     ref(x).sum().backward()
     for p, q in zip(model.parameters(), ref.parameters()):
         assert torch.allclose(p.grad, q.grad)
+    assert all(b["flat"] is None for b in red.buckets)         # one rank: nothing to exchange, nothing is copied
+    total = torch.sqrt(sum((q.grad.double() ** 2).sum() for q in ref.parameters())).float()
+    assert torch.allclose(red.grad_norm(), total, rtol=1e-5)
+    red.clip_(0.5 * float(total))
+    for p, q in zip(model.parameters(), ref.parameters()):
+        assert torch.allclose(p.grad, q.grad * 0.5, rtol=1e-4, atol=1e-7)
+    red.zero_grad()
+    assert all(p.grad is None for p in model.parameters())     # set_to_none: the next backward's gradients are adopted
     assert red.bytes_per_step() == sum(p.numel() * 4 for p in model.parameters())
     assert dp.shard_batch(64, 3, 8) == (24, 32)
