@@ -174,6 +174,10 @@ typedef struct spk_wgrad_desc {
      * Cout must be a multiple of 64.  0 / 1 = ordinary. */
     int32_t groups;
     int32_t group_in_stride;
+    /* fold (0 / 1 = none; must divide groups): groups q and q + groups/fold are the SAME conv applied to another set of
+     * images (IRFD runs each encoder on x_s and on x_t, model.py:84-90), so their weight gradients add: dw is
+     * [groups/fold * Cout, Cin, kh, kw], summed in the slab reduce instead of by a separate pass. */
+    int32_t fold;
 } spk_wgrad_desc;
 int64_t spk_conv2d_wgrad_workspace_bytes(int kh, int kw, int stride, int splits, int B, int Cin, int Cout, int H, int W);
 int spk_conv2d_wgrad(const spk_wgrad_desc* desc, void* stream);

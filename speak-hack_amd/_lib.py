@@ -64,7 +64,8 @@ class WgradDesc(C.Structure):
                 ("B", C.c_int32), ("Cin", C.c_int32), ("Cout", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
                 ("Hin", C.c_int32), ("Win", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32),
                 ("flags", C.c_uint32), ("scale", C.c_float), ("accumulate", C.c_int32), ("splits", C.c_int32),
-                ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("groups", C.c_int32), ("group_in_stride", C.c_int32)]
+                ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("groups", C.c_int32), ("group_in_stride", C.c_int32),
+                ("fold", C.c_int32)]
 
 
 _PROTOTYPES = {

@@ -430,9 +430,11 @@ __global__ __launch_bounds__(256) void wgrad3x3_pipe_kernel(const WgradArgs p) {
 
 // dW[co][ci][tap] (+)= scale * sum_slab slabs[slab][co][tap][ci]   (fixed order)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw,
-                                                          int n_slabs, int Cout, int Cin, int taps, float scale,
-                                                          int accumulate) {
-    const size_t total = (size_t)Cout * Cin * taps;
+                                                          int n_slabs, int Cout_all, int Cin, int taps, float scale,
+                                                          int accumulate, int fold) {
+    // fold > 1: output channel co also takes the slabs' channels co + Cout, co + 2 Cout, ... (the same conv on other images)
+    const int Cout = Cout_all / fold;
+    const size_t total = (size_t)Cout * Cin * taps, slab_stride = (size_t)Cout_all * Cin * taps;
     // walk the slabs in THEIR order ([co][tap][ci]: coalesced reads of n_slabs x total floats) and scatter the
     // (n_slabs times smaller) result into [co][ci][tap]
     for (size_t src = (size_t)blockIdx.x * blockDim.x + threadIdx.x; src < total; src += (size_t)gridDim.x * blockDim.x) {
@@ -440,15 +442,20 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         const int tap = (int)((src / Cin) % taps);
         const int co = (int)(src / ((size_t)Cin * taps));
         // four interleaved partial sums (slab s goes to sum s % 4): still one fixed order, but four loads in flight
-        float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
-        int s = 0;
-        for (; s + 4 <= n_slabs; s += 4) {
-            const float a0 = slabs[(size_t)s * total + src], a1 = slabs[(size_t)(s + 1) * total + src];
-            const float a2 = slabs[(size_t)(s + 2) * total + src], a3 = slabs[(size_t)(s + 3) * total + src];
-            v0 += a0; v1 += a1; v2 += a2; v3 += a3;
+        float v = 0.f;
+        for (int f = 0; f < fold; ++f) {
+            const float* sl = slabs + (size_t)f * total + src;
+            float v0 = 0.f, v1 = 0.f, v2 = 0.f, v3 = 0.f;
+            int s = 0;
+            for (; s + 4 <= n_slabs; s += 4) {
+                const float a0 = sl[(size_t)s * slab_stride], a1 = sl[(size_t)(s + 1) * slab_stride];
+                const float a2 = sl[(size_t)(s + 2) * slab_stride], a3 = sl[(size_t)(s + 3) * slab_stride];
+                v0 += a0; v1 += a1; v2 += a2; v3 += a3;
+            }
+            for (; s < n_slabs; ++s) v0 += sl[(size_t)s * slab_stride];
+            v += (v0 + v1) + (v2 + v3);
         }
-        for (; s < n_slabs; ++s) v0 += slabs[(size_t)s * total + src];
-        float v = ((v0 + v1) + (v2 + v3)) * scale;
+        v *= scale;
         const size_t idx = ((size_t)co * Cin + ci) * taps + tap;
         dw[idx] = accumulate ? dw[idx] + v : v;
     }
@@ -526,7 +533,7 @@ int run_wgrad(const spk_wgrad_desc* d, hipStream_t stream) {
         if (prc != SPK_OK) return prc;
         const unsigned pblocks = (unsigned)std::min<size_t>((slab_floats + 255) / 256, 2048);
         hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(pblocks), dim3(256), 0, stream, a.slabs, d->dw, g.n_slabs, G * d->Cout,
-                           d->Cin, SH::TAPS, d->scale, d->accumulate ? 1 : 0);
+                           d->Cin, SH::TAPS, d->scale, d->accumulate ? 1 : 0, d->fold > 1 ? d->fold : 1);
         return spk::check_launch("wgrad_reduce_kernel");
     }
     auto kern = fixed ? &wgrad_kernel<KH, KW, S, MODE, HAS_FIXED ? 1 : 0> : &wgrad_kernel<KH, KW, S, MODE, 0>;
@@ -545,7 +552,7 @@ int run_wgrad(const spk_wgrad_desc* d, hipStream_t stream) {
     if (rc != SPK_OK) return rc;
     const unsigned blocks = (unsigned)std::min<size_t>((slab_floats + 255) / 256, 2048);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, a.slabs, d->dw, g.n_slabs, G * d->Cout,
-                       d->Cin, SH::TAPS, d->scale, d->accumulate ? 1 : 0);
+                       d->Cin, SH::TAPS, d->scale, d->accumulate ? 1 : 0, d->fold > 1 ? d->fold : 1);
     return spk::check_launch("wgrad_reduce_kernel");
 }
 
@@ -735,7 +742,7 @@ int run_wgrad1x1(const spk_wgrad_desc* d, hipStream_t stream) {
     if (rc != SPK_OK) return rc;
     const unsigned blocks = (unsigned)std::min<size_t>((slab_floats + 255) / 256, 2048);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, a.slabs, d->dw, g.splits, G * d->Cout, d->Cin, 1,
-                       d->scale, d->accumulate ? 1 : 0);
+                       d->scale, d->accumulate ? 1 : 0, d->fold > 1 ? d->fold : 1);
     return spk::check_launch("wgrad_reduce_kernel");
 }
 
@@ -780,6 +787,7 @@ int spk_conv2d_wgrad(const spk_wgrad_desc* d, void* stream) {
     SPK_REQUIRE(d && d->g && d->x && d->dw, "wgrad: null pointer");
     SPK_REQUIRE(d->B > 0 && d->Cin > 0 && d->Cout > 0 && d->H > 0 && d->W > 0 && d->Hin > 0 && d->Win > 0, "wgrad: bad shape");
     SPK_REQUIRE(wg_supported(d->kh, d->kw, d->stride), "wgrad: unsupported kernel %dx%d stride %d", d->kh, d->kw, d->stride);
+    SPK_REQUIRE(d->fold <= 1 || (d->groups > 1 && d->groups % d->fold == 0), "wgrad: fold %d must divide groups %d", d->fold, d->groups);
     const bool ups = d->flags & SPK_CONV_UPSAMPLE2X, aff = d->flags & SPK_CONV_IN_AFFINE_RELU;
     SPK_REQUIRE(!(ups && aff), "wgrad: UPSAMPLE2X and IN_AFFINE_RELU are exclusive");
     SPK_REQUIRE(!ups || (d->kh == 3 && d->stride == 1), "wgrad: UPSAMPLE2X needs a 3x3 stride-1 kernel");

@@ -161,6 +161,9 @@ class _GroupPacked:
         return packed
 
 
+_PENDING_BN = "_pending_bn_grads"      # key (never a Parameter) under which per-image BatchNorm gradients wait for their fold
+
+
 class _GroupedConvBN:
     """The same conv + BatchNorm position of G trunks as ONE grouped launch (channels of the groups side by side).
     BatchNorm is per channel, so statistics, the folded affine, the residual add, the pools and the BatchNorm backward
@@ -214,18 +217,32 @@ class _GroupedConvBN:
         gamma, beta, rm, rv = self.flat
         ops.bn_finalize(rec["stats"], rec["count"], gamma, beta, rm, rv, rec["momentum"], self.bns[0].eps)
 
-    def _fold(self, t):
-        """Gradient of all groups [G*n, ...] -> per distinct module [T, n, ...]: groups i and i + T (the same trunk on
-        the second image) share their parameters, so their gradients add."""
-        T = len(self.uniq)
-        t = t.view(self.G // T, T, t.shape[0] // self.G, *t.shape[1:])
-        return t[0] if t.shape[0] == 1 else t.sum(0)
-
     def put_bn_grads(self, grads, dg, db):
-        dg, db = self._fold(dg), self._fold(db)
-        for q in range(len(self.uniq)):
-            bn = self.bns[q]
-            grads[bn.weight], grads[bn.bias] = dg[q], db[q]
+        if self.G == len(self.uniq):
+            for q in range(len(self.uniq)):
+                bn = self.bns[q]
+                grads[bn.weight], grads[bn.bias] = dg.view(self.G, -1)[q], db.view(self.G, -1)[q]
+        else:       # several images per trunk: folded for all layers at once at the end of the pass (flush_bn_grads)
+            grads.setdefault(_PENDING_BN, []).append((self, dg, db))
+
+    @staticmethod
+    def flush_bn_grads(grads):
+        """Sum the per-image BatchNorm gradients of every layer of the pass with ONE concatenation and ONE reduction
+        (they were two tiny reductions per layer: 106 launches per pass)."""
+        pend = grads.pop(_PENDING_BN, None)
+        if not pend:
+            return
+        imgs = pend[0][0].G // len(pend[0][0].uniq)
+        flat = torch.cat([t.view(imgs, -1) for _, dg, db in pend for t in (dg, db)], 1).sum(0)
+        off = 0
+        for m, dg, db in pend:
+            T, n = len(m.uniq), dg.numel() // m.G
+            for which in range(2):
+                part = flat[off:off + T * n].view(T, n)
+                off += T * n
+                for q in range(T):
+                    bn = m.bns[q]
+                    grads[bn.weight if which == 0 else bn.bias] = part[q]
 
     def bn_bwd(self, rec, g, mask_mode, mask_src=None, want_dz=False, **kw):
         return ops.bn_backward(g, rec["y"], rec["affine"], rec["mean"], rec["invstd"], mask_mode, mask_src,
@@ -236,10 +253,10 @@ class _GroupedConvBN:
         Cout, Cin = conv.out_channels, conv.in_channels
         x = rec["x"]
         B, _, H, W = x.shape
+        T = len(self.uniq)
         dw = ops.conv2d_wgrad(dr, x, Cout, Cin, self.k, self.stride, in_affine=rec["in_affine"], groups=G,
-                              shared_input=self.shared_input)
-        dw = self._fold(dw)
-        for q in range(len(self.uniq)):
+                              shared_input=self.shared_input, fold=G // T).view(T, Cout, Cin, self.k, self.k)
+        for q in range(T):
             grads[self.convs[q].weight] = dw[q]
         if not need_dx:
             return None
@@ -503,4 +520,5 @@ class ResNet50Trunk(nn.Sequential):
         dr0, dg, db = stem.bn_bwd(s, dv0, ops.MASK_RECOMPUTE)
         stem.put_bn_grads(grads, dg, db)
         stem.conv_bwd(s, dr0, grads, need_dx=False)       # the image itself takes no gradient
+        _GroupedConvBN.flush_bn_grads(grads)
         return grads

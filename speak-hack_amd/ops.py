@@ -296,9 +296,11 @@ def upsample2x_bilinear(x):
 
 # ---- backward launchers ------------------------------------------------------------------------------
 def conv2d_wgrad(g, x, Cout, Cin, k=3, stride=1, *, upsample=False, in_affine=None, scale=1.0, out=None,
-                 accumulate=False, splits=0, groups=1, shared_input=False):
+                 accumulate=False, splits=0, groups=1, shared_input=False, fold=1):
     """dW[Cout,Cin,k,k] = scale * sum_{b,h,w} g[b,co,h,w] * in(x)[b,ci,h*s+ky-p,w*s+kx-p].
-    ``groups`` > 1: Cout / Cin per group, g has groups*Cout channels, the result is [groups*Cout, Cin, k, k]."""
+    ``groups`` > 1: Cout / Cin per group, g has groups*Cout channels, the result is [groups*Cout, Cin, k, k].
+    ``fold`` > 1: groups q and q + groups/fold share their weights (the same conv on another image set): their
+    gradients are summed in the slab reduce and the result is [groups/fold*Cout, Cin, k, k]."""
     B, _, H, W = g.shape
     if upsample:
         # materialise the x2 image once (one HBM-bound pass) and run the plain kernel: measured 2x faster than
@@ -306,8 +308,11 @@ def conv2d_wgrad(g, x, Cout, Cin, k=3, stride=1, *, upsample=False, in_affine=No
         x, upsample = upsample2x_bilinear(x), False
     Hs, Ws = x.shape[-2:]
     G = int(groups)
+    fold = int(fold)
+    if fold < 1 or G % fold:
+        raise L.SpkError(f"conv2d_wgrad: fold {fold} must divide groups {G}")
     if out is None:
-        out = torch.empty((G * Cout, Cin, k, k), device=g.device, dtype=torch.float32)
+        out = torch.empty((G // fold * Cout, Cin, k, k), device=g.device, dtype=torch.float32)
     ws_bytes = L.lib().spk_conv2d_wgrad_workspace_bytes(k, k, stride, int(splits), B, Cin, G * Cout, H, W)
     if ws_bytes < 0:
         raise L.SpkError("conv2d_wgrad: unsupported problem")
@@ -319,7 +324,7 @@ def conv2d_wgrad(g, x, Cout, Cin, k=3, stride=1, *, upsample=False, in_affine=No
                     dw=L.dptr(out, "dw"), B=B, Cin=Cin, Cout=Cout, H=H, W=W, Hin=Hs, Win=Ws, kh=k, kw=k, stride=stride,
                     flags=flags, scale=float(scale), accumulate=1 if accumulate else 0, splits=int(splits),
                     workspace=ws.data_ptr(), workspace_bytes=ws.numel() * 4, groups=G,
-                    group_in_stride=0 if (shared_input or G == 1) else Cin)
+                    group_in_stride=0 if (shared_input or G == 1) else Cin, fold=fold)
     L.check(L.lib().spk_conv2d_wgrad(C.byref(d), L.stream_ptr()), "spk_conv2d_wgrad")
     return out
 

@@ -94,3 +94,22 @@ def test_grouped_weight_gradient(ops, k, stride, B, Cin, Cout, H, shared, aff):
                           in_affine=(torch.cat(sc), torch.cat(sh)) if aff else None)
     assert dw.shape == (G * Cout, Cin, k, k)
     assert torch.equal(dw, torch.cat(sep, dim=0))
+
+
+@pytest.mark.parametrize("k,stride,B,Cin,Cout,H", [(1, 1, 2, 64, 256, 16), (3, 1, 2, 64, 64, 16), (3, 2, 2, 128, 128, 16),
+                                                     (7, 2, 2, 3, 64, 32), (1, 1, 4, 1024, 2048, 4), (3, 1, 2, 64, 128, 24)])
+def test_grouped_weight_gradient_folded_over_images(ops, k, stride, B, Cin, Cout, H):
+    """``fold`` = 2: groups q and q + 3 are the same conv on a second image (IRFD runs every encoder on x_s and x_t);
+    the slab reduce adds their gradients: equal to the sum of the two halves of the unfolded result."""
+    dev, G = torch.device("cuda:0"), 6
+    torch.manual_seed(3)
+    Ho = ops.conv_out_size(H, k, stride)
+    x = torch.randn(B, G * Cin, H, H, device=dev)
+    g = torch.randn(B, G * Cout, Ho, Ho, device=dev)
+    full = ops.conv2d_wgrad(g, x, Cout, Cin, k, stride, splits=2, groups=G)
+    folded = ops.conv2d_wgrad(g, x, Cout, Cin, k, stride, splits=2, groups=G, fold=2)
+    assert folded.shape == (3 * Cout, Cin, k, k)
+    want = full.view(2, 3 * Cout, Cin, k, k).sum(0)
+    assert float((folded - want).abs().max()) <= 1e-5 * float(want.abs().max())
+    with pytest.raises(Exception):
+        ops.conv2d_wgrad(g, x, Cout, Cin, k, stride, groups=G, fold=4)
