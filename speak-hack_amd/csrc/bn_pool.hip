@@ -7,6 +7,8 @@
 #include "spk_common.hpp"
 
 #include <algorithm>
+#include <cstdint>
+#include <initializer_list>
 
 namespace {
 
@@ -217,6 +219,102 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     }
 }
 
+// 16-byte forms of the two passes (HW % 4 == 0, 16-byte aligned tensors -- every layer of the trunk): TPP threads share a
+// plane -- a whole workgroup for large planes, ONE WAVE for planes of <= 1024 floats (the 16^2 and 8^2 layers are 29 of
+// the trunk's 53 BatchNorms: a 256-thread workgroup per 64-float plane left most lanes idle) -- and a thread of the apply
+// pass handles at least four vectors (the dword form launched one workgroup per 256 elements and reached 43 % of HBM).
+__device__ __forceinline__ float bn_mask(float d, float rv, float mv, int mask_mode, float sc, float sh) {
+    if (mask_mode == MASK_RECOMPUTE) return (rv * sc + sh > 0.f) ? d : 0.f;
+    if (mask_mode == MASK_TENSOR) return (mv > 0.f) ? d : 0.f;
+    return d;
+}
+
+template <int TPP>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_vec_kernel(const float* __restrict__ g, const float* __restrict__ r,
+                                                               const float* __restrict__ mask_src, int mask_mode,
+                                                               const float* __restrict__ scale, const float* __restrict__ shift,
+                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                               float g_scale, long long g_plane_stride, float* __restrict__ sums,
+                                                               int C, long long HW, long long planes) {
+    __shared__ float red[4];
+    const int t = threadIdx.x % TPP;
+    const long long plane = (long long)blockIdx.x * (256 / TPP) + threadIdx.x / TPP;
+    const bool live = plane < planes;                       // whole waves (TPP >= 64)
+    float s0 = 0.f, s1 = 0.f;
+    if (live) {
+        const int c = (int)(plane % C);
+        const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
+        const float* rp = r + plane * HW;
+        const float* mp = mask_src ? mask_src + plane * HW : nullptr;
+        const float g1 = g_plane_stride ? 0.f : g[plane] * g_scale;
+        const float* gp = g + plane * g_plane_stride;
+        for (long long i = (long long)t * 4; i < HW; i += TPP * 4) {
+            const float4 rv = *reinterpret_cast<const float4*>(rp + i);
+            float4 d = make_float4(g1, g1, g1, g1), mv = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (g_plane_stride) {
+                d = *reinterpret_cast<const float4*>(gp + i);
+                d.x *= g_scale; d.y *= g_scale; d.z *= g_scale; d.w *= g_scale;
+            }
+            if (mask_mode == MASK_TENSOR) mv = *reinterpret_cast<const float4*>(mp + i);
+            d.x = bn_mask(d.x, rv.x, mv.x, mask_mode, sc, sh); d.y = bn_mask(d.y, rv.y, mv.y, mask_mode, sc, sh);
+            d.z = bn_mask(d.z, rv.z, mv.z, mask_mode, sc, sh); d.w = bn_mask(d.w, rv.w, mv.w, mask_mode, sc, sh);
+            s0 += (d.x + d.y) + (d.z + d.w);
+            s1 += (d.x * (rv.x - mu) + d.y * (rv.y - mu) + d.z * (rv.z - mu) + d.w * (rv.w - mu)) * is;
+        }
+    }
+    if (TPP == 256) {
+        s0 = bn_block_sum(s0, red);
+        s1 = bn_block_sum(s1, red);
+    } else {
+#pragma unroll
+        for (int off = 32; off >= 1; off >>= 1) { s0 += __shfl_xor(s0, off); s1 += __shfl_xor(s1, off); }
+    }
+    if (live && t == 0) { sums[plane * 2] = s0; sums[plane * 2 + 1] = s1; }
+}
+
+template <int TPP>
+__global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const float* __restrict__ g, const float* __restrict__ r,
+                                                              const float* __restrict__ mask_src, int mask_mode,
+                                                              const float* __restrict__ scale, const float* __restrict__ shift,
+                                                              const float* __restrict__ mean, const float* __restrict__ invstd,
+                                                              const float* __restrict__ csum, float inv_count, float g_scale,
+                                                              long long g_plane_stride, float* __restrict__ dr,
+                                                              float* __restrict__ dz_out, int C, long long HW, long long planes) {
+    const int t = threadIdx.x % TPP;
+    const long long plane = (long long)blockIdx.x * (256 / TPP) + threadIdx.x / TPP;
+    if (plane >= planes) return;
+    const int c = (int)(plane % C);
+    const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
+    const float c1 = csum[2 * c] * inv_count, c2 = csum[2 * c + 1] * inv_count;   // csum: sums reduced over the batch
+    const float* rp = r + plane * HW;
+    const float* mp = mask_src ? mask_src + plane * HW : nullptr;
+    const float g1 = g_plane_stride ? 0.f : g[plane] * g_scale;
+    const float* gp = g + plane * g_plane_stride;
+    for (long long i = ((long long)blockIdx.y * TPP + t) * 4; i < HW; i += (long long)gridDim.y * TPP * 4) {
+        const float4 rv = *reinterpret_cast<const float4*>(rp + i);
+        float4 d = make_float4(g1, g1, g1, g1), mv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (g_plane_stride) {
+            d = *reinterpret_cast<const float4*>(gp + i);
+            d.x *= g_scale; d.y *= g_scale; d.z *= g_scale; d.w *= g_scale;
+        }
+        if (mask_mode == MASK_TENSOR) mv = *reinterpret_cast<const float4*>(mp + i);
+        d.x = bn_mask(d.x, rv.x, mv.x, mask_mode, sc, sh); d.y = bn_mask(d.y, rv.y, mv.y, mask_mode, sc, sh);
+        d.z = bn_mask(d.z, rv.z, mv.z, mask_mode, sc, sh); d.w = bn_mask(d.w, rv.w, mv.w, mask_mode, sc, sh);
+        if (dz_out) *reinterpret_cast<float4*>(dz_out + plane * HW + i) = d;
+        float4 o;
+        o.x = sc * (d.x - c1 - (rv.x - mu) * is * c2); o.y = sc * (d.y - c1 - (rv.y - mu) * is * c2);     // sc = gamma * invstd
+        o.z = sc * (d.z - c1 - (rv.z - mu) * is * c2); o.w = sc * (d.w - c1 - (rv.w - mu) * is * c2);
+        *reinterpret_cast<float4*>(dr + plane * HW + i) = o;
+    }
+}
+
+inline bool bn_vec_ok(long long HW, std::initializer_list<const void*> ptrs) {
+    if (HW % 4) return false;
+    for (const void* q : ptrs)
+        if (q && (reinterpret_cast<uintptr_t>(q) & 15)) return false;
+    return true;
+}
+
 // y[2h, 2w] = x[h, w], zeros elsewhere ([planes,H,W] -> [planes,Ho,Wo], Ho in {2H-1, 2H}): turns the data gradient
 // of a stride-2 conv into a stride-1 conv with flipped weights.
 __global__ __launch_bounds__(256) void dilate2x_kernel(const float* __restrict__ x, float* __restrict__ y, long long planes,
@@ -341,8 +439,18 @@ int spk_bn_bwd_reduce(const float* g, const float* r, const float* mask_src, int
                       float* sums, int B, int C, int64_t HW, void* stream) {
     SPK_REQUIRE(g && r && scale && shift && mean && invstd && sums && B > 0 && C > 0 && HW > 0, "bn_bwd_reduce: bad arguments");
     SPK_REQUIRE(mask_mode != MASK_TENSOR || mask_src, "bn_bwd_reduce: MASK_TENSOR without mask tensor");
+    const long long planes = (long long)B * C, gps = g_per_plane ? 0 : HW;
+    if (bn_vec_ok(HW, {g_per_plane ? nullptr : g, r, mask_src})) {
+        if (HW <= 1024)
+            hipLaunchKernelGGL(bn_bwd_reduce_vec_kernel<64>, dim3((unsigned)((planes + 3) / 4)), dim3(256), 0, (hipStream_t)stream, g, r,
+                               mask_src, mask_mode, scale, shift, mean, invstd, g_scale, gps, sums, C, (long long)HW, planes);
+        else
+            hipLaunchKernelGGL(bn_bwd_reduce_vec_kernel<256>, dim3((unsigned)planes), dim3(256), 0, (hipStream_t)stream, g, r, mask_src,
+                               mask_mode, scale, shift, mean, invstd, g_scale, gps, sums, C, (long long)HW, planes);
+        return spk::check_launch("bn_bwd_reduce_vec_kernel");
+    }
     hipLaunchKernelGGL(bn_bwd_reduce_kernel, dim3((unsigned)(B * C)), dim3(256), 0, (hipStream_t)stream, g, r, mask_src, mask_mode,
-                       scale, shift, mean, invstd, g_scale, (long long)(g_per_plane ? 0 : HW), sums, C, (long long)HW);
+                       scale, shift, mean, invstd, g_scale, gps, sums, C, (long long)HW);
     return spk::check_launch("bn_bwd_reduce_kernel");
 }
 
@@ -352,6 +460,20 @@ int spk_bn_bwd_apply(const float* g, const float* r, const float* mask_src, int 
     SPK_REQUIRE(g && r && scale && shift && mean && invstd && csum && dr && B > 0 && C > 0 && HW > 0 && count > 0,
                 "bn_bwd_apply: bad arguments");
     SPK_REQUIRE(mask_mode != MASK_TENSOR || mask_src, "bn_bwd_apply: MASK_TENSOR without mask tensor");
+    const long long planes = (long long)B * C, gps = g_per_plane ? 0 : HW;
+    if (bn_vec_ok(HW, {g_per_plane ? nullptr : g, r, mask_src, dr, dz_out})) {
+        if (HW <= 1024) {
+            hipLaunchKernelGGL(bn_bwd_apply_vec_kernel<64>, dim3((unsigned)((planes + 3) / 4)), dim3(256), 0, (hipStream_t)stream, g, r,
+                               mask_src, mask_mode, scale, shift, mean, invstd, csum, 1.0f / (float)count, g_scale, gps, dr, dz_out,
+                               C, (long long)HW, planes);
+        } else {
+            const unsigned chunks = (unsigned)std::max(1ll, std::min((long long)HW / (256 * 4 * 4), 16ll));   // >= 4 vectors per thread
+            hipLaunchKernelGGL(bn_bwd_apply_vec_kernel<256>, dim3((unsigned)planes, chunks), dim3(256), 0, (hipStream_t)stream, g, r,
+                               mask_src, mask_mode, scale, shift, mean, invstd, csum, 1.0f / (float)count, g_scale, gps, dr, dz_out,
+                               C, (long long)HW, planes);
+        }
+        return spk::check_launch("bn_bwd_apply_vec_kernel");
+    }
     dim3 grid((unsigned)(B * C), (unsigned)std::max(1ll, std::min(((long long)HW + 255) / 256, 64ll)));
     hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(256), 0, (hipStream_t)stream, g, r, mask_src, mask_mode, scale, shift, mean,
                        invstd, csum, 1.0f / (float)count, g_scale, (long long)(g_per_plane ? 0 : HW), dr, dz_out, C, (long long)HW);

@@ -28,8 +28,10 @@ def dev():
     return torch.device("cuda:0")
 
 
-def test_bn_relu_backward_three_mask_modes(pkg, dev):
-    B, C, H = 3, 13, 9
+@pytest.mark.parametrize("B,C,H", [(3, 13, 9),     # odd plane: the dword kernels
+                                   (2, 5, 8), (5, 7, 32), (2, 6, 16),    # <= 1024 floats per plane: one wave per plane, 16-byte loads
+                                   (1, 3, 48), (2, 2, 128)])             # a workgroup per plane (and several chunks of it)
+def test_bn_relu_backward_three_mask_modes(pkg, dev, B, C, H):
     r = (recipe_input("bnb.r", (B, C, H, H)) * 1.5 + 0.3).requires_grad_(True)
     gamma = (1.0 + recipe_tensor("bnb.g", (C,), 0.3)).requires_grad_(True)
     beta = recipe_tensor("bnb.b", (C,), 0.3).requires_grad_(True)
