@@ -1,0 +1,254 @@
+// 1x1 stride-1 convolution as a plain GEMM on the gfx950 f32 MFMA pipe (tile config 12):
+//     y[b, co, pix] = epi( sum_ci W[co, ci] * in(x[b, ci, pix]) ),   in = identity or max(x * scale[ci] + shift[ci], 0)
+// The tap kernel (conv_mfma_f32.hpp) is built around 3x3 chunks of 36 k-steps; for a 1x1 a chunk is 8 k-steps, so its
+// staging dominates (55-80 TFLOP/s on the ResNet-50 trunk's bottleneck convs, half of that trunk's launches).  A 1x1 needs
+// no halo and no gather: rows of x are contiguous pixels, rows of W contiguous input channels.  A workgroup owns a
+// 128co x 128px block (2x2 waves, each 2x2 MFMA tiles of 32x32), walks 32-channel k-tiles with 16-byte loads (4 + 4 per
+// thread per k-tile against 64 MFMAs per wave), LDS double-buffered with one barrier per k-tile, fragments read one k-step
+// ahead.  Pixels are the flattened (b, pix) axis; HW % 32 == 0 keeps every 32-pixel fragment row inside one image.
+// Epilogue as in the tap kernel: out_scale -> bias -> lrelu -> accumulate -> store -> BatchNorm sums (reduced across the
+// waves in LDS, one copy per pixel tile).  Grouped launches as there (blockIdx.y = group * co tiles + co tile).
+//
+// STATUS (round 1): correct (tests/test_encoder_gpu.py::test_conv1x1_gemm_form) but slower than the tap kernel on the
+// trunk's shapes -- 186 us against 148 on 512->256 @32^2 x 6 groups, 259 against 87 on 2048->512 @8^2 (no split-K, 96
+// workgroups) -- so spk_conv2d_pick_config does not return it yet (SPK_CONV1X1_GEMM=1 does).  A k-tile's loads are
+// issued one tile (4K MFMA cycles, ~2 us) ahead, which does not cover an HBM miss; the tap kernel runs two chunks ahead.
+// Next: two k-tiles of register prefetch, split-K for the <= 16^2 layers, scalar loads for the folded affine.
+//
+// replaces: F.conv2d of every stride-1 1x1 conv of the torchvision trunk (conv1 / conv3 / downsample.0 of layer1,
+// model.py:60-62) forward, and -- on the transposed weight -- its data gradient.
+#include "conv_mfma_f32.hpp"
+
+namespace spkconv {
+
+namespace {
+
+constexpr int GM = 128, GN = 128, GK = 32, APITCH = GK + 1, BPITCH = GN + 4;
+constexpr int A_FLOATS = GM * APITCH, B_FLOATS = GK * BPITCH, GBUF = A_FLOATS + B_FLOATS;
+
+struct GemmArgs {
+    const float* x;
+    const float* w;          // [G][Cout][Cin] row-major (the "packed" image of config 12)
+    const float* bias;
+    const float* in_scale;
+    const float* in_shift;
+    double* stats;
+    float* y;
+    int B, Cin, Cout, HW;    // Cin / Cout per group
+    long long n_px;          // B * HW
+    int G, Cx, Cy, gin, co_tiles_g;
+    int stats_slots;
+    unsigned flags;
+    float slope, out_scale, act_gain;
+};
+
+template <bool AFF>
+__global__ __launch_bounds__(256) void conv1x1_gemm_kernel(const GemmArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][A | B]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l32 = lane & 31;
+    const int wm = wave & 1, wn = wave >> 1;
+
+    const int grp = (int)blockIdx.y / p.co_tiles_g;
+    const int co0 = ((int)blockIdx.y - grp * p.co_tiles_g) * GM;          // within the group
+    const int cx0 = grp * p.gin;
+    const long long P0 = (long long)blockIdx.x * GN;
+    const size_t HW = (size_t)p.HW;
+
+    // staging roles.  A: rows tid/8 + 32 i (i < 4), k = 4 (tid % 8) .. +3.  B: k rows tid/32 + 8 i, pixels 4 (tid % 32) .. +3.
+    const int arow = tid >> 3, acol = (tid & 7) * 4;
+    const int brow = tid >> 5, bcol = (tid & 31) * 4;
+    const long long Pb = P0 + bcol;
+    const bool b_ok = Pb < p.n_px;                                         // (n_px % 4 == 0: a vector is in or out as a whole)
+    const float* xb = p.x;
+    if (b_ok) {
+        const long long b = Pb / p.HW;
+        xb += ((size_t)b * p.Cx + cx0) * HW + (size_t)(Pb - b * p.HW);
+    }
+    const float* wb = p.w + ((size_t)grp * p.Cout + co0) * p.Cin;
+
+    float4 aq[4], bq[4];
+#define SPK_G_LOAD(kt_)                                                                                      \
+    {                                                                                                        \
+        const int k0_ = (kt_) * GK;                                                                          \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                      \
+            const int r = arow + 32 * i, k = k0_ + acol;                                                     \
+            aq[i] = (co0 + r < p.Cout && k < p.Cin) ? *reinterpret_cast<const float4*>(wb + (size_t)r * p.Cin + k) \
+                                                    : make_float4(0.f, 0.f, 0.f, 0.f);                       \
+            const int ci = k0_ + brow + 8 * i;                                                               \
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                      \
+            if (b_ok && ci < p.Cin) {                                                                        \
+                v = *reinterpret_cast<const float4*>(xb + (size_t)ci * HW);                                  \
+                if (AFF) {                                                                                   \
+                    const float sc = p.in_scale[cx0 + ci], sh = p.in_shift[cx0 + ci];                        \
+                    v.x = fmaxf(v.x * sc + sh, 0.f); v.y = fmaxf(v.y * sc + sh, 0.f);                        \
+                    v.z = fmaxf(v.z * sc + sh, 0.f); v.w = fmaxf(v.w * sc + sh, 0.f);                        \
+                }                                                                                            \
+            }                                                                                                \
+            bq[i] = v;                                                                                       \
+        }                                                                                                    \
+    }
+#define SPK_G_STORE(buf_)                                                                                    \
+    {                                                                                                        \
+        float* as_ = smem + (buf_) * GBUF;                                                                   \
+        float* bs_ = as_ + A_FLOATS;                                                                         \
+        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                      \
+            const int o = (arow + 32 * i) * APITCH + acol;                                                   \
+            as_[o] = aq[i].x; as_[o + 1] = aq[i].y; as_[o + 2] = aq[i].z; as_[o + 3] = aq[i].w;              \
+            *reinterpret_cast<float4*>(bs_ + (brow + 8 * i) * BPITCH + bcol) = bq[i];                        \
+        }                                                                                                    \
+    }
+
+    f32x16 acc[2][2];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    const int n_kt = (p.Cin + GK - 1) / GK;
+    SPK_G_LOAD(0);
+    SPK_G_STORE(0);
+    __syncthreads();
+    for (int kt = 0; kt < n_kt; ++kt) {
+        const int buf = kt & 1;
+        const bool more = kt + 1 < n_kt;
+        if (more) SPK_G_LOAD(kt + 1);
+        const float* as_ = smem + buf * GBUF + (wm * 64 + l32) * APITCH + half;
+        const float* bs_ = smem + buf * GBUF + A_FLOATS + half * BPITCH + wn * 64 + l32;
+        float fa[2][2], fb[2][2];
+#define SPK_G_FRAG(ks_, slot_)                                                                               \
+    {                                                                                                        \
+        fa[slot_][0] = as_[2 * (ks_)]; fa[slot_][1] = as_[32 * APITCH + 2 * (ks_)];                          \
+        fb[slot_][0] = bs_[2 * (ks_) * BPITCH]; fb[slot_][1] = bs_[2 * (ks_) * BPITCH + 32];                 \
+    }
+        SPK_G_FRAG(0, 0);
+        static_for<0, GK / 2>([&](auto s_) {
+            constexpr int ks = decltype(s_)::value;
+            if constexpr (ks + 1 < GK / 2) {
+                SPK_G_FRAG(ks + 1, (ks + 1) & 1);
+                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+            }
+#pragma unroll
+            for (int m = 0; m < 2; ++m)
+#pragma unroll
+                for (int n = 0; n < 2; ++n)
+                    acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ks & 1][m], fb[ks & 1][n], acc[m][n], 0, 0, 0);
+            __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
+        });
+#undef SPK_G_FRAG
+        if (more) SPK_G_STORE(buf ^ 1);
+        __syncthreads();
+    }
+#undef SPK_G_LOAD
+#undef SPK_G_STORE
+
+    // ---- epilogue ----
+    const bool f_bias = p.flags & SPK_EPI_BIAS, f_lrelu = p.flags & SPK_EPI_LRELU;
+    const bool f_accum = p.flags & SPK_EPI_ACCUM, f_stats = p.flags & SPK_EPI_STATS;
+    bool pv[2];
+    size_t poff[2];
+#pragma unroll
+    for (int n = 0; n < 2; ++n) {
+        const long long Pn = P0 + wn * 64 + n * 32;          // a 32-aligned group lies in one image (HW % 32 == 0)
+        pv[n] = Pn < p.n_px;
+        const long long b = pv[n] ? Pn / p.HW : 0;
+        poff[n] = pv[n] ? (size_t)b * p.Cy * HW + (size_t)(Pn - b * p.HW) + l32 : 0;
+    }
+    float* const red = smem;                                  // [2 (wn)][GM][2]; the last k-tile's barrier has passed
+#pragma unroll
+    for (int m = 0; m < 2; ++m) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int cl = wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            const int co = co0 + cl;
+            const bool cv = co < p.Cout;
+            const int cg = grp * p.Cout + co;
+            float ssum = 0.f, ssq = 0.f;
+            if (cv) {
+                const float bb = f_bias ? p.bias[cg] : 0.f;
+#pragma unroll
+                for (int n = 0; n < 2; ++n) {
+                    if (!pv[n]) continue;
+                    float* dst = p.y + poff[n] + (size_t)cg * HW;
+                    float v = acc[m][n][r] * p.out_scale + bb;
+                    if (f_lrelu) v = (v > 0.f ? v : v * p.slope) * p.act_gain;
+                    if (f_accum) v += *dst;
+                    *dst = v;
+                    ssum += v;
+                    ssq += v * v;
+                }
+            }
+            if (f_stats) {
+#pragma unroll
+                for (int off = 16; off >= 1; off >>= 1) {
+                    ssum += __shfl_xor(ssum, off);
+                    ssq += __shfl_xor(ssq, off);
+                }
+                if (l32 == 0) {
+                    red[(wn * GM + cl) * 2] = ssum;
+                    red[(wn * GM + cl) * 2 + 1] = ssq;
+                }
+            }
+        }
+    }
+    if (f_stats) {
+        __syncthreads();
+        const int co = co0 + tid;
+        if (tid < GM && co < p.Cout) {
+            const double s = (double)red[tid * 2] + (double)red[(GM + tid) * 2];
+            const double q = (double)red[tid * 2 + 1] + (double)red[(GM + tid) * 2 + 1];
+            const int cg = grp * p.Cout + co;
+            double* sp = p.stats + (size_t)((int)blockIdx.x % p.stats_slots) * 2 * p.Cy;
+            if (p.stats_slots >= (int)gridDim.x) {
+                sp[cg] = s;
+                sp[p.Cy + cg] = q;
+            } else {
+                atomicAdd(sp + cg, s);
+                atomicAdd(sp + p.Cy + cg, q);
+            }
+        }
+    }
+}
+
+}  // namespace
+
+bool gemm1x1_takes(int kh, int stride, int Cin, int H, int W) {
+    return kh == 1 && stride == 1 && Cin % 4 == 0 && ((long long)H * W) % 32 == 0;
+}
+
+long long gemm1x1_pixel_tiles(int B, int H, int W) { return ((long long)B * H * W + GN - 1) / GN; }
+
+int run_1x1_gemm(const spk_conv2d_desc* d, hipStream_t stream) {
+    SPK_REQUIRE(gemm1x1_takes(d->kh, d->stride, d->Cin, d->H, d->W), "conv2d: config 12 (GEMM form) takes stride-1 1x1 convs with Cin %% 4 == 0 and H*W %% 32 == 0");
+    SPK_REQUIRE(!(d->flags & ~(SPK_EPI_BIAS | SPK_EPI_LRELU | SPK_EPI_ACCUM | SPK_EPI_STATS | SPK_CONV_IN_AFFINE_RELU)) && !d->out_scale_bc && !d->y_pre,
+                "conv2d: config 12 (GEMM form) takes bias / lrelu / accum / stats / in-affine only");
+    SPK_REQUIRE(((reinterpret_cast<uintptr_t>(d->x) | reinterpret_cast<uintptr_t>(d->w_packed)) & 15) == 0, "conv2d: config 12 needs 16-byte aligned x and weights");
+    GemmArgs a;
+    a.x = d->x; a.w = d->w_packed; a.bias = d->bias; a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.stats = d->stats; a.y = d->y;
+    a.B = d->B; a.Cin = d->Cin; a.Cout = d->Cout; a.HW = d->H * d->W; a.n_px = (long long)d->B * a.HW;
+    a.G = d->groups > 1 ? d->groups : 1;
+    a.gin = a.G > 1 ? d->group_in_stride : d->Cin;
+    a.Cx = a.gin * (a.G - 1) + d->Cin;
+    a.Cy = a.G * d->Cout;
+    a.co_tiles_g = spk::ceil_div(d->Cout, GM);
+    a.stats_slots = d->stats_slots > 1 ? d->stats_slots : 1;
+    a.flags = d->flags; a.slope = d->lrelu_slope; a.out_scale = d->out_scale; a.act_gain = d->act_gain != 0.f ? d->act_gain : 1.f;
+    const long long gx = gemm1x1_pixel_tiles(d->B, d->H, d->W);
+    SPK_REQUIRE(gx < (1ll << 31) && (long long)a.G * a.co_tiles_g < 65536, "conv2d: grid too large");
+    const size_t lds = 2 * (size_t)GBUF * sizeof(float);
+    const bool aff = d->flags & SPK_CONV_IN_AFFINE_RELU;
+    auto kern = aff ? &conv1x1_gemm_kernel<true> : &conv1x1_gemm_kernel<false>;
+    static bool raised[2] = {false, false};
+    if (!raised[aff]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return spk::fail(SPK_ELAUNCH, "hipFuncSetAttribute(LDS): %s", hipGetErrorString(e));
+        raised[aff] = true;
+    }
+    hipLaunchKernelGGL(kern, dim3((unsigned)gx, (unsigned)(a.G * a.co_tiles_g)), dim3(256), lds, stream, a);
+    return spk::check_launch("conv1x1_gemm_kernel");
+}
+
+}  // namespace spkconv

@@ -176,12 +176,22 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
     wp[idx] = v;
 }
 
+// config 12: w[Cout][Cin] -> itself (tf = 0) or its transpose [Cin][Cout] (tf = 1)
+__global__ void pack_rowmajor_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout, int tf, long long n) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n) return;
+    if (!tf) { wp[idx] = w[idx]; return; }
+    const int co = (int)(idx % Cout), ci = (int)(idx / Cout);       // wp[ci][co]
+    wp[idx] = w[(size_t)co * Cin + ci];
+}
+
 struct CfgDims { int co_t, ci_t, pix_t; };
 static const CfgDims kDims[kNumConfigs] = {
     {Cfg0::CO_T, Cfg0::CI_T, Cfg0::PIX_T},   {Cfg1::CO_T, Cfg1::CI_T, Cfg1::PIX_T},   {Cfg2::CO_T, Cfg2::CI_T, Cfg2::PIX_T},
     {Cfg3::CO_T, Cfg3::CI_T, Cfg3::PIX_T},   {Cfg4::CO_T, Cfg4::CI_T, Cfg4::PIX_T},   {Cfg5::CO_T, Cfg5::CI_T, Cfg5::PIX_T},
     {Cfg6::CO_T, Cfg6::CI_T, Cfg6::PIX_T},   {Cfg7::CO_T, Cfg7::CI_T, Cfg7::PIX_T},   {Cfg8::CO_T, Cfg8::CI_T, Cfg8::PIX_T},
-    {Cfg9::CO_T, Cfg9::CI_T, Cfg9::PIX_T},   {Cfg10::CO_T, Cfg10::CI_T, Cfg10::PIX_T}, {Cfg11::CO_T, Cfg11::CI_T, Cfg11::PIX_T}};
+    {Cfg9::CO_T, Cfg9::CI_T, Cfg9::PIX_T},   {Cfg10::CO_T, Cfg10::CI_T, Cfg10::PIX_T}, {Cfg11::CO_T, Cfg11::CI_T, Cfg11::PIX_T},
+    {128, 32, 128}};
 
 static bool supported_kernel(int kh, int kw, int stride) {
     if (kh == 2 && kw == 2) return stride == 1;   // the parity form of the 3x3 stride-2 data gradient (SPK_CONV_DGRAD_S2)
@@ -190,6 +200,7 @@ static bool supported_kernel(int kh, int kw, int stride) {
 
 static bool config_valid(int cfg, int kh, int kw, int stride) {
     if (!supported_kernel(kh, kw, stride) || cfg < 0 || cfg >= kNumConfigs) return false;
+    if (cfg == kGemmConfig) return kh == 1 && stride == 1;
     if (kh == 1) return cfg >= 8;
     if (kh == 2) return cfg <= 3;
     if (kh == 3 && stride == 1) return cfg <= 7;
@@ -217,6 +228,15 @@ static Geometry geom_k(int cfg, int B, int Cin, int Cout, int H, int W) {
 static Geometry geometry_any(int kh, int stride, int cfg, int B, int Cin, int Cout, int H, int W) {
     Geometry g;
     if (!config_valid(cfg, kh, kh, stride)) { g.ok = false; return g; }
+    if (cfg == kGemmConfig) {            // no tile geometry to fit: pixel tiles of 128 over the flattened (b, pix) axis
+        g.ok = gemm1x1_takes(kh, stride, Cin, H, W);
+        g.TW = g.TH = g.TB = 1; g.PLANE = 1;
+        g.tiles_x = (int)gemm1x1_pixel_tiles(B, H, W); g.tiles_y = g.tiles_b = 1;
+        g.n_chunks = 1;                  // never splits K
+        g.co_tiles = spk::ceil_div(Cout, 128);
+        g.lds_bytes = 0;
+        return g;
+    }
     if (kh == 1) return stride == 1 ? geom_k<1, 1>(cfg, B, Cin, Cout, H, W) : geom_k<1, 2>(cfg, B, Cin, Cout, H, W);
     if (kh == 2) return geom_k<2, 1>(cfg, B, Cin, Cout, H, W);
     if (kh == 3) return stride == 1 ? geom_k<3, 1>(cfg, B, Cin, Cout, H, W) : geom_k<3, 2>(cfg, B, Cin, Cout, H, W);
@@ -233,6 +253,11 @@ static int pick_config(int kh, int stride, int B, int Cin, int Cout, int H, int 
     const int shape = Cout <= 32 ? 3 : (wide ? 1 : (Cout <= 64 ? 2 : (pixels >= 2048 ? 0 : 2)));
     const int base = kh == 1 ? 8 : (kh == 2 ? 0 : 4);   // 1x1 -> ids 8-11, 2x2 -> 0-3; everything else prefers ids 4-7
     const int lo = kh == 1 ? 8 : ((kh == 3 && stride == 1) || kh == 2 ? 0 : 4), hi = kh == 1 ? 11 : (kh == 2 ? 3 : 7);
+    // The GEMM form of a stride-1 1x1 (conv1x1_gemm.hip, config 12) is built and tested but NOT picked: in its first form
+    // (k-tiles prefetched one ahead, no split-K) it measured 15-100 % slower than the tap kernel on every trunk shape
+    // (tools/bench_encoder_layers.py with SPK_CONV1X1_GEMM=1: forward 8.7 ms against 7.1).  SPK_CONV1X1_GEMM=1 selects it.
+    static const bool allow_gemm = [] { const char* e = getenv("SPK_CONV1X1_GEMM"); return e && atoi(e) != 0; }();
+    if (allow_gemm && kh == 1 && stride == 1 && Cout >= 64 && pixels >= 128 && gemm1x1_takes(kh, stride, Cin, H, W)) return kGemmConfig;
     const int want = base + shape;
     if (geometry_any(kh, stride, want, B, Cin, Cout, H, W).ok) return want;
     static const int alt[4][3] = {{2, 3, 1}, {2, 3, 0}, {3, 0, 1}, {2, 0, 1}};
@@ -271,6 +296,7 @@ int spk_conv2d_config_info(int config, int* co_tile, int* ci_tile, int* pix_tile
 
 int64_t spk_conv2d_packed_floats(int config, int kh, int kw, int Cin, int Cout) {
     if (config < 0 || config >= kNumConfigs || Cin <= 0 || Cout <= 0 || kh <= 0 || kw <= 0) return -1;
+    if (config == kGemmConfig) return kh == 1 && kw == 1 ? (int64_t)Cout * Cin : -1;      // plain [Cout][Cin]
     const CfgDims& c = kDims[config];
     return (int64_t)spk::ceil_div(Cout, c.co_t) * spk::ceil_div(Cin, c.ci_t) * kh * kw * c.ci_t * c.co_t;
 }
@@ -306,6 +332,13 @@ int spk_conv2d_pack_weights(const float* w, float* w_packed, int kh, int kw, int
     SPK_REQUIRE(Cin > 0 && Cout > 0 && kh > 0 && kw > 0, "pack_weights: bad shape");
     SPK_REQUIRE(transpose_flip >= 0 && transpose_flip <= 2, "pack_weights: transpose_flip is 0, 1 or 2");
     SPK_REQUIRE(transpose_flip != 2 || (kh == 3 && kw == 3), "pack_weights: the stride-2 data-gradient form packs a 3x3 kernel");
+    if (config == kGemmConfig) {        // row-major [opCout][opCin]: the weight itself, or its transpose for the data gradient
+        SPK_REQUIRE(kh == 1 && kw == 1 && transpose_flip != 2, "pack_weights: config %d packs 1x1 kernels", kGemmConfig);
+        const long long n = (long long)Cin * Cout;
+        hipLaunchKernelGGL(pack_rowmajor_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, w_packed,
+                           Cin, Cout, transpose_flip, n);
+        return spk::check_launch("pack_rowmajor_kernel");
+    }
     const CfgDims& c = kDims[config];
     const int opCin = transpose_flip ? Cout : Cin, opCout = transpose_flip == 2 ? 4 * Cin : (transpose_flip ? Cin : Cout);
     const int taps = transpose_flip == 2 ? 4 : kh * kw;
@@ -370,6 +403,7 @@ int spk_conv2d_fwd(const spk_conv2d_desc* d, void* stream) {
     dd.config = cfg;
     const int mode = ups ? (bsc ? MODE_UPSAMPLE_BATCH_SCALE : MODE_UPSAMPLE) : (aff ? MODE_AFFINE_RELU : (bsc ? MODE_BATCH_SCALE : MODE_PLAIN));
     hipStream_t s = (hipStream_t)stream;
+    if (cfg == kGemmConfig) return run_1x1_gemm(&dd, s);
     if (d->kh == 1) return run_1x1(d->stride, cfg, mode, &dd, s);
     if (d->kh == 3 && d->stride == 1) return cfg <= 3 ? run_3x3s1_a(cfg, mode, &dd, s) : run_3x3s1_b(cfg, mode, &dd, s);
     return run_3x3s2_7x7s2(d->kh, cfg, mode, &dd, s);

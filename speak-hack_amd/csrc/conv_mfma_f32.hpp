@@ -726,7 +726,8 @@ typedef Cfg<2, 2, 2, 2, 16> Cfg8;  //  128   128   1x1 s1/s2   (16-channel chunk
 typedef Cfg<1, 4, 2, 2, 16> Cfg9;  //   64   256   1x1 s1/s2
 typedef Cfg<2, 2, 1, 1, 16> Cfg10; //   64    64   1x1 s1/s2
 typedef Cfg<1, 4, 1, 1, 16> Cfg11; //   32   128   1x1 s1/s2
-constexpr int kNumConfigs = 12;
+constexpr int kNumConfigs = 13;   // 12 = the GEMM form of a stride-1 1x1 (conv1x1_gemm.hip): 128co x 128px block, 32-channel k-tiles
+constexpr int kGemmConfig = 12;
 
 // per-family dispatchers, one translation unit each (parallel compilation)
 int run_3x3s1_a(int cfg, int mode, const spk_conv2d_desc* d, hipStream_t s);  // ids 0-3
@@ -734,5 +735,8 @@ int run_3x3s1_b(int cfg, int mode, const spk_conv2d_desc* d, hipStream_t s);  //
 int run_3x3s2_7x7s2(int kh, int cfg, int mode, const spk_conv2d_desc* d, hipStream_t s);  // ids 4-7
 int run_1x1(int stride, int cfg, int mode, const spk_conv2d_desc* d, hipStream_t s);      // ids 8-11
 int run_2x2_parity(int cfg, const spk_conv2d_desc* d, int Hd, int Wd, hipStream_t s);     // ids 0-3
+int run_1x1_gemm(const spk_conv2d_desc* d, hipStream_t s);                                // id 12
+bool gemm1x1_takes(int kh, int stride, int Cin, int H, int W);
+long long gemm1x1_pixel_tiles(int B, int H, int W);
 
 }  // namespace spkconv

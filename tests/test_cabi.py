@@ -42,6 +42,10 @@ def test_host_side_queries_and_argument_errors(pkg):
     for cfg in range(n):
         co, ci, px = pkg.ops.conv3x3_config_info(cfg)
         assert co % 32 == 0 and px % 32 == 0 and ci % 2 == 0
+        if lib.spk_conv2d_config_valid(cfg, 1, 1, 1) and not lib.spk_conv2d_config_valid(cfg, 1, 1, 2):
+            # the GEMM form of a stride-1 1x1: its packed image is the plain [Cout][Cin] matrix
+            assert lib.spk_conv2d_packed_floats(cfg, 1, 1, 8, 5) == 40 and lib.spk_conv2d_packed_floats(cfg, 3, 3, 3, 5) == -1
+            continue
         # packed image is zero-padded up to whole tiles
         assert lib.spk_conv2d_packed_floats(cfg, 3, 3, 3, 5) == -(-5 // co) * -(-3 // ci) * 9 * ci * co
     assert lib.spk_conv2d_packed_floats(99, 3, 3, 3, 5) < 0

@@ -205,3 +205,66 @@ def test_trunk_train_mode_batch_statistics_and_running_update(pkg, dev):
               "7.2.bn3.running_var", "7.2.bn3.running_mean"):
         assert rel_l2(got[k], sd[k]) < 1e-4, k
     assert int(got["6.3.bn1.num_batches_tracked"]) == 1
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,groups", [
+    (2, 64, 256, 8, 8, 1),       # 64-pixel planes: a 128-pixel tile spans two images
+    (3, 20, 72, 8, 12, 1),       # ragged channels (Cin % 32 != 0, Cout % 128 != 0), 288 pixels: a partial last tile
+    (1, 256, 64, 16, 16, 1),     # one co tile half empty
+    (2, 36, 136, 4, 8, 3),       # grouped, two co tiles per group (the second ragged)
+    (8, 128, 512, 32, 32, 1),    # a trunk shape
+])
+def test_conv1x1_gemm_form(pkg, dev, B, Cin, Cout, H, W, groups):
+    """Tile config 12: the stride-1 1x1 conv as a plain GEMM (128co x 128px blocks over the flattened pixel axis, packed
+    weight = the [Cout][Cin] matrix), with every epilogue / staging option it carries, against F.conv2d."""
+    ops, L = pkg.ops, pkg._lib
+    cfg = L.lib().spk_conv2d_num_configs() - 1
+    assert ops.conv2d_config_fits(cfg, 1, 1, B, Cin, Cout, H, W) and not ops.conv2d_config_fits(cfg, 3, 1, B, Cin, Cout, H, W)
+    tag = f"g1x1.{B}.{Cin}.{Cout}.{H}.{W}.{groups}"
+    G = groups
+    x = recipe_input(tag + ".x", (B, G * Cin, H, W))
+    ws = [recipe_tensor(tag + f".w{q}", (Cout, Cin, 1, 1)) for q in range(G)]
+    bias = recipe_tensor(tag + ".bias", (G * Cout,), 0.3)
+    a = 1.0 + recipe_tensor(tag + ".a", (G * Cin,), 0.3)
+    b = recipe_tensor(tag + ".b", (G * Cin,), 0.3)
+    base = recipe_input(tag + ".base", (B, G * Cout, H, W))
+
+    def ref(xin, with_bias, slope):
+        y = torch.cat([F.conv2d(xin[:, q * Cin:(q + 1) * Cin], ws[q]) for q in range(G)], 1)
+        if with_bias:
+            y = y + bias.view(1, -1, 1, 1)
+        return F.leaky_relu(y, slope) if slope is not None else y
+
+    wp = torch.cat([ops.pack_conv_weight(w.to(dev), cfg) for w in ws])
+    assert wp.numel() == G * Cout * Cin
+    xd = x.to(dev)
+    # plain
+    assert rel_l2(ops.conv2d_fused(xd, wp, Cout, 1, 1, config=cfg, groups=G), ref(x, False, None)) < TOL_OP
+    # bias + LeakyReLU
+    y = ops.conv2d_fused(xd, wp, Cout, 1, 1, config=cfg, groups=G, bias=bias.to(dev), lrelu_slope=0.2)
+    assert rel_l2(y, ref(x, True, 0.2)) < TOL_OP
+    # folded BatchNorm + ReLU on the way in, BatchNorm sums on the way out (one copy per pixel tile), accumulate
+    xin = F.relu(x * a.view(1, -1, 1, 1) + b.view(1, -1, 1, 1))
+    want = ref(xin, False, None)
+    slots = ops.stats_slots(cfg, 1, 1, B, Cin, Cout, H, W)
+    assert slots == -(-B * H * W // 128)
+    for s in (slots, 1):
+        stats = torch.zeros(s * 2 * G * Cout, device=dev, dtype=torch.float64)
+        out = base.to(dev).clone()
+        y = ops.conv2d_fused(xd, wp, Cout, 1, 1, config=cfg, groups=G, in_affine=(a.to(dev), b.to(dev)), stats=stats, out=out,
+                             accumulate=True)
+        assert y.data_ptr() == out.data_ptr() and rel_l2(y, want + base) < TOL_OP
+        tot = stats.view(s, 2, G * Cout).sum(0)
+        full = (want + base).double()
+        assert rel_l2(tot[0], full.sum((0, 2, 3))) < 1e-6 and rel_l2(tot[1], (full ** 2).sum((0, 2, 3))) < 1e-6
+    # the transposed pack = the data gradient
+    if G == 1:
+        xg = x.clone().requires_grad_(True)
+        g = recipe_input(tag + ".g", (B, Cout, H, W))
+        F.conv2d(xg, ws[0]).backward(g)
+        if ops.conv2d_config_fits(cfg, 1, 1, B, Cout, Cin, H, W):
+            wt = ops.pack_conv_weight(ws[0].to(dev), cfg, transpose_flip=True)
+            assert rel_l2(ops.conv2d_fused(g.to(dev), wt, Cin, 1, 1, config=cfg), xg.grad) < TOL_OP
+    # what it does not carry is refused, not mis-computed
+    with pytest.raises(L.SpkError):
+        ops.conv2d_fused(xd, wp, Cout, 1, 1, config=cfg, groups=G, noise_w=bias.to(dev), noise=torch.zeros(B, 1, H, W, device=dev))
