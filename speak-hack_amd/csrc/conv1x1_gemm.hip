@@ -9,11 +9,11 @@
 // Epilogue as in the tap kernel: out_scale -> bias -> lrelu -> accumulate -> store -> BatchNorm sums (reduced across the
 // waves in LDS, one copy per pixel tile).  Grouped launches as there (blockIdx.y = group * co tiles + co tile).
 //
-// STATUS (round 1): correct (tests/test_encoder_gpu.py::test_conv1x1_gemm_form) but slower than the tap kernel on the
-// trunk's shapes -- 186 us against 148 on 512->256 @32^2 x 6 groups, 259 against 87 on 2048->512 @8^2 (no split-K, 96
-// workgroups) -- so spk_conv2d_pick_config does not return it yet (SPK_CONV1X1_GEMM=1 does).  A k-tile's loads are
-// issued one tile (4K MFMA cycles, ~2 us) ahead, which does not cover an HBM miss; the tap kernel runs two chunks ahead.
-// Next: two k-tiles of register prefetch, split-K for the <= 16^2 layers, scalar loads for the folded affine.
+// STATUS (round 1): correct (tests/test_encoder_gpu.py::test_conv1x1_gemm_form) but still slower than the tap kernel on
+// the trunk's shapes, so spk_conv2d_pick_config does not return it (SPK_CONV1X1_GEMM=1 does).  Over the trunk's 1x1
+// layers (tools/bench_encoder_layers.py, 6 groups, B = 8): forward 8.2 ms against the tap kernel's 7.1, data gradient
+// 7.3 against 6.3 -- e.g. 170 us against 148 on 512->256 @32^2, 211 against 87 on 2048->512 @8^2 (96 workgroups: the
+// <= 16^2 layers need split-K).  The first form (one k-tile of prefetch, affine applied at the load) was at 8.7 ms.
 //
 // replaces: F.conv2d of every stride-1 1x1 conv of the torchvision trunk (conv1 / conv3 / downsample.0 of layer1,
 // model.py:60-62) forward, and -- on the transposed weight -- its data gradient.
@@ -43,7 +43,7 @@ struct GemmArgs {
 };
 
 template <bool AFF>
-__global__ __launch_bounds__(256) void conv1x1_gemm_kernel(const GemmArgs p) {
+__global__ __launch_bounds__(256, 2) void conv1x1_gemm_kernel(const GemmArgs p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];   // [2][A | B]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -68,37 +68,45 @@ __global__ __launch_bounds__(256) void conv1x1_gemm_kernel(const GemmArgs p) {
     }
     const float* wb = p.w + ((size_t)grp * p.Cout + co0) * p.Cin;
 
-    float4 aq[4], bq[4];
-#define SPK_G_LOAD(kt_)                                                                                      \
-    {                                                                                                        \
-        const int k0_ = (kt_) * GK;                                                                          \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                      \
-            const int r = arow + 32 * i, k = k0_ + acol;                                                     \
-            aq[i] = (co0 + r < p.Cout && k < p.Cin) ? *reinterpret_cast<const float4*>(wb + (size_t)r * p.Cin + k) \
-                                                    : make_float4(0.f, 0.f, 0.f, 0.f);                       \
-            const int ci = k0_ + brow + 8 * i;                                                               \
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);                                                      \
-            if (b_ok && ci < p.Cin) {                                                                        \
-                v = *reinterpret_cast<const float4*>(xb + (size_t)ci * HW);                                  \
-                if (AFF) {                                                                                   \
-                    const float sc = p.in_scale[cx0 + ci], sh = p.in_shift[cx0 + ci];                        \
-                    v.x = fmaxf(v.x * sc + sh, 0.f); v.y = fmaxf(v.y * sc + sh, 0.f);                        \
-                    v.z = fmaxf(v.z * sc + sh, 0.f); v.w = fmaxf(v.w * sc + sh, 0.f);                        \
-                }                                                                                            \
-            }                                                                                                \
-            bq[i] = v;                                                                                       \
-        }                                                                                                    \
-    }
-#define SPK_G_STORE(buf_)                                                                                    \
-    {                                                                                                        \
-        float* as_ = smem + (buf_) * GBUF;                                                                   \
-        float* bs_ = as_ + A_FLOATS;                                                                         \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                      \
-            const int o = (arow + 32 * i) * APITCH + acol;                                                   \
-            as_[o] = aq[i].x; as_[o + 1] = aq[i].y; as_[o + 2] = aq[i].z; as_[o + 3] = aq[i].w;              \
-            *reinterpret_cast<float4*>(bs_ + (brow + 8 * i) * BPITCH + bcol) = bq[i];                        \
-        }                                                                                                    \
-    }
+    // Two register sets: a k-tile's loads are issued TWO compute phases (8K MFMA cycles) before its LDS store, which
+    // covers an HBM miss; the folded affine is applied at the store, so nothing waits on a load before the MFMAs.
+    struct Stage { float4 a[4], b[4]; float sc[4], sh[4]; };
+    Stage sA, sB;
+    auto load = [&](Stage& st, int kt) {
+        const int k0 = kt * GK;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int r = arow + 32 * i, k = k0 + acol;
+            const bool a_ok = co0 + r < p.Cout && k < p.Cin;
+            st.a[i] = *reinterpret_cast<const float4*>(wb + (a_ok ? (size_t)r * p.Cin + k : 0));
+            if (!a_ok) st.a[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            const int ci = k0 + brow + 8 * i;
+            const bool x_ok = b_ok && ci < p.Cin;
+            st.b[i] = *reinterpret_cast<const float4*>(xb + (x_ok ? (size_t)ci * HW : 0));
+            if (AFF) {
+                // channels past Cin (or pixels past the tensor): scale 0, shift 0 -> max(0, 0) = 0
+                st.sc[i] = x_ok ? p.in_scale[cx0 + ci] : 0.f;
+                st.sh[i] = x_ok ? p.in_shift[cx0 + ci] : 0.f;
+            } else if (!x_ok) {
+                st.b[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            }
+        }
+    };
+    auto store = [&](const Stage& st, int buf) {
+        float* as_ = smem + buf * GBUF;
+        float* bs_ = as_ + A_FLOATS;
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const int o = (arow + 32 * i) * APITCH + acol;
+            as_[o] = st.a[i].x; as_[o + 1] = st.a[i].y; as_[o + 2] = st.a[i].z; as_[o + 3] = st.a[i].w;
+            float4 v = st.b[i];
+            if (AFF) {
+                v.x = fmaxf(v.x * st.sc[i] + st.sh[i], 0.f); v.y = fmaxf(v.y * st.sc[i] + st.sh[i], 0.f);
+                v.z = fmaxf(v.z * st.sc[i] + st.sh[i], 0.f); v.w = fmaxf(v.w * st.sc[i] + st.sh[i], 0.f);
+            }
+            *reinterpret_cast<float4*>(bs_ + (brow + 8 * i) * BPITCH + bcol) = v;
+        }
+    };
 
     f32x16 acc[2][2];
 #pragma unroll
@@ -108,14 +116,7 @@ __global__ __launch_bounds__(256) void conv1x1_gemm_kernel(const GemmArgs p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
-    const int n_kt = (p.Cin + GK - 1) / GK;
-    SPK_G_LOAD(0);
-    SPK_G_STORE(0);
-    __syncthreads();
-    for (int kt = 0; kt < n_kt; ++kt) {
-        const int buf = kt & 1;
-        const bool more = kt + 1 < n_kt;
-        if (more) SPK_G_LOAD(kt + 1);
+    auto compute = [&](int buf) {
         const float* as_ = smem + buf * GBUF + (wm * 64 + l32) * APITCH + half;
         const float* bs_ = smem + buf * GBUF + A_FLOATS + half * BPITCH + wn * 64 + l32;
         float fa[2][2], fb[2][2];
@@ -139,11 +140,26 @@ __global__ __launch_bounds__(256) void conv1x1_gemm_kernel(const GemmArgs p) {
             __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
         });
 #undef SPK_G_FRAG
-        if (more) SPK_G_STORE(buf ^ 1);
+    };
+
+    const int n_kt = (p.Cin + GK - 1) / GK;
+    load(sA, 0);
+    store(sA, 0);
+    __syncthreads();
+    if (n_kt > 1) load(sA, 1);
+    for (int kt = 0; kt < n_kt; kt += 2) {
+        // tile kt out of buffer 0; sA = tile kt+1 (in flight since the previous phase); sB <- tile kt+2
+        if (kt + 2 < n_kt) load(sB, kt + 2);
+        compute(0);
+        if (kt + 1 < n_kt) store(sA, 1);
+        __syncthreads();
+        if (kt + 1 >= n_kt) break;
+        // tile kt+1 out of buffer 1; sB = tile kt+2; sA <- tile kt+3
+        if (kt + 3 < n_kt) load(sA, kt + 3);
+        compute(1);
+        if (kt + 2 < n_kt) store(sB, 0);
         __syncthreads();
     }
-#undef SPK_G_LOAD
-#undef SPK_G_STORE
 
     // ---- epilogue ----
     const bool f_bias = p.flags & SPK_EPI_BIAS, f_lrelu = p.flags & SPK_EPI_LRELU;
