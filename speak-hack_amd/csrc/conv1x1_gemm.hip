@@ -9,11 +9,14 @@
 // Epilogue as in the tap kernel: out_scale -> bias -> lrelu -> accumulate -> store -> BatchNorm sums (reduced across the
 // waves in LDS, one copy per pixel tile).  Grouped launches as there (blockIdx.y = group * co tiles + co tile).
 //
-// STATUS (round 1): correct (tests/test_encoder_gpu.py::test_conv1x1_gemm_form) but still slower than the tap kernel on
-// the trunk's shapes, so spk_conv2d_pick_config does not return it (SPK_CONV1X1_GEMM=1 does).  Over the trunk's 1x1
-// layers (tools/bench_encoder_layers.py, 6 groups, B = 8): forward 8.2 ms against the tap kernel's 7.1, data gradient
-// 7.3 against 6.3 -- e.g. 170 us against 148 on 512->256 @32^2, 211 against 87 on 2048->512 @8^2 (96 workgroups: the
-// <= 16^2 layers need split-K).  The first form (one k-tile of prefetch, affine applied at the load) was at 8.7 ms.
+// Epilogue: the 128 x 128 block goes through LDS so that a channel row leaves as 512 contiguous bytes of 16-byte stores;
+// with the accumulators stored straight from the MFMA layout (128-byte pieces of a row at four different times) this
+// kernel -- like the tap kernel -- wrote the trunk's layer1 outputs at ~1.2 TB/s and lost to the tap kernel everywhere
+// (forward 8.2 ms over the trunk's 1x1 layers against 7.1); with the staged epilogue 64->256 @64^2 x 6 groups went from
+// 188 to 123 us (tap kernel: 168).
+// STATUS (round 1): spk_conv2d_pick_config returns it where it measured faster (Cout >= 128, contraction no deeper than
+// ~the output width, >= 2048 pixels); it has no split-K, so the deep-K / few-pixel layers (2048->512 @8^2: 200 us
+// against 87) stay on the tap kernel.  tools/bench_encoder_layers.py with SPK_CONV1X1_GEMM=0 / 1 compares the two.
 //
 // replaces: F.conv2d of every stride-1 1x1 conv of the torchvision trunk (conv1 / conv3 / downsample.0 of layer1,
 // model.py:60-62) forward, and -- on the transposed weight -- its data gradient.
@@ -161,69 +164,70 @@ __global__ __launch_bounds__(256, 2) void conv1x1_gemm_kernel(const GemmArgs p) 
         __syncthreads();
     }
 
-    // ---- epilogue ----
+    // ---- epilogue: the 128co x 128px block goes through LDS (it is exactly as large as the two staging buffers), so
+    // that a channel row leaves as 512 contiguous bytes of 16-byte stores instead of four 128-byte pieces at different
+    // times; a row is handled by one half-wave, so its BatchNorm sums need one 32-lane butterfly and no second stage ----
+    constexpr int OPITCH = GN + 4;
+    static_assert(GM * OPITCH <= 2 * GBUF, "the output tile reuses the staging buffers");
+    float* const ot = smem;                                   // the last k-tile's barrier has passed
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int n = 0; n < 2; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+                ot[(wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * OPITCH + wn * 64 + n * 32 + l32] = acc[m][n][r];
+    __syncthreads();
     const bool f_bias = p.flags & SPK_EPI_BIAS, f_lrelu = p.flags & SPK_EPI_LRELU;
     const bool f_accum = p.flags & SPK_EPI_ACCUM, f_stats = p.flags & SPK_EPI_STATS;
-    bool pv[2];
-    size_t poff[2];
-#pragma unroll
-    for (int n = 0; n < 2; ++n) {
-        const long long Pn = P0 + wn * 64 + n * 32;          // a 32-aligned group lies in one image (HW % 32 == 0)
-        pv[n] = Pn < p.n_px;
-        const long long b = pv[n] ? Pn / p.HW : 0;
-        poff[n] = pv[n] ? (size_t)b * p.Cy * HW + (size_t)(Pn - b * p.HW) + l32 : 0;
+    const int ocol = (tid & 31) * 4;
+    const long long Po = P0 + ocol;
+    const bool o_ok = Po < p.n_px;
+    size_t ooff = 0;
+    if (o_ok) {
+        const long long b = Po / p.HW;
+        ooff = (size_t)b * p.Cy * HW + (size_t)(Po - b * p.HW);
     }
-    float* const red = smem;                                  // [2 (wn)][GM][2]; the last k-tile's barrier has passed
-#pragma unroll
-    for (int m = 0; m < 2; ++m) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int cl = wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-            const int co = co0 + cl;
-            const bool cv = co < p.Cout;
-            const int cg = grp * p.Cout + co;
-            float ssum = 0.f, ssq = 0.f;
-            if (cv) {
-                const float bb = f_bias ? p.bias[cg] : 0.f;
-#pragma unroll
-                for (int n = 0; n < 2; ++n) {
-                    if (!pv[n]) continue;
-                    float* dst = p.y + poff[n] + (size_t)cg * HW;
-                    float v = acc[m][n][r] * p.out_scale + bb;
-                    if (f_lrelu) v = (v > 0.f ? v : v * p.slope) * p.act_gain;
-                    if (f_accum) v += *dst;
-                    *dst = v;
-                    ssum += v;
-                    ssq += v * v;
-                }
+    double* sp = f_stats ? p.stats + (size_t)((int)blockIdx.x % p.stats_slots) * 2 * p.Cy : nullptr;
+    const bool own_slot = p.stats_slots >= (int)gridDim.x;
+#pragma unroll 4
+    for (int i = 0; i < GM / 8; ++i) {
+        const int cl = (tid >> 5) + 8 * i;
+        const int co = co0 + cl;
+        const bool cv = co < p.Cout;                           // uniform over the half-wave
+        const int cg = grp * p.Cout + (cv ? co : 0);
+        float ssum = 0.f, ssq = 0.f;
+        if (cv && o_ok) {
+            float4 v = *reinterpret_cast<const float4*>(ot + cl * OPITCH + ocol);
+            const float bb = f_bias ? p.bias[cg] : 0.f;
+            v.x = v.x * p.out_scale + bb; v.y = v.y * p.out_scale + bb; v.z = v.z * p.out_scale + bb; v.w = v.w * p.out_scale + bb;
+            if (f_lrelu) {
+                v.x = (v.x > 0.f ? v.x : v.x * p.slope) * p.act_gain; v.y = (v.y > 0.f ? v.y : v.y * p.slope) * p.act_gain;
+                v.z = (v.z > 0.f ? v.z : v.z * p.slope) * p.act_gain; v.w = (v.w > 0.f ? v.w : v.w * p.slope) * p.act_gain;
             }
-            if (f_stats) {
-#pragma unroll
-                for (int off = 16; off >= 1; off >>= 1) {
-                    ssum += __shfl_xor(ssum, off);
-                    ssq += __shfl_xor(ssq, off);
-                }
-                if (l32 == 0) {
-                    red[(wn * GM + cl) * 2] = ssum;
-                    red[(wn * GM + cl) * 2 + 1] = ssq;
-                }
+            float4* dst = reinterpret_cast<float4*>(p.y + ooff + (size_t)cg * HW);
+            if (f_accum) {
+                const float4 old = *dst;
+                v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
             }
+            *dst = v;
+            ssum = (v.x + v.y) + (v.z + v.w);
+            ssq = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
         }
-    }
-    if (f_stats) {
-        __syncthreads();
-        const int co = co0 + tid;
-        if (tid < GM && co < p.Cout) {
-            const double s = (double)red[tid * 2] + (double)red[(GM + tid) * 2];
-            const double q = (double)red[tid * 2 + 1] + (double)red[(GM + tid) * 2 + 1];
-            const int cg = grp * p.Cout + co;
-            double* sp = p.stats + (size_t)((int)blockIdx.x % p.stats_slots) * 2 * p.Cy;
-            if (p.stats_slots >= (int)gridDim.x) {
-                sp[cg] = s;
-                sp[p.Cy + cg] = q;
-            } else {
-                atomicAdd(sp + cg, s);
-                atomicAdd(sp + p.Cy + cg, q);
+        if (f_stats) {
+#pragma unroll
+            for (int off = 16; off >= 1; off >>= 1) {
+                ssum += __shfl_xor(ssum, off);
+                ssq += __shfl_xor(ssq, off);
+            }
+            if (l32 == 0 && cv) {
+                if (own_slot) {
+                    sp[cg] = (double)ssum;
+                    sp[p.Cy + cg] = (double)ssq;
+                } else {
+                    atomicAdd(sp + cg, (double)ssum);
+                    atomicAdd(sp + p.Cy + cg, (double)ssq);
+                }
             }
         }
     }
@@ -241,7 +245,8 @@ int run_1x1_gemm(const spk_conv2d_desc* d, hipStream_t stream) {
     SPK_REQUIRE(gemm1x1_takes(d->kh, d->stride, d->Cin, d->H, d->W), "conv2d: config 12 (GEMM form) takes stride-1 1x1 convs with Cin %% 4 == 0 and H*W %% 32 == 0");
     SPK_REQUIRE(!(d->flags & ~(SPK_EPI_BIAS | SPK_EPI_LRELU | SPK_EPI_ACCUM | SPK_EPI_STATS | SPK_CONV_IN_AFFINE_RELU)) && !d->out_scale_bc && !d->y_pre,
                 "conv2d: config 12 (GEMM form) takes bias / lrelu / accum / stats / in-affine only");
-    SPK_REQUIRE(((reinterpret_cast<uintptr_t>(d->x) | reinterpret_cast<uintptr_t>(d->w_packed)) & 15) == 0, "conv2d: config 12 needs 16-byte aligned x and weights");
+    SPK_REQUIRE(((reinterpret_cast<uintptr_t>(d->x) | reinterpret_cast<uintptr_t>(d->w_packed) | reinterpret_cast<uintptr_t>(d->y)) & 15) == 0,
+                "conv2d: config 12 needs 16-byte aligned x, y and weights");
     GemmArgs a;
     a.x = d->x; a.w = d->w_packed; a.bias = d->bias; a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.stats = d->stats; a.y = d->y;
     a.B = d->B; a.Cin = d->Cin; a.Cout = d->Cout; a.HW = d->H * d->W; a.n_px = (long long)d->B * a.HW;

@@ -253,11 +253,16 @@ static int pick_config(int kh, int stride, int B, int Cin, int Cout, int H, int 
     const int shape = Cout <= 32 ? 3 : (wide ? 1 : (Cout <= 64 ? 2 : (pixels >= 2048 ? 0 : 2)));
     const int base = kh == 1 ? 8 : (kh == 2 ? 0 : 4);   // 1x1 -> ids 8-11, 2x2 -> 0-3; everything else prefers ids 4-7
     const int lo = kh == 1 ? 8 : ((kh == 3 && stride == 1) || kh == 2 ? 0 : 4), hi = kh == 1 ? 11 : (kh == 2 ? 3 : 7);
-    // The GEMM form of a stride-1 1x1 (conv1x1_gemm.hip, config 12) is built and tested but NOT picked: in its first form
-    // (k-tiles prefetched one ahead, no split-K) it measured 15-100 % slower than the tap kernel on every trunk shape
-    // (tools/bench_encoder_layers.py with SPK_CONV1X1_GEMM=1: forward 8.7 ms against 7.1).  SPK_CONV1X1_GEMM=1 selects it.
-    static const bool allow_gemm = [] { const char* e = getenv("SPK_CONV1X1_GEMM"); return e && atoi(e) != 0; }();
-    if (allow_gemm && kh == 1 && stride == 1 && Cout >= 64 && pixels >= 128 && gemm1x1_takes(kh, stride, Cin, H, W)) return kGemmConfig;
+    // The GEMM form of a stride-1 1x1 (conv1x1_gemm.hip, config 12), where it measured faster than the tap kernel on the
+    // trunk's shapes (tools/bench_encoder_layers.py, SPK_CONV1X1_GEMM=1 forces it everywhere it applies, =0 nowhere): a
+    // full 128-row block of output channels, a contraction no deeper than the output is wide (it has no split-K), and
+    // enough pixels -- e.g. 64->256 @64^2: 123 us against 168, 128->512 @32^2: 96 against 119; but 2048->512 @8^2: 200
+    // against 87.
+    static const int gemm_mode = [] { const char* e = getenv("SPK_CONV1X1_GEMM"); return e ? atoi(e) : -1; }();
+    if (kh == 1 && stride == 1 && gemm_mode != 0 && gemm1x1_takes(kh, stride, Cin, H, W)) {
+        const bool wins = Cout >= 128 && ((Cin <= Cout && pixels >= 2048) || (Cin <= 2 * Cout && pixels >= 8192));
+        if (gemm_mode > 0 ? (Cout >= 64 && pixels >= 128) : wins) return kGemmConfig;
+    }
     const int want = base + shape;
     if (geometry_any(kh, stride, want, B, Cin, Cout, H, W).ok) return want;
     static const int alt[4][3] = {{2, 3, 1}, {2, 3, 0}, {3, 0, 1}, {2, 0, 1}};
