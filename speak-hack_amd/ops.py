@@ -594,7 +594,8 @@ def stats_slots(config, k, stride, B, Cin, Cout, H, W):
     n = L.lib().spk_conv2d_stats_slots(int(config), k, k, stride, B, Cin, Cout, H, W)
     if n < 1:
         raise L.SpkError(f"stats_slots: config {config} cannot host k={k} s={stride} shape {(B, Cin, Cout, H, W)}")
-    return n
+    # very large batches: bound the copies (2048 x 2C doubles); beyond that a few tiles share a copy through atomics
+    return min(n, 2048)
 
 
 def bn_finalize(stats, count, gamma, beta, running_mean, running_var, momentum=0.1, eps=1e-5, save=False):
