@@ -39,6 +39,8 @@ def T(a):
     (3, 1, 2, 64, 64, 32, 32), (3, 1, 3, 20, 40, 9, 13), (3, 1, 1, 128, 72, 64, 64), (3, 1, 8, 512, 512, 8, 8),
     (1, 1, 2, 96, 160, 16, 16), (1, 2, 2, 64, 128, 16, 16), (3, 2, 2, 48, 80, 20, 20), (7, 2, 2, 3, 64, 40, 40),
     (3, 1, 1, 5, 3, 2, 2), (1, 1, 2, 2048, 512, 1, 1),
+    # the pipelined 3x3 form (16x4 tiles): partial tiles in both directions, channel blocks with 6 / 2 live rows
+    (3, 1, 3, 24, 40, 6, 20), (3, 1, 2, 70, 130, 12, 36),
 ])
 def test_wgrad_vs_autograd(pkg, dev, k, stride, B, Cin, Cout, H, W):
     tag = f"wg.{k}.{stride}.{B}.{Cin}.{Cout}.{H}.{W}"
