@@ -75,6 +75,7 @@ struct ConvArgs {
     // Cin, Cy = Cout.
     int G, Cx, Cy, gin, co_tiles_g;
     int Hd, Wd;              // 2x2 (parity) kernels: spatial size of the interleaved destination
+    int staged;              // epilogue through LDS with 16-byte stores (set by the host when the tile / tensors allow it)
 };
 
 template <int WM_, int WN_, int MT_, int NT_, int CIT_>
@@ -496,6 +497,104 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
     const bool f_lrelu = p.flags & SPK_EPI_LRELU, f_style = p.flags & SPK_EPI_STYLE;
     const bool f_accum = p.flags & SPK_EPI_ACCUM, f_stats = (p.flags & SPK_EPI_STATS) && !split;
     const size_t HW = (size_t)p.H * p.W;
+    if (p.staged) {
+        // ---- staged form (host: no split-K, not the parity kernel, W % 4 == 0, 16-byte aligned tensors, TW >= 4, and an
+        // LDS tile that does not cost a workgroup slot): the block goes through LDS and a thread finishes 4 consecutive
+        // pixels of a channel at a time -- 16 vector stores per lane instead of 64 dword stores, the bias / style /
+        // demodulation operands loaded once per vector instead of once per element.  Same arithmetic per element.
+        // (Knock-out measurement, profiles/r01_m_core_clock_under_load.txt: the dword epilogue is 8.7 % of the conv time.)
+        // p.staged == 2 (one wave row, two MFMA tiles high: the 64co x 256px configs): the block goes in two halves of 32
+        // channels, so that the LDS tile stays within the ring and the kernel keeps its three workgroups per CU.
+        constexpr int OP = C::PIX_T + 4, F4 = C::PIX_T / 4, RPI = C::NTHREADS / F4;
+        constexpr bool CAN_HALVE = C::WM == 1 && C::MT == 2;
+        float* const ot = smem;
+        const int rounds = (CAN_HALVE && p.staged == 2) ? 2 : 1;
+        const int f4 = tid % F4, row0 = tid / F4;
+        const int pt = 4 * f4;
+        const int px = pt & (TW - 1), py = (pt >> p.lgTW) & (TH - 1), tb = pt >> (p.lgTW + p.lgTH);
+        const int b = b0 + tb, yy = y0 + py, xx = x0 + px;
+        const bool pvv = tb < TB && b < p.B && yy < p.H && xx < p.W;      // W % 4 == 0: the vector is in or out as a whole
+        const size_t pix = (size_t)yy * p.W + xx;
+        const size_t o0 = pvv ? (size_t)b * p.Cy * HW + pix : 0;
+        float4 nzv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (f_noise && pvv) nzv = *reinterpret_cast<const float4*>(p.noise + (size_t)b * HW + pix);
+        const float* stp = (f_style && pvv) ? p.style + (size_t)b * p.style_stride : nullptr;
+        double* sp = f_stats ? p.stats + (size_t)((int)blockIdx.x % p.stats_slots) * 2 * p.Cy : nullptr;
+        const bool own_slot = p.stats_slots >= (int)gridDim.x;
+        for (int h = 0; h < rounds; ++h) {
+        __syncthreads();                                  // every wave is done reading the ring / the previous half
+#pragma unroll
+        for (int m = 0; m < C::MT; ++m) {
+            if (rounds == 2 && m != h) continue;
+            const int mrow = rounds == 2 ? 0 : (wm * C::MT + m) * 32;
+#pragma unroll
+            for (int n = 0; n < C::NT; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    ot[(mrow + (r & 3) + 8 * (r >> 2) + 4 * half) * OP + (wn * C::NT + n) * 32 + l32] = acc[m][n][r];
+        }
+        __syncthreads();
+        const int rows = C::CO_T / rounds;
+#pragma unroll 2
+        for (int i = 0; i < rows / RPI; ++i) {
+            const int cl = row0 + RPI * i;
+            const int co = co_tile0 + h * rows + cl;
+            const bool cv = co < p.Cout;
+            const int cg = grp * p.Cout + (cv ? co : 0);
+            float ssum = 0.f, ssq = 0.f;
+            if (cv && pvv) {
+                float4 v = *reinterpret_cast<const float4*>(ot + cl * OP + pt);
+                float sc = p.out_scale;
+                v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
+                if (p.out_scale_bc) {
+                    const float d = p.out_scale_bc[(size_t)b * p.Cy + cg];
+                    v.x *= d; v.y *= d; v.z *= d; v.w *= d;
+                }
+                const float bb = f_bias ? p.bias[cg] : 0.f;
+                v.x += bb; v.y += bb; v.z += bb; v.w += bb;
+                if (f_noise) {
+                    const float nwc = p.noise_w[cg];
+                    v.x += nwc * nzv.x; v.y += nwc * nzv.y; v.z += nwc * nzv.z; v.w += nwc * nzv.w;
+                }
+                if (f_lrelu) {
+                    v.x = (v.x > 0.f ? v.x : v.x * p.slope) * p.act_gain; v.y = (v.y > 0.f ? v.y : v.y * p.slope) * p.act_gain;
+                    v.z = (v.z > 0.f ? v.z : v.z * p.slope) * p.act_gain; v.w = (v.w > 0.f ? v.w : v.w * p.slope) * p.act_gain;
+                }
+                const size_t off = o0 + (size_t)cg * HW;
+                if (p.y_pre) *reinterpret_cast<float4*>(p.y_pre + off) = v;
+                if (f_style) {
+                    const float s0 = stp[cg] + 1.f, s1 = stp[p.Cy + cg];
+                    v.x = v.x * s0 + s1; v.y = v.y * s0 + s1; v.z = v.z * s0 + s1; v.w = v.w * s0 + s1;
+                }
+                float4* dst = reinterpret_cast<float4*>(p.y + off);
+                if (f_accum) {
+                    const float4 old = *dst;
+                    v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
+                }
+                *dst = v;
+                ssum = (v.x + v.y) + (v.z + v.w);
+                ssq = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
+            }
+            if (f_stats) {          // the F4 lanes of a row are consecutive: one butterfly finishes the row's sums
+#pragma unroll
+                for (int off = F4 / 2; off >= 1; off >>= 1) {
+                    ssum += __shfl_xor(ssum, off);
+                    ssq += __shfl_xor(ssq, off);
+                }
+                if (f4 == 0 && cv) {
+                    if (own_slot) {
+                        sp[cg] = (double)ssum;
+                        sp[p.Cy + cg] = (double)ssq;
+                    } else {
+                        atomicAdd(sp + cg, (double)ssum);
+                        atomicAdd(sp + p.Cy + cg, (double)ssq);
+                    }
+                }
+            }
+        }
+        }
+        return;
+    }
     float* ybase = p.y + (split ? (size_t)blockIdx.z * p.B * p.Cy * HW : 0);
     // per pixel group: validity, output offset, noise value, style row
     bool pv[C::NT];
@@ -519,6 +618,9 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
     }
     // BatchNorm sums: the waves' per-channel partial sums meet in LDS (the ring is idle by now), so that a workgroup
     // issues ONE add per channel and moment -- fp64 atomics are what limits this epilogue (~10-20 per ns chip-wide)
+#ifdef SPK_LAB_NOEPI   // lab: how much of a launch is the epilogue?  (skips it unless an impossible value turns up)
+    if (acc[0][0][0] != 123456.789f) return;
+#endif
     float* const red = smem;                              // [WN][CO_T][2]
     if (f_stats) __syncthreads();                         // every wave is done reading the ring
 #pragma unroll
@@ -685,6 +787,22 @@ int run(const spk_conv2d_desc* d, hipStream_t stream, int Hd = 0, int Wd = 0) {
     a.n_chunks = g.n_chunks;
     a.style_stride = d->style_stride; a.flags = d->flags; a.slope = d->lrelu_slope; a.out_scale = d->out_scale; a.act_gain = d->act_gain != 0.f ? d->act_gain : 1.f;
     const int ksplit = resolve_ksplit(g, d->ksplit, &a.chunks_per_split);
+    // staged epilogue: whenever its LDS tile costs no workgroup slot and the vectors are whole and aligned
+    a.staged = 0;
+    {
+        static const bool allow = [] { const char* e = getenv("SPK_CONV_STAGED_EPI"); return !e || atoi(e) != 0; }();
+        const size_t tile_bytes = (size_t)C::CO_T * (C::PIX_T + 4) * sizeof(float);
+        const size_t lds_now = g.lds_bytes;
+        const auto aligned = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+        const auto same_slots = [&](size_t bytes) { return (160 * 1024) / std::max(bytes, lds_now) == (160 * 1024) / lds_now; };
+        constexpr bool can_halve = C::WM == 1 && C::MT == 2;
+        const int rounds = same_slots(tile_bytes) ? 1 : ((can_halve && same_slots(tile_bytes / 2)) ? 2 : 0);
+        if (allow && rounds && KH != 2 && ksplit == 1 && g.TW >= 4 && d->W % 4 == 0 && C::NTHREADS % (C::PIX_T / 4) == 0 &&
+            (C::CO_T / rounds) % (C::NTHREADS / (C::PIX_T / 4)) == 0 && aligned(d->y) && aligned(d->y_pre) && aligned(d->noise)) {
+            a.staged = rounds;
+            g.lds_bytes = std::max(lds_now, tile_bytes / rounds);
+        }
+    }
     const size_t out_floats = (size_t)d->B * a.Cy * d->H * d->W;
     if (ksplit > 1) {
         SPK_REQUIRE(d->workspace && (size_t)d->workspace_bytes >= ksplit * out_floats * sizeof(float),
