@@ -503,10 +503,11 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
         // pixels of a channel at a time -- 16 vector stores per lane instead of 64 dword stores, the bias / style /
         // demodulation operands loaded once per vector instead of once per element.  Same arithmetic per element.
         // (Knock-out measurement, profiles/r01_m_core_clock_under_load.txt: the dword epilogue is 8.7 % of the conv time.)
-        // p.staged == 2 (one wave row, two MFMA tiles high: the 64co x 256px configs): the block goes in two halves of 32
-        // channels, so that the LDS tile stays within the ring and the kernel keeps its three workgroups per CU.
+        // p.staged == 2 (configs whose waves hold two MFMA tiles of channels, e.g. 64co x 256px on the 256^2 layers): the block
+        // goes in two halves -- every wave's upper tiles, then its lower ones -- so that the LDS tile stays within the ring
+        // and the kernel keeps its workgroups per CU.
         constexpr int OP = C::PIX_T + 4, F4 = C::PIX_T / 4, RPI = C::NTHREADS / F4;
-        constexpr bool CAN_HALVE = C::WM == 1 && C::MT == 2;
+        constexpr bool CAN_HALVE = C::MT == 2;
         float* const ot = smem;
         const int rounds = (CAN_HALVE && p.staged == 2) ? 2 : 1;
         const int f4 = tid % F4, row0 = tid / F4;
@@ -526,7 +527,7 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
 #pragma unroll
         for (int m = 0; m < C::MT; ++m) {
             if (rounds == 2 && m != h) continue;
-            const int mrow = rounds == 2 ? 0 : (wm * C::MT + m) * 32;
+            const int mrow = rounds == 2 ? wm * 32 : (wm * C::MT + m) * 32;
 #pragma unroll
             for (int n = 0; n < C::NT; ++n)
 #pragma unroll
@@ -538,7 +539,8 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
 #pragma unroll 2
         for (int i = 0; i < rows / RPI; ++i) {
             const int cl = row0 + RPI * i;
-            const int co = co_tile0 + h * rows + cl;
+            // row cl of a half belongs to wave row cl / 32, whose tiles m = 0, 1 sit 32 channels apart in the block
+            const int co = co_tile0 + (rounds == 2 ? (cl >> 5) * 64 + h * 32 + (cl & 31) : cl);
             const bool cv = co < p.Cout;
             const int cg = grp * p.Cout + (cv ? co : 0);
             float ssum = 0.f, ssq = 0.f;
@@ -795,7 +797,7 @@ int run(const spk_conv2d_desc* d, hipStream_t stream, int Hd = 0, int Wd = 0) {
         const size_t lds_now = g.lds_bytes;
         const auto aligned = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
         const auto same_slots = [&](size_t bytes) { return (160 * 1024) / std::max(bytes, lds_now) == (160 * 1024) / lds_now; };
-        constexpr bool can_halve = C::WM == 1 && C::MT == 2;
+        constexpr bool can_halve = C::MT == 2;
         const int rounds = same_slots(tile_bytes) ? 1 : ((can_halve && same_slots(tile_bytes / 2)) ? 2 : 0);
         if (allow && rounds && KH != 2 && ksplit == 1 && g.TW >= 4 && d->W % 4 == 0 && C::NTHREADS % (C::PIX_T / 4) == 0 &&
             (C::CO_T / rounds) % (C::NTHREADS / (C::PIX_T / 4)) == 0 && aligned(d->y) && aligned(d->y_pre) && aligned(d->noise)) {
