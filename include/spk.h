@@ -48,6 +48,12 @@ extern "C" {
                                   * tile config in 0-3 (spk_conv2d_pick_config(2, 2, 1, B, Cin, 4*Cout, Hin, Win));
                                   * SPK_EPI_ACCUM is the only other flag.  Computed by output parity -- dx[2m+py, 2n+px]
                                   * needs 1/2/2/4 of the 9 taps -- as four 2x2 kernels in one launch, stored interleaved. */
+#define SPK_CONV_TRANSPOSE4X4_S2 2048u /* kh = kw = 4, stride = 2: the FORWARD of nn.ConvTranspose2d(Cin, Cout, 4, stride=2,
+                                  * padding=1) -- the fused upscale of the legacy GBlock, replaces: styleganv1.py:231,258 --
+                                  * x [B,Cin,Hin,Win] -> y [B,Cout,2Hin,2Win]; w_packed from spk_conv2d_pack_weights(w[Cin][Cout]
+                                  * [4][4], kh = kw = 4, transpose_flip = 3), config in 0-3 (spk_conv2d_pick_config(2, 2, 1, B, Cin,
+                                  * 4*Cout, Hin+1, Win+1)); bias [Cout]; SPK_EPI_BIAS / SPK_EPI_ACCUM only.  Every output pixel
+                                  * (2m+py, 2n+px) takes exactly 2x2 of the 16 taps: four 2x2 kernels, one launch, interleaved. */
 #define SPK_CONV_UP_FIR1331 512u     /* with UPSAMPLE2X: the x2 interpolation is upfirdn2d(up=2, FIR [1,3,3,1], pad (2,1)) --
                                       * the same (.75,.25) taps as bilinear, but neighbours outside the image are zero */
 
@@ -141,6 +147,8 @@ int64_t spk_conv2d_workspace_bytes_grouped(int config, int ksplit, int kh, int k
  * transpose_flip = 2 (kh = kw = 3): the four output-parity 2x2 kernels of the STRIDE-2 data gradient
  * (SPK_CONV_DGRAD_S2), the image of a [4*Cin, Cout, 2, 2] weight: spk_conv2d_packed_floats(config, 2, 2, Cout, 4*Cin)
  * floats, config in 0-3.  2x2 is accepted by the size / config queries for that purpose only.
+ * transpose_flip = 3 (kh = kw = 4, w is the [Cin,Cout,4,4] weight of a ConvTranspose2d): the four output-parity 2x2 kernels
+ * of SPK_CONV_TRANSPOSE4X4_S2: spk_conv2d_packed_floats(config, 2, 2, Cin, 4*Cout) floats, config in 0-3.
  * replaces: nothing in the reference (layout change private to this library). */
 int spk_conv2d_pack_weights(const float* w, float* w_packed, int kh, int kw, int Cin, int Cout, int config,
                             int transpose_flip, void* stream);
@@ -342,6 +350,14 @@ int spk_instance_norm_affine_bwd(const float* x, const float* dy, const float* s
 int spk_blur2d_fwd(const float* x, float* y, const float* filter_host, int k, int64_t planes, int H, int W, int stride, void* stream);
 int spk_upscale2d_nearest_fwd(const float* x, float* y, int64_t planes, int H, int W, int factor, float gain, void* stream);
 int spk_fade_in_tanh_fwd(const float* a, const float* b, float* y, float alpha, int64_t n, void* stream);
+/* Adjoints of the three stand-alone ops above (what autograd derives from styleganv1.py:52-63, :113-120, :132-136 and
+ * stylegan.py:28-29 when the legacy modules are trained):
+ * spk_pixelnorm_bwd: dx = r*dy - x * r^3 * mean_c(x*dy), r = rsqrt(mean_c x^2 + eps) (both forward spellings);
+ * spk_blur2d_bwd: dx [planes,H,W] from dy [planes,Ho,Wo] (Ho = (H+2p-k)/stride+1), the same HOST filter as the forward;
+ * spk_upscale2d_nearest_bwd: dx[h,w] = gain * sum of the factor x factor block of dy. */
+int spk_pixelnorm_bwd(const float* x, const float* dy, float* dx, int B, int C, int64_t HW, float eps, void* stream);
+int spk_blur2d_bwd(const float* dy, float* dx, const float* filter_host, int k, int64_t planes, int H, int W, int stride, void* stream);
+int spk_upscale2d_nearest_bwd(const float* dy, float* dx, int64_t planes, int H, int W, int factor, float gain, void* stream);
 
 #ifdef __cplusplus
 }

@@ -50,3 +50,18 @@ def upscale2d(x, factor=2, gain=1):
     if factor > 1:
         x = x.repeat_interleave(factor, dim=2).repeat_interleave(factor, dim=3)
     return x
+
+
+def fused_upscale(x, weight, bias=None):
+    """``GBlock.up_sample`` for res >= 7 -- styleganv1.py:231,258: ``nn.ConvTranspose2d(Cin, Cout, 4, stride=2,
+    padding=1)``; ``weight`` is [Cin,Cout,4,4].  Restated as the scatter it is: every input pixel adds its 4x4 stamp at
+    (2y-1, 2x-1)."""
+    B, Cin, H, W = x.shape
+    Cout = weight.shape[1]
+    full = x.new_zeros(B, Cout, 2 * H + 2, 2 * W + 2)        # output rows -1 .. 2H: cropped below
+    stamp = torch.einsum("bihw,iokl->bohwkl", x, weight)
+    for ky in range(4):
+        for kx in range(4):
+            full[:, :, ky:ky + 2 * H:2, kx:kx + 2 * W:2] += stamp[..., ky, kx]
+    y = full[:, :, 1:2 * H + 1, 1:2 * W + 1]
+    return y + bias.view(1, -1, 1, 1) if bias is not None else y

@@ -38,6 +38,7 @@ class Conv2dDesc(C.Structure):
 CONV_IN_BATCH_SCALE = 256
 CONV_UP_FIR1331 = 512
 CONV_DGRAD_S2 = 1024
+CONV_TRANSPOSE4X4_S2 = 2048
 
 
 FC_MAX_GROUPS = 16
@@ -84,6 +85,10 @@ _PROTOTYPES = {
                                  C.c_void_p]),
     "spk_upscale2d_nearest_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "spk_fade_in_tanh_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_float, C.c_int64, C.c_void_p]),
+    "spk_pixelnorm_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_float, C.c_void_p]),
+    "spk_blur2d_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int,
+                                 C.c_void_p]),
+    "spk_upscale2d_nearest_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "spk_bn_bwd_reduce": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 4 +
                           [C.c_float, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p]),
     "spk_bn_bwd_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 5 +

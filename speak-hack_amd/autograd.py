@@ -44,7 +44,9 @@ class FusedConvFn(torch.autograd.Function):
     adjoint), the weight gradient on the MFMA wgrad kernel (upsampling re-formed on the fly)."""
 
     @staticmethod
-    def forward(ctx, x, weight, bias, noise_w, noise, style, upsample, slope, packed, grad_mode):
+    def forward(ctx, x, weight, bias, noise_w, noise, style, upsample, slope, packed, grad_mode, w_scale=1.0):
+        """``w_scale``: the conv runs on ``weight * w_scale`` (equalised learning rate, stylegan.py:31-46) without that
+        product ever existing: the factor rides on the accumulator (``out_scale``) forward and on dx / dw backward."""
         B, Cin, Hs, Ws = x.shape
         Cout = weight.shape[0]
         H, W = (2 * Hs, 2 * Ws) if upsample else (Hs, Ws)
@@ -52,16 +54,16 @@ class FusedConvFn(torch.autograd.Function):
         keep = _needs(ctx, grad_mode)
         a = torch.empty((B, Cout, H, W), device=x.device, dtype=torch.float32) if keep else None
         y = ops.conv2d_fused(x, packed.get(weight, cfg), Cout, 3, 1, bias=bias, noise_w=noise_w, noise=noise,
-                             style=style, upsample=upsample, lrelu_slope=slope, config=cfg, out_pre=a)
+                             style=style, upsample=upsample, lrelu_slope=slope, config=cfg, out_pre=a, out_scale=w_scale)
         if keep:
             ctx.save_for_backward(x, weight, a, noise, style)
-            ctx.conf = (upsample, slope, packed, bias is not None, noise_w is not None)
+            ctx.conf = (upsample, slope, packed, bias is not None, noise_w is not None, float(w_scale))
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, weight, a, noise, style = ctx.saved_tensors
-        upsample, slope, packed, has_bias, has_noise = ctx.conf
+        upsample, slope, packed, has_bias, has_noise, w_scale = ctx.conf
         B, Cin = x.shape[:2]
         Cout, H, W = a.shape[1:]
         dt, sums = ops.epilogue_bwd(dy.contiguous(), a, noise if has_noise else None, style,
@@ -72,12 +74,12 @@ class FusedConvFn(torch.autograd.Function):
         dx = dw = None
         if ctx.needs_input_grad[0]:
             cfg = ops.conv2d_pick_config(3, 1, B, Cout, Cin, H, W)
-            dx = ops.conv2d_fused(dt, packed.get(weight, cfg, transpose_flip=True), Cin, 3, 1, config=cfg)
+            dx = ops.conv2d_fused(dt, packed.get(weight, cfg, transpose_flip=True), Cin, 3, 1, config=cfg, out_scale=w_scale)
             if upsample:
                 dx = ops.upsample2x_bilinear_bwd(dx)
         if ctx.needs_input_grad[1]:
-            dw = ops.conv2d_wgrad(dt, x, Cout, Cin, 3, 1, upsample=upsample)
-        return dx, dw, dbias, dnw, None, dstyle, None, None, None, None
+            dw = ops.conv2d_wgrad(dt, x, Cout, Cin, 3, 1, upsample=upsample, scale=w_scale)
+        return dx, dw, dbias, dnw, None, dstyle, None, None, None, None, None
 
 
 class FCFn(torch.autograd.Function):
@@ -393,7 +395,7 @@ class InstanceNormAffineFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, scale = ctx.saved_tensors
         dx, dscale, dbias = ops.instance_norm_affine_bwd(x, dy.contiguous(), scale, ctx.eps, need_dx=ctx.needs_input_grad[0])
-        return dx, dscale, dbias, None, None
+        return dx, (dscale if ctx.needs_input_grad[1] else None), (dbias if ctx.needs_input_grad[2] else None), None, None
 
 
 class Upsample2xFn(torch.autograd.Function):
@@ -408,9 +410,52 @@ class Upsample2xFn(torch.autograd.Function):
         return ops.upsample2x_bilinear_bwd(dy.contiguous())
 
 
+class PixelNormFn(torch.autograd.Function):
+    """x * rsqrt(mean_c x^2 + eps) -- styleganv1.py:132-136 / stylegan.py:28-29."""
+
+    @staticmethod
+    def forward(ctx, x, eps, sqrt_form):
+        ctx.save_for_backward(x)
+        ctx.eps = eps
+        return ops.pixelnorm(x, eps, sqrt_form)
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        return ops.pixelnorm_bwd(x, dy.contiguous(), ctx.eps), None, None
+
+
+class Blur2dFn(torch.autograd.Function):
+    """Depthwise FIR (host filter), zero pad (k-1)/2, stride 1 or 2 -- styleganv1.py:52-63."""
+
+    @staticmethod
+    def forward(ctx, x, filt, stride):
+        ctx.conf = (filt, stride, tuple(x.shape[-2:]))
+        return ops.blur2d(x, filt, stride)
+
+    @staticmethod
+    def backward(ctx, dy):
+        filt, stride, hw = ctx.conf
+        return ops.blur2d_bwd(dy.contiguous(), filt, stride, hw), None, None
+
+
+class Upscale2dFn(torch.autograd.Function):
+    """Nearest-neighbour repeat with a gain -- styleganv1.py:113-120."""
+
+    @staticmethod
+    def forward(ctx, x, factor, gain):
+        ctx.conf = (factor, gain)
+        return ops.upscale2d_nearest(x, factor, gain)
+
+    @staticmethod
+    def backward(ctx, dy):
+        factor, gain = ctx.conf
+        return ops.upscale2d_nearest_bwd(dy.contiguous(), factor, gain), None, None
+
+
 # call-site spellings: sample the grad mode where it is still visible
-def fused_conv(x, weight, bias, noise_w, noise, style, upsample, slope, packed):
-    return FusedConvFn.apply(x, weight, bias, noise_w, noise, style, upsample, slope, packed, torch.is_grad_enabled())
+def fused_conv(x, weight, bias, noise_w, noise, style, upsample, slope, packed, w_scale=1.0):
+    return FusedConvFn.apply(x, weight, bias, noise_w, noise, style, upsample, slope, packed, torch.is_grad_enabled(), w_scale)
 
 
 def fc(x, weight, bias, wmul, bmul, slope):
@@ -451,3 +496,15 @@ def instance_norm_affine(x, scale, bias, eps):
 
 def upsample2x(x):
     return Upsample2xFn.apply(x)
+
+
+def pixelnorm(x, eps, sqrt_form=False):
+    return PixelNormFn.apply(x, eps, sqrt_form)
+
+
+def blur2d(x, filt, stride):
+    return Blur2dFn.apply(x, filt, stride)
+
+
+def upscale2d(x, factor, gain):
+    return Upscale2dFn.apply(x, factor, gain)

@@ -163,7 +163,14 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
     if (co < opCout && cig < opCin) {
         if (tf == 0) v = w[((size_t)co * Cin_orig + cig) * taps + tap];
         else if (tf == 1) v = w[((size_t)cig * Cin_orig + co) * taps + (taps - 1 - tap)];
-        else {
+        else if (tf == 3) {
+            // parity kernels of ConvTranspose2d(4, stride 2, pad 1) (taps = 4, w is [Cin][Cout][4][4], Cin_orig = Cout here):
+            // output channel co = q*Cout + co_o, q = (qy, qx); window position (a, b) = input pixel (y-1+a, x-1+b) for the
+            // output pixel (2y-1+qy, 2x-1+qx): oy = 2*iy - 1 + ky gives ky = 2, 0 for qy = 0 and ky = 3, 1 for qy = 1.
+            const int q = co / Cin_orig, co_o = co - q * Cin_orig, a = tap >> 1, b = tap & 1;
+            const int ky = (q >> 1) ? (a ? 1 : 3) : (a ? 0 : 2), kx = (q & 1) ? (b ? 1 : 3) : (b ? 0 : 2);
+            v = w[(((size_t)cig * Cin_orig + co_o) * 4 + ky) * 4 + kx];
+        } else {
             // parity kernels of the 3x3 stride-2 pad-1 data gradient (taps = 4 here, w is [Cout][Cin][3][3]): output
             // channel co = q*Cin + ci, q = (py, px); window position (a, b) = gradient pixel (m+a, n+b) for the input
             // pixel (2m+py, 2n+px).  Even coordinate: only a = 0 reaches it, through tap 1; odd: a = 0 through tap 2,
@@ -338,24 +345,26 @@ int spk_conv2d_pack_weights(const float* w, float* w_packed, int kh, int kw, int
     SPK_REQUIRE(w && w_packed, "pack_weights: null pointer");
     SPK_REQUIRE(config >= 0 && config < kNumConfigs, "pack_weights: bad config %d", config);
     SPK_REQUIRE(Cin > 0 && Cout > 0 && kh > 0 && kw > 0, "pack_weights: bad shape");
-    SPK_REQUIRE(transpose_flip >= 0 && transpose_flip <= 2, "pack_weights: transpose_flip is 0, 1 or 2");
+    SPK_REQUIRE(transpose_flip >= 0 && transpose_flip <= 3, "pack_weights: transpose_flip is 0, 1, 2 or 3");
     SPK_REQUIRE(transpose_flip != 2 || (kh == 3 && kw == 3), "pack_weights: the stride-2 data-gradient form packs a 3x3 kernel");
+    SPK_REQUIRE(transpose_flip != 3 || (kh == 4 && kw == 4), "pack_weights: the transposed-conv form packs a 4x4 kernel");
     if (config == kGemmConfig) {        // row-major [opCout][opCin]: the weight itself, or its transpose for the data gradient
-        SPK_REQUIRE(kh == 1 && kw == 1 && transpose_flip != 2, "pack_weights: config %d packs 1x1 kernels", kGemmConfig);
+        SPK_REQUIRE(kh == 1 && kw == 1 && transpose_flip < 2, "pack_weights: config %d packs 1x1 kernels", kGemmConfig);
         const long long n = (long long)Cin * Cout;
         hipLaunchKernelGGL(pack_rowmajor_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, w_packed,
                            Cin, Cout, transpose_flip, n);
         return spk::check_launch("pack_rowmajor_kernel");
     }
     const CfgDims& c = kDims[config];
-    const int opCin = transpose_flip ? Cout : Cin, opCout = transpose_flip == 2 ? 4 * Cin : (transpose_flip ? Cin : Cout);
-    const int taps = transpose_flip == 2 ? 4 : kh * kw;
+    const int opCin = (transpose_flip == 1 || transpose_flip == 2) ? Cout : Cin;
+    const int opCout = transpose_flip == 2 ? 4 * Cin : (transpose_flip == 3 ? 4 * Cout : (transpose_flip ? Cin : Cout));
+    const int taps = transpose_flip >= 2 ? 4 : kh * kw;
     const int n_chunks = spk::ceil_div(opCin, c.ci_t);
     const long long total = (long long)spk::ceil_div(opCout, c.co_t) * n_chunks * taps * c.ci_t * c.co_t;
     const int threads = 256;
     hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((total + threads - 1) / threads)), dim3(threads), 0,
-                       (hipStream_t)stream, w, w_packed, taps, Cin, opCin, opCout, c.co_t, c.ci_t, n_chunks,
-                       transpose_flip, total);
+                       (hipStream_t)stream, w, w_packed, taps, transpose_flip == 3 ? Cout : Cin, opCin, opCout, c.co_t, c.ci_t,
+                       n_chunks, transpose_flip, total);
     return spk::check_launch("pack_weights_kernel");
 }
 
@@ -363,6 +372,24 @@ int spk_conv2d_fwd(const spk_conv2d_desc* d, void* stream) {
     SPK_REQUIRE(d, "conv2d: null descriptor");
     SPK_REQUIRE(d->x && d->w_packed && d->y, "conv2d: null tensor pointer");
     SPK_REQUIRE(d->B > 0 && d->Cin > 0 && d->Cout > 0 && d->H > 0 && d->W > 0 && d->Hin > 0 && d->Win > 0, "conv2d: bad shape");
+    if (d->flags & SPK_CONV_TRANSPOSE4X4_S2) {
+        // forward of nn.ConvTranspose2d(Cin, Cout, 4, stride=2, padding=1): x [B,Cin,Hin,Win] -> y [B,Cout,2Hin,2Win]; the four
+        // output-parity classes are 2x2 kernels over the (Hin+1) x (Win+1) window anchors, stored interleaved
+        SPK_REQUIRE(d->kh == 4 && d->kw == 4 && d->stride == 2, "conv2d: TRANSPOSE4X4_S2 is a 4x4 stride-2 transposed conv");
+        SPK_REQUIRE(!(d->flags & ~(SPK_CONV_TRANSPOSE4X4_S2 | SPK_EPI_BIAS | SPK_EPI_ACCUM)) && !d->out_scale_bc && !d->y_pre,
+                    "conv2d: TRANSPOSE4X4_S2 takes SPK_EPI_BIAS / SPK_EPI_ACCUM only");
+        SPK_REQUIRE(!(d->flags & SPK_EPI_BIAS) || d->bias, "conv2d: SPK_EPI_BIAS without bias");
+        SPK_REQUIRE(d->H == 2 * d->Hin && d->W == 2 * d->Win, "conv2d: TRANSPOSE4X4_S2 output must be 2x the input (%dx%d vs %dx%d)",
+                    d->H, d->W, d->Hin, d->Win);
+        SPK_REQUIRE(d->groups <= 1, "conv2d: TRANSPOSE4X4_S2 is not grouped");
+        SPK_REQUIRE((long long)d->B * d->Cout * d->H * d->W < (1ll << 40), "conv2d: tensor too large");
+        spk_conv2d_desc dd = *d;
+        dd.kh = dd.kw = 2; dd.stride = 1; dd.Cout = 4 * d->Cout; dd.H = d->Hin + 1; dd.W = d->Win + 1; dd.ksplit = 1;
+        dd.flags = d->flags & (SPK_EPI_BIAS | SPK_EPI_ACCUM);
+        if (dd.config < 0) dd.config = pick_config(2, 1, dd.B, dd.Cin, dd.Cout, dd.H, dd.W);
+        SPK_REQUIRE(config_valid(dd.config, 2, 2, 1), "conv2d: TRANSPOSE4X4_S2 runs tile configs 0-3 (got %d)", dd.config);
+        return run_2x2_parity(dd.config, &dd, d->H, d->W, 1, (hipStream_t)stream);
+    }
     SPK_REQUIRE(supported_kernel(d->kh, d->kw, d->stride) && d->kh != 2, "conv2d: unsupported kernel %dx%d stride %d", d->kh, d->kw, d->stride);
     if (d->flags & SPK_CONV_DGRAD_S2) {
         // data gradient of a 3x3 stride-2 pad-1 conv: x = the output-side gradient [B, Cin, Hin, Win], y = the input-side
@@ -379,7 +406,7 @@ int spk_conv2d_fwd(const spk_conv2d_desc* d, void* stream) {
         dd.flags = d->flags & SPK_EPI_ACCUM; dd.out_scale = d->out_scale;
         if (dd.config < 0) dd.config = pick_config(2, 1, dd.B, dd.Cin, dd.Cout, dd.H, dd.W);
         SPK_REQUIRE(config_valid(dd.config, 2, 2, 1), "conv2d: DGRAD_S2 runs tile configs 0-3 (got %d)", dd.config);
-        return run_2x2_parity(dd.config, &dd, d->H, d->W, (hipStream_t)stream);
+        return run_2x2_parity(dd.config, &dd, d->H, d->W, 0, (hipStream_t)stream);
     }
     const bool ups = d->flags & SPK_CONV_UPSAMPLE2X, aff = d->flags & SPK_CONV_IN_AFFINE_RELU;
     const bool bsc = d->flags & SPK_CONV_IN_BATCH_SCALE;

@@ -75,6 +75,8 @@ struct ConvArgs {
     // Cin, Cy = Cout.
     int G, Cx, Cy, gin, co_tiles_g;
     int Hd, Wd;              // 2x2 (parity) kernels: spatial size of the interleaved destination
+    int pshift;              // 2x2 (parity) kernels: 1 = window rows y-1, y / destination pixel (2y-1+py, 2x-1+px) -- the
+                             // ConvTranspose2d(4, stride 2, pad 1) form; 0 = rows y, y+1 / (2y+py, 2x+px) -- the 3x3 s2 data gradient
     int staged;              // epilogue through LDS with 16-byte stores (set by the host when the tile / tensors allow it)
 };
 
@@ -198,7 +200,8 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
             const int q = wave * ppw + pl;
             const int ci = q >> p.lgTB, tb = q & (TB - 1);
             const int r = p.magic_pw ? (int)__umulhi((unsigned)pidx, p.magic_pw) : pidx, c = pidx - r * PW;
-            const int uy = (y0 * SL + r) * (S / SL) - PAD, ux = (x0 * SL + c) * (S / SL) - PAD;
+            const int psh = KH == 2 ? p.pshift : 0;
+            const int uy = (y0 * SL + r) * (S / SL) - PAD - psh, ux = (x0 * SL + c) * (S / SL) - PAD - psh;
             const bool past = ci >= ci_left_last;
             s_dst[s] = (unsigned)(W_FLOATS + wave * wave_elems + e) * 4u;
             unsigned off = (unsigned)(grp * p.gin + ci) * (unsigned)src_plane;  // padding elements read any address inside the tensor
@@ -634,7 +637,8 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
             const int cg = grp * p.Cout + co;              // channel in the output tensor (all groups)
             float ssum = 0.f, ssq = 0.f;
             if (cv) {
-                const float bb = (f_bias && !split) ? p.bias[cg] : 0.f;
+                // parity kernels: the bias belongs to the interleaved destination's channel (one value for the 4 classes)
+                const float bb = (f_bias && !split) ? p.bias[UNSH ? grp * (p.Cout >> 2) + co % (p.Cout >> 2) : cg] : 0.f;
                 const float nwc = (f_noise && !split) ? p.noise_w[cg] : 0.f;
 #pragma unroll
                 for (int n = 0; n < C::NT; ++n) {
@@ -642,8 +646,8 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
                     float* dst = ybase + poff[n] + (size_t)cg * HW;
                     if constexpr (UNSH) {
                         const int c4 = p.Cout >> 2, q = co / c4;
-                        const int Y = uy2[n] + (q >> 1), X = ux2[n] + (q & 1);
-                        if (Y >= p.Hd || X >= p.Wd) continue;
+                        const int Y = uy2[n] + (q >> 1) - p.pshift, X = ux2[n] + (q & 1) - p.pshift;
+                        if (Y < 0 || X < 0 || Y >= p.Hd || X >= p.Wd) continue;
                         dst = p.y + (((size_t)pb[n] * (p.G * c4) + grp * c4 + (co - q * c4)) * p.Hd + Y) * p.Wd + X;
                     }
                     if (split) {  // raw partial sums; splitk_epilogue_kernel finishes
@@ -762,9 +766,9 @@ int launch_splitk_epilogue(const ConvArgs& a, const float* ws, int ksplit, hipSt
 
 // Fill ConvArgs from the public descriptor, pick geometry / split-K, launch (and the split-K epilogue).
 template <class C, int KH, int KW, int S, int MODE>
-int run(const spk_conv2d_desc* d, hipStream_t stream, int Hd = 0, int Wd = 0) {
+int run(const spk_conv2d_desc* d, hipStream_t stream, int Hd = 0, int Wd = 0, int pshift = 0) {
     ConvArgs a;
-    a.Hd = Hd; a.Wd = Wd;
+    a.Hd = Hd; a.Wd = Wd; a.pshift = pshift;
     a.x = d->x; a.wp = d->w_packed; a.bias = d->bias; a.noise_w = d->noise_w; a.noise = d->noise;
     a.style = d->style; a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.stats = d->stats; a.stats_slots = d->stats_slots > 1 ? d->stats_slots : 1; a.y = d->y; a.y_pre = d->y_pre; a.out_scale_bc = d->out_scale_bc;
     a.B = d->B; a.Cin = d->Cin; a.Cout = d->Cout; a.H = d->H; a.W = d->W; a.Hs = d->Hin; a.Ws = d->Win;
@@ -854,7 +858,7 @@ int run_3x3s1_a(int cfg, int mode, const spk_conv2d_desc* d, hipStream_t s);  //
 int run_3x3s1_b(int cfg, int mode, const spk_conv2d_desc* d, hipStream_t s);  // ids 4-7
 int run_3x3s2_7x7s2(int kh, int cfg, int mode, const spk_conv2d_desc* d, hipStream_t s);  // ids 4-7
 int run_1x1(int stride, int cfg, int mode, const spk_conv2d_desc* d, hipStream_t s);      // ids 8-11
-int run_2x2_parity(int cfg, const spk_conv2d_desc* d, int Hd, int Wd, hipStream_t s);     // ids 0-3
+int run_2x2_parity(int cfg, const spk_conv2d_desc* d, int Hd, int Wd, int pshift, hipStream_t s);     // ids 0-3
 int run_1x1_gemm(const spk_conv2d_desc* d, hipStream_t s);                                // id 12
 bool gemm1x1_takes(int kh, int stride, int Cin, int H, int W);
 long long gemm1x1_pixel_tiles(int B, int H, int W);

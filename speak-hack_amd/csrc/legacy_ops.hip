@@ -133,6 +133,82 @@ __global__ __launch_bounds__(256) void upscale2d_kernel(const float* __restrict_
     }
 }
 
+// Adjoint of pixelnorm: with r = rsqrt(mean_c x^2 + eps):  dx_j = r*dy_j - x_j * r^3 * mean_c(x*dy)   (both spellings of the
+// forward are the same function).  One thread per pixel, channels strided by HW (coalesced across the wave).
+__global__ __launch_bounds__(256) void pixelnorm_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                           float* __restrict__ dx, int C, long long HW, long long total_px, float eps) {
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total_px; idx += (long long)gridDim.x * blockDim.x) {
+        const long long b = idx / HW, p = idx % HW;
+        const float* xp = x + b * C * HW + p;
+        const float* gp = dy + b * C * HW + p;
+        float s = 0.f, t = 0.f;
+        for (int c = 0; c < C; ++c) { const float v = xp[(size_t)c * HW]; s += v * v; t += v * gp[(size_t)c * HW]; }
+        const float r = rsqrtf(s / (float)C + eps);
+        const float k = r * r * r * (t / (float)C);
+        float* dp = dx + b * C * HW + p;
+        for (int c = 0; c < C; ++c) dp[(size_t)c * HW] = r * gp[(size_t)c * HW] - xp[(size_t)c * HW] * k;
+    }
+}
+
+// few pixels, many channels: one workgroup per pixel
+__global__ __launch_bounds__(256) void pixelnorm_bwd_wide_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                                float* __restrict__ dx, int C, long long HW, float eps) {
+    __shared__ float red[4];
+    const long long b = blockIdx.x / HW, p = blockIdx.x % HW;
+    const float* xp = x + b * C * HW + p;
+    const float* gp = dy + b * C * HW + p;
+    float s = 0.f, t = 0.f;
+    for (int c = threadIdx.x; c < C; c += 256) { const float v = xp[(size_t)c * HW]; s += v * v; t += v * gp[(size_t)c * HW]; }
+    const float ss = lg_block_sum(s, red), tt = lg_block_sum(t, red);
+    const float r = rsqrtf(ss / (float)C + eps);
+    const float k = r * r * r * (tt / (float)C);
+    float* dp = dx + b * C * HW + p;
+    for (int c = threadIdx.x; c < C; c += 256) dp[(size_t)c * HW] = r * gp[(size_t)c * HW] - xp[(size_t)c * HW] * k;
+}
+
+// Adjoint of blur2d_kernel (gather form): dx[iy,ix] = sum_{ky,kx} f[ky,kx] * dy[(iy+pad-ky)/s, (ix+pad-kx)/s] over the taps
+// whose quotient is exact and inside the output.
+__global__ __launch_bounds__(256) void blur2d_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, Fir fir, long long planes,
+                                                        int H, int W, int Ho, int Wo, int stride) {
+    const int k = fir.k, pad = (k - 1) / 2;
+    const long long total = planes * H * W;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int ix = (int)(idx % W), iy = (int)((idx / W) % H);
+        const long long pl = idx / ((long long)W * H);
+        const float* gp = dy + pl * Ho * Wo;
+        float acc = 0.f;
+        for (int ky = 0; ky < k; ++ky) {
+            const int ny = iy + pad - ky;
+            if (ny < 0 || ny % stride) continue;
+            const int oy = ny / stride;
+            if (oy >= Ho) continue;
+            for (int kx = 0; kx < k; ++kx) {
+                const int nx = ix + pad - kx;
+                if (nx < 0 || nx % stride) continue;
+                const int ox = nx / stride;
+                if (ox < Wo) acc += fir.f[ky * k + kx] * gp[(size_t)oy * Wo + ox];
+            }
+        }
+        dx[idx] = acc;
+    }
+}
+
+// Adjoint of upscale2d_kernel: dx[y,x] = gain * sum of the factor x factor block of dy
+__global__ __launch_bounds__(256) void upscale2d_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, long long planes, int H,
+                                                           int W, int factor, float gain) {
+    const int Wo = W * factor;
+    const long long total = planes * H * W;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int ix = (int)(idx % W), iy = (int)((idx / W) % H);
+        const long long pl = idx / ((long long)W * H);
+        const float* gp = dy + (pl * H * factor + (long long)iy * factor) * Wo + (long long)ix * factor;
+        float acc = 0.f;
+        for (int a = 0; a < factor; ++a)
+            for (int b = 0; b < factor; ++b) acc += gp[(size_t)a * Wo + b];
+        dx[idx] = acc * gain;
+    }
+}
+
 __global__ __launch_bounds__(256) void fade_in_tanh_kernel(const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y,
                                                           float alpha, long long n) {
     for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x)
@@ -191,6 +267,38 @@ int spk_upscale2d_nearest_fwd(const float* x, float* y, int64_t planes, int H, i
     hipLaunchKernelGGL(upscale2d_kernel, dim3(sgrid((long long)planes * H * W * factor * factor)), dim3(256), 0, (hipStream_t)stream,
                        x, y, (long long)planes, H, W, factor, gain);
     return spk::check_launch("upscale2d_kernel");
+}
+
+int spk_pixelnorm_bwd(const float* x, const float* dy, float* dx, int B, int C, int64_t HW, float eps, void* stream) {
+    SPK_REQUIRE(x && dy && dx && B > 0 && C > 0 && HW > 0, "pixelnorm_bwd: bad arguments");
+    if ((long long)B * HW <= 4096 && C >= 256) {
+        hipLaunchKernelGGL(pixelnorm_bwd_wide_kernel, dim3((unsigned)(B * HW)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, C,
+                           (long long)HW, eps);
+        return spk::check_launch("pixelnorm_bwd_wide_kernel");
+    }
+    hipLaunchKernelGGL(pixelnorm_bwd_kernel, dim3(sgrid((long long)B * HW)), dim3(256), 0, (hipStream_t)stream, x, dy, dx, C,
+                       (long long)HW, (long long)B * HW, eps);
+    return spk::check_launch("pixelnorm_bwd_kernel");
+}
+
+int spk_blur2d_bwd(const float* dy, float* dx, const float* filter_host, int k, int64_t planes, int H, int W, int stride, void* stream) {
+    SPK_REQUIRE(dy && dx && filter_host && k >= 1 && k <= 7 && planes > 0 && H > 0 && W > 0 && (stride == 1 || stride == 2),
+                "blur2d_bwd: bad arguments (k <= 7, stride 1 or 2)");
+    Fir fir;
+    fir.k = k;
+    for (int i = 0; i < k * k; ++i) fir.f[i] = filter_host[i];
+    const int pad = (k - 1) / 2;
+    const int Ho = (H + 2 * pad - k) / stride + 1, Wo = (W + 2 * pad - k) / stride + 1;
+    hipLaunchKernelGGL(blur2d_bwd_kernel, dim3(sgrid((long long)planes * H * W)), dim3(256), 0, (hipStream_t)stream, dy, dx, fir,
+                       (long long)planes, H, W, Ho, Wo, stride);
+    return spk::check_launch("blur2d_bwd_kernel");
+}
+
+int spk_upscale2d_nearest_bwd(const float* dy, float* dx, int64_t planes, int H, int W, int factor, float gain, void* stream) {
+    SPK_REQUIRE(dy && dx && planes > 0 && H > 0 && W > 0 && factor >= 1, "upscale2d_bwd: bad arguments");
+    hipLaunchKernelGGL(upscale2d_bwd_kernel, dim3(sgrid((long long)planes * H * W)), dim3(256), 0, (hipStream_t)stream, dy, dx,
+                       (long long)planes, H, W, factor, gain);
+    return spk::check_launch("upscale2d_bwd_kernel");
 }
 
 int spk_fade_in_tanh_fwd(const float* a, const float* b, float* y, float alpha, int64_t n, void* stream) {

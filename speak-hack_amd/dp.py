@@ -6,26 +6,36 @@ wrapper for ``model.D`` / ``model.Gd``).  This is the MI355X-side
 mini-batch is sharded by rank (no data-path collective in forward), and the ONE exchange step of a
 training iteration -- summing parameter gradients over ranks -- is done here:
 
-* parameters are grouped, in reverse registration order (~ the order autograd finishes them: toRGB
-  first, mapping last), into flat fp32 buckets;
+* construction broadcasts every parameter from rank 0 (replicas start identical whatever the callers seeded);
+* parameters are grouped into flat fp32 buckets.  The first backward runs on buckets in reverse registration
+  order; the order in which the per-parameter hooks actually fired is recorded, rank 0's order is broadcast, and
+  the buckets are REBUILT in that order (``rebuilt``): the first bucket then holds what autograd finishes first
+  (toRGB, the 256^2 layers) and parameters that never receive a gradient (``Cm`` in a reconstruction-only step,
+  SURVEY.md 3.1) sit in trailing buckets of their own instead of stalling a hot one;
 * ``zero_grad()`` drops the gradients (``p.grad = None``), so backward's first -- here only -- gradient of a
-  parameter is simply adopted by autograd: no zero-fill of 386 MB and no ``grad += g`` kernel per parameter
-  (630 launches, 2 ms of the generator step when the gradients lived inside pre-zeroed buckets);
-* a post-accumulate hook per parameter counts arrivals; when a bucket is complete its gradients are gathered into
-  the flat buffer by ONE multi-tensor copy, ``param.grad`` is re-pointed at its slice of the buffer, and the
-  all-reduce is launched asynchronously -- on GPU that is RCCL over xGMI on its own stream, overlapping the rest
-  of backward (the big low-resolution 512x512x3x3 weight gradients, 9.4 MB each, arrive last and are the only
-  exposed part).  With one rank there is nothing to exchange and nothing is copied;
-* ``finish()`` waits for the outstanding collectives (stream-side on GPU) and leaves ``1/world``-scaled
-  sums in place, exactly what DDP's gradient averaging leaves.
+  parameter is simply adopted by autograd: no zero-fill of 386 MB and no ``grad += g`` kernel per parameter;
+* a post-accumulate hook per parameter counts arrivals; when a bucket is complete AND every lower-index bucket has
+  been launched (collectives must pair up in the same order on every rank) its gradients are gathered into the flat
+  buffer by ONE multi-tensor copy, ``param.grad`` is re-pointed at its slice of the buffer, and the all-reduce is
+  launched asynchronously -- on GPU that is RCCL over xGMI on its own stream, overlapping the rest of backward
+  (the big low-resolution 512x512x3x3 weight gradients, 9.4 MB each, arrive last and are the only exposed part).
+  With one rank there is nothing to exchange and nothing is copied;
+* ``finish()`` launches, in index order, what the hooks could not (buckets with parameters that got no gradient
+  this step: they contribute zeros), waits for the outstanding collectives (stream-side on GPU) and leaves
+  ``1/world``-scaled sums in place, exactly what DDP's gradient averaging leaves;
+* ``no_sync()`` / ``GradAccumulator``: the gradient-accumulation schedule of ``accelerator.accumulate``
+  (train.py:152,335; config.yaml gradient_accumulation_steps): micro-steps inside ``no_sync`` only accumulate
+  locally, the last micro-step exchanges the sums.
 
 Bucket size: xGMI is point-to-point (7 links x ~153 GB/s per GPU), so a ring all-reduce of S bytes costs
 about 2*(7/8)*S/153 GB/s; 32 MiB buckets keep each collective ~0.4 ms (far above the ~20 us launch
 latency) and give the decoder's 104 MB of gradients 4 chances to overlap.  The same class runs on CPU
-tensors with the ``gloo`` backend (tests/test_dp_gloo.py, world size 2).
+tensors with the ``gloo`` backend (tests/test_dp_gloo.py, world size 2) and on HIP tensors with ``gloo``
+(two ranks on one GPU: tests/test_dp_gpu.py) or RCCL.
 """
 from __future__ import annotations
 
+import contextlib
 from typing import Iterable, List, Optional
 
 import torch
@@ -34,35 +44,65 @@ import torch.distributed as dist
 
 class GradBucketReducer:
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 32 << 20,
-                 process_group: Optional[dist.ProcessGroup] = None, average: bool = True):
+                 process_group: Optional[dist.ProcessGroup] = None, average: bool = True,
+                 broadcast_parameters: bool = True, rebuild_after_first_step: bool = True):
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.average = average
+        self.bucket_bytes = int(bucket_bytes)
         plist = [p for p in params if p.requires_grad]
         if not plist:
             raise ValueError("GradBucketReducer: no trainable parameters")
-        self.params = list(reversed(plist))
-        dev, dtype = self.params[0].device, self.params[0].dtype
-        # ---- assign parameters to buckets ----
-        self.buckets: List[dict] = []
-        cur, cur_bytes = [], 0
-        for p in self.params:
+        dev, dtype = plist[0].device, plist[0].dtype
+        for p in plist:
             if p.device != dev or p.dtype != dtype:
                 raise ValueError("GradBucketReducer: parameters must share device and dtype")
-            nbytes = p.numel() * p.element_size()
-            if cur and cur_bytes + nbytes > bucket_bytes:
-                self._seal(cur, dev, dtype)
-                cur, cur_bytes = [], 0
-            cur.append(p)
-            cur_bytes += nbytes
-        if cur:
-            self._seal(cur, dev, dtype)
+        self._registration = plist                         # index space of the recorded / broadcast order
+        self._index = {id(p): i for i, p in enumerate(plist)}
+        self.params = list(reversed(plist))                # ~ the order autograd finishes them (refined after step 1)
+        if broadcast_parameters and self.world > 1:
+            self._broadcast_parameters()
+        self.buckets: List[dict] = []
+        self._build(self.params, cold=())
+        self.rebuilt = not rebuild_after_first_step or self.world == 1
+        self._fired: List[int] = []                        # registration indices in hook order (first synced backward)
+        self._sync = True
         self._handles = []
-        self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(bi))
-                       for bi, b in enumerate(self.buckets) for p in b["params"]]
+        self._next = 0                                     # lowest bucket index not launched yet
+        self.stats = {"launched_by_hook": [], "launched_by_finish": []}     # bucket indices, last step
+        self._hooks = [p.register_post_accumulate_grad_hook(self._hook) for p in plist]
         self.zero_grad()
 
-    def _seal(self, plist, dev, dtype):
+    # ---- construction --------------------------------------------------------------------------
+    def _broadcast_parameters(self):
+        """Replicas must start identical: rank 0's values win (DDP does the same at construction)."""
+        with torch.no_grad():
+            flat = torch.cat([p.detach().reshape(-1) for p in self._registration])
+            dist.broadcast(flat, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+            off = 0
+            for p in self._registration:
+                p.copy_(flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+
+    def _build(self, ordered, cold):
+        """Bucket ``ordered`` (hot parameters, in completion order) then ``cold`` (never seen a gradient) separately."""
+        dev, dtype = ordered[0].device if ordered else cold[0].device, self._registration[0].dtype
+        self.buckets = []
+        for group in (ordered, cold):
+            cur, cur_bytes = [], 0
+            for p in group:
+                nbytes = p.numel() * p.element_size()
+                if cur and cur_bytes + nbytes > self.bucket_bytes:
+                    self._seal(cur, dev, dtype, cold=group is cold)
+                    cur, cur_bytes = [], 0
+                cur.append(p)
+                cur_bytes += nbytes
+            if cur:
+                self._seal(cur, dev, dtype, cold=group is cold)
+        self._bucket_of = {id(p): bi for bi, b in enumerate(self.buckets) for p in b["params"]}
+        self.params = [p for b in self.buckets for p in b["params"]]
+
+    def _seal(self, plist, dev, dtype, cold=False):
         total = sum(p.numel() for p in plist)
         flat = views = None
         if self.world > 1:                     # the communication buffer and each parameter's slice of it
@@ -72,17 +112,30 @@ class GradBucketReducer:
                 views.append(flat[off:off + p.numel()].view_as(p))
                 off += p.numel()
         self.buckets.append({"params": plist, "flat": flat, "views": views, "numel": total, "pending": len(plist),
-                             "n": len(plist)})
+                             "n": len(plist), "ready": False, "launched": False, "cold": cold})
 
-    def _make_hook(self, bi):
-        def hook(param):
-            b = self.buckets[bi]
-            b["pending"] -= 1
-            if b["pending"] == 0:
-                self._launch(b)
-        return hook
+    # ---- backward-time protocol ----------------------------------------------------------------
+    def _hook(self, param):
+        if not self._sync:                     # accumulation micro-step: gradients only pile up locally
+            return
+        if not self.rebuilt:
+            self._fired.append(self._index[id(param)])
+        b = self.buckets[self._bucket_of[id(param)]]
+        b["pending"] -= 1
+        if b["pending"] == 0:
+            b["ready"] = True
+            self._drain(by_hook=True)
 
-    def _launch(self, b):
+    def _drain(self, by_hook):
+        """Launch ready buckets strictly in index order: every rank issues the same sequence of collectives."""
+        while self._next < len(self.buckets) and self.buckets[self._next]["ready"]:
+            self._launch(self._next)
+            self.stats["launched_by_hook" if by_hook else "launched_by_finish"].append(self._next)
+            self._next += 1
+
+    def _launch(self, bi):
+        b = self.buckets[bi]
+        b["launched"] = True
         if self.world == 1:
             return
         have_v, have_g, missing = [], [], []
@@ -104,57 +157,134 @@ class GradBucketReducer:
         self._handles.append(dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     # ---- step protocol -------------------------------------------------------------------------
+    def _rearm(self):
+        for b in self.buckets:
+            b["pending"], b["ready"], b["launched"] = b["n"], False, False
+        self._next = 0
+        self._handles = []
+
     def zero_grad(self):
         """Drop the gradients (``set_to_none``) and re-arm the buckets."""
         for b in self.buckets:
             for p in b["params"]:
                 p.grad = None
-            b["pending"] = b["n"]
-        self._handles = []
+        self._rearm()
+        self.stats = {"launched_by_hook": [], "launched_by_finish": []}
+
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Backward passes inside this context accumulate into ``param.grad`` without any exchange (the first k-1
+        micro-steps of ``accelerator.accumulate``, train.py:152); the next backward outside it exchanges the sums."""
+        prev, self._sync = self._sync, False
+        try:
+            yield
+        finally:
+            self._sync = prev
 
     def finish(self):
-        """Call after ``loss.backward()``: launches buckets whose parameters got no gradient this step
-        (unused parameters contribute zeros), then waits for every collective."""
+        """Call after a synchronising ``loss.backward()``: launches, in index order, the buckets the hooks could not
+        (a parameter without a gradient this step contributes zeros), waits for every collective, and -- once, after
+        the first step -- re-buckets the parameters in the order autograd completed them."""
         for b in self.buckets:
-            if b["pending"] > 0:           # incomplete or untouched: still takes part, in bucket order on every rank
-                self._launch(b)
-            b["pending"] = b["n"]
+            b["ready"] = True
+        self._drain(by_hook=False)
         for h in self._handles:
             h.wait()
         self._handles = []
+        if not self.rebuilt:
+            self._rebuild()
+        self._rearm()                          # a caller that never zeroes (the reference's encoder gradients) may go on
 
+    def _rebuild(self):
+        """Parameters in rank 0's hook order first, never-fired ones ("cold") in trailing buckets of their own.  The
+        gradients just reduced stay valid: they are moved into the new flat buffers."""
+        n = len(self._registration)
+        order = torch.full((n,), -1, dtype=torch.int64)
+        seen = list(dict.fromkeys(self._fired))
+        order[:len(seen)] = torch.tensor(seen, dtype=torch.int64) if seen else order[:0]
+        if self.world > 1:                                  # every rank adopts rank 0's order
+            dev = self._registration[0].device
+            t = order.to(dev)
+            dist.broadcast(t, src=dist.get_global_rank(self.group, 0) if self.group is not None else 0, group=self.group)
+            order = t.cpu()
+        hot_idx = [int(i) for i in order.tolist() if i >= 0]
+        hot_set = set(hot_idx)
+        hot = [self._registration[i] for i in hot_idx]
+        cold = [p for i, p in reversed(list(enumerate(self._registration))) if i not in hot_set]
+        grads = {id(p): p.grad for p in self._registration}
+        self._build(hot, cold)
+        if self.world > 1:
+            with torch.no_grad():
+                for b in self.buckets:
+                    src = [grads[id(p)] for p in b["params"]]
+                    dst = [v for v, g in zip(b["views"], src) if g is not None]
+                    src = [g for g in src if g is not None]
+                    if dst:
+                        torch._foreach_copy_(dst, src)
+                    for p, v in zip(b["params"], b["views"]):
+                        if grads[id(p)] is not None:
+                            p.grad = v
+        self.rebuilt = True
+        self._fired = []
+        self._rearm()
+
+    # ---- gradient norm / clipping ----------------------------------------------------------------
     def _grads(self):
         return [p.grad for p in self.params if p.grad is not None]
 
     def grad_norm(self) -> torch.Tensor:
         """Global L2 norm of the (already synchronised, hence rank-identical) gradients -- what
-        ``clip_grad_norm_`` (train.py:207-208) needs; no further collective."""
-        if self.world > 1:
-            return torch.sqrt(sum((b["flat"].double() ** 2).sum() for b in self.buckets)).float()
-        grads = self._grads()
-        if not grads:
+        ``clip_grad_norm_`` (train.py:207-208) needs; no further collective and no fp64 copy of the buckets:
+        one multi-tensor norm launch, the handful of partial norms combined in fp64."""
+        tensors = [b["flat"] for b in self.buckets] if self.world > 1 else self._grads()
+        if not tensors:
             return torch.zeros((), device=self.params[0].device)
-        return torch.linalg.vector_norm(torch.stack(torch._foreach_norm(grads)).double()).float()
+        return torch.linalg.vector_norm(torch.stack(torch._foreach_norm(tensors)).double()).float()
 
     def clip_(self, max_norm: float) -> torch.Tensor:
         total = self.grad_norm()
         coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
-        if self.world > 1:
-            for b in self.buckets:
-                b["flat"].mul_(coef)
-        else:
-            grads = self._grads()
-            if grads:
-                torch._foreach_mul_(grads, coef)
+        tensors = [b["flat"] for b in self.buckets] if self.world > 1 else self._grads()
+        if tensors:
+            torch._foreach_mul_(tensors, coef)
         return total
 
     def bytes_per_step(self) -> int:
-        return sum(b["numel"] * p.element_size() for b in self.buckets for p in b["params"][:1])
+        return sum(b["numel"] * b["params"][0].element_size() for b in self.buckets)
 
     def remove(self):
         for h in self._hooks:
             h.remove()
         self._hooks = []
+
+
+class GradAccumulator:
+    """``accelerator.accumulate(model)`` + ``accelerator.backward(loss)`` (train.py:152,182,205) on the reducer:
+    ``backward(loss)`` scales the loss by 1/k, runs the first k-1 micro-steps of every group of k without exchange and
+    the k-th with it; ``sync_gradients`` tells the caller when to clip and step (train.py:207)."""
+
+    def __init__(self, reducer: GradBucketReducer, steps: int = 1):
+        if steps < 1:
+            raise ValueError("GradAccumulator: steps must be >= 1")
+        self.reducer, self.steps, self._micro = reducer, int(steps), 0
+        self.sync_gradients = False
+
+    def backward(self, loss):
+        self._micro += 1
+        self.sync_gradients = self._micro % self.steps == 0
+        loss = loss / self.steps if self.steps > 1 else loss
+        if self.sync_gradients:
+            loss.backward()
+            self.reducer.finish()
+        else:
+            with self.reducer.no_sync():
+                loss.backward()
+        return self.sync_gradients
+
+    def zero_grad(self):
+        """Only after a synchronised step (gradients of unfinished groups must survive)."""
+        if self._micro % self.steps == 0:
+            self.reducer.zero_grad()
 
 
 def shard_batch(global_batch: int, rank: int, world: int):

@@ -1,12 +1,16 @@
 """The stand-alone StyleGAN1 ops of the reference's legacy ``G_synthesis`` port (styleganv1.py:29-152):
 ``Blur2d``, ``Upscale2d``, ``PixelNorm``, ``InstanceNorm`` -- same constructors and forward signatures, on
-the HIP kernels.  (The ``G_synthesis`` graph itself is dead code in the reference -- nothing instantiates it
+the HIP kernels, forward and backward (``autograd.Blur2dFn`` / ``Upscale2dFn`` / ``PixelNormFn`` /
+``InstanceNormAffineFn``) -- and ``FusedUpscale``, the ``nn.ConvTranspose2d(4, stride=2, padding=1)`` that
+``GBlock`` uses as its upsampler from 128^2 on (styleganv1.py:231,258), forward on the MFMA parity kernels.
+(The ``G_synthesis`` graph itself is dead code in the reference -- nothing instantiates it
 and its constructor needs a CUDA device -- and is not rebuilt)"""
 from __future__ import annotations
 
 import torch
 import torch.nn as nn
 
+from . import autograd as AG
 from . import ops
 
 
@@ -29,7 +33,7 @@ class Blur2d(nn.Module):
     def forward(self, x):
         if self.f is None:
             return x
-        return ops.blur2d(x.contiguous(), self.f[0, 0], self.stride)
+        return AG.blur2d(x.contiguous(), self.f[0, 0], self.stride)
 
 
 class Upscale2d(nn.Module):
@@ -40,7 +44,7 @@ class Upscale2d(nn.Module):
     def forward(self, x):
         if self.factor <= 1 and self.gain == 1:
             return x
-        return ops.upscale2d_nearest(x.contiguous(), max(self.factor, 1), self.gain)
+        return AG.upscale2d(x.contiguous(), max(self.factor, 1), self.gain)
 
 
 class PixelNorm(nn.Module):
@@ -49,7 +53,7 @@ class PixelNorm(nn.Module):
         self.epsilon = epsilon
 
     def forward(self, x):
-        return ops.pixelnorm(x.contiguous(), self.epsilon, sqrt_form=False)
+        return AG.pixelnorm(x.contiguous(), self.epsilon, False)
 
 
 class InstanceNorm(nn.Module):
@@ -58,4 +62,19 @@ class InstanceNorm(nn.Module):
         self.epsilon = epsilon
 
     def forward(self, x):
-        return ops.instance_norm_affine(x.contiguous(), None, None, self.epsilon)
+        return AG.instance_norm_affine(x.contiguous(), None, None, self.epsilon)
+
+
+class FusedUpscale(nn.ConvTranspose2d):
+    """``GBlock.up_sample`` for res >= 7 (styleganv1.py:231: ``nn.ConvTranspose2d(nf(res-3), nf(res-2), 4, stride=2,
+    padding=1)``): same parameters and ``state_dict`` keys (``weight`` [Cin,Cout,4,4], ``bias``); the forward runs as four
+    output-parity 2x2 MFMA kernels in one launch (include/spk.h, SPK_CONV_TRANSPOSE4X4_S2).  Inference only."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__(in_channels, out_channels, 4, stride=2, padding=1)
+        self._pk = ops.PackedConvWeight()
+
+    def forward(self, x):
+        if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
+            raise NotImplementedError("FusedUpscale: forward only (the legacy G_synthesis graph is never trained in the reference)")
+        return ops.conv_transpose4x4_s2(x.contiguous(), self.weight, self.bias, self._pk)

@@ -5,22 +5,27 @@ torch's current HIP stream.
 from __future__ import annotations
 
 import ctypes as C
+import weakref
 
 import torch
 
 from . import _lib as L
 
-# bench.py sets this to a list to collect (start, end) HIP-event pairs around every conv launch
-# (events are recorded on torch's current stream, the one the kernel is launched on).
-CONV_EVENTS = None
-CONV_SKIP = False          # bench.py: capture the step WITHOUT its conv launches to time them by difference
+
+
+def _launch_conv2d(desc):
+    """The one place a conv launch leaves Python (measurement harnesses wrap THIS function from outside the package;
+    the product path carries no switches)."""
+    L.check(L.lib().spk_conv2d_fwd(C.byref(desc), L.stream_ptr()), "spk_conv2d_fwd")
 
 
 # --------------------------------------------------------------------------------------------------
 class PackedConvWeight:
     """A [Cout,Cin,k,k] weight re-laid for one tile config of the MFMA conv kernel
-    ([co_tile][ci_chunk][tap][ci][co], zero padded).  Re-packed when the source parameter changes
-    (its autograd version counter / storage pointer), e.g. after an optimizer step."""
+    ([co_tile][ci_chunk][tap][ci][co], zero padded).  Re-packed when the source tensor changes: the cache is keyed
+    on the tensor OBJECT (a weak reference -- a fresh temporary such as ``w * scale`` can be handed the address, shape
+    and version 0 of last step's temporary by the caching allocator, so pointer + version alone would serve stale
+    weights after an optimizer step) plus its autograd version counter and storage pointer."""
 
     def __init__(self):
         self._cache = {}
@@ -29,10 +34,10 @@ class PackedConvWeight:
         key = (config, transpose_flip)
         stamp = (weight.data_ptr(), weight._version, tuple(weight.shape))
         hit = self._cache.get(key)
-        if hit is not None and hit[0] == stamp:
+        if hit is not None and hit[0] == stamp and hit[2]() is weight:
             return hit[1]
         packed = pack_conv_weight(weight.detach(), config, transpose_flip)
-        self._cache[key] = (stamp, packed)
+        self._cache[key] = (stamp, packed, weakref.ref(weight))
         return packed
 
     def clear(self):
@@ -60,11 +65,15 @@ def conv2d_config_info(config: int):
 
 def pack_conv_weight(weight: torch.Tensor, config: int, transpose_flip=False) -> torch.Tensor:
     """``transpose_flip``: False = the forward operator; True (1) = the data-gradient operator of a stride-1 conv (run
-    by the forward kernel); 2 = the four output-parity 2x2 kernels of a 3x3 STRIDE-2 conv's data gradient."""
+    by the forward kernel); 2 = the four output-parity 2x2 kernels of a 3x3 STRIDE-2 conv's data gradient; 3 = those of a
+    ConvTranspose2d(4, stride 2, pad 1) forward (``weight`` is then [Cin,Cout,4,4])."""
     Cout, Cin, kh, kw = weight.shape
     tf = int(transpose_flip)
     if tf == 2:
         n = L.lib().spk_conv2d_packed_floats(config, 2, 2, Cout, 4 * Cin)
+    elif tf == 3:        # ConvTranspose2d weight [Cin,Cout,4,4] -> the four parity 2x2 kernels (SPK_CONV_TRANSPOSE4X4_S2)
+        Cin, Cout = weight.shape[:2]
+        n = L.lib().spk_conv2d_packed_floats(config, 2, 2, Cin, 4 * Cout)
     else:
         n = L.lib().spk_conv2d_packed_floats(config, kh, kw, Cout if tf else Cin, Cin if tf else Cout)
     if n <= 0:
@@ -77,15 +86,25 @@ def pack_conv_weight(weight: torch.Tensor, config: int, transpose_flip=False) ->
 
 
 _workspaces = {}
+_retired = []            # outgrown scratch buffers: never freed (a captured hipGraph may have their address baked in)
 
 
 def _workspace(device, nbytes: int):
-    """Per-device scratch for split-K partial sums, grown on demand (stream-ordered reuse: every
-    consumer of the scratch is enqueued on the same stream right behind its producer)."""
-    ws = _workspaces.get(device)
+    """Scratch for split-K partial sums, one buffer per (device, stream), grown on demand.  Reuse is stream-ordered:
+    every consumer of the scratch is enqueued on the same stream right behind its producer, and two streams never
+    share a buffer.  An outgrown buffer is retired, not freed, so launches already queued -- or captured into a
+    hipGraph -- keep writing into memory nobody else owns.  During stream capture a larger request is served by a
+    tensor of the capture's own memory pool (it lives and dies with that graph) and the cache is left alone; warm
+    the shapes up before capturing, as bench.py does, to share one buffer."""
+    key = (device, torch.cuda.current_stream(device).cuda_stream)
+    ws = _workspaces.get(key)
     if ws is None or ws.numel() * 4 < nbytes:
-        ws = torch.empty((nbytes + 3) // 4, device=device, dtype=torch.float32)
-        _workspaces[device] = ws
+        fresh = torch.empty((max(nbytes, 1 << 20) + 3) // 4, device=device, dtype=torch.float32)
+        if torch.cuda.is_current_stream_capturing():
+            return fresh
+        if ws is not None:
+            _retired.append(ws)
+        ws = _workspaces[key] = fresh
     return ws
 
 
@@ -175,15 +194,7 @@ def conv2d_fused(x, w_packed, Cout: int, k: int = 3, stride: int = 1, *, bias=No
                      config=int(config), ksplit=int(ksplit), workspace=ws.data_ptr() if ws is not None else None,
                      workspace_bytes=ws.numel() * 4 if ws is not None else 0, groups=G,
                      group_in_stride=0 if (shared_input or G == 1) else Cin, stats_slots=slots)
-    if CONV_SKIP:           # measurement aid (bench.py): everything but the conv launch itself
-        return out
-    if CONV_EVENTS is not None:
-        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        e0.record()
-    L.check(L.lib().spk_conv2d_fwd(C.byref(d), L.stream_ptr()), "spk_conv2d_fwd")
-    if CONV_EVENTS is not None:
-        e1.record()
-        CONV_EVENTS.append((e0, e1))
+    _launch_conv2d(d)
     return out
 
 
@@ -485,6 +496,58 @@ def upscale2d_nearest(x, factor=2, gain=1.0):
     return y
 
 
+def pixelnorm_bwd(x, dy, eps=1e-8):
+    B, Cc = x.shape[:2]
+    HW = x.numel() // (B * Cc)
+    dx = torch.empty_like(x)
+    L.check(L.lib().spk_pixelnorm_bwd(L.dptr(x, "x"), L.dptr(dy, "dy"), L.dptr(dx), B, Cc, HW, float(eps), L.stream_ptr()),
+            "spk_pixelnorm_bwd")
+    return dx
+
+
+def blur2d_bwd(dy, filt2d, stride, in_hw):
+    """Adjoint of ``blur2d``: dy [B,C,Ho,Wo] -> dx [B,C,H,W] with (H, W) = ``in_hw``."""
+    B, Cc = dy.shape[:2]
+    H, W = in_hw
+    f = torch.as_tensor(filt2d, dtype=torch.float32).contiguous().cpu()
+    k = f.shape[0]
+    pad = (k - 1) // 2
+    if tuple(dy.shape[-2:]) != ((H + 2 * pad - k) // stride + 1, (W + 2 * pad - k) // stride + 1):
+        raise L.SpkError(f"blur2d_bwd: gradient {tuple(dy.shape)} is not the output of a {k}x{k} stride-{stride} blur of {H}x{W}")
+    dx = torch.empty((B, Cc, H, W), device=dy.device, dtype=torch.float32)
+    arr = (C.c_float * (k * k))(*f.flatten().tolist())
+    L.check(L.lib().spk_blur2d_bwd(L.dptr(dy, "dy"), L.dptr(dx), arr, k, B * Cc, H, W, int(stride), L.stream_ptr()), "spk_blur2d_bwd")
+    return dx
+
+
+def upscale2d_nearest_bwd(dy, factor=2, gain=1.0):
+    B, Cc, Ho, Wo = dy.shape
+    if Ho % factor or Wo % factor:
+        raise L.SpkError(f"upscale2d_nearest_bwd: {Ho}x{Wo} is not a multiple of the factor {factor}")
+    dx = torch.empty((B, Cc, Ho // factor, Wo // factor), device=dy.device, dtype=torch.float32)
+    L.check(L.lib().spk_upscale2d_nearest_bwd(L.dptr(dy, "dy"), L.dptr(dx), B * Cc, Ho // factor, Wo // factor, int(factor),
+                                              float(gain), L.stream_ptr()), "spk_upscale2d_nearest_bwd")
+    return dx
+
+
+def conv_transpose4x4_s2(x, weight, bias=None, packed=None):
+    """nn.ConvTranspose2d(Cin, Cout, 4, stride=2, padding=1) forward (styleganv1.py:231) as four output-parity 2x2 MFMA
+    kernels in one launch.  ``weight`` is the module's [Cin,Cout,4,4] parameter; ``packed``: an optional PackedConvWeight."""
+    B, Cin, H, W = x.shape
+    if tuple(weight.shape[0:1]) != (Cin,) or tuple(weight.shape[2:]) != (4, 4):
+        raise L.SpkError(f"conv_transpose4x4_s2: weight {tuple(weight.shape)} does not match [Cin={Cin},Cout,4,4]")
+    Cout = weight.shape[1]
+    cfg = conv2d_pick_config(2, 1, B, Cin, 4 * Cout, H + 1, W + 1)
+    wp = packed.get(weight, cfg, 3) if packed is not None else pack_conv_weight(weight, cfg, 3)
+    out = torch.empty((B, Cout, 2 * H, 2 * W), device=x.device, dtype=torch.float32)
+    d = L.Conv2dDesc(x=L.dptr(x, "x"), w_packed=L.dptr(wp, "w_packed"), bias=L.dptr(bias, "bias"), y=L.dptr(out, "out"), B=B, Cin=Cin,
+                     Cout=Cout, H=2 * H, W=2 * W, Hin=H, Win=W, kh=4, kw=4, stride=2,
+                     flags=L.CONV_TRANSPOSE4X4_S2 | (L.EPI_BIAS if bias is not None else 0), lrelu_slope=1.0, out_scale=1.0,
+                     config=int(cfg), ksplit=1, groups=1, group_in_stride=0)
+    _launch_conv2d(d)
+    return out
+
+
 def fade_in_tanh(a, b, alpha):
     y = torch.empty_like(a)
     L.check(L.lib().spk_fade_in_tanh_fwd(L.dptr(a, "a"), L.dptr(b, "b"), L.dptr(y), float(alpha), a.numel(), L.stream_ptr()),
@@ -562,9 +625,7 @@ def _dgrad_s2_parity(g, weight_packed, Cin, in_hw, config, out, accumulate, grou
                      Cout=Cin, H=H, W=W, Hin=Hg, Win=Wg, kh=3, kw=3, stride=2,
                      flags=L.CONV_DGRAD_S2 | (L.EPI_ACCUM if accumulate else 0), lrelu_slope=1.0, out_scale=1.0,
                      config=int(config), ksplit=1, groups=G, group_in_stride=0 if G == 1 else Cg // G)
-    if CONV_SKIP:
-        return out
-    L.check(L.lib().spk_conv2d_fwd(C.byref(d), L.stream_ptr()), "spk_conv2d_fwd")
+    _launch_conv2d(d)
     return out
 
 

@@ -42,9 +42,7 @@ class PixelNorm(nn.Module):
         self.epsilon = 1e-8
 
     def forward(self, x):
-        if torch.is_grad_enabled() and x.requires_grad:      # [B,512] latent: the gradient is plain torch algebra
-            return x / torch.sqrt(torch.mean(x ** 2, dim=1, keepdim=True) + self.epsilon)
-        return ops.pixelnorm(x.contiguous(), self.epsilon, sqrt_form=True)
+        return AG.pixelnorm(x.contiguous(), self.epsilon, True)       # forward and adjoint on the HIP kernels
 
 
 class WSConv2d(nn.Module):
@@ -71,7 +69,8 @@ class WSConv2d(nn.Module):
         if train:
             if k != 3:
                 raise NotImplementedError("WSConv2d backward: 3x3 and the 1x1 toRGB are on the HIP path")
-            return AG.fused_conv(x.contiguous(), w * self.scale, self.bias, noise_w, noise, None, upsample, lrelu, self._pk)
+            # the cache is keyed on the Parameter itself; the equalised-lr scale rides on the accumulator (and on dx / dw)
+            return AG.fused_conv(x.contiguous(), w, self.bias, noise_w, noise, None, upsample, lrelu, self._pk, w_scale=self.scale)
         B, _, H, W = x.shape
         Ho, Wo = (2 * H, 2 * W) if upsample else (H, W)
         cfg = ops.conv2d_pick_config(k, 1, B, Cin, Cout, Ho, Wo)

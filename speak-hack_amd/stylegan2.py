@@ -167,10 +167,7 @@ class StyleGAN2Generator(nn.Module):
 
     def forward(self, features, noises=None):
         train = torch.is_grad_enabled() and (features.requires_grad or any(p.requires_grad for p in self.parameters()))
-        if train:       # [B,6144] vector: the normalisation's gradient is plain torch algebra
-            w = features * torch.rsqrt(features.pow(2).mean(dim=1, keepdim=True) + 1e-8)
-        else:
-            w = ops.pixelnorm(features.contiguous(), 1e-8, sqrt_form=False)
+        w = AG.pixelnorm(features.contiguous(), 1e-8, False)
         for layer in self.style:
             w = layer(w)
         B = w.size(0)

@@ -12,8 +12,9 @@ import torch
 import torch.nn.functional as F
 
 
-def add_instance_noise(x, std=0.05):
-    return x + std * torch.randn_like(x)
+def add_instance_noise(x, std=0.1):
+    """train.py:148-149 (std 0.1 on all four real / fake discriminator inputs, :160-171)."""
+    return x + torch.randn_like(x) * std
 
 
 def compute_r1_reg(D, real_img):

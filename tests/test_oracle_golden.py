@@ -186,6 +186,15 @@ def test_legacy_ops(golden):
         assert rel_l2(x.grad, g[f"{tag}.gx"]) < TOL, tag
 
 
+def test_fused_upscale(golden):
+    """styleganv1.py:231: the ConvTranspose2d(4, s2, p1) of the reference's own GBlock(res=7) (512 -> 256 channels)."""
+    from oracle.weights_recipe import recipe_tensor
+    g = golden("legacy_fused_upscale.npz")
+    w = recipe_tensor("legacy.fused_upscale.weight", (512, 256, 4, 4), 1.0) * (512 * 4) ** -0.5
+    b = recipe_tensor("legacy.fused_upscale.bias", (256,), 0.5)
+    assert rel_l2(LG.fused_upscale(T(g["x"]), w, b), g["y"]) < TOL
+
+
 def test_flop_accounting_matches_survey():
     f = R.decoder_flops_per_frame(256)
     assert abs(f["total"] / 1e9 - 56.214) < 0.01          # SURVEY.md 2a / 8d

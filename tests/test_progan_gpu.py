@@ -76,6 +76,92 @@ def test_legacy_ops_vs_reference_goldens(dev, golden):
     assert rel_l2(ops.blur2d(x, k2), ref) < 2e-6
 
 
+def test_legacy_ops_backward_vs_reference_goldens(dev, golden):
+    """F3: Blur2d / Upscale2d / PixelNorm / InstanceNorm train on the HIP path too: input gradients against the ``gx`` the
+    reference's own modules produced for the recorded ``gy`` (styleganv1.py:29-152, stylegan.py:23-29)."""
+    g = golden("legacy_ops.npz")
+    lg = importlib.import_module("speak-hack_amd.legacy")
+    import stylegan
+    mods = {"pixelnorm": lg.PixelNorm(), "instnorm": lg.InstanceNorm(), "blur": lg.Blur2d(), "blur_s2": lg.Blur2d(stride=2),
+            "blur_flip": lg.Blur2d(f=[1, 2, 3], flip=True), "upscale": lg.Upscale2d(), "upscale_g": lg.Upscale2d(factor=2, gain=0.5),
+            "pixelnorm_sqrt": stylegan.PixelNorm()}
+    for tag, mod in mods.items():
+        x = T(g["x"]).to(dev).requires_grad_(True)
+        y = mod(x)
+        assert rel_l2(y, g[f"{tag}.y"]) < 2e-6, tag
+        y.backward(T(g[f"{tag}.gy"]).to(dev))
+        assert rel_l2(x.grad, g[f"{tag}.gx"]) < 5e-6, tag
+
+
+def test_pixelnorm_backward_wide_latent(dev):
+    """The [B,6144] latent form (one workgroup per row) of the PixelNorm adjoint, against autograd of the oracle in fp64."""
+    from oracle import legacy_ops_ref as LG
+    lg = importlib.import_module("speak-hack_amd.legacy")
+    x = recipe_input("pn.wide.x", (3, 6144))
+    gy = recipe_input("pn.wide.gy", (3, 6144))
+    xr = x.double().requires_grad_(True)
+    LG.pixel_norm(xr).backward(gy.double())
+    xd = x.to(dev).requires_grad_(True)
+    lg.PixelNorm()(xd).backward(gy.to(dev))
+    assert rel_l2(xd.grad, xr.grad) < 5e-6
+
+
+def test_fused_upscale_vs_reference_golden(dev, golden):
+    """F3: ``GBlock.up_sample`` for res >= 7 = nn.ConvTranspose2d(512, 256, 4, stride=2, padding=1) (styleganv1.py:231) on the
+    four output-parity 2x2 MFMA kernels, against the output of the reference's own constructed GBlock."""
+    from oracle.weights_recipe import recipe_tensor
+    g = golden("legacy_fused_upscale.npz")
+    lg = importlib.import_module("speak-hack_amd.legacy")
+    m = lg.FusedUpscale(512, 256)
+    assert sorted(m.state_dict()) == ["bias", "weight"] and tuple(m.weight.shape) == (512, 256, 4, 4)
+    with torch.no_grad():
+        m.weight.copy_(recipe_tensor("legacy.fused_upscale.weight", (512, 256, 4, 4), 1.0) * (512 * 4) ** -0.5)
+        m.bias.copy_(recipe_tensor("legacy.fused_upscale.bias", (256,), 0.5))
+        y = m.to(dev)(T(g["x"]).to(dev))
+    assert y.shape == (2, 256, 16, 12)
+    assert rel_l2(y, g["y"]) < 2e-5
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,bias", [(1, 3, 5, 4, 4, True), (2, 20, 33, 7, 9, False), (3, 64, 32, 16, 16, True),
+                                                  (1, 130, 70, 33, 5, True), (8, 128, 64, 32, 32, False)])
+def test_fused_upscale_ragged_shapes_vs_oracle(dev, B, Cin, Cout, H, W, bias):
+    """Odd sizes, channel counts off the tile grid, with and without bias, every tile config the heuristic reaches."""
+    from oracle import legacy_ops_ref as LG
+    from oracle.weights_recipe import recipe_tensor
+    ops = importlib.import_module("speak-hack_amd.ops")
+    x = recipe_input(f"fu.x.{B}.{Cin}.{H}.{W}", (B, Cin, H, W))
+    w = recipe_tensor(f"fu.w.{Cin}.{Cout}", (Cin, Cout, 4, 4), (4 * Cin) ** -0.5)
+    b = recipe_tensor(f"fu.b.{Cout}", (Cout,), 0.3) if bias else None
+    ref = LG.fused_upscale(x.double(), w.double(), b.double() if bias else None)
+    y = ops.conv_transpose4x4_s2(x.to(dev), w.to(dev), b.to(dev) if bias else None)
+    assert y.shape == ref.shape
+    assert rel_l2(y, ref) < 2e-5
+
+
+def test_wsconv_training_repacks_after_optimizer_step(dev):
+    """the packed-weight cache must follow the Parameter through optimizer steps -- two training steps of a
+    WSConv2d; the second forward has to see the updated weights (and equal a fresh module loaded with them)."""
+    prog = importlib.import_module("speak-hack_amd.progan")
+    torch.manual_seed(5)
+    m = prog.WSConv2d(16, 24).to(dev)
+    x = recipe_input("wsc.x", (2, 16, 8, 8)).to(dev)
+    opt = torch.optim.SGD(m.parameters(), lr=0.5)
+    outs = []
+    for _ in range(2):
+        opt.zero_grad()
+        y = m(x, lrelu=0.2)
+        outs.append(y.detach().clone())
+        (y ** 2).mean().backward()
+        opt.step()
+    assert rel_l2(outs[1], outs[0]) > 1e-3                       # the step changed the weights and the output followed
+    fresh = prog.WSConv2d(16, 24).to(dev)
+    fresh.load_state_dict(m.state_dict())
+    with torch.no_grad():
+        assert rel_l2(m(x, lrelu=0.2), fresh(x, lrelu=0.2)) < 1e-6
+        ref = torch.nn.functional.leaky_relu(torch.nn.functional.conv2d(x * m.scale, m.conv.weight, m.bias, padding=1), 0.2)
+        assert rel_l2(m(x, lrelu=0.2), ref) < 2e-5
+
+
 @pytest.mark.parametrize("steps,alpha", [(0, 1.0), (2, 0.3), (3, 1.0)])
 def test_generator_backward_vs_oracle_autograd(dev, steps, alpha):
     """A12 backward: mapping network + generator, gradients of a quadratic loss w.r.t. every parameter and z, against

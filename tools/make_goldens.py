@@ -245,6 +245,20 @@ def gen_legacy(ref_sg, ref_progan):
     save("legacy_ops.npz", **out)
 
 
+def gen_fused_upscale(ref_sg):
+    """F3: the fused ``ConvTranspose2d(4, stride 2, pad 1)`` upscale the reference's ``GBlock`` builds for res >= 7
+    (styleganv1.py:231), taken from a constructed ``GBlock`` (real channel counts nf(4)=512 -> nf(5)=256, small ragged image)."""
+    blk = ref_sg.GBlock(7, True, True, False, True, noise_input=None)
+    up = blk.up_sample
+    assert isinstance(up, torch.nn.ConvTranspose2d) and tuple(up.weight.shape) == (512, 256, 4, 4)
+    with torch.no_grad():
+        up.weight.copy_(recipe_tensor("legacy.fused_upscale.weight", up.weight.shape, 1.0) * (512 * 4) ** -0.5)
+        up.bias.copy_(recipe_tensor("legacy.fused_upscale.bias", up.bias.shape, 0.5))
+        x = recipe_input("legacy.fused_upscale.x", (2, 512, 8, 6))
+        y = up(x)
+    save("legacy_fused_upscale.npz", x=npf(x), y=npf(y))
+
+
 def progan_noise_shapes(B, steps):
     shapes = [(1, 1, 4, 4), (B, 1, 4, 4)]        # initial_noise1 sees the un-expanded constant
     for s in range(steps):
@@ -281,6 +295,10 @@ def main():
     feeder = NoiseFeeder()
     patch_noise(ref_sg, ref_progan, feeder)
     print("generating goldens from", REF)
+    if "--only-fused-upscale" in sys.argv:     # added in round 2: leaves the other fixtures untouched
+        gen_fused_upscale(ref_sg)
+        return
+    gen_fused_upscale(ref_sg)
     gen_ops(ref_sg)
     gen_blocks(ref_sg, feeder)
     gen_e2e(ref_sg, feeder)

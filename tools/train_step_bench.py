@@ -79,7 +79,7 @@ def main():
 
     def d_step():
         red.zero_grad()
-        noise = lambda t: t + 0.05 * torch.randn_like(t)
+        noise = T.add_instance_noise               # std 0.1, train.py:148-149
         loss = (bce(net.D(noise(x_s)), 0.9) + bce(net.D(noise(x_t)), 0.9)) / 2 \
             + (bce(net.D(noise(fake_s)), 0.1) + bce(net.D(noise(fake_t)), 0.1)) / 2 + 10.0 * (r1(x_s) + r1(x_t)) / 2
         loss.backward()
