@@ -184,12 +184,13 @@ def main():
             # packet with a cache flush: ~30 us per conv when launches are queued back to back) and, launch by launch,
             # would also count this box's host latency.  Instead the SAME step is captured a second time without its
             # conv launches, and both graphs are timed by HIP events around R replays: conv time = the difference.
+            real_launch = pkg.ops._launch_conv2d
             try:
-                pkg.ops.CONV_SKIP = True
+                pkg.ops._launch_conv2d = lambda desc: None      # measurement only, and only here: the package has no switch
                 graph_nc = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(graph_nc):
                     eager_step()
-                pkg.ops.CONV_SKIP = False
+                pkg.ops._launch_conv2d = real_launch
                 R = 20
 
                 def timed(g):
@@ -207,16 +208,27 @@ def main():
             except Exception as e:
                 print(f"bench: conv-less capture failed ({type(e).__name__}: {e}); timing conv launches with event pairs", file=sys.stderr)
             finally:
-                pkg.ops.CONV_SKIP = False
+                pkg.ops._launch_conv2d = real_launch
         if roof_how is None:
-            pkg.ops.CONV_EVENTS = []
+            events, real_launch = [], pkg.ops._launch_conv2d
+
+            def timed_launch(desc):
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                real_launch(desc)
+                e1.record()
+                events.append((e0, e1))
+
             prof_steps = 5
-            for _ in range(prof_steps):
-                eager_step()
+            try:
+                pkg.ops._launch_conv2d = timed_launch
+                for _ in range(prof_steps):
+                    eager_step()
+            finally:
+                pkg.ops._launch_conv2d = real_launch
             torch.cuda.synchronize()
-            conv_ms = sum(a.elapsed_time(b) for a, b in pkg.ops.CONV_EVENTS) / prof_steps
-            n_launch = len(pkg.ops.CONV_EVENTS) // prof_steps
-            pkg.ops.CONV_EVENTS = None
+            conv_ms = sum(a.elapsed_time(b) for a, b in events) / prof_steps
+            n_launch = len(events) // prof_steps
             roof_how = "HIP event pair around every conv launch of 5 eager steps"
 
         # ---- the build-defined StyleGAN2 variant (modulated conv + upfirdn2d, A11) on the same workload ----
