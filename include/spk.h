@@ -329,6 +329,11 @@ int spk_upfirdn2d_fwd(const float* x, float* y, const float* filter_host, int k,
                       int pad0, int pad1, float gain, void* stream);
 int spk_conv1x1_small_mod_fwd(const float* x, const float* w, const float* mod, const float* bias, float* y, int B, int C, int O,
                               int64_t HW, float in_scale, void* stream);
+/* The whole skip-generator toRGB step of StyleGAN2 in one launch: y = modulated 1x1 conv (as above) + bias +
+ * upfirdn2d(skip, up = 2, FIR [1,3,3,1], pad (2,1)); x [B,C,H,W], skip [B,O,H/2,W/2] or NULL, y [B,O,H,W].  The 3-channel
+ * upsample + add ride in the epilogue of the kernel that streams the C-channel activations (two HBM passes fewer). */
+int spk_torgb_mod_skip_fwd(const float* x, const float* w, const float* mod, const float* bias, const float* skip, float* y, int B,
+                           int C, int O, int H, int W, float in_scale, void* stream);
 
 /* ---- stand-alone StyleGAN1 / ProGAN ops (the reference's only definitions of the PixelNorm / FIR-blur family) ----
  * spk_pixelnorm_fwd: y = x * rsqrt(mean_c x^2 + eps) over dim 1 of [B,C,HW] (HW = 1 for latents).
@@ -358,6 +363,42 @@ int spk_fade_in_tanh_fwd(const float* a, const float* b, float* y, float alpha, 
 int spk_pixelnorm_bwd(const float* x, const float* dy, float* dx, int B, int C, int64_t HW, float eps, void* stream);
 int spk_blur2d_bwd(const float* dy, float* dx, const float* filter_host, int k, int64_t planes, int H, int W, int stride, void* stream);
 int spk_upscale2d_nearest_bwd(const float* dy, float* dx, int64_t planes, int H, int W, int factor, float gain, void* stream);
+
+/* ---- launch lists: a whole module forward per C call ---------------------------------------------------------------
+ * The reference's callers run a decoder pass as one Python call (model.py:113-114 `self.Gd(gen_input)`,
+ * styleganv1.py:593-610 SynthesisNetwork.forward); behind it sit ~25 kernel launches whose descriptors depend only on
+ * (module, batch size, device).  spk_launch_list enqueues a HOST array of pre-built ops in order on `stream` -- exactly
+ * the entry points above with exactly their arguments -- so the per-call host cost is one crossing plus ~4 us per
+ * launch instead of a descriptor build, a config query and a crossing per launch.  `kind_mask`: bit k set = ops of kind
+ * k are launched, the others skipped (~0u = everything; measurement harnesses time one kernel family of a step this
+ * way, e.g. 1u << SPK_OP_CONV2D, without any switch inside the library).  Stops at the first failing op and returns
+ * its code.  replaces: nothing in the reference's arithmetic -- the host-side loop over ATen calls. */
+enum {
+    SPK_OP_CONV2D = 1,            /* desc: spk_conv2d_desc          -> spk_conv2d_fwd */
+    SPK_OP_FC = 2,                /* desc: spk_fc_args              -> spk_fc_fwd */
+    SPK_OP_FC_GROUPED = 3,        /* desc: spk_fc_grouped_args      -> spk_fc_grouped_fwd */
+    SPK_OP_BIAS_NOISE_STYLE = 4,  /* desc: spk_bias_noise_style_args-> spk_bias_noise_style_fwd */
+    SPK_OP_TORGB = 5,             /* desc: spk_torgb_args           -> spk_conv1x1_small_fwd / spk_torgb_mod_skip_fwd */
+    SPK_OP_DEMOD_GROUPED = 6,     /* desc: spk_demod_grouped_args   -> spk_modconv_demod_grouped */
+    SPK_OP_PIXELNORM = 7          /* desc: spk_pixelnorm_args       -> spk_pixelnorm_fwd */
+};
+typedef struct spk_op { int32_t kind; int32_t reserved; const void* desc; } spk_op;
+typedef struct spk_fc_args {
+    const float* x; int64_t x_stride; const float* w; const float* bias; float* out; int64_t out_stride;
+    int32_t B, I, O; float wmul, bmul, slope;
+} spk_fc_args;
+typedef struct spk_fc_grouped_args { const spk_fc_group* groups; int32_t n_groups, B; } spk_fc_grouped_args;
+typedef struct spk_bias_noise_style_args {
+    const float* x; int64_t x_batch_stride; const float* bias; const float* noise_w; const float* noise; const float* style;
+    int64_t style_stride; float* y; int32_t B, C, HW, reserved;
+} spk_bias_noise_style_args;
+typedef struct spk_torgb_args {   /* mod NULL: plain 1x1 (styleganv1.py:607); else modulated (+ optional skip [B,O,H/2,W/2]) */
+    const float* x; const float* w; const float* mod; const float* bias; const float* skip; float* y;
+    int32_t B, C, O, H, W; float in_scale;
+} spk_torgb_args;
+typedef struct spk_demod_grouped_args { const spk_demod_group* groups; int32_t n_groups, B; float eps; int32_t reserved; } spk_demod_grouped_args;
+typedef struct spk_pixelnorm_args { const float* x; float* y; int32_t B, C; int64_t HW; float eps; int32_t sqrt_form; } spk_pixelnorm_args;
+int spk_launch_list(const spk_op* ops, int n_ops, uint32_t kind_mask, void* stream);
 
 #ifdef __cplusplus
 }

@@ -58,6 +58,46 @@ class DemodGroup(C.Structure):
                 ("taps", C.c_int32), ("scale", C.c_float)]
 
 
+# ---- launch lists (include/spk.h: spk_launch_list) ----
+OP_CONV2D, OP_FC, OP_FC_GROUPED, OP_BIAS_NOISE_STYLE, OP_TORGB, OP_DEMOD_GROUPED, OP_PIXELNORM = 1, 2, 3, 4, 5, 6, 7
+ALL_OPS = 0xFFFFFFFF
+
+
+class Op(C.Structure):
+    _fields_ = [("kind", C.c_int32), ("reserved", C.c_int32), ("desc", C.c_void_p)]
+
+
+class FcArgs(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("x_stride", C.c_int64), ("w", C.c_void_p), ("bias", C.c_void_p), ("out", C.c_void_p),
+                ("out_stride", C.c_int64), ("B", C.c_int32), ("I", C.c_int32), ("O", C.c_int32), ("wmul", C.c_float),
+                ("bmul", C.c_float), ("slope", C.c_float)]
+
+
+class FcGroupedArgs(C.Structure):
+    _fields_ = [("groups", C.c_void_p), ("n_groups", C.c_int32), ("B", C.c_int32)]
+
+
+class BiasNoiseStyleArgs(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("x_batch_stride", C.c_int64), ("bias", C.c_void_p), ("noise_w", C.c_void_p),
+                ("noise", C.c_void_p), ("style", C.c_void_p), ("style_stride", C.c_int64), ("y", C.c_void_p),
+                ("B", C.c_int32), ("C", C.c_int32), ("HW", C.c_int32), ("reserved", C.c_int32)]
+
+
+class ToRGBArgs(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("w", C.c_void_p), ("mod", C.c_void_p), ("bias", C.c_void_p), ("skip", C.c_void_p),
+                ("y", C.c_void_p), ("B", C.c_int32), ("C", C.c_int32), ("O", C.c_int32), ("H", C.c_int32), ("W", C.c_int32),
+                ("in_scale", C.c_float)]
+
+
+class DemodGroupedArgs(C.Structure):
+    _fields_ = [("groups", C.c_void_p), ("n_groups", C.c_int32), ("B", C.c_int32), ("eps", C.c_float), ("reserved", C.c_int32)]
+
+
+class PixelNormArgs(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("B", C.c_int32), ("C", C.c_int32), ("HW", C.c_int64), ("eps", C.c_float),
+                ("sqrt_form", C.c_int32)]
+
+
 class WgradDesc(C.Structure):
     """Mirror of spk_wgrad_desc (include/spk.h)."""
     _fields_ = [("g", C.c_void_p), ("x", C.c_void_p), ("in_scale", C.c_void_p), ("in_shift", C.c_void_p),
@@ -76,6 +116,7 @@ _PROTOTYPES = {
     "spk_upfirdn2d_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.POINTER(C.c_float), C.c_int, C.c_int64, C.c_int, C.c_int, C.c_int,
                                     C.c_int, C.c_int, C.c_int, C.c_float, C.c_void_p]),
     "spk_conv1x1_small_mod_fwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_float, C.c_void_p]),
+    "spk_torgb_mod_skip_fwd": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 5 + [C.c_float, C.c_void_p]),
     "spk_pixelnorm_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_float, C.c_int, C.c_void_p]),
     "spk_instance_norm_affine_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
                                                C.c_int64, C.c_float, C.c_void_p]),
@@ -104,6 +145,7 @@ _PROTOTYPES = {
     "spk_conv1x1_small_bwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_float, C.c_void_p]),
     "spk_fc_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                              C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    "spk_launch_list": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p]),
     "spk_version": (C.c_char_p, []),
     "spk_last_error": (C.c_char_p, []),
     "spk_conv2d_num_configs": (C.c_int, []),

@@ -339,26 +339,31 @@ class ModConvFn(torch.autograd.Function):
 
 
 class ModToRGBFn(torch.autograd.Function):
-    """y = scale * conv1x1(x * s[b,ci], w) + bias to <= 4 channels (StyleGAN2 toRGB, no demodulation)."""
+    """y = scale * conv1x1(x * s[b,ci], w) + bias [+ upfirdn2d_up2(skip)] to <= 4 channels (StyleGAN2 toRGB, no
+    demodulation; the skip image's x2 upsample + add ride in the same launch)."""
 
     @staticmethod
-    def forward(ctx, x, weight, s, bias, scale, grad_mode):
-        y = ops.conv1x1_small_mod(x, weight, s, bias, in_scale=scale)
+    def forward(ctx, x, weight, s, bias, scale, skip, fir, grad_mode):
+        y = ops.conv1x1_small_mod(x, weight, s, bias, in_scale=scale, skip=skip)
         if _needs(ctx, grad_mode):
             ctx.save_for_backward(x, weight, s)
-            ctx.conf = (scale, bias is not None)
+            ctx.conf = (scale, bias is not None, skip is not None, fir)
         return y
 
     @staticmethod
     def backward(ctx, dy):
         x, weight, s = ctx.saved_tensors
-        scale, has_bias = ctx.conf
+        scale, has_bias, has_skip, fir = ctx.conf
         B = x.shape[0]
+        dy = dy.contiguous()
         rows = _scale_rows(s)
         xs = ops.bias_noise_style(x, B, None, None, None, rows)
-        dxs, dw, db = ops.conv1x1_small_bwd(xs, weight, dy.contiguous(), need_dx=True, in_scale=scale)
+        dxs, dw, db = ops.conv1x1_small_bwd(xs, weight, dy, need_dx=True, in_scale=scale)
         dx, sums = ops.epilogue_bwd(dxs, x, None, rows, 1.0)
-        return dx, dw, sums[..., 1], (db if has_bias else None), None, None
+        dskip = None
+        if has_skip and ctx.needs_input_grad[5]:      # adjoint of upfirdn2d(up=2, pad (2,1)): down=2 with the flipped FIR, pad (1,1)
+            dskip = ops.upfirdn2d(dy, torch.flip(fir, [0, 1]), up=1, down=2, pad=(1, 1))
+        return dx, dw, sums[..., 1], (db if has_bias else None), None, dskip, None, None
 
 
 class UpFirDnFn(torch.autograd.Function):
@@ -482,8 +487,8 @@ def mod_conv(x, weight, s, d, bias, noise_w, noise, scale, upsample, slope, gain
     return ModConvFn.apply(x, weight, s, d, bias, noise_w, noise, scale, upsample, slope, gain, fir, packed, torch.is_grad_enabled())
 
 
-def mod_to_rgb(x, weight, s, bias, scale):
-    return ModToRGBFn.apply(x, weight, s, bias, scale, torch.is_grad_enabled())
+def mod_to_rgb(x, weight, s, bias, scale, skip=None, fir=None):
+    return ModToRGBFn.apply(x, weight, s, bias, scale, skip, fir, torch.is_grad_enabled())
 
 
 def upfirdn(x, fir, up, down, pad):

@@ -60,7 +60,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
             raise RuntimeError(f"hipcc failed for {src}:\n{r.stdout}\n{r.stderr}")
         return obj
 
-    with ThreadPoolExecutor(max_workers=4) as ex:
+    with ThreadPoolExecutor(max_workers=6) as ex:
         objs = list(ex.map(compile_one, sources()))
     tmp = LIB + ".tmp"
     r = subprocess.run([hipcc, "-shared", "-fPIC", f"--offload-arch={ARCH}", "-o", tmp, *objs],

@@ -30,12 +30,36 @@ __global__ __launch_bounds__(256) void bias_noise_style_kernel(const float* __re
     }
 }
 
-// 1x1 conv with O <= 4 outputs.  VEC: each thread owns 4 consecutive pixels.
+// StyleGAN2's skip connection: upfirdn2d(skip, up = 2, FIR [1,3,3,1] * 4 / 16 per axis, pad (2,1)) evaluated at output
+// pixel(s) of a [2Hs, 2Ws] image -- per axis out[2i] = .25 in[i-1] + .75 in[i], out[2i+1] = .75 in[i] + .25 in[i+1],
+// samples outside the image count as zero.  The 3-channel skip image is tiny next to the 64..512-channel activations
+// the toRGB kernel streams, so the upsample + add ride in its epilogue instead of being two more passes.
+__device__ __forceinline__ float skip_px(const float* __restrict__ sk, int Hs, int Ws, int r, int c) {
+    return (r >= 0 && r < Hs && c >= 0 && c < Ws) ? sk[(size_t)r * Ws + c] : 0.f;
+}
+__device__ __forceinline__ float upfir2x_1(const float* __restrict__ sk, int Hs, int Ws, int y, int x) {
+    const int ra = (y >> 1) - 1 + (y & 1), ca = (x >> 1) - 1 + (x & 1);
+    const float wa = (y & 1) ? 0.75f : 0.25f, wb = 1.f - wa, ua = (x & 1) ? 0.75f : 0.25f, ub = 1.f - ua;
+    return wa * (ua * skip_px(sk, Hs, Ws, ra, ca) + ub * skip_px(sk, Hs, Ws, ra, ca + 1)) +
+           wb * (ua * skip_px(sk, Hs, Ws, ra + 1, ca) + ub * skip_px(sk, Hs, Ws, ra + 1, ca + 1));
+}
+// four consecutive pixels x .. x+3 of row y (x a multiple of 4)
+__device__ __forceinline__ float4 upfir2x_4(const float* __restrict__ sk, int Hs, int Ws, int y, int x) {
+    const int ra = (y >> 1) - 1 + (y & 1), c0 = x >> 1;
+    const float wa = (y & 1) ? 0.75f : 0.25f, wb = 1.f - wa;
+    float r[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) r[k] = wa * skip_px(sk, Hs, Ws, ra, c0 - 1 + k) + wb * skip_px(sk, Hs, Ws, ra + 1, c0 - 1 + k);
+    return make_float4(0.25f * r[0] + 0.75f * r[1], 0.75f * r[1] + 0.25f * r[2], 0.25f * r[1] + 0.75f * r[2], 0.75f * r[2] + 0.25f * r[3]);
+}
+
+// 1x1 conv with O <= 4 outputs.  VEC: each thread owns 4 consecutive pixels.  ``skip`` (optional, [B,O,H/2,W/2] with W the
+// row length of y): y += upfir2x(skip).
 template <bool VEC>
 __global__ __launch_bounds__(256) void conv1x1_small_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                            const float* __restrict__ bias, float* __restrict__ y, int C,
                                                            int O, long long HW, float in_scale,
-                                                           const float* __restrict__ mod) {
+                                                           const float* __restrict__ mod, const float* __restrict__ skip, int W) {
     extern __shared__ float w_s[];  // [O][C]; with ``mod`` [B,C] the weight is modulated per image (StyleGAN2 toRGB)
     const int b = blockIdx.y;
     for (int i = threadIdx.x; i < O * C; i += blockDim.x) w_s[i] = w[i] * in_scale * (mod ? mod[(size_t)b * C + (i % C)] : 1.f);
@@ -64,8 +88,17 @@ __global__ __launch_bounds__(256) void conv1x1_small_kernel(const float* __restr
                 }
             }
 #pragma unroll
-            for (int o = 0; o < 4; ++o)
-                if (o < O) reinterpret_cast<float4*>(yb + (size_t)o * HW)[p4] = acc[o];
+            for (int o = 0; o < 4; ++o) {
+                if (o < O) {
+                    if (skip) {
+                        const int Hs = (int)(HW / W) >> 1, Ws = W >> 1;
+                        const long long p = 4 * p4;
+                        const float4 u = upfir2x_4(skip + ((size_t)b * O + o) * Hs * Ws, Hs, Ws, (int)(p / W), (int)(p % W));
+                        acc[o].x += u.x; acc[o].y += u.y; acc[o].z += u.z; acc[o].w += u.w;
+                    }
+                    reinterpret_cast<float4*>(yb + (size_t)o * HW)[p4] = acc[o];
+                }
+            }
         }
     } else {
         for (long long p = (long long)blockIdx.x * blockDim.x + threadIdx.x; p < HW;
@@ -80,8 +113,15 @@ __global__ __launch_bounds__(256) void conv1x1_small_kernel(const float* __restr
                     if (o < O) acc[o] += w_s[o * C + c] * xv;
             }
 #pragma unroll
-            for (int o = 0; o < 4; ++o)
-                if (o < O) yb[(size_t)o * HW + p] = acc[o];
+            for (int o = 0; o < 4; ++o) {
+                if (o < O) {
+                    if (skip) {
+                        const int Hs = (int)(HW / W) >> 1, Ws = W >> 1;
+                        acc[o] += upfir2x_1(skip + ((size_t)b * O + o) * Hs * Ws, Hs, Ws, (int)(p / W), (int)(p % W));
+                    }
+                    yb[(size_t)o * HW + p] = acc[o];
+                }
+            }
         }
     }
 }
@@ -92,7 +132,7 @@ __global__ __launch_bounds__(256) void conv1x1_small_kernel(const float* __restr
 __global__ __launch_bounds__(256) void conv1x1_small_csplit_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                   const float* __restrict__ bias, float* __restrict__ y, int C,
                                                                   int O, long long HW, float in_scale,
-                                                                  const float* __restrict__ mod) {
+                                                                  const float* __restrict__ mod, const float* __restrict__ skip, int W) {
     extern __shared__ float sm[];           // [O][C] weights, then [4 waves][4 outputs][64 lanes] float4 partials
     float* w_s = sm;
     float4* part = reinterpret_cast<float4*>(sm + ((O * C + 3) & ~3));
@@ -131,6 +171,12 @@ __global__ __launch_bounds__(256) void conv1x1_small_csplit_kernel(const float* 
         for (int k = 0; k < 4; ++k) {
             const float4 t = part[(k * 4 + o) * 64 + lane];
             r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
+        }
+        if (skip) {
+            const int Hs = (int)(HW / W) >> 1, Ws = W >> 1;
+            const long long p = 4 * p4;
+            const float4 u = upfir2x_4(skip + ((size_t)b * O + o) * Hs * Ws, Hs, Ws, (int)(p / W), (int)(p % W));
+            r.x += u.x; r.y += u.y; r.z += u.z; r.w += u.w;
         }
         reinterpret_cast<float4*>(yb + (size_t)o * HW)[p4] = r;
     }
@@ -193,27 +239,29 @@ int spk_bias_noise_style_fwd(const float* x, int64_t x_batch_stride, const float
 }
 
 static int conv1x1_small_launch(const float* x, const float* w, const float* mod, const float* bias, float* y, int B, int C, int O,
-                                int64_t HW, float in_scale, void* stream) {
+                                int64_t HW, float in_scale, void* stream, const float* skip = nullptr, int W = 0) {
     SPK_REQUIRE(x && w && y, "conv1x1_small: null pointer");
     SPK_REQUIRE(B > 0 && C > 0 && O > 0 && O <= 4 && HW > 0, "conv1x1_small: bad shape (O must be <= 4)");
     SPK_REQUIRE((size_t)O * C * sizeof(float) <= 48 * 1024, "conv1x1_small: weight too large for LDS");
-    const bool vec = (HW % 4 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0);
+    SPK_REQUIRE(!skip || (W > 0 && W % 2 == 0 && HW % W == 0 && (HW / W) % 2 == 0), "conv1x1_small: skip needs an even H x W image");
+    // with a skip image a pixel quad must stay inside one row
+    const bool vec = (HW % 4 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0) && (!skip || W % 4 == 0);
     const size_t lds = (size_t)O * C * sizeof(float);
     if (vec && C >= 64 && (HW / 4 + 255) / 256 * B < 512) {   // too few pixel quads for one thread each: split the channels
         dim3 grid((unsigned)((HW / 4 + 63) / 64), (unsigned)B);
         const size_t lds2 = ((size_t)((O * C + 3) & ~3) + 4 * 4 * 64 * 4) * sizeof(float);
         hipLaunchKernelGGL(conv1x1_small_csplit_kernel, grid, dim3(256), lds2, (hipStream_t)stream, x, w, bias, y, C, O,
-                           (long long)HW, in_scale, mod);
+                           (long long)HW, in_scale, mod, skip, W);
         return spk::check_launch("conv1x1_small_csplit_kernel");
     }
     if (vec) {
         dim3 grid(stream_grid(HW / 4, 256), (unsigned)B);
         hipLaunchKernelGGL(conv1x1_small_kernel<true>, grid, dim3(256), lds, (hipStream_t)stream, x, w, bias, y, C, O,
-                           (long long)HW, in_scale, mod);
+                           (long long)HW, in_scale, mod, skip, W);
     } else {
         dim3 grid(stream_grid(HW, 256), (unsigned)B);
         hipLaunchKernelGGL(conv1x1_small_kernel<false>, grid, dim3(256), lds, (hipStream_t)stream, x, w, bias, y, C, O,
-                           (long long)HW, in_scale, mod);
+                           (long long)HW, in_scale, mod, skip, W);
     }
     return spk::check_launch("conv1x1_small_kernel");
 }
@@ -227,6 +275,13 @@ int spk_conv1x1_small_mod_fwd(const float* x, const float* w, const float* mod, 
                               int64_t HW, float in_scale, void* stream) {
     SPK_REQUIRE(mod, "conv1x1_small_mod: null modulation");
     return conv1x1_small_launch(x, w, mod, bias, y, B, C, O, HW, in_scale, stream);
+}
+
+int spk_torgb_mod_skip_fwd(const float* x, const float* w, const float* mod, const float* bias, const float* skip, float* y, int B,
+                           int C, int O, int H, int W, float in_scale, void* stream) {
+    SPK_REQUIRE(mod, "torgb_mod_skip: null modulation");
+    SPK_REQUIRE(H > 0 && W > 0, "torgb_mod_skip: bad shape");
+    return conv1x1_small_launch(x, w, mod, bias, y, B, C, O, (int64_t)H * W, in_scale, stream, skip, W);
 }
 
 int spk_upsample2x_bilinear_fwd(const float* x, float* y, int64_t planes, int Hin, int Win, void* stream) {

@@ -24,6 +24,7 @@ import torch.nn as nn
 
 from . import ops
 from . import autograd as AG
+from . import plan as PL
 
 LRELU = 0.2
 
@@ -139,11 +140,22 @@ class SynthesisNetwork(nn.Module):
             shapes += [(batch, 1, s, s)] * 2
         return shapes
 
+    use_plan = True      # inference forwards go out as one pre-built launch list (plan.DecoderPlan); False: launch by launch
+
+    def _inference(self, x):
+        return not (torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())))
+
     def forward(self, w, noises=None):
         """``w``: [B, num_layers, 512]; ``noises``: optional list of the 2*len(layers)+1 noise
         tensors in call order (drawn on the device when omitted, as the reference does)."""
         B = w.size(0)
         w = w.contiguous()
+        if noises is not None and len(noises) != 2 * len(self.layers) + 1:
+            raise ValueError(f"expected {2 * len(self.layers) + 1} noise tensors, got {len(noises)}")
+        if self.use_plan and w.is_cuda and len(self.layers) * 2 + 1 <= ops.L.FC_MAX_GROUPS and self._inference(w):
+            key = (B, w.device, torch.cuda.current_stream(w.device).cuda_stream, "w")
+            p = PL.plan_for(self, key, lambda: PL.DecoderPlan(self, B, w.device))
+            return p.run(w, None if noises is None else [n.contiguous() for n in noises])
         if noises is None:
             # one device draw for the whole step, cut into the 13 per-layer tensors (the reference draws them one by
             # one inside ApplyNoise.forward, styleganv1.py:455; device RNG streams are not comparable across
@@ -191,6 +203,17 @@ class StyleGenerator(nn.Module):
         """``style_mix`` (optional, tests): ``(mix_features, mix_layer)`` replacing the three RNG draws of the
         train-mode mixing branch, or ``False`` to skip the branch."""
         L = self.synthesis.num_layers
+        syn = self.synthesis
+        if (not self.training and syn.use_plan and features.is_cuda and features.dim() == 2 and len(syn.layers) * 2 + 1 <= ops.L.FC_MAX_GROUPS
+                and not (torch.is_grad_enabled() and (features.requires_grad or any(p.requires_grad for p in self.parameters())))):
+            # eval + no gradient: mapping, truncation and synthesis as ONE launch list (one crossing of the C boundary)
+            if noises is not None and len(noises) != 2 * len(syn.layers) + 1:
+                raise ValueError(f"expected {2 * len(syn.layers) + 1} noise tensors, got {len(noises)}")
+            B = features.size(0)
+            key = (B, features.device, torch.cuda.current_stream(features.device).cuda_stream, "features")
+            p = PL.plan_for(self, key, lambda: PL.DecoderPlan(syn, B, features.device, generator=self))
+            return p.run(features if features.stride(1) == 1 else features.contiguous(),
+                         None if noises is None else [n.contiguous() for n in noises])
         w = self.mapping(features).unsqueeze(1).repeat(1, L, 1)
         if self.truncation_psi and self.truncation_cutoff:
             coefs = torch.ones_like(w)

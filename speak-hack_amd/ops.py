@@ -63,7 +63,7 @@ def conv2d_config_info(config: int):
     return co.value, ci.value, px.value
 
 
-def pack_conv_weight(weight: torch.Tensor, config: int, transpose_flip=False) -> torch.Tensor:
+def pack_conv_weight(weight: torch.Tensor, config: int, transpose_flip=False, out=None) -> torch.Tensor:
     """``transpose_flip``: False = the forward operator; True (1) = the data-gradient operator of a stride-1 conv (run
     by the forward kernel); 2 = the four output-parity 2x2 kernels of a 3x3 STRIDE-2 conv's data gradient; 3 = those of a
     ConvTranspose2d(4, stride 2, pad 1) forward (``weight`` is then [Cin,Cout,4,4])."""
@@ -78,7 +78,10 @@ def pack_conv_weight(weight: torch.Tensor, config: int, transpose_flip=False) ->
         n = L.lib().spk_conv2d_packed_floats(config, kh, kw, Cout if tf else Cin, Cin if tf else Cout)
     if n <= 0:
         raise L.SpkError("spk_conv2d_packed_floats: bad arguments")
-    out = torch.empty(n, device=weight.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty(n, device=weight.device, dtype=torch.float32)
+    elif out.numel() != n or not out.is_contiguous() or out.device != weight.device:
+        raise L.SpkError(f"pack_conv_weight: out must be a contiguous buffer of {n} floats on {weight.device}")
     L.check(L.lib().spk_conv2d_pack_weights(L.dptr(weight.contiguous(), "weight"), L.dptr(out), kh, kw, Cin, Cout,
                                             config, tf, L.stream_ptr()),
             "spk_conv2d_pack_weights")
@@ -428,11 +431,19 @@ def upfirdn2d(x, filt2d, up=1, down=1, pad=(0, 0), gain=1.0):
     return y
 
 
-def conv1x1_small_mod(x, weight, mod, bias=None, in_scale=1.0):
-    """Modulated (not demodulated) 1x1 conv to <= 4 channels: the StyleGAN2 toRGB."""
+def conv1x1_small_mod(x, weight, mod, bias=None, in_scale=1.0, skip=None):
+    """Modulated (not demodulated) 1x1 conv to <= 4 channels: the StyleGAN2 toRGB.  ``skip`` [B,O,H/2,W/2]: the previous
+    resolution's image, upsampled (upfirdn2d up=2, [1,3,3,1]) and added in the same launch."""
     B, Cc, H, W = x.shape
     O = weight.shape[0]
     y = torch.empty((B, O, H, W), device=x.device, dtype=torch.float32)
+    if skip is not None:
+        if tuple(skip.shape) != (B, O, H // 2, W // 2) or H % 2 or W % 2:
+            raise L.SpkError(f"conv1x1_small_mod: skip {tuple(skip.shape)} is not [B,O,H/2,W/2] of {(B, O, H, W)}")
+        L.check(L.lib().spk_torgb_mod_skip_fwd(L.dptr(x, "x"), L.dptr(weight.reshape(O, Cc), "weight"), L.dptr(mod, "mod"),
+                                               L.dptr(bias, "bias"), L.dptr(skip, "skip"), L.dptr(y), B, Cc, O, H, W, float(in_scale),
+                                               L.stream_ptr()), "spk_torgb_mod_skip_fwd")
+        return y
     L.check(L.lib().spk_conv1x1_small_mod_fwd(L.dptr(x, "x"), L.dptr(weight.reshape(O, Cc), "weight"), L.dptr(mod, "mod"),
                                               L.dptr(bias, "bias"), L.dptr(y), B, Cc, O, H * W, float(in_scale), L.stream_ptr()),
             "spk_conv1x1_small_mod_fwd")

@@ -68,13 +68,16 @@ class ModulatedConv2d(nn.Module):
         self.modulation = EqualLinear(style_dim, in_channel, bias_init=1.0)
         self._pk = ops.PackedConvWeight()
 
-    def forward(self, x, style, bias=None, noise_w=None, noise=None, lrelu=None, act_gain=1.0, upsample=False, s=None, d=None):
+    def forward(self, x, style, bias=None, noise_w=None, noise=None, lrelu=None, act_gain=1.0, upsample=False, s=None, d=None,
+                skip=None):
         """``s`` / ``d`` (optional): the modulation ``self.modulation(style)`` and the demodulation vector computed
-        elsewhere (grouped launches)."""
+        elsewhere (grouped launches).  ``skip`` (toRGB only): the previous resolution's image; its [1,3,3,1] x2 upsample
+        and the sum happen inside the toRGB launch."""
         if s is None:
             s = self.modulation(style)
         if self.kernel_size == 1 and self.out_channel <= 4 and not self.demodulate:
-            return AG.mod_to_rgb(x.contiguous(), self.weight, s.contiguous(), bias, self.scale)
+            return AG.mod_to_rgb(x.contiguous(), self.weight, s.contiguous(), bias, self.scale,
+                                 None if skip is None else skip.contiguous(), _UP_FIR)
         if self.kernel_size != 3:
             raise NotImplementedError("ModulatedConv2d: 3x3 (styled convs) and 1x1 toRGB are on the HIP path")
         if self.demodulate and d is None:
@@ -132,10 +135,10 @@ class ToRGB(nn.Module):
         self.bias = nn.Parameter(torch.zeros(1, 3, 1, 1))
 
     def forward(self, x, style, skip=None, s=None):
-        out = self.conv(x, style, bias=self.bias.view(-1), s=s)
-        if skip is not None:
-            out = out + self.upsample(skip)         # 3-channel skip sum
-        return out
+        if skip is not None and (self.upsample is None or skip.shape[-1] * 2 != x.shape[-1]):
+            return self.conv(x, style, bias=self.bias.view(-1), s=s) + (skip if self.upsample is None else self.upsample(skip))
+        # one launch: modulated 1x1 + bias + upfirdn2d(skip, up=2, [1,3,3,1]) + add
+        return self.conv(x, style, bias=self.bias.view(-1), s=s, skip=skip)
 
 
 class ConstantInput(nn.Module):
@@ -165,8 +168,16 @@ class StyleGAN2Generator(nn.Module):
             self.to_rgbs.append(ToRGB(cout, style_dim))
             cin = cout
 
+    use_plan = True      # inference forwards go out as one pre-built launch list (plan.StyleGAN2Plan)
+
     def forward(self, features, noises=None):
         train = torch.is_grad_enabled() and (features.requires_grad or any(p.requires_grad for p in self.parameters()))
+        if not train and self.use_plan and features.is_cuda and features.dim() == 2:
+            from . import plan as PL
+            B = features.size(0)
+            key = (B, features.device, torch.cuda.current_stream(features.device).cuda_stream, "features")
+            p = PL.plan_for(self, key, lambda: PL.StyleGAN2Plan(self, B, features.device))
+            return p.run(features.contiguous(), None if noises is None else [n.contiguous() for n in noises])
         w = AG.pixelnorm(features.contiguous(), 1e-8, False)
         for layer in self.style:
             w = layer(w)

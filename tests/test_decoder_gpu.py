@@ -270,3 +270,49 @@ def test_hipgraph_replay_matches_eager(pkg, dev):
         graph.replay()
         torch.cuda.synchronize()
         assert torch.equal(out, g(feats, noises))
+
+
+def test_launch_plan_equals_launch_by_launch(pkg, dev):
+    """The inference forward goes out as one pre-built launch list (plan.DecoderPlan, spk_launch_list); it must be the
+    launch-by-launch path bit for bit (same kernels, same arguments) -- with explicit noise, from features and from
+    dlatents -- follow in-place parameter updates, and hand back a fresh output tensor per call."""
+    g, sd = _generator(pkg, dev)
+    B = 3
+    feats = recipe_input("plan.features", (B, 6144)).to(dev)
+    noises = [n.to(dev) for n in recipe_noises("plan", B, 256)]
+    syn = g.synthesis
+    with torch.no_grad():
+        y_plan = g(feats, noises)
+        assert any(k[3] == "features" for k in g.__dict__["_plans"])
+        type(syn).use_plan = False
+        try:
+            y_ref = g(feats, noises)
+            w = g.mapping(feats).unsqueeze(1).repeat(1, syn.num_layers, 1).contiguous()
+            y_w_ref = syn(w, noises)
+        finally:
+            type(syn).use_plan = True
+        # (the truncation scale rides on the style FCs' multiplier in the plan: one rounding apart from psi * w)
+        assert rel_l2(y_plan, y_ref) < 1e-6
+        y_w = syn(w, noises)
+        assert torch.equal(y_w, y_w_ref)
+        assert any(k[3] == "w" for k in syn.__dict__["_plans"])
+        # a second call returns a NEW tensor and leaves the first one intact
+        keep = y_plan.clone()
+        y2 = g(feats * 0.5, noises)
+        assert y2.data_ptr() != y_plan.data_ptr() and torch.equal(y_plan, keep) and not torch.equal(y2, keep)
+        # in-place parameter update (an optimizer step / load_state_dict): the plan re-packs
+        syn.layers[2].conv1.weight.mul_(1.5)
+        syn.to_rgb.bias.add_(0.25)
+        y3 = g(feats, noises)
+        type(syn).use_plan = False
+        try:
+            y3_ref = g(feats, noises)
+        finally:
+            type(syn).use_plan = True
+        assert rel_l2(y3, y3_ref) < 1e-6 and rel_l2(y3, y_ref) > 1e-3
+        # device-drawn noise path: finite, and different draws per call
+        a, b = g(feats), g(feats)
+        assert torch.isfinite(a).all() and not torch.equal(a, b)
+        with pytest.raises(ValueError):
+            g(feats, noises[:-1])
+    g.load_state_dict(sd)

@@ -222,3 +222,52 @@ def test_variant_generator_backward(sg2, dev):
     for k in out["ref64"][1]:
         ok, info = grad_close(out["hip"][1][k], out["ref32"][1][k], out["ref64"][1][k])
         assert ok, (k, info)
+
+
+def test_variant_launch_plan_equals_launch_by_launch(sg2, dev):
+    """The variant's inference forward as one launch list (plan.StyleGAN2Plan) against its launch-by-launch path, which
+    runs the skip upsample as the stand-alone upfirdn2d + a torch add when handed a non-matching skip -- here both paths
+    use the fused toRGB, so they agree to the bit; the fused toRGB itself is held to the oracle in test_styled_conv_and_to_rgb."""
+    torch.manual_seed(9)
+    g = sg2.StyleGAN2Generator(6144, resolution=64).eval().to(dev)
+    with torch.no_grad():
+        for n, p in g.named_parameters():
+            if n.endswith("noise.weight"):
+                p.fill_(0.2)
+    B = 3
+    feats = recipe_input("sg2.plan.f", (B, 6144)).to(dev)
+    noises = [recipe_input(f"sg2.plan.n{i}", s).to(dev) for i, s in enumerate(M.noise_shapes(B, 64))]
+    with torch.no_grad():
+        y = g(feats, noises)
+        assert "_plans" in g.__dict__
+        sg2.StyleGAN2Generator.use_plan = False
+        try:
+            y_ref = g(feats, noises)
+        finally:
+            sg2.StyleGAN2Generator.use_plan = True
+        assert torch.equal(y, y_ref)
+        g.convs[1].conv.weight.mul_(1.3)
+        g.convs[2].noise.weight.fill_(0.5)
+        y2 = g(feats, noises)
+        sg2.StyleGAN2Generator.use_plan = False
+        try:
+            y2_ref = g(feats, noises)
+        finally:
+            sg2.StyleGAN2Generator.use_plan = True
+        assert torch.equal(y2, y2_ref) and not torch.equal(y2, y)
+
+
+@pytest.mark.parametrize("B,C,H,W", [(2, 32, 16, 16), (1, 70, 6, 10), (3, 512, 8, 8), (8, 64, 64, 64)])
+def test_to_rgb_with_fused_skip_upsample(ops, dev, B, C, H, W):
+    """Modulated 1x1 + bias + upfirdn2d(skip, up=2, [1,3,3,1]) + add in one launch -- every kernel variant (vector,
+    channel-split, scalar for W % 4 != 0) -- against the oracle's materialised Upsample and sum."""
+    x = recipe_input(f"rgbs.x.{B}.{C}.{H}.{W}", (B, C, H, W))
+    wt = recipe_input(f"rgbs.w.{C}", (3, C, 1, 1))
+    mod = 1.0 + 0.3 * recipe_input(f"rgbs.m.{B}.{C}", (B, C))
+    bias = recipe_input("rgbs.b", (3,))
+    skip = recipe_input(f"rgbs.s.{B}.{H}.{W}", (B, 3, H // 2, W // 2))
+    sc = C ** -0.5
+    ref = torch.einsum("oc,bc,bchw->bohw", wt.view(3, C).double(), mod.double(), x.double()) * sc + bias.double().view(1, 3, 1, 1) \
+        + M.upsample2x(skip.double())
+    y = ops.conv1x1_small_mod(x.to(dev), wt.to(dev), mod.to(dev), bias.to(dev), in_scale=sc, skip=skip.to(dev))
+    assert rel_l2(y, ref) < 2e-6
