@@ -11,11 +11,19 @@ end to end (exact-f32 MFMA).  N > 1: launched by torch.distributed.run, one rank
 an independent replica on its own batch (the forward path has no exchange step -- SURVEY.md 8e);
 barrier + synchronize on both sides of the timed region, MAX over ranks, rank 0 prints ONE JSON line.
 
-Extra objects in the line:
-  roofline     -- the dominant kernel (spkconv::conv_kernel, MFMA-bound): algorithmic conv FLOPs per
-                  step / conv kernel time per step, timed live with HIP events on the launch stream.
-  cpu_baseline -- the CPU oracle (a port of the reference's algorithm, parity-pinned to it) timed
-                  on this box's host cores on the same B=8 workload (rank 0, N=1 only).
+Extra objects in the line (headline fields unchanged):
+  roofline       -- the dominant kernel (spkconv::conv_kernel, MFMA-bound): algorithmic conv FLOPs per
+                    step / conv kernel time per step, timed live with HIP events on the launch stream.
+  cpu_baseline   -- the CPU oracle (a port of the reference's algorithm, parity-pinned to it) timed
+                    on this box's host cores on the same B=8 workload (rank 0, N=1 only).
+  eager          -- the same step WITHOUT the hipGraph: what an unchanged ``model.Gd(x)`` caller gets (one
+                    launch list per call, plan.DecoderPlan).
+  stylegan2_variant -- the build-defined StyleGAN2 decoder (A11) on the same workload, with its own roofline.
+  decoder_512_b4 -- BASELINE config 5: SynthesisNetwork(512), batch 4.
+  train_step     -- BASELINE config 3: the IRFD generator step (3 encoders x 2 images + 2 decoder passes,
+                    fwd + bwd + clip + Adam) at batch 16.
+  d_step         -- the discriminator step of train.py:155-183 at batch 8.
+(the last four on rank 0 at N=1 only; ``--headline-only`` skips them.)
 """
 from __future__ import annotations
 
@@ -34,10 +42,11 @@ sys.path.insert(0, ROOT)
 BATCH = 8
 RES = 256
 F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
+GFLOP_PER_PAIR = 593.5            # IRFD fwd+bwd, decoder x3, checkpointed encoders x4
 
 
 def decoder_conv_flops(batch, resolution=RES):
-    """Algorithmic FLOPs (2*MAC) of the twelve 3x3 convs per step -- SURVEY.md 8(d): 56.17 GFLOP/frame."""
+    """Algorithmic FLOPs (2*MAC) of the 3x3 convs per step -- SURVEY.md 8(d): 56.17 GFLOP/frame at 256^2."""
     total, res, cin = 0, 8, 512
     while res <= resolution:
         cout = min(int(8192 / (2.0 ** (res.bit_length() - 2))), 512)
@@ -81,15 +90,121 @@ def cpu_baseline(threads):
                       f"({med * 1e3:.0f} ms/step)"}
 
 
+def event_ms(fn, reps):
+    """HIP events on the launch stream around ``reps`` calls of ``fn`` (after one untimed call)."""
+    fn()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / reps
+
+
+_SIDE = None
+
+
+def capture(fn):
+    """``fn`` replayed as one hipGraph (the C ABI neither allocates nor synchronises; the noise draw is graph-safe Philox).
+    Warm-up and capture run on ONE side stream: launch plans are per stream, so the capture reuses the warmed plan instead
+    of building (and re-packing weights) inside the graph."""
+    global _SIDE
+    if _SIDE is None:
+        _SIDE = torch.cuda.Stream()
+    side = _SIDE
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        for _ in range(3):
+            fn()                                   # warm every cache (plans, packed weights, workspace) before capture
+    torch.cuda.current_stream().wait_stream(side)
+    torch.cuda.synchronize()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g, stream=side):
+        out = fn()
+    torch.cuda.synchronize()
+    return g, out
+
+
+def plan_of(module):
+    plans = module.__dict__.get("_plans")
+    return next(reversed(plans.values())) if plans else None
+
+
+def conv_time_ms(module, feats, L):
+    """Time of a step's conv launches.  Events between individual launches would sit on the GPU timeline themselves (a
+    marker packet with a cache flush: ~30 us per conv when launches are queued back to back).  Instead the step's launch
+    list is captured twice -- whole, and with ``kind_mask`` leaving out the conv launches (spk_launch_list's documented
+    measurement use: no switch inside the library) -- and both graphs are timed by HIP events around R replays."""
+    capture(lambda: module(feats))                # make sure the side stream's plan exists and is the most recent one
+    plan = plan_of(module)
+    if plan is None:
+        return None, None
+    g_all, _ = capture(lambda: plan.run(feats))
+    g_nc, _ = capture(lambda: plan.run(feats, kind_mask=L.ALL_OPS & ~(1 << L.OP_CONV2D)))
+    R = 20
+    ms = event_ms(g_all.replay, R) - event_ms(g_nc.replay, R)
+    n = sum(1 for kind, _ in plan.ops if kind == L.OP_CONV2D)
+    return ms, n
+
+
+def irfd_steps(pkg, dev, which, B, steps, warmup):
+    """The generator step (config 3) / discriminator step of train.py:150-210 on synthetic pairs -- tools/train_step_bench.py
+    in brief.  Returns ms per step."""
+    import model as M
+    import torch.nn.functional as F
+    dp = importlib.import_module("speak-hack_amd.dp")
+    T = importlib.import_module("speak-hack_amd.training")
+    torch.manual_seed(0)
+    net = M.IRFD().to(dev).train()
+    for n, p in net.named_parameters():
+        p.requires_grad_(n.startswith("D.") == (which == "d"))
+    params = [p for p in net.parameters() if p.requires_grad]
+    red = dp.GradBucketReducer(params)
+    opt = torch.optim.Adam(net.D.parameters() if which == "d" else net.Gd.parameters(), lr=1e-4, betas=(0.5, 0.999))
+    x_s, x_t, f_s, f_t = (torch.rand(B, 3, 256, 256, device=dev) * 2 - 1 for _ in range(4))
+    bce = lambda pred, label: F.binary_cross_entropy_with_logits(pred, torch.full_like(pred, label))
+
+    def step():
+        red.zero_grad()
+        if which == "d":
+            nz = T.add_instance_noise
+            loss = (bce(net.D(nz(x_s)), 0.9) + bce(net.D(nz(x_t)), 0.9)) / 2 + (bce(net.D(nz(f_s)), 0.1) + bce(net.D(nz(f_t)), 0.1)) / 2 \
+                + 10.0 * (T.compute_r1_reg(net.D, x_s) + T.compute_r1_reg(net.D, x_t)) / 2
+            loss.backward()
+            red.finish()
+        else:
+            out = net(x_s, x_t)
+            loss = ((out[0] - x_s) ** 2).mean() + ((out[1] - x_t) ** 2).mean()
+            loss.backward()
+            red.finish()
+            red.clip_(1.0)
+        opt.step()
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    torch.cuda.synchronize()
+    ms = (time.perf_counter() - t0) / steps * 1e3
+    red.remove()
+    del net, opt, red
+    torch.cuda.empty_cache()
+    return ms
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=10)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--headline-only", action="store_true", help="skip the extra objects (variant, 512^2, training steps)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to "
                     "rehearse the multi-rank path on a box with fewer GPUs than ranks, together with SPK_BENCH_ONE_DEVICE=1)")
-    ap.add_argument("--no-graph", action="store_true", help="launch the step's kernels one by one instead of replaying "
+    ap.add_argument("--no-graph", action="store_true", help="launch the step's kernels eagerly instead of replaying "
                     "the hipGraph captured from them")
     args = ap.parse_args()
 
@@ -114,7 +229,8 @@ def main():
             dist.init_process_group(args.backend)
 
     pkg = importlib.import_module("speak-hack_amd")
-    pkg._lib.lib()
+    L = pkg._lib
+    L.lib()
     torch.manual_seed(1 + rank)
     gen = pkg.StyleGenerator(6144).eval().to(dev)          # random-init weights of the architecture
     with torch.no_grad():                                   # default init zeroes the noise weights; wake them up
@@ -126,43 +242,31 @@ def main():
     def eager_step():
         return gen(feats)
 
-    # The step is ~35 launches of 30-700 us each; captured once into a hipGraph (the C ABI neither allocates nor
-    # synchronises, the noise draw is graph-safe Philox), every timed step is ONE graph launch -- the same kernels
-    # with the same arguments, and a fresh noise draw per replay, but no dependence on how fast this box's host
-    # thread can issue launches.
+    # The step is ~25 launches of 10-700 us each, issued as one launch list per call; captured once into a hipGraph every
+    # timed step is ONE graph launch -- the same kernels with the same arguments, and a fresh noise draw per replay, but no
+    # dependence on how fast this box's host thread can issue launches.  The eager number is reported beside it.
     graph = None
-    if not args.no_graph:
-        try:
-            with torch.no_grad():
-                side = torch.cuda.Stream()
-                side.wait_stream(torch.cuda.current_stream())
-                with torch.cuda.stream(side):
-                    for _ in range(3):
-                        eager_step()                      # warm every cache (packed weights, workspace) before capture
-                torch.cuda.current_stream().wait_stream(side)
-                torch.cuda.synchronize()
-                graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
-                    graph_out = eager_step()
-            torch.cuda.synchronize()
-        except Exception as e:                            # capture is an optimisation, never a requirement
-            print(f"bench: hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
-            graph = None
-            torch.cuda.synchronize()
-
-    def step():
-        if graph is not None:
-            graph.replay()
-            return graph_out
-        return eager_step()
-
-    def barrier():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-            torch.cuda.synchronize()
-
     with torch.no_grad():
+        if not args.no_graph:
+            try:
+                graph, graph_out = capture(eager_step)
+            except Exception as e:                            # capture is an optimisation, never a requirement
+                print(f"bench: hipGraph capture failed ({type(e).__name__}: {e}); running eagerly", file=sys.stderr)
+                graph = None
+                torch.cuda.synchronize()
+
+        def step():
+            if graph is not None:
+                graph.replay()
+                return graph_out
+            return eager_step()
+
+        def barrier():
+            torch.cuda.synchronize()
+            if dist is not None:
+                dist.barrier()
+                torch.cuda.synchronize()
+
         for _ in range(args.warmup):
             step()
         barrier()
@@ -176,89 +280,80 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             elapsed = float(t.item())
 
-        # ---- roofline of the dominant kernel: time of the step's conv launches, with HIP events on the launch stream ----
-        n_launch = 2 * len(gen.synthesis.layers)
-        roof_how = None
-        if graph is not None:
-            # Events between individual launches would sit on the GPU timeline themselves (an event record is a marker
-            # packet with a cache flush: ~30 us per conv when launches are queued back to back) and, launch by launch,
-            # would also count this box's host latency.  Instead the SAME step is captured a second time without its
-            # conv launches, and both graphs are timed by HIP events around R replays: conv time = the difference.
-            real_launch = pkg.ops._launch_conv2d
-            try:
-                pkg.ops._launch_conv2d = lambda desc: None      # measurement only, and only here: the package has no switch
-                graph_nc = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph_nc):
-                    eager_step()
-                pkg.ops._launch_conv2d = real_launch
-                R = 20
-
-                def timed(g):
-                    g.replay()
-                    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                    e0.record()
-                    for _ in range(R):
-                        g.replay()
-                    e1.record()
-                    torch.cuda.synchronize()
-                    return e0.elapsed_time(e1) / R
-
-                conv_ms = timed(graph) - timed(graph_nc)
-                roof_how = "HIP events around 20 replays of the step's hipGraph minus 20 replays of the same graph captured without its conv launches"
-            except Exception as e:
-                print(f"bench: conv-less capture failed ({type(e).__name__}: {e}); timing conv launches with event pairs", file=sys.stderr)
-            finally:
-                pkg.ops._launch_conv2d = real_launch
-        if roof_how is None:
-            events, real_launch = [], pkg.ops._launch_conv2d
-
-            def timed_launch(desc):
-                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-                e0.record()
-                real_launch(desc)
-                e1.record()
-                events.append((e0, e1))
-
-            prof_steps = 5
-            try:
-                pkg.ops._launch_conv2d = timed_launch
-                for _ in range(prof_steps):
-                    eager_step()
-            finally:
-                pkg.ops._launch_conv2d = real_launch
-            torch.cuda.synchronize()
-            conv_ms = sum(a.elapsed_time(b) for a, b in events) / prof_steps
-            n_launch = len(events) // prof_steps
-            roof_how = "HIP event pair around every conv launch of 5 eager steps"
-
-        # ---- the build-defined StyleGAN2 variant (modulated conv + upfirdn2d, A11) on the same workload ----
-        sg2 = importlib.import_module("speak-hack_amd.stylegan2")
-        gen2 = sg2.StyleGAN2Generator(6144).eval().to(dev)
-        for n, p in gen2.named_parameters():
-            if n.endswith("noise.weight"):
-                p.fill_(0.1)
-        for _ in range(max(2, args.warmup // 2)):
-            gen2(feats)
-        torch.cuda.synchronize()
-        step2 = lambda: gen2(feats)
-        if graph is not None:                             # same launch mode as the headline
-            try:
-                graph2 = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph2):
-                    gen2(feats)
-                step2 = graph2.replay
-            except Exception as e:
-                print(f"bench: hipGraph capture of the StyleGAN2 variant failed ({e}); eager", file=sys.stderr)
-            torch.cuda.synchronize()
-        step2()
+        # ---- eager: the same step as an unchanged caller gets it (no graph) ----
+        for _ in range(3):
+            eager_step()
         torch.cuda.synchronize()
         t1 = time.perf_counter()
-        sg2_steps = max(5, args.steps // 2)
-        for _ in range(sg2_steps):
-            step2()
+        n_eager = max(10, args.steps // 2)
+        for _ in range(n_eager):
+            eager_step()
         torch.cuda.synchronize()
-        sg2_ms = (time.perf_counter() - t1) / sg2_steps * 1e3
-        del gen2
+        eager_ms = (time.perf_counter() - t1) / n_eager * 1e3
+
+        # ---- roofline of the dominant kernel ----
+        conv_ms, n_launch = conv_time_ms(gen, feats, L)
+        roof_how = ("HIP events around 20 replays of the step's hipGraph minus 20 replays of the same launch list captured "
+                    "without its conv launches (spk_launch_list kind_mask)")
+        if conv_ms is None:
+            raise SystemExit("bench: the decoder did not run through its launch plan")
+
+    extras = {}
+    if rank == 0 and world == 1 and not args.headline_only:
+        with torch.no_grad():
+            # ---- the build-defined StyleGAN2 variant (modulated conv + upfirdn2d, A11) on the same workload ----
+            sg2 = importlib.import_module("speak-hack_amd.stylegan2")
+            gen2 = sg2.StyleGAN2Generator(6144).eval().to(dev)
+            for n, p in gen2.named_parameters():
+                if n.endswith("noise.weight"):
+                    p.fill_(0.1)
+            g2, _ = capture(lambda: gen2(feats))
+            sg2_ms = event_ms(g2.replay, max(10, args.steps // 2))
+            c2_ms, n2 = conv_time_ms(gen2, feats, L)
+            t2 = time.perf_counter()
+            for _ in range(10):
+                gen2(feats)
+            torch.cuda.synchronize()
+            sg2_eager = (time.perf_counter() - t2) / 10 * 1e3
+            fl = decoder_conv_flops(BATCH) + 2 * 9 * 16 * 512 * 512 * BATCH        # + the 4x4 styled conv the variant starts with
+            a2 = fl / (c2_ms * 1e-3) / 1e12
+            extras["stylegan2_variant"] = {
+                "what": "speak-hack_amd.stylegan2.StyleGAN2Generator (modulated 3x3 conv + demod, upfirdn2d [1,3,3,1] folded into "
+                        "staging, skip toRGB with the skip upsample + add fused; same channel schedule; parity unpinned by the reference)",
+                "frames_per_s_per_gpu": round(BATCH / sg2_ms * 1e3, 2), "ms_per_step": round(sg2_ms, 4), "eager_ms_per_step": round(sg2_eager, 4),
+                "roofline": {"bound": "mfma", "kernel": "spkconv::conv_kernel<Cfg,3,3,1,MODE_(UPSAMPLE_)BATCH_SCALE>", "achieved": round(a2, 2),
+                             "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(a2 / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                             "launches_per_step": n2, "conv_ms_per_step": round(c2_ms, 4), "conv_share_of_step": round(c2_ms / sg2_ms, 3),
+                             "algorithmic_gflop_per_step": round(fl / 1e9, 2)}}
+            del gen2, g2
+            # ---- config 5: the 512^2 decoder at batch 4 ----
+            s512 = pkg.SynthesisNetwork(resolution=512).eval().to(dev)
+            for n, p in s512.named_parameters():
+                if "noise" in n:
+                    p.normal_(0, 0.1)
+            w512 = torch.randn(4, 16, 512, device=dev)
+            g5, _ = capture(lambda: s512(w512))
+            ms5 = event_ms(g5.replay, 20)
+            c5_ms, n5 = conv_time_ms(s512, w512, L)
+            fl5 = decoder_conv_flops(4, 512)
+            extras["decoder_512_b4"] = {"what": "BASELINE config 5: SynthesisNetwork(resolution=512) forward, batch 4, fp32 (hipGraph replay)",
+                                        "ms_per_step": round(ms5, 4), "frames_per_s_per_gpu": round(4 / ms5 * 1e3, 2),
+                                        "conv_ms_per_step": round(c5_ms, 4), "conv_tflops": round(fl5 / (c5_ms * 1e-3) / 1e12, 2),
+                                        "conv_frac_of_f32_mfma_peak": round(fl5 / (c5_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4)}
+            del s512, g5
+        torch.cuda.empty_cache()
+        # ---- config 3: the IRFD generator step at batch 16; the discriminator step at batch 8 ----
+        g_ms = irfd_steps(pkg, dev, "g", 16, steps=5, warmup=2)
+        extras["train_step"] = {"what": "BASELINE config 3: IRFD generator step (3 ResNet-50 encoders x 2 images, train-mode BatchNorm, "
+                                        "checkpoint semantics; 2 decoder passes; reconstruction loss; fwd + bwd + global-norm clip + Adam on Gd), "
+                                        "batch 16, fp32, eager launches",
+                                "ms_per_step": round(g_ms, 2), "pairs_per_s": round(16 / g_ms * 1e3, 1),
+                                "algorithmic_tflops": round(16 / g_ms * 1e3 * GFLOP_PER_PAIR / 1e3, 1),
+                                "frac_of_f32_mfma_peak": round(16 / g_ms * 1e3 * GFLOP_PER_PAIR / 1e3 / F32_MFMA_PEAK_TFLOPS, 4)}
+        d_ms = irfd_steps(pkg, dev, "d", 8, steps=5, warmup=2)
+        extras["d_step"] = {"what": "discriminator step of train.py:155-183 (4 D fwd+bwd with instance noise + BCE, 2 R1 double backward, "
+                                    "Adam on D), batch 8, fp32, eager launches", "ms_per_step": round(d_ms, 2),
+                            "pairs_per_s": round(8 / d_ms * 1e3, 1)}
 
     if rank == 0:
         traffic = None
@@ -289,10 +384,11 @@ def main():
                          "launches_per_step": n_launch, "conv_ms_per_step": round(conv_ms, 4),
                          "conv_share_of_step": round(conv_ms / ms_per_step, 3),
                          "algorithmic_gflop_per_step": round(flops / 1e9, 2), "measured_by": roof_how},
+            "eager": {"what": "the same step without the hipGraph: one spk_launch_list call per forward (plan.DecoderPlan), as an "
+                              "unchanged `model.Gd(x)` caller runs it", "ms_per_step": round(eager_ms, 4),
+                      "frames_per_s_per_gpu": round(BATCH / eager_ms * 1e3, 2), "vs_graph": round(eager_ms / ms_per_step, 3)},
         }
-        line["stylegan2_variant"] = {"what": "speak-hack_amd.stylegan2.StyleGAN2Generator (modulated 3x3 conv + demod, upfirdn2d "
-                                             "[1,3,3,1], skip toRGB; same channel schedule; parity unpinned by the reference)",
-                                     "frames_per_s_per_gpu": round(BATCH / sg2_ms * 1e3, 2), "ms_per_step": round(sg2_ms, 4)}
+        line.update(extras)
         if world == 1 and not args.no_cpu_baseline:
             line["cpu_baseline"] = cpu_baseline(host_cores())
         print(json.dumps(line), flush=True)

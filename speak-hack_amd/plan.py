@@ -270,6 +270,11 @@ def plan_for(owner, key, build):
     plan = cache.pop(key, None)
     if plan is None or not plan.valid_for():
         plan = build()
+        if torch.cuda.is_current_stream_capturing():
+            # built inside a stream capture: its buffers belong to that graph's memory pool and its packing launches were
+            # recorded into the graph -- correct, but not something to keep for later eager calls.  Warm the stream up
+            # before capturing (as bench.py does) to capture a plain launch list.
+            return plan
     cache[key] = plan                      # re-insert: most recently used last
     while len(cache) > MAX_PLANS:
         cache.pop(next(iter(cache)))

@@ -292,7 +292,7 @@ def test_launch_plan_equals_launch_by_launch(pkg, dev):
         finally:
             type(syn).use_plan = True
         # (the truncation scale rides on the style FCs' multiplier in the plan: one rounding apart from psi * w)
-        assert rel_l2(y_plan, y_ref) < 1e-6
+        assert rel_l2(y_plan, y_ref) < 1e-5
         y_w = syn(w, noises)
         assert torch.equal(y_w, y_w_ref)
         assert any(k[3] == "w" for k in syn.__dict__["_plans"])
@@ -309,7 +309,7 @@ def test_launch_plan_equals_launch_by_launch(pkg, dev):
             y3_ref = g(feats, noises)
         finally:
             type(syn).use_plan = True
-        assert rel_l2(y3, y3_ref) < 1e-6 and rel_l2(y3, y_ref) > 1e-3
+        assert rel_l2(y3, y3_ref) < 1e-5 and rel_l2(y3, y_ref) > 1e-3
         # device-drawn noise path: finite, and different draws per call
         a, b = g(feats), g(feats)
         assert torch.isfinite(a).all() and not torch.equal(a, b)
