@@ -22,6 +22,7 @@
 #include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int I, int N, class F>
 __device__ __forceinline__ void wg_static_for(F&& f) {
@@ -428,6 +429,240 @@ __global__ __launch_bounds__(256) void wgrad3x3_pipe_kernel(const WgradArgs p) {
         }
 }
 
+// ---- 3x3 stride-1 weight gradient, two accumulator tile sets per wave, 16-byte global loads ------------------------
+// The kernels above are bound by the ISSUE of their loads, not by the MFMA pipe (profiles/r01_k_wgrad_phases.txt: 48 dword
+// loads per thread and tile, ~1 000 line requests against 18.4K cycles of MFMA; a 64co x 64ci block needs 9.6 bytes per
+// cycle and CU from L2, which is all a CU takes in).  This form attacks both numbers:
+//   * each of the four waves owns MCO x MCI accumulator tiles of 32co x 32ci x 9 taps -- a 128co x 64ci (or, for the
+//     Cout = 64 layers, 64co x 128ci) block: 1.5x the FLOPs per staged byte, 18 MFMAs per k-step against 11 (19) fragment
+//     reads.  288 accumulator registers per lane: one wave per SIMD with the whole 512-entry file, as the kernels above;
+//   * rows are loaded 16 bytes per lane: a gradient row of the 16 x 4 tile is 4 aligned float4, an input row its 4 aligned
+//     float4 plus the two halo columns as single dwords: 17 (22) load instructions per thread and tile of 576 MFMAs,
+//     where the 64 x 64 form issues 48 per 288.
+// Staging roles make everything but the tile origin a launch constant: piece i of the input tile is plane ROW i % 6 of
+// 64 channels, so its global offset is a per-thread base plus a wave-uniform term, its LDS address an immediate offset
+// and its row test a scalar compare.  Same tile (16 x 4 pixels, 18 x 6 input plane), LDS images (odd row pitch), per-element
+// accumulation order and slab layout as the kernels above: results are bitwise equal to theirs for equal pixel splits.
+// MCO = MCI = 1 is the 64co x 64ci block of wgrad3x3_pipe_kernel with the wide loads.
+// Needs W % 4 == 0, W >= 16 and 16-byte aligned tensors (host-checked).
+template <int MCO, int MCI>
+struct WideShape {
+    static constexpr int CO_T = 64 * MCO, CI_T = 64 * MCI, NT = 256;
+    static constexpr int TW = 16, TH = 4, PW = TW + 2, PH = TH + 2, PLANE = PH * PW;
+    static constexpr int GPITCH = TW * TH + 1, XPITCH = PLANE | 1;
+    static constexpr int BUF = (CO_T * GPITCH + CI_T * XPITCH + 3) & ~3;           // floats per buffer
+    static constexpr int NG4 = CO_T / 16;            // float4 pieces of the gradient tile per thread (16 channels per piece)
+    static constexpr int NX4 = 6 * MCI;              // float4 pieces of the input tile (piece = one plane row of 64 channels)
+    static constexpr int NXH = 3 * MCI;              // halo-dword pieces (piece = two plane rows x 2 sides of 64 channels)
+    static constexpr int NL = NG4 + NX4 + NXH, NS = 4 * NG4 + 4 * NX4 + NXH;
+    static constexpr int STEPS = 32, HS = STEPS / 2;
+    static constexpr int PL = (NL + HS - 1) / HS, PS = (NS + HS - 1) / HS;
+    static constexpr int NMFMA = MCO * MCI * 9, NFRAG = MCO + 9 * MCI;
+};
+
+template <int MCO, int MCI, int MODE>
+__global__ __launch_bounds__(256) void wgrad3x3_wide_kernel(const WgradArgs p) {
+    using SH = WideShape<MCO, MCI>;
+    constexpr int TAPS = 9, CO_T = SH::CO_T, CI_T = SH::CI_T, PW = SH::PW, GPITCH = SH::GPITCH, XPITCH = SH::XPITCH, BUF = SH::BUF;
+    constexpr int NG4 = SH::NG4, NX4 = SH::NX4, NXH = SH::NXH, NL = SH::NL, NS = SH::NS, STEPS = SH::STEPS, HS = SH::HS;
+    constexpr int PL = SH::PL, PS = SH::PS, NMFMA = SH::NMFMA;
+    constexpr bool AFF = MODE == WG_AFFINE_RELU;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l32 = lane & 31;
+    const int wco = wave & 1, wci = wave >> 1;
+
+    const int co0 = blockIdx.x * CO_T;
+    const int grp = co0 / p.Cout;
+    const int co_end = (grp + 1) * p.Cout;
+    const int cx0 = grp * p.gin;
+    const int ci0 = blockIdx.y * CI_T;
+    const int nci = min(CI_T, p.Cin - ci0);
+    const int HW = p.H * p.W;                    // host: every tensor has < 2^31 elements
+
+    // ---- staging roles (launch constants; only the tile origin moves) ----
+    // gradient piece i: float4 gk of tile row grow of channel (tid >> 4) + 16 i
+    const int gk = tid & 3, grow = (tid >> 2) & 3;
+    int g_off[NG4];
+#pragma unroll
+    for (int i = 0; i < NG4; ++i)
+        g_off[i] = (min(co0 + (tid >> 4) + 16 * i, co_end - 1) * p.H + grow) * p.W + 4 * gk;    // rows past the last channel: clamped (never written out)
+    const int g_dst = (tid >> 4) * GPITCH + grow * 16 + 4 * gk;                                   // + 16 i GPITCH + j
+    // input piece i: float4 xk of plane row i % 6 of channel (tid >> 2) + 64 (i / 6)
+    const int xk = tid & 3, xc = tid >> 2;
+    int x_base[MCI];
+    float x_sc[AFF ? MCI : 1], x_sh[AFF ? MCI : 1];
+#pragma unroll
+    for (int m = 0; m < MCI; ++m) {
+        const int c = cx0 + ci0 + min(xc + 64 * m, nci - 1);
+        x_base[m] = (c * p.Hs - 1) * p.Ws + 4 * xk;                                               // + (i % 6) Ws
+        if (AFF) { x_sc[m] = p.in_scale[c]; x_sh[m] = p.in_shift[c]; }
+    }
+    const int x_dst = CO_T * GPITCH + xc * XPITCH + 1 + 4 * xk;                                   // + 64 (i / 6) XPITCH + (i % 6) PW + j
+    // halo piece i: column -1 / 16 (hs) of plane row 2 (i % 3) + hr of channel ((tid >> 1) & 63) + 64 (i / 3)
+    const int hs = tid & 1, hc = (tid >> 1) & 63, hr = tid >> 7;
+    int h_base[MCI];
+    float h_sc[AFF ? MCI : 1], h_sh[AFF ? MCI : 1];
+#pragma unroll
+    for (int m = 0; m < MCI; ++m) {
+        const int c = cx0 + ci0 + min(hc + 64 * m, nci - 1);
+        h_base[m] = (c * p.Hs + hr - 1) * p.Ws + (hs ? 16 : -1);                                  // + 2 (i % 3) Ws
+        if (AFF) { h_sc[m] = p.in_scale[c]; h_sh[m] = p.in_shift[c]; }
+    }
+    const int h_dst = CO_T * GPITCH + hc * XPITCH + hr * PW + (hs ? 17 : 0);                      // + 64 (i / 3) XPITCH + 2 (i % 3) PW
+
+    f32x16 acc[MCO][MCI][TAPS];
+#pragma unroll
+    for (int m = 0; m < MCO; ++m)
+#pragma unroll
+        for (int n = 0; n < MCI; ++n)
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[m][n][t][r] = 0.f;
+
+    // prefetch registers and, for the tile being staged: its base pointers, origin row and which of this thread's columns exist
+    f32x4 gq[NG4], xq[NX4];
+    float hq[NXH];
+    const float* gbase = p.g;
+    const float* xbase = p.x;
+    int ty0 = 0;
+    bool g_ok = false, xcol_ok = false, hcol_ok = false;
+    auto aim = [&](int tile) {
+        const int tx = tile % p.tiles_x;
+        const int q = tile / p.tiles_x;
+        const int ty = q % p.tiles_y, b = q / p.tiles_y;
+        const int y0 = ty * 4, x0 = tx * 16;
+        ty0 = y0;
+        gbase = p.g + ((size_t)b * p.Cy * p.H + y0) * p.W + x0;
+        xbase = p.x + ((size_t)b * p.Cx * p.Hs + y0) * p.Ws + x0;
+        g_ok = y0 + grow < p.H && x0 + 4 * gk < p.W;
+        xcol_ok = x0 + 4 * xk < p.Ws;
+        hcol_ok = (unsigned)(x0 + (hs ? 16 : -1)) < (unsigned)p.Ws;
+    };
+    auto x_row_ok = [&](int r) { return (unsigned)(ty0 + r - 1) < (unsigned)p.Hs; };    // plane row r of the tile being staged
+    auto load_piece = [&](auto j_) {
+        constexpr int j = decltype(j_)::value;
+        if constexpr (j < NG4) {
+            gq[j] = *reinterpret_cast<const f32x4*>(g_ok ? gbase + g_off[j] : p.g);
+        } else if constexpr (j < NG4 + NX4) {
+            constexpr int i = j - NG4, m = i / 6, r = i % 6;
+            const bool ok = xcol_ok && x_row_ok(r);
+            xq[i] = *reinterpret_cast<const f32x4*>(ok ? xbase + (x_base[m] + r * p.Ws) : p.x);
+        } else if constexpr (j < NL) {
+            constexpr int i = j - NG4 - NX4, m = i / 3, r2 = 2 * (i % 3);
+            const bool ok = hcol_ok && x_row_ok(r2 + hr);
+            hq[i] = *(ok ? xbase + (h_base[m] + r2 * p.Ws) : p.x);
+        }
+    };
+    auto store_piece = [&](float* buf, auto s_) {
+        constexpr int s = decltype(s_)::value;
+        if constexpr (s < 4 * NG4) {
+            constexpr int i = s / 4, j = s % 4;
+            buf[g_dst + 16 * i * GPITCH + j] = g_ok ? gq[i][j] : 0.f;        // only the PIXEL axis (the contraction) needs zeros
+        } else if constexpr (s < 4 * NG4 + 4 * NX4) {
+            constexpr int i = (s - 4 * NG4) / 4, j = (s - 4 * NG4) % 4, m = i / 6, r = i % 6;
+            float v = xq[i][j];
+            if (AFF) v = fmaxf(v * x_sc[m] + x_sh[m], 0.f);
+            buf[x_dst + 64 * m * XPITCH + r * PW + j] = (xcol_ok && x_row_ok(r)) ? v : 0.f;
+        } else if constexpr (s < NS) {
+            constexpr int i = s - 4 * NG4 - 4 * NX4, m = i / 3, r2 = 2 * (i % 3);
+            float v = hq[i];
+            if (AFF) v = fmaxf(v * h_sc[m] + h_sh[m], 0.f);
+            buf[h_dst + 64 * m * XPITCH + r2 * PW] = (hcol_ok && x_row_ok(r2 + hr)) ? v : 0.f;
+        }
+    };
+
+    int tile = blockIdx.z;
+    int cur = 0;
+    if (tile < p.n_tiles) {                  // first tile: staged the serial way
+        aim(tile);
+        wg_static_for<0, NL>([&](auto j_) { load_piece(j_); });
+        wg_static_for<0, NS>([&](auto s_) { store_piece(smem, s_); });
+    }
+    __syncthreads();
+
+    // one tile's 32 k-steps out of buffer `cur`; PIPE: the next tile is staged into the other buffer on the way (its loads
+    // behind the first half of the k-steps, its LDS stores behind the second half)
+    auto run_tile = [&](auto pipe_) {
+        constexpr bool PIPE = decltype(pipe_)::value;
+        const float* cbuf = smem + cur * BUF;
+        float* nbuf = smem + (cur ^ 1) * BUF;
+        const float* ga = cbuf + (wco * 32 * MCO + l32) * GPITCH + half;
+        const float* xb = cbuf + CO_T * GPITCH + (wci * 32 * MCI + l32) * XPITCH + half;
+        float fa[2][MCO], fb[2][MCI][TAPS];
+#define SPK_WW_FRAG(st_, slot_)                                                                               \
+    {                                                                                                         \
+        constexpr int px_ = (2 * (st_)) & 15, py_ = (2 * (st_)) >> 4;                                         \
+        _Pragma("unroll") for (int m = 0; m < MCO; ++m) fa[slot_][m] = ga[m * 32 * GPITCH + 2 * (st_)];       \
+        _Pragma("unroll") for (int n = 0; n < MCI; ++n)                                                       \
+            _Pragma("unroll") for (int t = 0; t < TAPS; ++t)                                                  \
+                fb[slot_][n][t] = xb[n * 32 * XPITCH + (py_ + t / 3) * PW + px_ + t % 3];                     \
+    }
+        SPK_WW_FRAG(0, 0);
+        wg_static_for<0, STEPS>([&](auto s_) {
+            constexpr int st = decltype(s_)::value;
+            if constexpr (st + 1 < STEPS) SPK_WW_FRAG(st + 1, (st + 1) & 1);
+            constexpr int nl = (PIPE && st < HS) ? ((PL * st + PL <= NL) ? PL : (PL * st < NL ? NL - PL * st : 0)) : 0;
+            constexpr int s0 = PS * (st - HS);
+            constexpr int ns = (PIPE && st >= HS) ? ((s0 + PS <= NS) ? PS : (s0 < NS ? NS - s0 : 0)) : 0;
+            if constexpr (nl > 0) wg_static_for<PL * st, PL * st + nl>([&](auto j_) { load_piece(j_); });
+            if constexpr (ns > 0) wg_static_for<s0, s0 + ns>([&](auto q_) { store_piece(nbuf, q_); });
+#pragma unroll
+            for (int m = 0; m < MCO; ++m)
+#pragma unroll
+                for (int n = 0; n < MCI; ++n)
+#pragma unroll
+                    for (int t = 0; t < TAPS; ++t)
+                        acc[m][n][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[st & 1][m], fb[st & 1][n][t], acc[m][n][t], 0, 0, 0);
+            // order: next step's fragments first, then the MFMAs with the staging accesses spread between them
+            if constexpr (st + 1 < STEPS) __builtin_amdgcn_sched_group_barrier(0x100, SH::NFRAG, 0);
+            constexpr int np = nl > 0 ? nl : ns;
+            if constexpr (np > 0) {
+                constexpr int per = NMFMA / (np + 1);
+                wg_static_for<0, np>([&](auto k_) {
+                    __builtin_amdgcn_sched_group_barrier(0x8, per, 0);
+                    __builtin_amdgcn_sched_group_barrier(nl > 0 ? 0x20 : 0x200, 1, 0);
+                });
+                __builtin_amdgcn_sched_group_barrier(0x8, NMFMA - per * np, 0);
+            } else {
+                __builtin_amdgcn_sched_group_barrier(0x8, NMFMA, 0);
+            }
+        });
+#undef SPK_WW_FRAG
+    };
+
+    for (; tile < p.n_tiles; tile += gridDim.z) {
+        const int next = tile + (int)gridDim.z;
+        if (next < p.n_tiles) {               // uniform
+            aim(next);
+            run_tile(std::true_type{});
+        } else {
+            run_tile(std::false_type{});
+        }
+        __syncthreads();                      // every wave is done with `cur`, and the other buffer is complete
+        cur ^= 1;
+    }
+
+    // ---- partial block -> slab [slab][co][tap][ci] (ci contiguous: 128-B stores per half wave) ----
+    float* out = p.slabs + (size_t)blockIdx.z * p.Cy * TAPS * p.Cin;
+#pragma unroll
+    for (int m = 0; m < MCO; ++m)
+#pragma unroll
+        for (int n = 0; n < MCI; ++n) {
+            const int ci = ci0 + (wci * MCI + n) * 32 + l32;
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + (wco * MCO + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                    if (co < co_end && ci < p.Cin) out[((size_t)co * TAPS + t) * p.Cin + ci] = acc[m][n][t][r];
+                }
+        }
+}
+
 // dW[co][ci][tap] (+)= scale * sum_slab slabs[slab][co][tap][ci]   (fixed order)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw,
                                                           int n_slabs, int Cout_all, int Cin, int taps, float scale,
@@ -493,10 +728,83 @@ WGeom wgeom(int B, int Cin, int Cout, int H, int W, int want_splits) {
     return g;
 }
 
+// geometry of the wide form: 16 x 4 pixel tiles, one workgroup per CU
+struct WideGeom { int tiles_x, tiles_y, n_tiles, splits, n_slabs; };
+inline WideGeom wide_geom(int co_t, int ci_t, int B, int Cin, int Cout_all, int H, int W, int want_splits) {
+    WideGeom g;
+    g.tiles_x = spk::ceil_div(W, 16);
+    g.tiles_y = spk::ceil_div(H, 4);
+    g.n_tiles = g.tiles_x * g.tiles_y * B;
+    const int blocks = spk::ceil_div(Cout_all, co_t) * spk::ceil_div(Cin, ci_t);
+    static const int target = [] { const char* e = getenv("SPK_WGRAD_WIDE_TARGET"); return e ? atoi(e) : 256; }();
+    const int sp = want_splits > 0 ? want_splits : std::max(1, target / blocks);
+    g.splits = std::max(1, std::min(sp, g.n_tiles));
+    g.n_slabs = g.splits;
+    return g;
+}
+// which block shape the wide form uses for a problem: 0 = 128co x 64ci, 1 = 64co x 128ci, 2 = 64co x 64ci,
+// -1 = not applicable (Cout per group must fill whole co blocks when grouped)
+inline int wide_variant(int groups, int Cout, int Cin) {
+    const int G = groups > 1 ? groups : 1;
+    // (the two-tile-set shapes hold 288 accumulator registers per lane; hipcc keeps MFMA accumulators in the 256 AGPRs only
+    // and spills the rest, so they are not instantiated: 0 and 1 are never returned)
+    if (Cout % 64 == 0 || G == 1) return 2;
+    return -1;
+}
+inline bool wide_takes(const spk_wgrad_desc* d) {
+    static const bool allow = [] { const char* e = getenv("SPK_WGRAD_WIDE"); return !e || atoi(e) != 0; }();
+    const int G = d->groups > 1 ? d->groups : 1;
+    const auto aligned = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    return allow && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->W >= 16 && d->W % 4 == 0 && d->H >= 4 && aligned(d->g) && aligned(d->x) &&
+           (long long)G * d->Cout * d->H * d->W < (1ll << 31) && ((long long)d->group_in_stride * (G - 1) + d->Cin) * d->H * d->W < (1ll << 31) &&
+           wide_variant(d->groups, d->Cout, d->Cin) >= 0;
+}
+
+template <int MCO, int MCI, int MODE>
+int run_wgrad_wide(const spk_wgrad_desc* d, hipStream_t stream) {
+    using SH = WideShape<MCO, MCI>;
+    const int G = d->groups > 1 ? d->groups : 1;
+    const WideGeom g = wide_geom(SH::CO_T, SH::CI_T, d->B, d->Cin, G * d->Cout, d->H, d->W, d->splits);
+    const size_t slab_floats = (size_t)G * d->Cout * d->Cin * 9;
+    SPK_REQUIRE(d->workspace && (size_t)d->workspace_bytes >= g.n_slabs * slab_floats * sizeof(float),
+                "wgrad: needs a %zu-byte workspace (see spk_conv2d_wgrad_workspace_bytes)", g.n_slabs * slab_floats * sizeof(float));
+    WgradArgs a;
+    a.g = d->g; a.x = d->x; a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.slabs = static_cast<float*>(d->workspace);
+    a.B = d->B; a.Cin = d->Cin; a.Cout = d->Cout; a.H = d->H; a.W = d->W; a.Hs = d->Hin; a.Ws = d->Win;
+    a.gin = G > 1 ? d->group_in_stride : d->Cin;
+    a.Cx = a.gin * (G - 1) + d->Cin;
+    a.Cy = G * d->Cout;
+    a.lgTW = 4; a.lgTH = 2; a.lgTB = 0;
+    a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y; a.n_tiles = g.n_tiles;
+    auto kern = &wgrad3x3_wide_kernel<MCO, MCI, MODE>;
+    static bool raised = false;
+    if (!raised) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return spk::fail(SPK_ELAUNCH, "hipFuncSetAttribute(LDS): %s", hipGetErrorString(e));
+        raised = true;
+    }
+    dim3 grid((unsigned)spk::ceil_div(G * d->Cout, SH::CO_T), (unsigned)spk::ceil_div(d->Cin, SH::CI_T), (unsigned)g.splits);
+    hipLaunchKernelGGL(kern, grid, dim3(256), 2 * SH::BUF * sizeof(float), stream, a);
+    int rc = spk::check_launch("wgrad3x3_wide_kernel");
+    if (rc != SPK_OK) return rc;
+    const unsigned blocks = (unsigned)std::min<size_t>((slab_floats + 255) / 256, 2048);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, a.slabs, d->dw, g.n_slabs, G * d->Cout, d->Cin, 9,
+                       d->scale, d->accumulate ? 1 : 0, d->fold > 1 ? d->fold : 1);
+    return spk::check_launch("wgrad_reduce_kernel");
+}
+
+template <int MODE>
+int run_wgrad_wide_any(const spk_wgrad_desc* d, hipStream_t stream) {
+    return run_wgrad_wide<1, 1, MODE>(d, stream);
+}
+
 template <int KH, int KW, int S, int MODE>
 int run_wgrad(const spk_wgrad_desc* d, hipStream_t stream) {
     using SH = WShape<KH, KW, S>;
     const int G = d->groups > 1 ? d->groups : 1;
+    if constexpr (KH == 3 && S == 1 && (MODE == WG_PLAIN || MODE == WG_AFFINE_RELU)) {
+        if (wide_takes(d)) return run_wgrad_wide_any<MODE>(d, stream);
+    }
     SPK_REQUIRE(!SH::PACK || KW * d->Cin <= 32, "wgrad: the %dx%d kernel packs (kx, ci) into 32 lanes: Cin <= %d", KH, KW, 32 / KW);
     SPK_REQUIRE(G == 1 || d->Cout % SH::CO_T == 0, "wgrad: grouped launches need Cout (per group) to be a multiple of %d", SH::CO_T);
     const WGeom g = wgeom<KH, KW, S>(d->B, d->Cin, G * d->Cout, d->H, d->W, d->splits);
@@ -780,7 +1088,13 @@ int64_t spk_conv2d_wgrad_workspace_bytes(int kh, int kw, int stride, int splits,
     }
     else if (kh == 3) g = stride == 1 ? wgeom<3, 3, 1>(B, Cin, Cout, H, W, splits) : wgeom<3, 3, 2>(B, Cin, Cout, H, W, splits);
     else g = wgeom<7, 7, 2>(B, Cin, Cout, H, W, splits);
-    return (int64_t)g.n_slabs * Cout * Cin * kh * kw * (int64_t)sizeof(float);
+    int n_slabs = g.n_slabs;
+    if (kh == 3 && stride == 1) {     // the 8-wave form may take the problem (the group count is not known here: the largest of its shapes)
+        n_slabs = std::max(n_slabs, wide_geom(128, 64, B, Cin, Cout, H, W, splits).n_slabs);
+        n_slabs = std::max(n_slabs, wide_geom(64, 128, B, Cin, Cout, H, W, splits).n_slabs);
+        n_slabs = std::max(n_slabs, wide_geom(64, 64, B, Cin, Cout, H, W, splits).n_slabs);
+    }
+    return (int64_t)n_slabs * Cout * Cin * kh * kw * (int64_t)sizeof(float);
 }
 
 int spk_conv2d_wgrad(const spk_wgrad_desc* d, void* stream) {
