@@ -364,6 +364,31 @@ int spk_pixelnorm_bwd(const float* x, const float* dy, float* dx, int B, int C, 
 int spk_blur2d_bwd(const float* dy, float* dx, const float* filter_host, int k, int64_t planes, int H, int W, int stride, void* stream);
 int spk_upscale2d_nearest_bwd(const float* dy, float* dx, int64_t planes, int H, int W, int factor, float gain, void* stream);
 
+/* ---- spectral normalisation of many layers at once (StyleDiscriminator) ------------------------------------------------
+ * One power iteration + division for up to SPK_SN_MAX_GROUPS weight matrices W[R, C] (R = Cout, C = Cin*kh*kw, row major):
+ *   power_iteration != 0:  v <- normalize(W^T u), u <- normalize(W v)   (in place, eps inside max(|.|, eps))
+ *   sigma = u^T W v  (written to *sigma, a device float);  w_hat = W / sigma.
+ * Five launches for all layers together, every sum in a fixed order (no atomics).
+ * replaces: torch.nn.utils.spectral_norm's pre-forward hook (SpectralNorm.compute_weight) on the 16 layers wrapped at
+ *   styleganv1.py:644-657,662-672 -- about a dozen ATen launches per layer and forward, six forwards per iteration.
+ * spk_spectral_norm_bwd_grouped: with the group's `w_hat` slot holding the gradient G w.r.t. w_hat,
+ *   dw = (G - <G, W> / sigma * u v^T) / sigma   -- autograd of W / sigma with u, v held constant, as in the hook.
+ * `workspace`: device scratch of spk_spectral_norm_workspace_bytes(groups, n) bytes (same for both calls). */
+#define SPK_SN_MAX_GROUPS 24
+typedef struct spk_sn_group {
+    const float* w;       /* [R, C] weight_orig */
+    float* u;             /* [R] weight_u (updated in place when power_iteration) */
+    float* v;             /* [C] weight_v */
+    float* w_hat;         /* [R, C] out: W / sigma        (backward: in: the gradient G w.r.t. w_hat) */
+    float* sigma;         /* [1]    out: the spectral norm estimate (backward: in) */
+    float* dw;            /* backward only: [R, C] out */
+    int32_t R, C;
+} spk_sn_group;
+int64_t spk_spectral_norm_workspace_bytes(const spk_sn_group* groups, int n_groups);
+int spk_spectral_norm_grouped(const spk_sn_group* groups, int n_groups, int power_iteration, float eps, void* workspace,
+                              int64_t workspace_bytes, void* stream);
+int spk_spectral_norm_bwd_grouped(const spk_sn_group* groups, int n_groups, void* workspace, int64_t workspace_bytes, void* stream);
+
 /* ---- launch lists: a whole module forward per C call ---------------------------------------------------------------
  * The reference's callers run a decoder pass as one Python call (model.py:113-114 `self.Gd(gen_input)`,
  * styleganv1.py:593-610 SynthesisNetwork.forward); behind it sit ~25 kernel launches whose descriptors depend only on

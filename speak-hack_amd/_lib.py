@@ -98,6 +98,15 @@ class PixelNormArgs(C.Structure):
                 ("sqrt_form", C.c_int32)]
 
 
+SN_MAX_GROUPS = 24
+
+
+class SnGroup(C.Structure):
+    """``spk_sn_group`` (include/spk.h)."""
+    _fields_ = [("w", C.c_void_p), ("u", C.c_void_p), ("v", C.c_void_p), ("w_hat", C.c_void_p), ("sigma", C.c_void_p),
+                ("dw", C.c_void_p), ("R", C.c_int32), ("C", C.c_int32)]
+
+
 class WgradDesc(C.Structure):
     """Mirror of spk_wgrad_desc (include/spk.h)."""
     _fields_ = [("g", C.c_void_p), ("x", C.c_void_p), ("in_scale", C.c_void_p), ("in_shift", C.c_void_p),
@@ -145,6 +154,9 @@ _PROTOTYPES = {
     "spk_conv1x1_small_bwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_float, C.c_void_p]),
     "spk_fc_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p,
                              C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p]),
+    "spk_spectral_norm_workspace_bytes": (C.c_int64, [C.c_void_p, C.c_int]),
+    "spk_spectral_norm_grouped": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_float, C.c_void_p, C.c_int64, C.c_void_p]),
+    "spk_spectral_norm_bwd_grouped": (C.c_int, [C.c_void_p, C.c_int, C.c_void_p, C.c_int64, C.c_void_p]),
     "spk_launch_list": (C.c_int, [C.c_void_p, C.c_int, C.c_uint32, C.c_void_p]),
     "spk_version": (C.c_char_p, []),
     "spk_last_error": (C.c_char_p, []),

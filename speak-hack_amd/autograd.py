@@ -415,6 +415,41 @@ class Upsample2xFn(torch.autograd.Function):
         return ops.upsample2x_bilinear_bwd(dy.contiguous())
 
 
+class SpectralNormAllFn(torch.autograd.Function):
+    """W_hat_l = W_l / sigma_l for every spectral-norm wrapped layer of a module in one grouped call (the pre-forward hook of
+    torch.nn.utils.spectral_norm, styleganv1.py:644-672): in training mode one power iteration updates the layers' u / v
+    buffers in place first.  Backward = autograd of W / sigma with u, v constant (as the hook has it, under ``no_grad``):
+    dW = (G - <G, W_hat> u v^T) / sigma, with the u, v, sigma of THIS call (a discriminator runs several forwards before one
+    backward, train.py:160-182; torch clones the vectors for the same reason)."""
+
+    @staticmethod
+    def forward(ctx, bufs, power_iteration, eps, *weights):
+        us, vs = [b[0] for b in bufs], [b[1] for b in bufs]
+        hats, sigma = ops.spectral_norm_grouped([w.detach() for w in weights], us, vs, power_iteration, eps)
+        if any(ctx.needs_input_grad[3:]):
+            ru, cv = [u.numel() for u in us], [v.numel() for v in vs]
+            ctx.save_for_backward(torch.cat([u.reshape(-1) for u in us]), torch.cat([v.reshape(-1) for v in vs]), sigma, *weights)
+            ctx.sizes = (ru, cv)
+        return tuple(hats)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *grads):
+        u_flat, v_flat, sigma, *weights = ctx.saved_tensors
+        ru, cv = ctx.sizes
+        us, vs = list(u_flat.split(ru)), list(v_flat.split(cv))
+        gs = [None if (g is None or not ctx.needs_input_grad[3 + i]) else g.contiguous() for i, g in enumerate(grads)]
+        dws = ops.spectral_norm_grouped_bwd(gs, weights, us, vs, sigma)
+        return (None, None, None) + tuple(dws)
+
+
+def spectral_norm_all(modules, training, eps=1e-12):
+    """Normalised weights of torch ``spectral_norm``-wrapped ``modules`` (attributes ``weight_orig`` / ``weight_u`` /
+    ``weight_v``), in order."""
+    bufs = [(m.weight_u, m.weight_v) for m in modules]
+    return SpectralNormAllFn.apply(bufs, bool(training), eps, *[m.weight_orig for m in modules])
+
+
 class PixelNormFn(torch.autograd.Function):
     """x * rsqrt(mean_c x^2 + eps) -- styleganv1.py:132-136 / stylegan.py:28-29."""
 

@@ -391,6 +391,52 @@ def fc_bwd(dout, out, x, weight, wmul=1.0, bmul=1.0, slope=1.0, need_dx=True, ne
     return dx, dw, db
 
 
+# ---- spectral normalisation, all layers of a module in one call ---------------------------------------------
+def _sn_groups(items):
+    arr = (L.SnGroup * len(items))()
+    for q, (w, u, v, w_hat, sigma, dw) in zip(arr, items):
+        R = w.shape[0]
+        q.w, q.u, q.v = L.dptr(w, "weight_orig"), L.dptr(u, "weight_u"), L.dptr(v, "weight_v")
+        q.w_hat, q.sigma, q.dw = L.dptr(w_hat, "w_hat"), sigma.data_ptr(), L.dptr(dw, "dw")
+        q.R, q.C = R, w.numel() // R
+        if u.numel() != q.R or v.numel() != q.C:
+            raise L.SpkError(f"spectral_norm: u / v sizes {u.numel()} / {v.numel()} do not match the [{q.R},{q.C}] matrix")
+    return arr
+
+
+def spectral_norm_grouped(weights, us, vs, power_iteration, eps=1e-12):
+    """-> (list of W / sigma, sigma [n]); ``us`` / ``vs`` are updated in place when ``power_iteration``."""
+    n = len(weights)
+    if n > L.SN_MAX_GROUPS:
+        raise L.SpkError(f"spectral_norm_grouped: at most {L.SN_MAX_GROUPS} layers per call")
+    dev = weights[0].device
+    sigma = torch.empty(n, device=dev, dtype=torch.float32)
+    hats = [torch.empty_like(w, memory_format=torch.contiguous_format) for w in weights]
+    arr = _sn_groups([(w, u, v, h, sigma[i:i + 1], None) for i, (w, u, v, h) in enumerate(zip(weights, us, vs, hats))])
+    nbytes = L.lib().spk_spectral_norm_workspace_bytes(C.cast(arr, C.c_void_p), n)
+    ws = _workspace(dev, nbytes)
+    L.check(L.lib().spk_spectral_norm_grouped(C.cast(arr, C.c_void_p), n, 1 if power_iteration else 0, float(eps), ws.data_ptr(),
+                                              ws.numel() * 4, L.stream_ptr()), "spk_spectral_norm_grouped")
+    return hats, sigma
+
+
+def spectral_norm_grouped_bwd(grads, weights, us, vs, sigma):
+    """dW = (G - <G, W>/sigma u v^T) / sigma for every layer with a gradient (``grads[i]`` None -> None)."""
+    idx = [i for i, g in enumerate(grads) if g is not None]
+    out = [None] * len(grads)
+    if not idx:
+        return out
+    dws = {i: torch.empty_like(weights[i], memory_format=torch.contiguous_format) for i in idx}
+    arr = _sn_groups([(weights[i], us[i], vs[i], grads[i], sigma[i:i + 1], dws[i]) for i in idx])
+    nbytes = L.lib().spk_spectral_norm_workspace_bytes(C.cast(arr, C.c_void_p), len(idx))
+    ws = _workspace(weights[0].device, nbytes)
+    L.check(L.lib().spk_spectral_norm_bwd_grouped(C.cast(arr, C.c_void_p), len(idx), ws.data_ptr(), ws.numel() * 4, L.stream_ptr()),
+            "spk_spectral_norm_bwd_grouped")
+    for i in idx:
+        out[i] = dws[i]
+    return out
+
+
 # ---- StyleGAN2 pieces (build-defined variant) ---------------------------------------------------------------
 def modconv_demod(weight, s, scale, eps=1e-8):
     """d[b,co] = rsqrt(scale^2 * sum_{ci,k} (w[co,ci,k]*s[b,ci])^2 + eps)."""

@@ -35,16 +35,31 @@ def rel_l2(a, b):
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
 
 
-def grad_close(got, ref32, ref64):
-    """Mask-flip-robust gradient criterion for deep ReLU / LeakyReLU nets.  A pre-activation within rounding of zero
-    flips its mask, and one flipped element among millions moves a gradient by ~1e-3 rel-L2; whether the reference's
-    own fp32 evaluation happens to flip one is luck.  Both parts are against the fp64 evaluation of the reference:
-    rel-L2 <= max(5e-3, 3 * err(reference fp32)) -- a wrong slope, stride or tap order is off by > 1e-1 -- and the 90th
-    percentile of |difference| <= 1e-4 * rms(reference): outside the few flipped receptive fields the agreement is at
-    fp32 rounding level.  Returns (ok, (err, err_ref32, p90/rms))."""
+def grad_close(got, ref32, ref64, pixels=None):
+    """Mask-flip-aware gradient criterion for deep ReLU / LeakyReLU nets; both parts are against the fp64 evaluation of
+    the reference.
+
+    Where the noise comes from: the HIP path and the reference sum in different orders, so a pre-activation within rounding
+    (~1e-6 of its scale) of zero can land on the other side and flip its mask.  With N activations about 1e-6 * N of them
+    are that close: one or two per pass of the nets tested here, and whether the reference's OWN fp32 evaluation flips one
+    is luck (``ref32`` is a single sample of that lottery).  What one flip does: at a layer with P = batch x pixels
+    positions it removes / adds one position's contribution, i.e. it moves a DENSE gradient (a weight, bias or style
+    gradient sums over all P positions -- and every second-order gradient couples all of them) by about 1/P of its size,
+    everywhere at once; only activation-shaped gradients see a localised change.
+
+      (1) rel-L2 <= max(5e-3, 3 * err(ref32)): a wrong slope, stride, tap order or a missing term is off by > 1e-1;
+      (2) the 90th percentile of |difference| <= rms(reference) * max(1e-4, 4 * p90(ref32 error) / rms, 8 / P): outside
+          the flipped receptive fields the agreement is at fp32 rounding level, and a dense gradient may carry the 1/P
+          footprint of a few flips (``pixels`` = P of the largest layer, i.e. batch x input pixels; None = unknown: no
+          flip allowance, the round-1 form).  The fixed 1e-4 of round 1 sat AT that footprint for the 32^2..64^2 test nets
+          (1 / (2 * 64 * 64) = 1.2e-4) and tripped on any change of summation order.
+
+    Returns (ok, (err, err_ref32, p90/rms))."""
     import torch
     got, ref32, ref64 = (t.detach().cpu().double() for t in (got, ref32, ref64))
     e_got, e_ref = rel_l2(got, ref64), rel_l2(ref32, ref64)
     rms = float(ref64.pow(2).mean().sqrt())
     p90 = float(torch.quantile((got - ref64).abs().flatten()[:4_000_000], 0.9))
-    return e_got <= max(5e-3, 3 * e_ref) and p90 <= 1e-4 * rms, (e_got, e_ref, p90 / max(rms, 1e-300))
+    p90_ref = float(torch.quantile((ref32 - ref64).abs().flatten()[:4_000_000], 0.9))
+    bound = max(1e-4 * rms, 4 * p90_ref, (8.0 / pixels) * rms if pixels else 0.0)
+    return e_got <= max(5e-3, 3 * e_ref) and p90 <= bound, (e_got, e_ref, p90 / max(rms, 1e-300))

@@ -65,10 +65,10 @@ def grads(mod):
     return {n: p.grad.detach().cpu().double() for n, p in mod.named_parameters() if p.grad is not None}
 
 
-def check(got, ref32, ref64, what):
+def check(got, ref32, ref64, what, pixels=None):
     assert set(got) == set(ref64), what
     for k in ref64:
-        ok, info = grad_close(got[k], ref32[k], ref64[k])
+        ok, info = grad_close(got[k], ref32[k], ref64[k], pixels=pixels)
         assert ok, (what, k, info)
 
 
@@ -89,7 +89,7 @@ def test_discriminator_first_order(disc, res, B, train):
         outs[name] = (pred.detach().cpu().double(), g)
     assert rel_l2(outs["hip"][0], outs["ref64"][0]) < 1e-4
     assert any(k.endswith("weight_orig") for k in outs["hip"][1])        # gradients reach the spectral-norm parameters
-    check(outs["hip"][1], outs["ref32"][1], outs["ref64"][1], "first order")
+    check(outs["hip"][1], outs["ref32"][1], outs["ref64"][1], "first order", pixels=B * res * res)
 
 
 @pytest.mark.parametrize("res,B", [(32, 2), (64, 2)])
@@ -110,7 +110,7 @@ def test_discriminator_r1_double_backward(disc, res, B):
     assert "fromrgb.weight_orig" in got and "blocks.0.conv2.weight_orig" in got and "dense0.weight_orig" in got
     # biases enter the penalty only through the masks: their exact gradient is zero, as is dense1.bias's
     nz = {k for k, v in outs["ref64"][1].items() if float(v.abs().max()) > 0}
-    check({k: got[k] for k in nz}, {k: outs["ref32"][1][k] for k in nz}, {k: outs["ref64"][1][k] for k in nz}, "R1")
+    check({k: got[k] for k in nz}, {k: outs["ref32"][1][k] for k in nz}, {k: outs["ref64"][1][k] for k in nz}, "R1", pixels=B * res * res)
     for k in set(got) - nz:
         assert float(got[k].abs().max()) == 0.0, k
 
@@ -148,3 +148,45 @@ def test_generator_step_gradient_flows_through_discriminator(disc):
         res[name] = xin.grad.detach().cpu().double()
     ok, info = grad_close(res["hip"], res["ref32"], res["ref64"])
     assert ok, info
+
+
+def test_grouped_spectral_norm_vs_torch_hook():
+    """All wrapped layers' power iteration + W / sigma in one grouped call (autograd.SpectralNormAllFn) against
+    torch.nn.utils.spectral_norm's own pre-forward hook on CPU copies: W_hat, the in-place u / v update (training), the
+    eval-mode form (stored u, v), and the gradient w.r.t. weight_orig -- including two forwards before one backward, where each
+    call's gradient must use ITS u, v, sigma."""
+    from torch import nn
+    from torch.nn.utils import spectral_norm
+    dev = torch.device("cuda:0")
+    A = importlib.import_module("speak-hack_amd.autograd")
+    torch.manual_seed(11)
+    mods = [spectral_norm(nn.Conv2d(3, 64, 1)), spectral_norm(nn.Conv2d(64, 64, 3, padding=1)),
+            spectral_norm(nn.Conv2d(64, 130, 3, padding=1, stride=2)), spectral_norm(nn.Linear(70, 33)), spectral_norm(nn.Linear(33, 1))]
+    ref = copy.deepcopy(mods)
+    for m in mods:
+        m.to(dev)
+
+    def torch_hook(m, training):
+        m.train(training)
+        for hook in m._forward_pre_hooks.values():
+            hook(m, None)
+        return m.weight
+
+    for training in (True, True, False):
+        hats = A.spectral_norm_all(mods, training)
+        for m, r, h in zip(mods, ref, hats):
+            want = torch_hook(r, training)
+            assert rel_l2(h, want) < 2e-6
+            assert rel_l2(m.weight_u, r.weight_u) < 2e-6 and rel_l2(m.weight_v, r.weight_v) < 2e-6
+    # two training-mode forwards, then one backward through both
+    gs = [[torch.randn_like(r.weight_orig) for r in ref] for _ in range(2)]
+    loss = loss_ref = 0.0
+    for k in range(2):
+        hats = A.spectral_norm_all(mods, True)
+        for m, r, h, g in zip(mods, ref, hats, gs[k]):
+            loss = loss + (h * g.to(dev)).sum()
+            loss_ref = loss_ref + (torch_hook(r, True) * g).sum()
+    loss.backward()
+    loss_ref.backward()
+    for m, r in zip(mods, ref):
+        assert rel_l2(m.weight_orig.grad, r.weight_orig.grad) < 5e-6
