@@ -260,7 +260,12 @@ static int pick_config(int kh, int stride, int B, int Cin, int Cout, int H, int 
     // 1x1 on the tap kernel: the 64x64 tile beats the 128x128 one up to 16^2 x 8 pixels, and for Cout = 128 up to 32^2 x 8
     // (sweep of configs 8-12 over the trunk's shapes, 6 groups: e.g. 256->1024 @16^2 data gradient 76 us against 85)
     const bool small1x1 = kh == 1 && (pixels <= 2048 || (Cout <= 128 && pixels <= 8192));
-    const int shape = Cout <= 32 ? 3 : (wide ? 1 : (Cout <= 64 || small1x1 ? 2 : (pixels >= 2048 ? 0 : 2)));
+    // 3x3 stride-1 with a short contraction and few pixels (the trunk's 128 -> 128 @32^2 and 256 -> 256 @16^2 layers, per group):
+    // the 64x64 tile fills the chip where the 128x128 one leaves CUs idle (config sweep of round 1, -0.5 ms per G step; it
+    // changes the summation order of the discriminator's small layers, which the round-1 gradient criterion could not absorb)
+    static const bool small3_on = [] { const char* e = getenv("SPK_CONV_SMALL3X3"); return !e || atoi(e) != 0; }();
+    const bool small3x3 = small3_on && kh == 3 && stride == 1 && Cin <= 256 && Cout > 64 && pixels <= 8192;
+    const int shape = Cout <= 32 ? 3 : (wide ? 1 : (Cout <= 64 || small1x1 || small3x3 ? 2 : (pixels >= 2048 ? 0 : 2)));
     const int base = kh == 1 ? 8 : (kh == 2 ? 0 : 4);   // 1x1 -> ids 8-11, 2x2 -> 0-3; everything else prefers ids 4-7
     const int lo = kh == 1 ? 8 : ((kh == 3 && stride == 1) || kh == 2 ? 0 : 4), hi = kh == 1 ? 11 : (kh == 2 ? 3 : 7);
     // The GEMM form of a stride-1 1x1 (conv1x1_gemm.hip, config 12), where it measured faster than the tap kernel on the

@@ -871,37 +871,43 @@ int run_wgrad(const spk_wgrad_desc* d, hipStream_t stream) {
 // 64 MFMAs per wave against 8 float4 loads per thread, LDS double-buffered (one barrier per k-tile), fragments read one
 // k-step ahead.  Pixels are the contraction: rows of G and X are contiguous in memory (16-byte loads, stride 1), and
 // LDS rows have pitch 33 so that the 32 lanes of a fragment (32 channels, one pixel) hit 32 banks.
-constexpr int G1_T = 128, G1_KT = 32, G1_PITCH = G1_KT + 1;
+constexpr int G1_KT = 32, G1_PITCH = G1_KT + 1;
 
-template <int S, int MODE>
+// MT x NT = MFMA tiles per wave along co / ci (1 or 2): the block is (64 MT) co x (64 NT) ci.  2 x 2 is the general form;
+// the narrow forms serve the trunk's layer1 shapes (64 -> 256, 256 -> 64, 64 -> 64 at 64^2), where a 128-wide block would
+// multiply half a block of zeros.
+template <int S, int MODE, int MT, int NT>
 __global__ __launch_bounds__(256) void wgrad1x1_kernel(const WgradArgs p, int tiles_per_split) {
     constexpr bool AFF = MODE == WG_AFFINE_RELU;
+    constexpr int BM = 64 * MT, BN = 64 * NT;             // block rows of G / of X
+    constexpr int RG = BM / 32, RX = BN / 32;             // staging rounds: row = tid/8 + 32 i
     extern __shared__ __attribute__((aligned(16))) float smem[];
-    float* const gs = smem;                               // [2][128][33]
-    float* const xs = smem + 2 * G1_T * G1_PITCH;         // [2][128][33]
+    float* const gs = smem;                               // [2][BM][33]
+    float* const xs = smem + 2 * BM * G1_PITCH;           // [2][BN][33]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l32 = lane & 31;
     const int wm = wave & 1, wn = wave >> 1;
 
-    const int co0 = blockIdx.x * G1_T;                    // in the gradient tensor (all groups)
+    const int co0 = blockIdx.x * BM;                      // in the gradient tensor (all groups)
     const int grp = co0 / p.Cout;
     const int co_end = (grp + 1) * p.Cout;
-    const int ci0 = blockIdx.y * G1_T;                    // within the group
+    const int ci0 = blockIdx.y * BN;                      // within the group
     const int cx0 = grp * p.gin + ci0;                    // first x channel of this block
     const size_t HW = (size_t)p.H * p.W, src_plane = (size_t)p.Hs * p.Ws;
     const int tpi = (int)(HW / G1_KT);                    // k-tiles per image (HW % 32 == 0: checked on the host)
     const int t_begin = blockIdx.z * tiles_per_split, t_end = min(p.n_tiles, t_begin + tiles_per_split);
 
-    // staging roles: row = tid/8 + 32*i (i < 4), pixels 4*(tid%8) .. +3 of the k-tile
+    // staging roles: row = tid/8 + 32*i, pixels 4*(tid%8) .. +3 of the k-tile
     const int srow = tid >> 3, scol = (tid & 7) * 4;
-    float4 gq[4], xq[4];
-    float a_sc[4], a_sh[4];
-    bool g_ok[4], x_ok[4];
+    float4 gq[RG], xq[RX];
+    float a_sc[RX], a_sh[RX];
+    bool g_ok[RG], x_ok[RX];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < RG; ++i) g_ok[i] = co0 + srow + 32 * i < co_end;
+#pragma unroll
+    for (int i = 0; i < RX; ++i) {
         const int r = srow + 32 * i;
-        g_ok[i] = co0 + r < co_end;
         x_ok[i] = ci0 + r < p.Cin;
         a_sc[i] = 1.f; a_sh[i] = 0.f;
         if (AFF && x_ok[i]) { a_sc[i] = p.in_scale[cx0 + r]; a_sh[i] = p.in_shift[cx0 + r]; }
@@ -911,10 +917,13 @@ __global__ __launch_bounds__(256) void wgrad1x1_kernel(const WgradArgs p, int ti
     {                                                                                                        \
         const int b_ = (t_) / tpi;                                                                           \
         const size_t q0_ = (size_t)((t_) - b_ * tpi) * G1_KT + scol;          /* output pixel in the image */  \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                      \
+        _Pragma("unroll") for (int i = 0; i < RG; ++i) {                                                     \
             const int r = srow + 32 * i;                                                                     \
             const size_t go = ((size_t)b_ * p.Cy + (g_ok[i] ? co0 + r : co0)) * HW + q0_;                     \
             gq[i] = *reinterpret_cast<const float4*>(p.g + go);                                              \
+        }                                                                                                    \
+        _Pragma("unroll") for (int i = 0; i < RX; ++i) {                                                     \
+            const int r = srow + 32 * i;                                                                     \
             const float* xr = p.x + ((size_t)b_ * p.Cx + (x_ok[i] ? cx0 + r : cx0)) * src_plane;             \
             if (S == 1) {                                                                                    \
                 xq[i] = *reinterpret_cast<const float4*>(xr + q0_);                                          \
@@ -927,12 +936,15 @@ __global__ __launch_bounds__(256) void wgrad1x1_kernel(const WgradArgs p, int ti
     }
 #define SPK_G1_STORE(buf_)                                                                                   \
     {                                                                                                        \
-        float* gd = gs + (buf_) * G1_T * G1_PITCH;                                                           \
-        float* xd = xs + (buf_) * G1_T * G1_PITCH;                                                           \
-        _Pragma("unroll") for (int i = 0; i < 4; ++i) {                                                      \
+        float* gd = gs + (buf_) * BM * G1_PITCH;                                                             \
+        float* xd = xs + (buf_) * BN * G1_PITCH;                                                             \
+        _Pragma("unroll") for (int i = 0; i < RG; ++i) {                                                     \
             const int o = (srow + 32 * i) * G1_PITCH + scol;                                                 \
             const float4 gv = g_ok[i] ? gq[i] : make_float4(0.f, 0.f, 0.f, 0.f);                             \
             gd[o] = gv.x; gd[o + 1] = gv.y; gd[o + 2] = gv.z; gd[o + 3] = gv.w;                              \
+        }                                                                                                    \
+        _Pragma("unroll") for (int i = 0; i < RX; ++i) {                                                     \
+            const int o = (srow + 32 * i) * G1_PITCH + scol;                                                 \
             float4 xv = xq[i];                                                                               \
             if (AFF) {                                                                                       \
                 xv.x = fmaxf(xv.x * a_sc[i] + a_sh[i], 0.f); xv.y = fmaxf(xv.y * a_sc[i] + a_sh[i], 0.f);    \
@@ -943,11 +955,11 @@ __global__ __launch_bounds__(256) void wgrad1x1_kernel(const WgradArgs p, int ti
         }                                                                                                    \
     }
 
-    f32x16 acc[2][2];
+    f32x16 acc[MT][NT];
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int n = 0; n < 2; ++n)
+        for (int n = 0; n < NT; ++n)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
@@ -960,27 +972,27 @@ __global__ __launch_bounds__(256) void wgrad1x1_kernel(const WgradArgs p, int ti
         const int buf = (t - t_begin) & 1;
         const bool more = t + 1 < t_end;
         if (more) SPK_G1_LOAD(t + 1);
-        const float* ga = gs + buf * G1_T * G1_PITCH + (wm * 64 + l32) * G1_PITCH + half;
-        const float* xb = xs + buf * G1_T * G1_PITCH + (wn * 64 + l32) * G1_PITCH + half;
-        float fa[2][2], fb[2][2];
+        const float* ga = gs + buf * BM * G1_PITCH + (wm * 32 * MT + l32) * G1_PITCH + half;
+        const float* xb = xs + buf * BN * G1_PITCH + (wn * 32 * NT + l32) * G1_PITCH + half;
+        float fa[2][MT], fb[2][NT];
 #define SPK_G1_FRAG(ks_, slot_)                                                                              \
     {                                                                                                        \
-        fa[slot_][0] = ga[2 * (ks_)]; fa[slot_][1] = ga[32 * G1_PITCH + 2 * (ks_)];                          \
-        fb[slot_][0] = xb[2 * (ks_)]; fb[slot_][1] = xb[32 * G1_PITCH + 2 * (ks_)];                          \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m) fa[slot_][m] = ga[m * 32 * G1_PITCH + 2 * (ks_)];     \
+        _Pragma("unroll") for (int n = 0; n < NT; ++n) fb[slot_][n] = xb[n * 32 * G1_PITCH + 2 * (ks_)];     \
     }
         SPK_G1_FRAG(0, 0);
         wg_static_for<0, G1_KT / 2>([&](auto s_) {
             constexpr int ks = decltype(s_)::value;
             if constexpr (ks + 1 < G1_KT / 2) {
                 SPK_G1_FRAG(ks + 1, (ks + 1) & 1);
-                __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);
+                __builtin_amdgcn_sched_group_barrier(0x100, MT + NT, 0);
             }
 #pragma unroll
-            for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < MT; ++m)
 #pragma unroll
-                for (int n = 0; n < 2; ++n)
+                for (int n = 0; n < NT; ++n)
                     acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[ks & 1][m], fb[ks & 1][n], acc[m][n], 0, 0, 0);
-            __builtin_amdgcn_sched_group_barrier(0x8, 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x8, MT * NT, 0);
         });
 #undef SPK_G1_FRAG
         if (more) SPK_G1_STORE(buf ^ 1);
@@ -992,26 +1004,34 @@ __global__ __launch_bounds__(256) void wgrad1x1_kernel(const WgradArgs p, int ti
     // partial block -> slab [slab][co][ci] (ci contiguous)
     float* out = p.slabs + (size_t)blockIdx.z * p.Cy * p.Cin;
 #pragma unroll
-    for (int m = 0; m < 2; ++m)
+    for (int m = 0; m < MT; ++m)
 #pragma unroll
-        for (int n = 0; n < 2; ++n) {
-            const int ci = ci0 + wn * 64 + n * 32 + l32;
+        for (int n = 0; n < NT; ++n) {
+            const int ci = ci0 + (wn * NT + n) * 32 + l32;
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
-                const int co = co0 + wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                const int co = co0 + (wm * MT + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (co < co_end && ci < p.Cin) out[(size_t)co * p.Cin + ci] = acc[m][n][r];
             }
         }
 }
 
+// block shape of the GEMM form for a problem: tiles per wave along co / ci
+inline void g1_shape(int groups, int Cout, int Cin, int* mt, int* nt) {
+    const int G = groups > 1 ? groups : 1;
+    *mt = (Cout % 128 == 0 || (G == 1 && Cout > 64)) ? 2 : 1;
+    *nt = Cin > 64 ? 2 : 1;
+}
+
 // geometry of the GEMM form: pixel k-tiles and how many slabs (pixel splits) fill the chip
 struct G1Geom { int n_tiles, splits, tiles_per_split; bool ok; };
-inline G1Geom g1geom(int B, int Cin, int Cout_all, int H, int W, int want_splits) {
+inline G1Geom g1geom(int bm, int bn, int B, int Cin, int Cout_all, int H, int W, int want_splits) {
     G1Geom g;
     const long long HW = (long long)H * W;
     g.ok = HW % G1_KT == 0 && W % 4 == 0;
     g.n_tiles = (int)(B * HW / G1_KT);
-    const int blocks = spk::ceil_div(Cout_all, G1_T) * spk::ceil_div(Cin, G1_T);
+    if (!g.ok || g.n_tiles == 0) { g.ok = false; g.splits = 1; g.tiles_per_split = 1; return g; }
+    const int blocks = spk::ceil_div(Cout_all, bm) * spk::ceil_div(Cin, bn);
     int sp = want_splits > 0 ? want_splits : std::max(1, 512 / blocks);
     sp = std::max(1, std::min(sp, std::max(1, g.n_tiles / 4)));       // at least 4 k-tiles per workgroup
     g.tiles_per_split = spk::ceil_div(g.n_tiles, sp);
@@ -1019,11 +1039,11 @@ inline G1Geom g1geom(int B, int Cin, int Cout_all, int H, int W, int want_splits
     return g;
 }
 
-template <int S, int MODE>
-int run_wgrad1x1(const spk_wgrad_desc* d, hipStream_t stream) {
+template <int S, int MODE, int MT, int NT>
+int run_wgrad1x1_shape(const spk_wgrad_desc* d, hipStream_t stream) {
+    constexpr int BM = 64 * MT, BN = 64 * NT;
     const int G = d->groups > 1 ? d->groups : 1;
-    SPK_REQUIRE(G == 1 || d->Cout % G1_T == 0 || d->Cout % 64 == 0, "wgrad: grouped launches need Cout (per group) to be a multiple of 64");
-    const G1Geom g = g1geom(d->B, d->Cin, G * d->Cout, d->H, d->W, d->splits);
+    const G1Geom g = g1geom(BM, BN, d->B, d->Cin, G * d->Cout, d->H, d->W, d->splits);
     const size_t slab_floats = (size_t)G * d->Cout * d->Cin;
     SPK_REQUIRE(d->workspace && (size_t)d->workspace_bytes >= g.splits * slab_floats * sizeof(float),
                 "wgrad: needs a %zu-byte workspace (see spk_conv2d_wgrad_workspace_bytes)", g.splits * slab_floats * sizeof(float));
@@ -1034,17 +1054,17 @@ int run_wgrad1x1(const spk_wgrad_desc* d, hipStream_t stream) {
     a.Cx = a.gin * (G - 1) + d->Cin;
     a.Cy = G * d->Cout;
     a.lgTW = a.lgTH = a.lgTB = 0; a.tiles_x = a.tiles_y = 0; a.n_tiles = g.n_tiles;
-    auto kern = &wgrad1x1_kernel<S, MODE>;
-    const size_t lds = 4 * (size_t)G1_T * G1_PITCH * sizeof(float);
+    auto kern = &wgrad1x1_kernel<S, MODE, MT, NT>;
+    const size_t lds = 2 * (size_t)(BM + BN) * G1_PITCH * sizeof(float);
     static bool raised = false;
     if (!raised) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return spk::fail(SPK_ELAUNCH, "hipFuncSetAttribute(LDS): %s", hipGetErrorString(e));
         raised = true;
     }
-    // a co block must not straddle two groups: blocks are per group when Cout is not a multiple of 128
-    SPK_REQUIRE(G == 1 || d->Cout % G1_T == 0, "wgrad 1x1 GEMM form: grouped launches need Cout %% 128 == 0 (use the tap kernel)");
-    dim3 grid((unsigned)spk::ceil_div(G * d->Cout, G1_T), (unsigned)spk::ceil_div(d->Cin, G1_T), (unsigned)g.splits);
+    // a co block must not straddle two groups
+    SPK_REQUIRE(G == 1 || d->Cout % BM == 0, "wgrad 1x1 GEMM form: grouped launches need Cout %% %d == 0 (use the tap kernel)", BM);
+    dim3 grid((unsigned)spk::ceil_div(G * d->Cout, BM), (unsigned)spk::ceil_div(d->Cin, BN), (unsigned)g.splits);
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a, g.tiles_per_split);
     int rc = spk::check_launch("wgrad1x1_kernel");
     if (rc != SPK_OK) return rc;
@@ -1054,10 +1074,18 @@ int run_wgrad1x1(const spk_wgrad_desc* d, hipStream_t stream) {
     return spk::check_launch("wgrad_reduce_kernel");
 }
 
+template <int S, int MODE>
+int run_wgrad1x1(const spk_wgrad_desc* d, hipStream_t stream) {
+    int mt, nt;
+    g1_shape(d->groups, d->Cout, d->Cin, &mt, &nt);
+    if (mt == 2) return nt == 2 ? run_wgrad1x1_shape<S, MODE, 2, 2>(d, stream) : run_wgrad1x1_shape<S, MODE, 2, 1>(d, stream);
+    return nt == 2 ? run_wgrad1x1_shape<S, MODE, 1, 2>(d, stream) : run_wgrad1x1_shape<S, MODE, 1, 1>(d, stream);
+}
+
 // whether the GEMM form takes this 1x1 problem (else the tap kernel does)
 inline bool g1_takes(int groups, int Cout, int H, int W) {
     const int G = groups > 1 ? groups : 1;
-    return ((long long)H * W) % G1_KT == 0 && W % 4 == 0 && (G == 1 || Cout % G1_T == 0);
+    return ((long long)H * W) % G1_KT == 0 && W % 4 == 0 && (G == 1 || Cout % 64 == 0);
 }
 
 template <int KH, int KW, int S>
@@ -1081,9 +1109,16 @@ int64_t spk_conv2d_wgrad_workspace_bytes(int kh, int kw, int stride, int splits,
         // Cout here is the channel count of the gradient tensor (groups * Cout for a grouped launch); the GEMM form
         // needs no more than the tap kernel whenever it applies, so the larger of the two is always enough
         g = stride == 1 ? wgeom<1, 1, 1>(B, Cin, Cout, H, W, splits) : wgeom<1, 1, 2>(B, Cin, Cout, H, W, splits);
-        const G1Geom g1 = g1geom(B, Cin, Cout, H, W, splits);
+        int g1_splits = 0;       // the group count is not known here: the largest over the GEMM form's block shapes
+        bool g1_ok = false;
+        for (int bm = 64; bm <= 128; bm += 64)
+            for (int bn = 64; bn <= 128; bn += 64) {
+                const G1Geom g1 = g1geom(bm, bn, B, Cin, Cout, H, W, splits);
+                g1_ok = g1.ok;
+                g1_splits = std::max(g1_splits, g1.splits);
+            }
         const int64_t tap = (int64_t)g.n_slabs * Cout * Cin * (int64_t)sizeof(float);
-        const int64_t gemm = g1.ok ? (int64_t)g1.splits * Cout * Cin * (int64_t)sizeof(float) : 0;
+        const int64_t gemm = g1_ok ? (int64_t)g1_splits * Cout * Cin * (int64_t)sizeof(float) : 0;
         return std::max(tap, gemm);
     }
     else if (kh == 3) g = stride == 1 ? wgeom<3, 3, 1>(B, Cin, Cout, H, W, splits) : wgeom<3, 3, 2>(B, Cin, Cout, H, W, splits);

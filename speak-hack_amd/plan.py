@@ -319,8 +319,13 @@ class StyleGAN2Plan(LaunchPlan):
             for q, m in zip(arr, part):
                 wt = m.conv.weight
                 self.track(wt)
-                q.w, q.s, q.d = L.dptr(wt, "weight"), s_of[id(m)].data_ptr(), dvec[id(m)].data_ptr()
-                q.Cin, q.Cout, q.taps, q.scale = wt.shape[1], wt.shape[0], wt.shape[2] * wt.shape[3], float(m.conv.scale)
+                # d[b,co] = rsqrt(scale^2 sum_ci s^2 (sum_k w^2) + eps): the tap sum depends on the weights only, so the plan
+                # keeps n[co,ci] = sqrt(sum_k w[co,ci,k]^2) (refreshed with the parameter) and the demodulation launch reads
+                # it as a one-tap kernel -- a ninth of the bytes of the 3x3 weights on every call
+                wn = self.buf(wt.shape[0], wt.shape[1])
+                self._refreshers.append(lambda src=wt, dst=wn: torch.sqrt(src.detach().pow(2).sum((2, 3)), out=dst))
+                q.w, q.s, q.d = wn.data_ptr(), s_of[id(m)].data_ptr(), dvec[id(m)].data_ptr()
+                q.Cin, q.Cout, q.taps, q.scale = wt.shape[1], wt.shape[0], 1, float(m.conv.scale)
             self.keep.append(arr)
             self.add(L.OP_DEMOD_GROUPED, L.DemodGroupedArgs(groups=C.addressof(arr), n_groups=len(part), B=B, eps=1e-8))
         # ---- noise ----

@@ -245,7 +245,7 @@ def test_variant_launch_plan_equals_launch_by_launch(sg2, dev):
             y_ref = g(feats, noises)
         finally:
             sg2.StyleGAN2Generator.use_plan = True
-        assert torch.equal(y, y_ref)
+        assert rel_l2(y, y_ref) < 1e-5          # (the plan reads cached per-(co,ci) weight norms for the demodulation: one rounding apart)
         g.convs[1].conv.weight.mul_(1.3)
         g.convs[2].noise.weight.fill_(0.5)
         y2 = g(feats, noises)
@@ -254,7 +254,7 @@ def test_variant_launch_plan_equals_launch_by_launch(sg2, dev):
             y2_ref = g(feats, noises)
         finally:
             sg2.StyleGAN2Generator.use_plan = True
-        assert torch.equal(y2, y2_ref) and not torch.equal(y2, y)
+        assert rel_l2(y2, y2_ref) < 1e-5 and not torch.equal(y2, y)
 
 
 @pytest.mark.parametrize("B,C,H,W", [(2, 32, 16, 16), (1, 70, 6, 10), (3, 512, 8, 8), (8, 64, 64, 64)])
