@@ -54,6 +54,11 @@ extern "C" {
                                   * [4][4], kh = kw = 4, transpose_flip = 3), config in 0-3 (spk_conv2d_pick_config(2, 2, 1, B, Cin,
                                   * 4*Cout, Hin+1, Win+1)); bias [Cout]; SPK_EPI_BIAS / SPK_EPI_ACCUM only.  Every output pixel
                                   * (2m+py, 2n+px) takes exactly 2x2 of the 16 taps: four 2x2 kernels, one launch, interleaved. */
+#define SPK_CONV_BF16X3 4096u    /* OPT-IN speed path for 3x3 stride-1 forward convs: operands split into bf16 hi + lo halves
+                                  * (16 significant bits), three bf16 MFMAs per product into an fp32 accumulator -- 5.3x the
+                                  * exact-f32 matrix rate at ~3e-5 rel-L2 through the whole decoder (csrc/conv3x3_bf16x3.hip).
+                                  * w_packed from spk_conv2d_pack_weights_bf16x3; flags: BIAS / NOISE / LRELU / STYLE /
+                                  * UPSAMPLE2X (+ UP_FIR1331) / IN_BATCH_SCALE (+ out_scale_bc); config / ksplit ignored. */
 #define SPK_CONV_UP_FIR1331 512u     /* with UPSAMPLE2X: the x2 interpolation is upfirdn2d(up=2, FIR [1,3,3,1], pad (2,1)) --
                                       * the same (.75,.25) taps as bilinear, but neighbours outside the image are zero */
 
@@ -153,6 +158,12 @@ int64_t spk_conv2d_workspace_bytes_grouped(int config, int ksplit, int kh, int k
 int spk_conv2d_pack_weights(const float* w, float* w_packed, int kh, int kw, int Cin, int Cout, int config,
                             int transpose_flip, void* stream);
 int spk_conv2d_fwd(const spk_conv2d_desc* desc, void* stream);
+/* The SPK_CONV_BF16X3 path: packed image size in BYTES / packer (w is the fp32 [Cout,Cin,3,3] parameter; the hi / lo split
+ * happens here, once per weight update) / whether a shape is served / the launch itself (spk_conv2d_fwd forwards to it). */
+int64_t spk_conv2d_packed_bytes_bf16x3(int Cin, int Cout);
+int spk_conv2d_pack_weights_bf16x3(const float* w, void* w_packed, int Cin, int Cout, void* stream);
+int spk_conv2d_bf16x3_supported(int B, int Cin, int Cout, int H, int W);
+int spk_conv2d_bf16x3_fwd(const spk_conv2d_desc* desc, void* stream);
 
 /* ---- backward of the convolution ---------------------------------------------------------------------
  * Data gradient: spk_conv2d_fwd itself on the output gradient with weights packed transpose_flip = 1

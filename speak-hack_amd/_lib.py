@@ -39,6 +39,7 @@ CONV_IN_BATCH_SCALE = 256
 CONV_UP_FIR1331 = 512
 CONV_DGRAD_S2 = 1024
 CONV_TRANSPOSE4X4_S2 = 2048
+CONV_BF16X3 = 4096
 
 
 FC_MAX_GROUPS = 16
@@ -170,6 +171,10 @@ _PROTOTYPES = {
     "spk_conv2d_pack_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_void_p]),
     "spk_conv2d_fwd": (C.c_int, [C.POINTER(Conv2dDesc), C.c_void_p]),
+    "spk_conv2d_packed_bytes_bf16x3": (C.c_int64, [C.c_int, C.c_int]),
+    "spk_conv2d_pack_weights_bf16x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "spk_conv2d_bf16x3_supported": (C.c_int, [C.c_int] * 5),
+    "spk_conv2d_bf16x3_fwd": (C.c_int, [C.POINTER(Conv2dDesc), C.c_void_p]),
     "spk_conv2d_stats_slots": (C.c_int, [C.c_int] * 9),
     "spk_bn_finalize": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
                                   C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),

@@ -141,6 +141,10 @@ class SynthesisNetwork(nn.Module):
         return shapes
 
     use_plan = True      # inference forwards go out as one pre-built launch list (plan.DecoderPlan); False: launch by launch
+    # "f32": exact fp32 arithmetic on the f32 MFMA pipe (the default, the reference's precision).  "bf16x3": OPT-IN speed path for
+    # inference -- the 3x3 convs of the >= 32^2 layers on the bf16 matrix pipe with every operand split hi + lo (three MFMAs per
+    # product, fp32 accumulation; csrc/conv3x3_bf16x3.hip): ~3e-5 rel-L2 against the reference where the bound is 1e-3.
+    precision = "f32"
 
     def _inference(self, x):
         return not (torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())))
@@ -153,8 +157,8 @@ class SynthesisNetwork(nn.Module):
         if noises is not None and len(noises) != 2 * len(self.layers) + 1:
             raise ValueError(f"expected {2 * len(self.layers) + 1} noise tensors, got {len(noises)}")
         if self.use_plan and w.is_cuda and len(self.layers) * 2 + 1 <= ops.L.FC_MAX_GROUPS and self._inference(w):
-            key = (B, w.device, torch.cuda.current_stream(w.device).cuda_stream, "w")
-            p = PL.plan_for(self, key, lambda: PL.DecoderPlan(self, B, w.device))
+            key = (B, w.device, torch.cuda.current_stream(w.device).cuda_stream, "w", self.precision)
+            p = PL.plan_for(self, key, lambda: PL.DecoderPlan(self, B, w.device, precision=self.precision))
             return p.run(w, None if noises is None else [n.contiguous() for n in noises])
         if noises is None:
             # one device draw for the whole step, cut into the 13 per-layer tensors (the reference draws them one by
@@ -210,8 +214,8 @@ class StyleGenerator(nn.Module):
             if noises is not None and len(noises) != 2 * len(syn.layers) + 1:
                 raise ValueError(f"expected {2 * len(syn.layers) + 1} noise tensors, got {len(noises)}")
             B = features.size(0)
-            key = (B, features.device, torch.cuda.current_stream(features.device).cuda_stream, "features")
-            p = PL.plan_for(self, key, lambda: PL.DecoderPlan(syn, B, features.device, generator=self))
+            key = (B, features.device, torch.cuda.current_stream(features.device).cuda_stream, "features", syn.precision)
+            p = PL.plan_for(self, key, lambda: PL.DecoderPlan(syn, B, features.device, generator=self, precision=syn.precision))
             return p.run(features if features.stride(1) == 1 else features.contiguous(),
                          None if noises is None else [n.contiguous() for n in noises])
         w = self.mapping(features).unsqueeze(1).repeat(1, L, 1)

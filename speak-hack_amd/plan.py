@@ -57,11 +57,36 @@ class LaunchPlan:
     def track(self, *params):
         self._params.extend(params)
 
+    # layers with at least this many output pixels (batch x H x W) take the split-precision path when the plan asks for it:
+    # below it the 64co x 256px blocks cannot fill 256 CUs without a split-K the bf16x3 kernel does not have
+    BF16X3_MIN_PIXELS = 8192
+
     def conv(self, x, weight, Cout, *, bias=None, noise_w=None, noise=None, style=None, upsample=False, up_fir=False, slope=None,
-             out, out_scale=1.0, batch_scale=None, demod=None, act_gain=1.0):
-        """One fused 3x3 stride-1 conv launch (the descriptor ``ops.conv2d_fused`` would build), weights packed here."""
+             out, out_scale=1.0, batch_scale=None, demod=None, act_gain=1.0, precision="f32"):
+        """One fused 3x3 stride-1 conv launch (the descriptor ``ops.conv2d_fused`` would build), weights packed here.
+        ``precision`` "bf16x3": the opt-in split-precision kernel (include/spk.h SPK_CONV_BF16X3) where it serves the shape."""
         B, Cin, Hs, Ws = x.shape
         H, W = (2 * Hs, 2 * Ws) if upsample else (Hs, Ws)
+        if precision == "bf16x3" and B * H * W >= self.BF16X3_MIN_PIXELS and ops.bf16x3_supported(B, Cin, Cout, H, W):
+            packed = torch.empty(L.lib().spk_conv2d_packed_bytes_bf16x3(Cin, Cout), device=self.device, dtype=torch.uint8)
+            self.keep.append(packed)
+            self._refreshers.append(lambda w=weight, p=packed: ops.pack_conv_weight_bf16x3(w.detach(), out=p))
+            self.track(weight)
+            flags = L.CONV_BF16X3 | (L.EPI_BIAS if bias is not None else 0) | (L.EPI_NOISE if noise is not None else 0) | \
+                (L.EPI_LRELU if slope is not None else 0) | (L.EPI_STYLE if style is not None else 0) | \
+                (L.CONV_UPSAMPLE2X if upsample else 0) | (L.CONV_UP_FIR1331 if (upsample and up_fir) else 0) | \
+                (L.CONV_IN_BATCH_SCALE if batch_scale is not None else 0)
+            d = L.Conv2dDesc(x=x.data_ptr(), w_packed=packed.data_ptr(), bias=L.dptr(bias, "bias"),
+                             noise_w=L.dptr(noise_w, "noise_w") if noise is not None else None,
+                             noise=noise.data_ptr() if noise is not None else None,
+                             style=style.data_ptr() if style is not None else None,
+                             in_scale=batch_scale.data_ptr() if batch_scale is not None else None, in_shift=None,
+                             out_scale_bc=demod.data_ptr() if demod is not None else None, act_gain=float(act_gain), stats=None,
+                             y=out.data_ptr(), y_pre=None, B=B, Cin=Cin, Cout=Cout, H=H, W=W, Hin=Hs, Win=Ws, kh=3, kw=3, stride=1,
+                             style_stride=int(style.stride(0)) if style is not None else 0, flags=flags,
+                             lrelu_slope=float(slope if slope is not None else 1.0), out_scale=float(out_scale), config=-1,
+                             ksplit=1, workspace=None, workspace_bytes=0, groups=1, group_in_stride=0, stats_slots=0)
+            return self.add(L.OP_CONV2D, d)
         cfg = ops.conv2d_pick_config(3, 1, B, Cin, Cout, H, W)
         if batch_scale is not None and cfg < 4:
             cfg += 4
@@ -146,9 +171,10 @@ class DecoderPlan(LaunchPlan):
     truncation (styleganv1.py:528-543): 8 FC launches (with the mapping), one grouped launch for the 13+ style affines,
     the constant prologue, 2 fused conv launches per block, toRGB."""
 
-    def __init__(self, synthesis, B, device, generator=None):
+    def __init__(self, synthesis, B, device, generator=None, precision="f32"):
         super().__init__(device)
         s = self.synthesis = synthesis
+        self.precision = precision
         self.B, self.with_mapping = B, generator is not None
         mods = [s.style_mod] + [m for layer in s.layers for m in (layer.style_mod1, layer.style_mod2)]
         if len(mods) > L.FC_MAX_GROUPS:
@@ -209,7 +235,7 @@ class DecoderPlan(LaunchPlan):
                 k = 1 + 2 * i + half
                 self.track(conv.bias, nmod.weight)
                 d = self.conv(x, conv.weight, Cout, bias=conv.bias, noise_w=nmod.weight, noise=self.noise_views[k],
-                              style=self.styles[k], upsample=up, slope=LRELU, out=y)
+                              style=self.styles[k], upsample=up, slope=LRELU, out=y, precision=precision)
                 self.noise_ops.append(d)
                 x, cur = y, 1 - cur
         # ---- toRGB (styleganv1.py:607) ----
@@ -287,10 +313,11 @@ class StyleGAN2Plan(LaunchPlan):
     two modulated MFMA convs (upfirdn2d x2 folded into the first one's staging) and ONE toRGB launch that also upsamples
     and adds the skip image."""
 
-    def __init__(self, gen, B, device):
+    def __init__(self, gen, B, device, precision="f32"):
         super().__init__(device)
         from .stylegan2 import SQRT2, StyledConv
         self.B = B
+        self.precision = precision
         # ---- PixelNorm + style MLP ----
         self.pn = self.add(L.OP_PIXELNORM, L.PixelNormArgs(x=None, y=None, B=B, C=gen.input_dim, HW=1, eps=1e-8, sqrt_form=0))
         wn = self.buf(B, gen.input_dim)
@@ -353,7 +380,7 @@ class StyleGAN2Plan(LaunchPlan):
             self.track(m.noise.weight, m.activate.bias)
             d = self.conv(x, m.conv.weight, Cout, bias=m.activate.bias, noise_w=nw, noise=self.noise_views[k], upsample=m.upsample,
                           up_fir=True, slope=0.2, out=y, out_scale=m.conv.scale, batch_scale=s_of[id(m)], demod=dvec[id(m)],
-                          act_gain=SQRT2)
+                          act_gain=SQRT2, precision=precision)
             self.noise_ops.append(d)
             return y
 

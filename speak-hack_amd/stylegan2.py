@@ -169,14 +169,15 @@ class StyleGAN2Generator(nn.Module):
             cin = cout
 
     use_plan = True      # inference forwards go out as one pre-built launch list (plan.StyleGAN2Plan)
+    precision = "f32"    # "bf16x3": opt-in split-precision convs for inference (see decoder.SynthesisNetwork.precision)
 
     def forward(self, features, noises=None):
         train = torch.is_grad_enabled() and (features.requires_grad or any(p.requires_grad for p in self.parameters()))
         if not train and self.use_plan and features.is_cuda and features.dim() == 2:
             from . import plan as PL
             B = features.size(0)
-            key = (B, features.device, torch.cuda.current_stream(features.device).cuda_stream, "features")
-            p = PL.plan_for(self, key, lambda: PL.StyleGAN2Plan(self, B, features.device))
+            key = (B, features.device, torch.cuda.current_stream(features.device).cuda_stream, "features", self.precision)
+            p = PL.plan_for(self, key, lambda: PL.StyleGAN2Plan(self, B, features.device, precision=self.precision))
             return p.run(features.contiguous(), None if noises is None else [n.contiguous() for n in noises])
         w = AG.pixelnorm(features.contiguous(), 1e-8, False)
         for layer in self.style:
