@@ -25,6 +25,7 @@
 
 #include <algorithm>
 #include <cstdlib>
+#include <type_traits>
 
 namespace spkbf {
 
@@ -56,6 +57,7 @@ struct Args {
     int style_stride;
     unsigned flags;
     float slope, out_scale, act_gain;
+    int staged;                  // epilogue through LDS with 16-byte stores (host: W % 4 == 0, TW >= 4, aligned tensors)
 };
 
 __device__ __forceinline__ unsigned pack_bf16(float lo, float hi) {       // two RNE conversions, lo in the low half
@@ -109,14 +111,20 @@ __global__ __launch_bounds__(NT) void conv3x3_bf16x3_kernel(const Args p) {
     // ---- gather items: item = h * NPOS + pos (a k-group of 8 channels at one plane position); thread t owns items t + 256 r ----
     unsigned it_off[MAX_ROUNDS], it_dst[MAX_ROUNDS], it_ok[MAX_ROUNDS], it_sc[MAX_ROUNDS];
     int it_h[MAX_ROUNDS];
-    unsigned it_dx[UPS ? MAX_ROUNDS : 1], it_dy[UPS ? MAX_ROUNDS : 1];
+    // UPS: the x2 interpolation reads a low-resolution SOURCE tile kept in LDS as fp32 ([h][source position][8 channels], 32
+    // bytes per slot): it_s00 = byte offset of the item's first tap (iy0, ix0) in a source buffer, it_dx / it_dy = byte steps
+    // to the second column / row tap (0 where the tap is clamped away), the four tap weights.
+    constexpr int MAX_SR = 2;                               // source-tile gather rounds: 2 * SNPOS items <= 512
+    const int SPW = (TW >> 1) + 2, SPLANE = ((TH >> 1) + 2) * SPW, SNPOS = TB * SPLANE;
+    const int S_BYTES = 2 * SNPOS * 32;
+    unsigned it_s00[UPS ? MAX_ROUNDS : 1], it_dx[UPS ? MAX_ROUNDS : 1], it_dy[UPS ? MAX_ROUNDS : 1];
     float it_lx0[UPS ? MAX_ROUNDS : 1], it_lx1[UPS ? MAX_ROUNDS : 1], it_ly0[UPS ? MAX_ROUNDS : 1], it_ly1[UPS ? MAX_ROUNDS : 1];
 #pragma unroll
     for (int r = 0; r < MAX_ROUNDS; ++r) {
         const int item = tid + NT * r;
         it_off[r] = 0; it_ok[r] = 0; it_h[r] = 0; it_sc[r] = 0;
         it_dst[r] = 0xffffffffu;                          // no item: nothing is stored
-        if (UPS) { it_dx[r] = it_dy[r] = 0; it_lx0[r] = it_ly0[r] = 1.f; it_lx1[r] = it_ly1[r] = 0.f; }
+        if (UPS) { it_s00[r] = it_dx[r] = it_dy[r] = 0; it_lx0[r] = it_ly0[r] = 1.f; it_lx1[r] = it_ly1[r] = 0.f; }
         if (item < 2 * NPOS) {
             const int h = item / NPOS, pos = item - h * NPOS;
             const int tb = pos / PLANE, pidx = pos - tb * PLANE;
@@ -140,8 +148,10 @@ __global__ __launch_bounds__(NT) void conv3x3_bf16x3_kernel(const Args p) {
                     const int iy0 = uy == 0 ? 0 : (uy - 1) >> 1, ix0 = ux == 0 ? 0 : (ux - 1) >> 1;
                     unsigned ly = uy == 0 ? (zb ? 3u : 0u) : ((uy & 1) ? 1u : 2u);
                     unsigned lx = ux == 0 ? (zb ? 3u : 0u) : ((ux & 1) ? 1u : 2u);
-                    if (iy0 + 1 < p.Hs) it_dy[r] = (unsigned)p.Ws; else if (zb) ly = 3u;
-                    if (ix0 + 1 < p.Ws) it_dx[r] = 1u; else if (zb) lx = 3u;
+                    if (iy0 + 1 < p.Hs) it_dy[r] = (unsigned)(SPW * 32); else if (zb) ly = 3u;
+                    if (ix0 + 1 < p.Ws) it_dx[r] = 32u; else if (zb) lx = 3u;
+                    // the source tile starts at source pixel (y0/2 - 1, x0/2 - 1)
+                    it_s00[r] = (unsigned)((h * SNPOS + tb * SPLANE + (iy0 - (y0 >> 1) + 1) * SPW + (ix0 - (x0 >> 1) + 1)) * 32);
                     it_lx0[r] = lx == 0 ? 1.f : (lx == 2 ? 0.25f : 0.75f); it_lx1[r] = lx == 1 ? 0.25f : (lx == 2 ? 0.75f : 0.f);
                     it_ly0[r] = ly == 0 ? 1.f : (ly == 2 ? 0.25f : 0.75f); it_ly1[r] = ly == 1 ? 0.25f : (ly == 2 ? 0.75f : 0.f);
                     goff = iy0 * p.Ws + ix0;
@@ -152,6 +162,29 @@ __global__ __launch_bounds__(NT) void conv3x3_bf16x3_kernel(const Args p) {
         }
     }
     const int rounds = (2 * NPOS + NT - 1) / NT;            // uniform (<= MAX_ROUNDS: host-checked)
+    // UPS: source-tile items (h, source position): thread t owns items t + 256 r.  Positions outside the source image load a
+    // clamped (finite) neighbour: the interpolation gives them weight zero.
+    unsigned si_off[UPS ? MAX_SR : 1], si_dst[UPS ? MAX_SR : 1], si_sc[UPS ? MAX_SR : 1];
+    int si_h[UPS ? MAX_SR : 1];
+    const int s_rounds = UPS ? (2 * SNPOS + NT - 1) / NT : 0;
+    if constexpr (UPS) {
+#pragma unroll
+        for (int r = 0; r < MAX_SR; ++r) {
+            const int item = tid + NT * r;
+            si_off[r] = 0; si_dst[r] = 0xffffffffu; si_sc[r] = 0; si_h[r] = 0;
+            if (item < 2 * SNPOS) {
+                const int h = item / SNPOS, sp = item - h * SNPOS;
+                const int tb = sp / SPLANE, sidx = sp - tb * SPLANE;
+                const int sr = sidx / SPW, sc = sidx - sr * SPW;
+                const int iy = min(max((y0 >> 1) - 1 + sr, 0), p.Hs - 1), ix = min(max((x0 >> 1) - 1 + sc, 0), p.Ws - 1);
+                const int tbc = b0 + tb < p.B ? tb : 0;
+                si_h[r] = h;
+                si_dst[r] = (unsigned)((h * SNPOS + sp) * 32);
+                si_off[r] = (unsigned)((size_t)(tbc * p.Cin + 8 * h) * src_plane) + (unsigned)(iy * p.Ws + ix);
+                si_sc[r] = (unsigned)((b0 + tbc) * p.Cin + 8 * h);
+            }
+        }
+    }
 
     // ---- fragment addresses (bytes inside a stage) ----
     // A: W image [hl][tap][h][co][16 B]; this lane: row co = m * 32 + l32, k-group `half`
@@ -177,10 +210,16 @@ __global__ __launch_bounds__(NT) void conv3x3_bf16x3_kernel(const Args p) {
 
     const char* wsrc = p.wp + (size_t)co_tile * p.n_chunks * W_BYTES;
 
-    // gather registers of one round: 8 channels (x 4 bilinear taps)
-    float gx[UPS ? 32 : 8];
-    float gsc[8];
-    auto issue_loads = [&](int chunk, int r) {
+    // gather registers: per round 8 channels (x 4 bilinear taps).  All rounds of the next chunk are issued at the top of a
+    // chunk and consumed one to two tap rows (1 150 - 2 300 MFMA cycles) later: issued right before the tap row that precedes
+    // their use they came back late and every wave stalled on the same vmcnt (knock-out timing, gpurun_out/r2/bf_lab.txt)
+    constexpr int GXN = 8;                                  // (the UPS path stages a source tile instead: s_issue / interp_store)
+    float gxa[MAX_ROUNDS][GXN];
+    float gsa[MAX_ROUNDS][8];
+    auto issue_loads = [&](int chunk, auto r_) {
+        constexpr int r = decltype(r_)::value;
+        float (&gx)[GXN] = gxa[r];
+        float (&gsc)[8] = gsa[r];
         // chunk's channels [16 chunk, 16 chunk + 16); the ragged last chunk clamps missing channels onto a valid one (masked at store)
         const bool lastc = chunk == p.n_chunks - 1;
         const float* xc = xblk + (size_t)chunk * CI_T * src_plane;
@@ -189,27 +228,21 @@ __global__ __launch_bounds__(NT) void conv3x3_bf16x3_kernel(const Args p) {
         for (int j = 0; j < 8; ++j) {
             const bool live = !lastc || h8 + j < ci_last;
             const float* src = xc + it_off[r] + (ptrdiff_t)(live ? j : -h8) * (ptrdiff_t)src_plane;   // dead channel: the chunk's first plane
-            if (!UPS) {
-                gx[j] = *src;
-            } else {
-                gx[4 * j + 0] = src[0];
-                gx[4 * j + 1] = src[it_dx[r]];
-                gx[4 * j + 2] = src[it_dy[r]];
-                gx[4 * j + 3] = src[it_dy[r] + it_dx[r]];
-            }
+            gx[j] = *src;
             if (bsc) gsc[j] = p.in_scale[it_sc[r] + chunk * CI_T + (live ? j : -h8)];
         }
     };
-    auto convert_store = [&](char* stage, int chunk, int r) {
+    auto convert_store = [&](char* stage, int chunk, auto r_) {
+        constexpr int r = decltype(r_)::value;
+        float (&gx)[GXN] = gxa[r];
+        float (&gsc)[8] = gsa[r];
         if (it_dst[r] == 0xffffffffu) return;
         const bool lastc = chunk == p.n_chunks - 1;
         const int h8 = 8 * it_h[r];
         float v[8];
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-            float t;
-            if (!UPS) t = gx[j];
-            else t = it_ly0[r] * (it_lx0[r] * gx[4 * j] + it_lx1[r] * gx[4 * j + 1]) + it_ly1[r] * (it_lx0[r] * gx[4 * j + 2] + it_lx1[r] * gx[4 * j + 3]);
+            float t = gx[j];
             if (bsc) t *= gsc[j];
             v[j] = (it_ok[r] && (!lastc || h8 + j < ci_last)) ? t : 0.f;
         }
@@ -218,6 +251,58 @@ __global__ __launch_bounds__(NT) void conv3x3_bf16x3_kernel(const Args p) {
         *reinterpret_cast<u32x4*>(stage + it_dst[r]) = hi;
         *reinterpret_cast<u32x4*>(stage + it_dst[r] + hl_x) = lo;
     };
+    // ---- UPS: source tile -> LDS (fp32, modulation applied here), then LDS -> LDS interpolation + split into the X image ----
+    float sga[UPS ? MAX_SR : 1][8];
+    auto s_issue = [&](int chunk, auto r_) {
+        constexpr int r = decltype(r_)::value;
+        const bool lastc = chunk == p.n_chunks - 1;
+        const float* xc = xblk + (size_t)chunk * CI_T * src_plane;
+        const int h8 = 8 * si_h[r];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const bool live = !lastc || h8 + j < ci_last;
+            float v = xc[si_off[r] + (ptrdiff_t)(live ? j : -h8) * (ptrdiff_t)src_plane];
+            if (bsc) v *= p.in_scale[si_sc[r] + chunk * CI_T + (live ? j : -h8)];
+            sga[r][j] = v;
+        }
+    };
+    auto s_store = [&](char* sbuf, int chunk, auto r_) {
+        constexpr int r = decltype(r_)::value;
+        if (si_dst[r] == 0xffffffffu) return;
+        const bool lastc = chunk == p.n_chunks - 1;
+        const int h8 = 8 * si_h[r];
+        f32x4 a, b;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            a[j] = (!lastc || h8 + j < ci_last) ? sga[r][j] : 0.f;
+            b[j] = (!lastc || h8 + 4 + j < ci_last) ? sga[r][4 + j] : 0.f;
+        }
+        *reinterpret_cast<f32x4*>(sbuf + si_dst[r]) = a;
+        *reinterpret_cast<f32x4*>(sbuf + si_dst[r] + 16) = b;
+    };
+    auto interp_store = [&](char* stage, const char* sbuf, auto r_) {
+        constexpr int r = decltype(r_)::value;
+        if (it_dst[r] == 0xffffffffu) return;
+        float v[8];
+        const char* s00 = sbuf + it_s00[r];
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            const f32x4 a = *reinterpret_cast<const f32x4*>(s00 + 16 * q);
+            const f32x4 b = *reinterpret_cast<const f32x4*>(s00 + it_dx[r] + 16 * q);
+            const f32x4 c = *reinterpret_cast<const f32x4*>(s00 + it_dy[r] + 16 * q);
+            const f32x4 d = *reinterpret_cast<const f32x4*>(s00 + it_dy[r] + it_dx[r] + 16 * q);
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const float t = it_ly0[r] * (it_lx0[r] * a[j] + it_lx1[r] * b[j]) + it_ly1[r] * (it_lx0[r] * c[j] + it_lx1[r] * d[j]);
+                v[4 * q + j] = it_ok[r] ? t : 0.f;
+            }
+        }
+        u32x4 hi, lo;
+        split8(v, hi, lo);
+        *reinterpret_cast<u32x4*>(stage + it_dst[r]) = hi;
+        *reinterpret_cast<u32x4*>(stage + it_dst[r] + hl_x) = lo;
+    };
+
     auto dma_weights = [&](char* stage, int chunk) {
         const char* src = wsrc + (size_t)chunk * W_BYTES;
 #pragma unroll
@@ -228,10 +313,34 @@ __global__ __launch_bounds__(NT) void conv3x3_bf16x3_kernel(const Args p) {
     };
 
     // ---- prologue: chunk 0 -> stage 0 ----
+    using I0 = std::integral_constant<int, 0>;
+    using I1 = std::integral_constant<int, 1>;
+    using I2 = std::integral_constant<int, 2>;
+    char* const sb0 = smem + 2 * STAGE;                     // UPS: the two source-tile buffers sit behind the stages
     dma_weights(smem, 0);
-    for (int r = 0; r < rounds; ++r) {
-        issue_loads(0, r);
-        convert_store(smem, 0, r);
+    if constexpr (UPS) {
+        // source tiles of chunks 0 and 1, then X(0) by interpolation out of S(0)
+        s_issue(0, I0{});
+        if (s_rounds > 1) s_issue(0, I1{});
+        s_store(sb0, 0, I0{});
+        if (s_rounds > 1) s_store(sb0, 0, I1{});
+        if (p.n_chunks > 1) {
+            s_issue(1, I0{});
+            if (s_rounds > 1) s_issue(1, I1{});
+            s_store(sb0 + S_BYTES, 1, I0{});
+            if (s_rounds > 1) s_store(sb0 + S_BYTES, 1, I1{});
+        }
+        __syncthreads();
+        interp_store(smem, sb0, I0{});
+        if (rounds > 1) interp_store(smem, sb0, I1{});
+        if (rounds > 2) interp_store(smem, sb0, I2{});
+    } else {
+        issue_loads(0, I0{});
+        if (rounds > 1) issue_loads(0, I1{});
+        if (rounds > 2) issue_loads(0, I2{});
+        convert_store(smem, 0, I0{});
+        if (rounds > 1) convert_store(smem, 0, I1{});
+        if (rounds > 2) convert_store(smem, 0, I2{});
     }
     __builtin_amdgcn_s_waitcnt(0x0f70);                    // vmcnt(0): this wave's LDS-DMA blocks have landed
     __syncthreads();
@@ -257,22 +366,55 @@ __global__ __launch_bounds__(NT) void conv3x3_bf16x3_kernel(const Args p) {
             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[slot_][0][m], fb[slot_][0][n], acc[m][n], 0, 0, 0); \
         }
 
+    const bool lab_nostage = p.flags & (1u << 29), lab_noepi = p.flags & (1u << 30), lab_nomfma = p.flags & (1u << 28);
     for (int i = 0; i < p.n_chunks; ++i) {
         char* cur = smem + (i & 1) * STAGE;
         char* nxt = smem + ((i + 1) & 1) * STAGE;
-        const bool more = i + 1 < p.n_chunks;               // uniform
-        if (more) dma_weights(nxt, i + 1);
+        const bool more = i + 1 < p.n_chunks && !lab_nostage;               // uniform
+        const bool more2 = i + 2 < p.n_chunks && !lab_nostage;   // UPS: the source tile runs two chunks ahead
+        char* const s_nxt = sb0 + ((i + 1) & 1) * S_BYTES;       // holds S(i + 1); S(i + 2) goes where S(i) was
+        char* const s_nn = sb0 + (i & 1) * S_BYTES;
+        if (more) {
+            dma_weights(nxt, i + 1);
+            if constexpr (!UPS) {
+                issue_loads(i + 1, I0{});
+                if (rounds > 1) issue_loads(i + 1, I1{});
+                if (rounds > 2) issue_loads(i + 1, I2{});
+            }
+        }
+        if constexpr (UPS) {
+            if (more2) {
+                s_issue(i + 2, I0{});
+                if (s_rounds > 1) s_issue(i + 2, I1{});
+            }
+        }
         SPK_BF_FRAG(cur, 0, 0);
 #pragma unroll
         for (int row = 0; row < 3; ++row) {
-            if (more && row < rounds) issue_loads(i + 1, row);
 #pragma unroll
             for (int k = 0; k < 3; ++k) {
                 const int tap = row * 3 + k;
                 if (tap + 1 < TAPS) SPK_BF_FRAG(cur, tap + 1, (tap + 1) & 1);
-                SPK_BF_MFMA(tap & 1);
+                if (!lab_nomfma) SPK_BF_MFMA(tap & 1);
             }
-            if (more && row < rounds) convert_store(nxt, i + 1, row);
+            if constexpr (!UPS) {
+                if (more && row == 1) convert_store(nxt, i + 1, I0{});
+                if (more && row == 2) {
+                    if (rounds > 1) convert_store(nxt, i + 1, I1{});
+                    if (rounds > 2) convert_store(nxt, i + 1, I2{});
+                }
+            } else {
+                // X(i + 1) out of S(i + 1) (in LDS since the previous chunk's barrier): one round behind each tap row
+                if (more && row == 0) interp_store(nxt, s_nxt, I0{});
+                if (more && row == 1 && rounds > 1) interp_store(nxt, s_nxt, I1{});
+                if (more && row == 2 && rounds > 2) interp_store(nxt, s_nxt, I2{});
+            }
+        }
+        if constexpr (UPS) {
+            if (more2) {                                       // S(i) was last read while X(i) was built, a chunk ago
+                s_store(s_nn, i + 2, I0{});
+                if (s_rounds > 1) s_store(s_nn, i + 2, I1{});
+            }
         }
         __builtin_amdgcn_s_waitcnt(0x0f70);                // vmcnt(0): the next stage's weight image has landed
         __syncthreads();
@@ -281,9 +423,60 @@ __global__ __launch_bounds__(NT) void conv3x3_bf16x3_kernel(const Args p) {
 #undef SPK_BF_MFMA
 
     // ---- epilogue (element for element the f32 kernel's): out_scale, demodulation, bias, noise, LeakyReLU * gain, style ----
+    if (lab_noepi && acc[0][0][0] != 123456.789f) return;      // measurement builds only (SPK_BF_LAB): see the host side
     const bool f_bias = p.flags & SPK_EPI_BIAS, f_noise = p.flags & SPK_EPI_NOISE;
     const bool f_lrelu = p.flags & SPK_EPI_LRELU, f_style = p.flags & SPK_EPI_STYLE;
     const size_t HW = (size_t)p.H * p.W;
+    if (p.staged) {
+        // Through LDS (both stages are free now: every wave passed the last chunk's barrier): the 64 x 256 block is written in
+        // accumulator order and read back as rows, so a thread finishes FOUR consecutive pixels of a channel per step --
+        // 16 vector stores per thread instead of 64 dword stores, the per-channel / per-image operands loaded once per vector.
+        // With the dword form the epilogue was HALF of the 256^2 layers' time (gpurun_out/r2/bf_lab.txt).
+        constexpr int OP = PIX_T + 4, F4 = PIX_T / 4, RPI = NT / F4;          // 4 rows per pass
+        float* const ot = reinterpret_cast<float*>(smem);
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int n = 0; n < 2; ++n)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    ot[(m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * OP + (wave * 2 + n) * 32 + l32] = acc[m][n][r];
+        __syncthreads();
+        const int f4 = tid % F4, row0 = tid / F4;
+        const int pt = 4 * f4;
+        const int px = pt & (TW - 1), py = (pt >> p.lgTW) & (TH - 1), tb = pt >> (p.lgTW + p.lgTH);
+        const int b = b0 + tb, yy = y0 + py, xx = x0 + px;
+        const bool pvv = tb < TB && b < p.B && yy < p.H && xx < p.W;      // W % 4 == 0: the vector is in or out as a whole
+        if (!pvv) return;
+        const size_t pix = (size_t)yy * p.W + xx;
+        const size_t o0 = (size_t)b * p.Cout * HW + pix;
+        f32x4 nzv = {0.f, 0.f, 0.f, 0.f};
+        if (f_noise) nzv = *reinterpret_cast<const f32x4*>(p.noise + (size_t)b * HW + pix);
+        const float* stp = f_style ? p.style + (size_t)b * p.style_stride : nullptr;
+#pragma unroll 4
+        for (int i = 0; i < CO_T / RPI; ++i) {
+            const int cl = row0 + RPI * i, co = co0 + cl;
+            if (co >= p.Cout) continue;
+            f32x4 v = *reinterpret_cast<const f32x4*>(ot + cl * OP + pt);
+            const float dm = p.out_scale_bc ? p.out_scale_bc[(size_t)b * p.Cout + co] : 1.f;
+            const float bb = f_bias ? p.bias[co] : 0.f;
+            const float nwc = f_noise ? p.noise_w[co] : 0.f;
+            float s0 = 1.f, s1 = 0.f;
+            if (f_style) { s0 = stp[co] + 1.f; s1 = stp[p.Cout + co]; }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                float t = v[k] * p.out_scale;
+                if (p.out_scale_bc) t *= dm;
+                t += bb;
+                if (f_noise) t += nwc * nzv[k];
+                if (f_lrelu) t = (t > 0.f ? t : t * p.slope) * p.act_gain;
+                if (f_style) t = t * s0 + s1;
+                v[k] = t;
+            }
+            *reinterpret_cast<f32x4*>(p.y + o0 + (size_t)co * HW) = v;
+        }
+        return;
+    }
     bool pv[2];
     size_t poff[2];
     int pb[2];
@@ -390,6 +583,7 @@ int spk_conv2d_bf16x3_fwd(const spk_conv2d_desc* d, void* stream) {
     SPK_REQUIRE(d && d->x && d->w_packed && d->y, "conv2d bf16x3: null pointer");
     SPK_REQUIRE(d->kh == 3 && d->kw == 3 && d->stride == 1, "conv2d bf16x3: 3x3 stride-1 kernels only");
     SPK_REQUIRE(d->groups <= 1, "conv2d bf16x3: not grouped");
+    static const unsigned lab = [] { const char* e = getenv("SPK_BF_LAB"); return e ? (unsigned)atoi(e) << 28 : 0u; }();   // timing knock-outs
     const unsigned allowed = SPK_CONV_BF16X3 | SPK_EPI_BIAS | SPK_EPI_NOISE | SPK_EPI_LRELU | SPK_EPI_STYLE | SPK_CONV_UPSAMPLE2X |
                              SPK_CONV_UP_FIR1331 | SPK_CONV_IN_BATCH_SCALE;
     SPK_REQUIRE(!(d->flags & ~allowed) && !d->y_pre && !d->stats, "conv2d bf16x3: forward-only epilogue flags (bias, noise, lrelu, style, "
@@ -412,9 +606,14 @@ int spk_conv2d_bf16x3_fwd(const spk_conv2d_desc* d, void* stream) {
     a.lgTW = spk::ilog2(g.TW); a.lgTH = spk::ilog2(g.TH); a.lgTB = spk::ilog2(g.TB);
     a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y;
     a.n_chunks = spk::ceil_div(d->Cin, CI_T);
-    a.style_stride = d->style_stride; a.flags = d->flags; a.slope = d->lrelu_slope; a.out_scale = d->out_scale;
+    a.style_stride = d->style_stride; a.flags = d->flags | lab; a.slope = d->lrelu_slope; a.out_scale = d->out_scale;
     a.act_gain = d->act_gain != 0.f ? d->act_gain : 1.f;
-    const size_t lds = 2 * (size_t)(W_BYTES + 4 * g.NPOS * 16);
+    const auto aligned16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    a.staged = (d->W % 4 == 0 && g.TW >= 4 && aligned16(d->y) && aligned16(d->noise)) ? 1 : 0;
+    const int snpos = g.TB * ((g.TH >> 1) + 2) * ((g.TW >> 1) + 2);          // UPS: source-tile positions
+    SPK_REQUIRE(!ups || 2 * snpos <= 2 * NT, "conv2d bf16x3: source tile too large");
+    const size_t lds = std::max(2 * (size_t)(W_BYTES + 4 * g.NPOS * 16) + (ups ? 2 * (size_t)(2 * snpos * 32) : (size_t)0),
+                                a.staged ? (size_t)CO_T * (PIX_T + 4) * sizeof(float) : (size_t)0);
     SPK_REQUIRE(lds <= 160 * 1024, "conv2d bf16x3: tile does not fit LDS");
     auto kern = ups ? &conv3x3_bf16x3_kernel<true> : &conv3x3_bf16x3_kernel<false>;
     static bool raised[2] = {false, false};
