@@ -5,6 +5,8 @@
 #include "spk_common.hpp"
 
 #include <algorithm>
+#include <cmath>
+#include <cstdlib>
 
 namespace {
 
@@ -92,6 +94,82 @@ __global__ __launch_bounds__(256) void upfirdn2d_kernel(const float* __restrict_
     }
 }
 
+// Separable form (every FIR StyleGAN2 uses is an outer product, e.g. [1,3,3,1] x [1,3,3,1]): a wave owns 64 consecutive output
+// columns of one output row.  For each tap ROW that lands on a real (non-inserted) input row the wave loads the row segment it
+// needs once -- one or two coalesced dwords per lane -- and every lane picks its taps' operands out of its neighbours'
+// registers with wave shuffles (ds_bpermute: the LDS crossbar, no memory traffic); up / down / k are compile-time, so the
+// zero-insertion is a parity select and the floor divisions are shifts -- no integer division or modulo in any loop.
+struct Fir1 { float fx[8], fy[8]; };      // FLIPPED 1-D factors (true convolution), fx * fy^T = the 2-D filter
+
+template <int UP, int DOWN, int K>
+__global__ __launch_bounds__(256) void upfirdn2d_sep_kernel(const float* __restrict__ x, float* __restrict__ y, Fir1 fir, int H, int W, int Ho,
+                                                           int Wo, int pad0, float gain) {
+    constexpr int LG = UP == 2 ? 1 : 0;                    // UP in {1, 2}
+    constexpr int NLD = (64 * DOWN + K + UP - 1) / UP / 64 + 1;          // 64-column register segments a wave needs per input row
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ox0 = blockIdx.x * 64, ox = ox0 + lane;
+    const int oy = blockIdx.y * 4 + wave;
+    if (oy >= Ho) return;                                  // whole wave
+    const float* xp = x + (size_t)blockIdx.z * H * W;
+    const int c0 = (ox0 * DOWN - pad0) >> LG;              // first input column any lane of this wave can touch (floor division)
+    float acc = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky) {
+        const int uy = oy * DOWN + ky - pad0;
+        if (uy < 0 || (uy & (UP - 1)) || (uy >> LG) >= H) continue;          // wave-uniform
+        const float* row = xp + (size_t)(uy >> LG) * W;
+        float r[NLD];
+#pragma unroll
+        for (int q = 0; q < NLD; ++q) {
+            const int c = c0 + lane + 64 * q;
+            r[q] = (c >= 0 && c < W) ? row[c] : 0.f;
+        }
+        float hs = 0.f;
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+            const int u = ox * DOWN + kx - pad0;
+            const int idx = (u >> LG) - c0;                // 0 <= idx < 64 NLD
+            float v = __shfl(r[0], idx & 63);
+#pragma unroll
+            for (int q = 1; q < NLD; ++q) {
+                const float w = __shfl(r[q], idx & 63);
+                v = (idx >> 6) == q ? w : v;
+            }
+            hs += (u & (UP - 1)) ? 0.f : fir.fx[kx] * v;   // an inserted zero column
+        }
+        acc += fir.fy[ky] * hs;
+    }
+    if (ox < Wo) y[((size_t)blockIdx.z * Ho + oy) * Wo + ox] = acc * gain;
+}
+
+template <int UP, int DOWN>
+static bool launch_sep(int k, const float* x, float* y, const Fir1& fir, long long planes, int H, int W, int Ho, int Wo, int pad0,
+                       float gain, hipStream_t s) {
+    dim3 grid((unsigned)((Wo + 63) / 64), (unsigned)((Ho + 3) / 4), (unsigned)planes);
+    if (k == 4) hipLaunchKernelGGL((upfirdn2d_sep_kernel<UP, DOWN, 4>), grid, dim3(256), 0, s, x, y, fir, H, W, Ho, Wo, pad0, gain);
+    else if (k == 3) hipLaunchKernelGGL((upfirdn2d_sep_kernel<UP, DOWN, 3>), grid, dim3(256), 0, s, x, y, fir, H, W, Ho, Wo, pad0, gain);
+    else if (k == 2) hipLaunchKernelGGL((upfirdn2d_sep_kernel<UP, DOWN, 2>), grid, dim3(256), 0, s, x, y, fir, H, W, Ho, Wo, pad0, gain);
+    else return false;
+    return true;
+}
+
+// f2d[i][j] == fy[i] * fx[j]?  (rank one; the factors of the FLIPPED filter are the flipped factors)
+static bool separate(const float* f, int k, float* fx, float* fy) {
+    int pi = -1, pj = -1;
+    for (int i = 0; i < k && pi < 0; ++i)
+        for (int j = 0; j < k; ++j)
+            if (f[i * k + j] != 0.f) { pi = i; pj = j; break; }
+    if (pi < 0) return false;
+    const float piv = f[pi * k + pj];
+    float scale = 0.f;
+    for (int j = 0; j < k; ++j) { fx[j] = f[pi * k + j]; scale = std::max(scale, std::fabs(fx[j])); }
+    for (int i = 0; i < k; ++i) fy[i] = f[i * k + pj] / piv;
+    for (int i = 0; i < k; ++i)
+        for (int j = 0; j < k; ++j)
+            if (std::fabs(f[i * k + j] - fy[i] * fx[j]) > 1e-6f * scale) return false;
+    return true;
+}
+
 inline unsigned sgrid2(long long n) { return (unsigned)std::max(1ll, std::min((n + 255) / 256, 256ll * 16)); }
 
 }  // namespace
@@ -128,6 +206,18 @@ int spk_upfirdn2d_fwd(const float* x, float* y, const float* filter_host, int k,
                 "upfirdn2d: bad arguments (k <= 7)");
     const int Ho = (H * up + pad0 + pad1 - k) / down + 1, Wo = (W * up + pad0 + pad1 - k) / down + 1;
     SPK_REQUIRE(Ho > 0 && Wo > 0, "upfirdn2d: empty output");
+    static const bool allow_sep = [] { const char* e = getenv("SPK_UPFIRDN_SEP"); return !e || atoi(e) != 0; }();
+    float fx[8], fy[8];
+    if (allow_sep && k <= 4 && up <= 2 && down <= 2 && planes < 65536 && (Ho + 3) / 4 < 65536 && separate(filter_host, k, fx, fy)) {
+        Fir1 f1;
+        for (int i = 0; i < k; ++i) { f1.fx[i] = fx[k - 1 - i]; f1.fy[i] = fy[k - 1 - i]; }     // flipped: upfirdn2d is a true convolution
+        bool ok;
+        if (up == 1) ok = down == 1 ? launch_sep<1, 1>(k, x, y, f1, planes, H, W, Ho, Wo, pad0, gain, (hipStream_t)stream)
+                                    : launch_sep<1, 2>(k, x, y, f1, planes, H, W, Ho, Wo, pad0, gain, (hipStream_t)stream);
+        else ok = down == 1 ? launch_sep<2, 1>(k, x, y, f1, planes, H, W, Ho, Wo, pad0, gain, (hipStream_t)stream)
+                            : launch_sep<2, 2>(k, x, y, f1, planes, H, W, Ho, Wo, pad0, gain, (hipStream_t)stream);
+        if (ok) return spk::check_launch("upfirdn2d_sep_kernel");
+    }
     Fir2 fir;
     fir.k = k;
     for (int i = 0; i < k * k; ++i) fir.f[i] = filter_host[i];
