@@ -200,6 +200,9 @@ typedef struct spk_wgrad_desc {
 } spk_wgrad_desc;
 int64_t spk_conv2d_wgrad_workspace_bytes(int kh, int kw, int stride, int splits, int B, int Cin, int Cout, int H, int W);
 int spk_conv2d_wgrad(const spk_wgrad_desc* desc, void* stream);
+/* whether spk_conv2d_wgrad takes SPK_CONV_UPSAMPLE2X for a 3x3 stride-1 problem with OUTPUT size H x W (x is then the
+ * low-resolution [B,Cin,H/2,W/2] tensor and the x2 image is never materialised); 0: upsample first. */
+int spk_conv2d_wgrad_up_supported(int B, int Cin, int Cout, int H, int W);
 
 /* Adjoint of the fused epilogue of spk_conv2d_fwd, one pass.  With y = a*(s0+1)+s1, a = lrelu(t),
  * t = conv + bias + noise_w*noise and dy = dL/dy:

@@ -148,6 +148,7 @@ _PROTOTYPES = {
     "spk_maxpool3x3s2_bwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p]),
     "spk_conv2d_wgrad_workspace_bytes": (C.c_int64, [C.c_int] * 9),
     "spk_conv2d_wgrad": (C.c_int, [C.POINTER(WgradDesc), C.c_void_p]),
+    "spk_conv2d_wgrad_up_supported": (C.c_int, [C.c_int] * 5),
     "spk_epilogue_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p,
                                    C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p]),
     "spk_upsample2x_bilinear_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),

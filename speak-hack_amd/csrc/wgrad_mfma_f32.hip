@@ -663,6 +663,205 @@ __global__ __launch_bounds__(256) void wgrad3x3_wide_kernel(const WgradArgs p) {
         }
 }
 
+// ---- 3x3 stride-1 weight gradient of a conv that reads the BILINEAR x2 UPSAMPLING of x (styleganv1.py:624-625) ---------
+// dW[co][ci][tap] = sum g[b,co,y,x] * up(x)[b,ci,y+ky-1,x+kx-1] without up(x) ever existing in HBM (round 1 materialised it:
+// 268 MB written and read back at [8,128,256,256]).  Same block, tile, LDS images and arithmetic order as
+// wgrad3x3_wide_kernel<1,1>; what differs is where the 18 x 6 input plane comes from: the tile's low-resolution SOURCE patch
+// (4 x 10 pixels per channel, 2.7x fewer bytes than the plane) is loaded with 16-byte row loads two tiles ahead into a small
+// fp32 LDS buffer, and the plane of the NEXT tile is interpolated LDS -> LDS while this tile's MFMAs run -- one element per
+// thread and k-step, its tap offsets and weights wave-uniform scalars (a wave owns a quarter of the plane's positions, a lane
+// one channel).  An earlier attempt formed the four bilinear taps with global gathers inside the staging and lost 2x to the
+// materialised form: those 4 loads per element could not be prefetched; LDS reads need no prefetch.
+constexpr int US_PW = 10, US_PH = 4, US_PITCH = US_PW * US_PH + 1, US_FLOATS = 64 * US_PITCH;
+
+__global__ __launch_bounds__(256) void wgrad3x3_up_kernel(const WgradArgs p) {
+    using SH = WideShape<1, 1>;
+    constexpr int TAPS = 9, CO_T = 64, CI_T = 64, PW = SH::PW, PLANE = SH::PLANE, GPITCH = SH::GPITCH, XPITCH = SH::XPITCH, BUF = SH::BUF;
+    constexpr int NG4 = 4, STEPS = 32, HS = 16, EPT = CI_T * PLANE / 256;       // 27 plane elements per thread
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    float* const sbuf = smem + 2 * BUF;                  // two source-patch buffers behind the two tile buffers
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l32 = lane & 31;
+    const int wco = wave & 1, wci = wave >> 1;
+
+    const int co0 = blockIdx.x * CO_T;
+    const int grp = co0 / p.Cout;
+    const int co_end = (grp + 1) * p.Cout;
+    const int cx0 = grp * p.gin;
+    const int ci0 = blockIdx.y * CI_T;
+    const int nci = min(CI_T, p.Cin - ci0);
+
+    // ---- staging roles ----
+    const int gk = tid & 3, grow = (tid >> 2) & 3;
+    int g_off[NG4];
+#pragma unroll
+    for (int i = 0; i < NG4; ++i) g_off[i] = (min(co0 + (tid >> 4) + 16 * i, co_end - 1) * p.H + grow) * p.W + 4 * gk;
+    const int g_dst = (tid >> 4) * GPITCH + grow * 16 + 4 * gk;
+    // source patch: piece i in {0, 1} = source row rh + 2 i of channel sc: float4 sk (columns x0/2 + 4 sk ..) and the halo column
+    // x0/2 - 1 (sk = 0) / x0/2 + 8 (sk = 1)
+    const int sk = tid & 1, sc = (tid >> 1) & 63, rh = tid >> 7;
+    const int s_chan = (cx0 + ci0 + min(sc, nci - 1)) * p.Hs;
+    const int s_dst4 = sc * US_PITCH + rh * US_PW + 1 + 4 * sk;      // + 2 i US_PW + j
+    const int s_dsth = sc * US_PITCH + rh * US_PW + (sk ? 9 : 0);    // + 2 i US_PW
+
+    f32x16 acc[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    // per-tile state: (g) the gradient tile being staged; (s) the source patch being staged; (i) the tile being interpolated
+    f32x4 gq[NG4], sq[2];
+    float sh[2];
+    const float* gbase = p.g;
+    const float* sbase = p.x;
+    bool g_ok = false, s4col = false, shcol = false;
+    int s_y0 = 0, i_y0 = 0, i_x0 = 0;
+    auto origin = [&](int tile, int& b, int& y0, int& x0) {
+        const int tx = tile % p.tiles_x;
+        const int q = tile / p.tiles_x;
+        b = q / p.tiles_y; y0 = (q % p.tiles_y) * 4; x0 = tx * 16;
+    };
+    auto aim_g = [&](int tile) {
+        int b, y0, x0;
+        origin(tile, b, y0, x0);
+        gbase = p.g + ((size_t)b * p.Cy * p.H + y0) * p.W + x0;
+        g_ok = y0 + grow < p.H && x0 + 4 * gk < p.W;
+    };
+    auto aim_s = [&](int tile) {
+        int b, y0, x0;
+        origin(tile, b, y0, x0);
+        s_y0 = (y0 >> 1) - 1;                                         // first source row of the patch (may be -1)
+        sbase = p.x + ((size_t)b * p.Cx * p.Hs) * p.Ws + (x0 >> 1);
+        s4col = (x0 >> 1) + 4 * sk < p.Ws;                             // Ws % 4 == 0: the vector is in or out as a whole
+        shcol = (unsigned)((x0 >> 1) + (sk ? 8 : -1)) < (unsigned)p.Ws;
+    };
+    auto aim_i = [&](int tile) { int b; origin(tile, b, i_y0, i_x0); };
+    auto s_row = [&](int i) { return s_y0 + rh + 2 * i; };
+    auto load_g = [&](auto j_) { constexpr int j = decltype(j_)::value; gq[j] = *reinterpret_cast<const f32x4*>(g_ok ? gbase + g_off[j] : p.g); };
+    auto store_g = [&](float* buf, auto s_) {
+        constexpr int s = decltype(s_)::value, i = s / 4, j = s % 4;
+        buf[g_dst + 16 * i * GPITCH + j] = g_ok ? gq[i][j] : 0.f;
+    };
+    auto load_s = [&](auto j_) {              // j: 0, 1 = float4 of piece j; 2, 3 = halo of piece j - 2
+        constexpr int j = decltype(j_)::value, i = j & 1;
+        const int row = s_row(i);
+        const bool rok = (unsigned)row < (unsigned)p.Hs;
+        if constexpr (j < 2) sq[i] = *reinterpret_cast<const f32x4*>((rok && s4col) ? sbase + (size_t)(s_chan + row) * p.Ws + 4 * sk : p.x);
+        else sh[i] = *((rok && shcol) ? sbase + (size_t)(s_chan + row) * p.Ws + (sk ? 8 : -1) : p.x);
+    };
+    auto store_s = [&](float* sb, auto s_) {  // s: 0..7 = element s % 4 of float4 piece s / 4; 8, 9 = halo of piece s - 8
+        constexpr int s = decltype(s_)::value;
+        if constexpr (s < 8) {
+            constexpr int i = s / 4, j = s % 4;
+            sb[s_dst4 + 2 * i * US_PW + j] = ((unsigned)s_row(i) < (unsigned)p.Hs && s4col) ? sq[i][j] : 0.f;
+        } else {
+            constexpr int i = s - 8;
+            sb[s_dsth + 2 * i * US_PW] = ((unsigned)s_row(i) < (unsigned)p.Hs && shcol) ? sh[i] : 0.f;
+        }
+    };
+    // plane element e = wave * 27 + i of channel `lane` (a wave owns a quarter of the 108 positions): everything but the
+    // channel is wave-uniform, so the tap offsets and weights live in scalar registers
+    const float* const s_lane = nullptr;
+    auto interp = [&](float* buf, const float* sb, int i) {
+        const int e = wave * EPT + i;
+        const int r = e / PW, c = e - r * PW;
+        const int uy = i_y0 - 1 + r, ux = i_x0 - 1 + c;
+        float v = 0.f;
+        if (uy >= 0 && uy < p.H && ux >= 0 && ux < p.W) {          // uniform
+            const int iy0 = uy == 0 ? 0 : (uy - 1) >> 1, ix0 = ux == 0 ? 0 : (ux - 1) >> 1;
+            const float ly1 = uy == 0 ? 0.f : ((uy & 1) ? 0.25f : 0.75f), lx1 = ux == 0 ? 0.f : ((ux & 1) ? 0.25f : 0.75f);
+            const int dy = iy0 + 1 < p.Hs ? US_PW : 0, dx = ix0 + 1 < p.Ws ? 1 : 0;
+            const float* q = sb + lane * US_PITCH + (iy0 - (i_y0 >> 1) + 1) * US_PW + (ix0 - (i_x0 >> 1) + 1);
+            const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
+            v = ly0 * (lx0 * q[0] + lx1 * q[dx]) + ly1 * (lx0 * q[dy] + lx1 * q[dy + dx]);
+        }
+        buf[CO_T * GPITCH + lane * XPITCH + e] = v;
+    };
+    (void)s_lane;
+
+    const int stride = (int)gridDim.z;
+    int tile = blockIdx.z;
+    int cur = 0, par = 0;                      // tile buffer in use; source buffer holding the patch of tile `tile + stride`... see below
+    // ---- prologue: S(k = 0) -> sbuf[0], S(k = 1) -> sbuf[1], G(0) -> buf 0; barrier; plane(0) by interpolation; barrier ----
+    if (tile < p.n_tiles) {
+        aim_s(tile);
+        wg_static_for<0, 4>([&](auto j_) { load_s(j_); });
+        wg_static_for<0, 10>([&](auto s_) { store_s(sbuf, s_); });
+        if (tile + stride < p.n_tiles) {
+            aim_s(tile + stride);
+            wg_static_for<0, 4>([&](auto j_) { load_s(j_); });
+            wg_static_for<0, 10>([&](auto s_) { store_s(sbuf + US_FLOATS, s_); });
+        }
+        aim_g(tile);
+        wg_static_for<0, NG4>([&](auto j_) { load_g(j_); });
+        wg_static_for<0, 4 * NG4>([&](auto s_) { store_g(smem, s_); });
+        __syncthreads();
+        aim_i(tile);
+        for (int i = 0; i < EPT; ++i) interp(smem, sbuf, i);
+    }
+    __syncthreads();
+
+    // iteration k computes tile k out of buf[cur]; meanwhile G(k+1) is loaded / stored into the other tile buffer, the plane of
+    // tile k+1 is interpolated into it from sbuf[(k+1) & 1], and the source patch of tile k+2 is loaded and stored into
+    // sbuf[k & 1] (whose previous content, the patch of tile k, was last read during iteration k - 1)
+    auto run_tile = [&](auto has1_, auto has2_) {
+        constexpr bool H1 = decltype(has1_)::value, H2 = decltype(has2_)::value;
+        const float* cbuf = smem + cur * BUF;
+        float* nbuf = smem + (cur ^ 1) * BUF;
+        const float* s_next = sbuf + (par ^ 1) * US_FLOATS;          // patch of tile k+1
+        float* s_fill = sbuf + par * US_FLOATS;                       // patch of tile k+2 goes here
+        const float* ga = cbuf + (wco * 32 + l32) * GPITCH + half;
+        const float* xb = cbuf + CO_T * GPITCH + (wci * 32 + l32) * XPITCH + half;
+        float fa[2], fb[2][TAPS];
+#define SPK_WU_FRAG(st_, slot_)                                                                               \
+    {                                                                                                         \
+        constexpr int px_ = (2 * (st_)) & 15, py_ = (2 * (st_)) >> 4;                                         \
+        fa[slot_] = ga[2 * (st_)];                                                                            \
+        _Pragma("unroll") for (int t = 0; t < TAPS; ++t) fb[slot_][t] = xb[(py_ + t / 3) * PW + px_ + t % 3];  \
+    }
+        SPK_WU_FRAG(0, 0);
+        wg_static_for<0, STEPS>([&](auto s_) {
+            constexpr int st = decltype(s_)::value;
+            if constexpr (st + 1 < STEPS) SPK_WU_FRAG(st + 1, (st + 1) & 1);
+            if constexpr (H1 && st < NG4) load_g(std::integral_constant<int, st < NG4 ? st : 0>{});
+            if constexpr (H2 && st >= NG4 && st < NG4 + 4) load_s(std::integral_constant<int, (st >= NG4 && st < NG4 + 4) ? st - NG4 : 0>{});
+            if constexpr (H1 && st < EPT) interp(nbuf, s_next, st);
+            if constexpr (H1 && st >= HS) store_g(nbuf, std::integral_constant<int, st >= HS ? st - HS : 0>{});
+            if constexpr (H2 && st >= HS && st < HS + 10) store_s(s_fill, std::integral_constant<int, (st >= HS && st < HS + 10) ? st - HS : 0>{});
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[st & 1], fb[st & 1][t], acc[t], 0, 0, 0);
+        });
+#undef SPK_WU_FRAG
+    };
+
+    for (; tile < p.n_tiles; tile += stride) {
+        const bool has1 = tile + stride < p.n_tiles, has2 = tile + 2 * stride < p.n_tiles;      // uniform
+        if (has1) { aim_g(tile + stride); aim_i(tile + stride); }
+        if (has2) aim_s(tile + 2 * stride);
+        if (has2) run_tile(std::true_type{}, std::true_type{});
+        else if (has1) run_tile(std::true_type{}, std::false_type{});
+        else run_tile(std::false_type{}, std::false_type{});
+        __syncthreads();
+        cur ^= 1;
+        par ^= 1;
+    }
+
+    // ---- partial block -> slab [slab][co][tap][ci] ----
+    float* out = p.slabs + (size_t)blockIdx.z * p.Cy * TAPS * p.Cin;
+    const int ci = ci0 + wci * 32 + l32;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (co < co_end && ci < p.Cin) out[((size_t)co * TAPS + t) * p.Cin + ci] = acc[t][r];
+        }
+}
+
 // dW[co][ci][tap] (+)= scale * sum_slab slabs[slab][co][tap][ci]   (fixed order)
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, float* __restrict__ dw,
                                                           int n_slabs, int Cout_all, int Cin, int taps, float scale,
@@ -786,6 +985,46 @@ int run_wgrad_wide(const spk_wgrad_desc* d, hipStream_t stream) {
     dim3 grid((unsigned)spk::ceil_div(G * d->Cout, SH::CO_T), (unsigned)spk::ceil_div(d->Cin, SH::CI_T), (unsigned)g.splits);
     hipLaunchKernelGGL(kern, grid, dim3(256), 2 * SH::BUF * sizeof(float), stream, a);
     int rc = spk::check_launch("wgrad3x3_wide_kernel");
+    if (rc != SPK_OK) return rc;
+    const unsigned blocks = (unsigned)std::min<size_t>((slab_floats + 255) / 256, 2048);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, a.slabs, d->dw, g.n_slabs, G * d->Cout, d->Cin, 9,
+                       d->scale, d->accumulate ? 1 : 0, d->fold > 1 ? d->fold : 1);
+    return spk::check_launch("wgrad_reduce_kernel");
+}
+
+// the upsample-folded form: x is the LOW-resolution tensor [B, Cin, H/2, W/2]
+inline bool up_takes(const spk_wgrad_desc* d) {
+    const int G = d->groups > 1 ? d->groups : 1;
+    const auto aligned = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    return d->kh == 3 && d->kw == 3 && d->stride == 1 && d->W >= 16 && d->W % 8 == 0 && d->H >= 4 && d->H % 2 == 0 && aligned(d->g) &&
+           aligned(d->x) && (long long)G * d->Cout * d->H * d->W < (1ll << 31) && (G == 1 || d->Cout % 64 == 0) &&
+           ((long long)d->group_in_stride * (G - 1) + d->Cin) * d->Hin * d->Win < (1ll << 31);
+}
+
+int run_wgrad_up(const spk_wgrad_desc* d, hipStream_t stream) {
+    using SH = WideShape<1, 1>;
+    const int G = d->groups > 1 ? d->groups : 1;
+    const WideGeom g = wide_geom(SH::CO_T, SH::CI_T, d->B, d->Cin, G * d->Cout, d->H, d->W, d->splits);
+    const size_t slab_floats = (size_t)G * d->Cout * d->Cin * 9;
+    SPK_REQUIRE(d->workspace && (size_t)d->workspace_bytes >= g.n_slabs * slab_floats * sizeof(float),
+                "wgrad: needs a %zu-byte workspace (see spk_conv2d_wgrad_workspace_bytes)", g.n_slabs * slab_floats * sizeof(float));
+    WgradArgs a;
+    a.g = d->g; a.x = d->x; a.in_scale = nullptr; a.in_shift = nullptr; a.slabs = static_cast<float*>(d->workspace);
+    a.B = d->B; a.Cin = d->Cin; a.Cout = d->Cout; a.H = d->H; a.W = d->W; a.Hs = d->Hin; a.Ws = d->Win;
+    a.gin = G > 1 ? d->group_in_stride : d->Cin;
+    a.Cx = a.gin * (G - 1) + d->Cin;
+    a.Cy = G * d->Cout;
+    a.lgTW = 4; a.lgTH = 2; a.lgTB = 0;
+    a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y; a.n_tiles = g.n_tiles;
+    static bool raised = false;
+    if (!raised) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_up_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return spk::fail(SPK_ELAUNCH, "hipFuncSetAttribute(LDS): %s", hipGetErrorString(e));
+        raised = true;
+    }
+    dim3 grid((unsigned)spk::ceil_div(G * d->Cout, SH::CO_T), (unsigned)spk::ceil_div(d->Cin, SH::CI_T), (unsigned)g.splits);
+    hipLaunchKernelGGL(wgrad3x3_up_kernel, grid, dim3(256), (2 * SH::BUF + 2 * US_FLOATS) * sizeof(float), stream, a);
+    int rc = spk::check_launch("wgrad3x3_up_kernel");
     if (rc != SPK_OK) return rc;
     const unsigned blocks = (unsigned)std::min<size_t>((slab_floats + 255) / 256, 2048);
     hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, a.slabs, d->dw, g.n_slabs, G * d->Cout, d->Cin, 9,
@@ -1132,6 +1371,11 @@ int64_t spk_conv2d_wgrad_workspace_bytes(int kh, int kw, int stride, int splits,
     return (int64_t)n_slabs * Cout * Cin * kh * kw * (int64_t)sizeof(float);
 }
 
+int spk_conv2d_wgrad_up_supported(int B, int Cin, int Cout, int H, int W) {
+    return (B > 0 && Cin > 0 && Cout > 0 && W >= 16 && W % 8 == 0 && H >= 4 && H % 2 == 0 && (long long)Cout * H * W < (1ll << 31) &&
+            (long long)Cin * H * W / 4 < (1ll << 31)) ? 1 : 0;
+}
+
 int spk_conv2d_wgrad(const spk_wgrad_desc* d, void* stream) {
     SPK_REQUIRE(d && d->g && d->x && d->dw, "wgrad: null pointer");
     SPK_REQUIRE(d->B > 0 && d->Cin > 0 && d->Cout > 0 && d->H > 0 && d->W > 0 && d->Hin > 0 && d->Win > 0, "wgrad: bad shape");
@@ -1147,9 +1391,13 @@ int spk_conv2d_wgrad(const spk_wgrad_desc* d, void* stream) {
                      "wgrad: output size %dx%d does not match input %dx%d", d->H, d->W, d->Hin, d->Win);
     hipStream_t s = (hipStream_t)stream;
     const int mode = aff ? WG_AFFINE_RELU : WG_PLAIN;
-    // the bilinear-folded variant lost to "materialise the x2 image once, then plain wgrad" by 2x (4 gathers per
-    // element cannot be prefetched in registers); callers upsample with spk_upsample2x_bilinear_fwd first
-    if (ups) return spk::fail(SPK_EUNSUPPORTED, "wgrad: pass the upsampled input (spk_upsample2x_bilinear_fwd) instead of SPK_CONV_UPSAMPLE2X");
+    // SPK_CONV_UPSAMPLE2X: x is the low-resolution tensor; the x2 plane is interpolated LDS -> LDS from a source patch
+    // (wgrad3x3_up_kernel).  Shapes it does not take (W % 8 != 0, planes under 16 x 4): callers upsample with
+    // spk_upsample2x_bilinear_fwd first -- spk_conv2d_wgrad_up_supported tells which.
+    if (ups) {
+        if (up_takes(d)) return run_wgrad_up(d, s);
+        return spk::fail(SPK_EUNSUPPORTED, "wgrad: SPK_CONV_UPSAMPLE2X does not take this shape: pass the upsampled input (spk_upsample2x_bilinear_fwd)");
+    }
     if (d->kh == 1 && g1_takes(d->groups, d->Cout, d->H, d->W)) {
         if (d->stride == 1) return aff ? run_wgrad1x1<1, WG_AFFINE_RELU>(d, s) : run_wgrad1x1<1, WG_PLAIN>(d, s);
         return aff ? run_wgrad1x1<2, WG_AFFINE_RELU>(d, s) : run_wgrad1x1<2, WG_PLAIN>(d, s);

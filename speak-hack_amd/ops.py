@@ -360,9 +360,10 @@ def conv2d_wgrad(g, x, Cout, Cin, k=3, stride=1, *, upsample=False, in_affine=No
     ``fold`` > 1: groups q and q + groups/fold share their weights (the same conv on another image set): their
     gradients are summed in the slab reduce and the result is [groups/fold*Cout, Cin, k, k]."""
     B, _, H, W = g.shape
-    if upsample:
-        # materialise the x2 image once (one HBM-bound pass) and run the plain kernel: measured 2x faster than
-        # forming the bilinear taps inside the wgrad staging, whose 4 gathers per element cannot be prefetched
+    if upsample and (int(groups) > 1 or not L.lib().spk_conv2d_wgrad_up_supported(B, Cin, int(groups) * Cout, H, W)
+                     or x.data_ptr() % 16 or g.data_ptr() % 16):
+        # small or odd planes: materialise the x2 image once and run the plain kernel.  Everything else (W % 8 == 0, at least
+        # 16 x 4) interpolates the plane LDS -> LDS from a low-resolution source patch inside the kernel: no x2 tensor in HBM.
         x, upsample = upsample2x_bilinear(x), False
     Hs, Ws = x.shape[-2:]
     G = int(groups)

@@ -229,3 +229,25 @@ def test_batch8_training_step_vs_oracle(pkg, dev):
               "synthesis.layers.3.conv1.bias", "synthesis.layers.4.noise1.weight", "synthesis.layers.5.conv1.weight",
               "synthesis.layers.5.style_mod2.linear.weight", "synthesis.to_rgb.weight"):
         assert rel_l2(got[k].grad, sd_ref[k].grad) < tol(k), k
+
+
+@pytest.mark.parametrize("B,Cin,Cout,Hs,Ws", [(2, 64, 64, 16, 16), (1, 20, 40, 12, 12), (3, 70, 130, 6, 20), (2, 64, 64, 32, 32),
+                                               (1, 128, 72, 10, 36), (8, 128, 64, 16, 16)])
+def test_wgrad_of_upsampled_input_without_materialising_it(pkg, dev, B, Cin, Cout, Hs, Ws):
+    """dW of conv3x3(bilinear_x2(x)) from the LOW-resolution x (SPK_CONV_UPSAMPLE2X in spk_conv2d_wgrad: the x2 plane is
+    interpolated LDS -> LDS from a source patch; round 1 wrote the x2 tensor to HBM first) against autograd of
+    F.interpolate + F.conv2d -- partial tiles in both directions, ragged channel blocks, one workgroup walking many tiles
+    (splits = 1) so that the two-tile-ahead pipeline is exercised, and the accumulate / scale form."""
+    tag = f"wgu.{B}.{Cin}.{Cout}.{Hs}.{Ws}"
+    x = recipe_input(tag + ".x", (B, Cin, Hs, Ws))
+    w = recipe_tensor(tag + ".weight", (Cout, Cin, 3, 3)).requires_grad_(True)
+    y = F.conv2d(F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False), w, padding=1)
+    g = recipe_input(tag + ".g", y.shape)
+    y.backward(g)
+    assert pkg._lib.lib().spk_conv2d_wgrad_up_supported(B, Cin, Cout, 2 * Hs, 2 * Ws)
+    for splits in (0, 1, 3):
+        dw = pkg.ops.conv2d_wgrad(g.to(dev), x.to(dev), Cout, Cin, 3, 1, upsample=True, splits=splits)
+        assert rel_l2(dw, w.grad) < TOL, splits
+    base = recipe_tensor(tag + ".base", w.shape).to(dev)
+    acc = pkg.ops.conv2d_wgrad(g.to(dev), x.to(dev), Cout, Cin, 3, 1, upsample=True, scale=0.5, out=base.clone(), accumulate=True)
+    assert rel_l2(acc, base.cpu() + 0.5 * w.grad) < TOL
