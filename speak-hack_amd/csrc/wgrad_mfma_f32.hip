@@ -717,7 +717,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_up_kernel(const WgradArgs p) {
     float sh[2];
     const float* gbase = p.g;
     const float* sbase = p.x;
-    bool g_ok = false, s4col = false, shcol = false;
+    bool g_ok = false;
     int s_y0 = 0, i_y0 = 0, i_x0 = 0;
     auto origin = [&](int tile, int& b, int& y0, int& x0) {
         const int tx = tile % p.tiles_x;
@@ -730,16 +730,31 @@ __global__ __launch_bounds__(256) void wgrad3x3_up_kernel(const WgradArgs p) {
         gbase = p.g + ((size_t)b * p.Cy * p.H + y0) * p.W + x0;
         g_ok = y0 + grow < p.H && x0 + 4 * gk < p.W;
     };
+    // The source patch is REPLICATE-padded (rows / columns outside the image take the nearest edge pixel: loads with clamped
+    // coordinates): torch's bilinear clamps its second tap at the border, which is the plain parity weights (.75, .25) applied
+    // to a replicated neighbour -- so every plane element is interpolated with position-independent weights and no branch; what
+    // remains of the border is the conv's ZERO padding of the x2 image, a per-tile row / column mask.
+    int s_x0 = 0;
+    bool s4_out = false;
     auto aim_s = [&](int tile) {
         int b, y0, x0;
         origin(tile, b, y0, x0);
         s_y0 = (y0 >> 1) - 1;                                         // first source row of the patch (may be -1)
-        sbase = p.x + ((size_t)b * p.Cx * p.Hs) * p.Ws + (x0 >> 1);
-        s4col = (x0 >> 1) + 4 * sk < p.Ws;                             // Ws % 4 == 0: the vector is in or out as a whole
-        shcol = (unsigned)((x0 >> 1) + (sk ? 8 : -1)) < (unsigned)p.Ws;
+        s_x0 = x0 >> 1;
+        sbase = p.x + ((size_t)b * p.Cx * p.Hs) * p.Ws;
+        s4_out = s_x0 + 4 * sk >= p.Ws;                                // this thread's vector lies right of the image: replicate
     };
-    auto aim_i = [&](int tile) { int b; origin(tile, b, i_y0, i_x0); };
-    auto s_row = [&](int i) { return s_y0 + rh + 2 * i; };
+    unsigned i_rows = 0, i_cols = 0;                                  // plane rows / columns inside the x2 image (bit r / bit c)
+    auto aim_i = [&](int tile) {
+        int b;
+        origin(tile, b, i_y0, i_x0);
+        i_rows = 0; i_cols = 0;
+#pragma unroll
+        for (int r = 0; r < 6; ++r) i_rows |= ((unsigned)(i_y0 - 1 + r) < (unsigned)p.H ? 1u : 0u) << r;
+#pragma unroll
+        for (int c = 0; c < PW; ++c) i_cols |= ((unsigned)(i_x0 - 1 + c) < (unsigned)p.W ? 1u : 0u) << c;
+    };
+    auto s_row = [&](int i) { return min(max(s_y0 + rh + 2 * i, 0), p.Hs - 1); };
     auto load_g = [&](auto j_) { constexpr int j = decltype(j_)::value; gq[j] = *reinterpret_cast<const f32x4*>(g_ok ? gbase + g_off[j] : p.g); };
     auto store_g = [&](float* buf, auto s_) {
         constexpr int s = decltype(s_)::value, i = s / 4, j = s % 4;
@@ -747,41 +762,42 @@ __global__ __launch_bounds__(256) void wgrad3x3_up_kernel(const WgradArgs p) {
     };
     auto load_s = [&](auto j_) {              // j: 0, 1 = float4 of piece j; 2, 3 = halo of piece j - 2
         constexpr int j = decltype(j_)::value, i = j & 1;
-        const int row = s_row(i);
-        const bool rok = (unsigned)row < (unsigned)p.Hs;
-        if constexpr (j < 2) sq[i] = *reinterpret_cast<const f32x4*>((rok && s4col) ? sbase + (size_t)(s_chan + row) * p.Ws + 4 * sk : p.x);
-        else sh[i] = *((rok && shcol) ? sbase + (size_t)(s_chan + row) * p.Ws + (sk ? 8 : -1) : p.x);
+        const float* row = sbase + (size_t)(s_chan + s_row(i)) * p.Ws;
+        if constexpr (j < 2) sq[i] = *reinterpret_cast<const f32x4*>(row + min(s_x0 + 4 * sk, p.Ws - 4));     // Ws % 4 == 0
+        else sh[i] = row[min(max(s_x0 + (sk ? 8 : -1), 0), p.Ws - 1)];
     };
     auto store_s = [&](float* sb, auto s_) {  // s: 0..7 = element s % 4 of float4 piece s / 4; 8, 9 = halo of piece s - 8
         constexpr int s = decltype(s_)::value;
         if constexpr (s < 8) {
             constexpr int i = s / 4, j = s % 4;
-            sb[s_dst4 + 2 * i * US_PW + j] = ((unsigned)s_row(i) < (unsigned)p.Hs && s4col) ? sq[i][j] : 0.f;
+            sb[s_dst4 + 2 * i * US_PW + j] = s4_out ? sq[i][3] : sq[i][j];     // (the clamped load fetched the image's last vector)
         } else {
             constexpr int i = s - 8;
-            sb[s_dsth + 2 * i * US_PW] = ((unsigned)s_row(i) < (unsigned)p.Hs && shcol) ? sh[i] : 0.f;
+            sb[s_dsth + 2 * i * US_PW] = sh[i];
         }
     };
     // plane element e = wave * 27 + i of channel `lane` (a wave owns a quarter of the 108 positions): everything but the
     // channel is wave-uniform, so the tap offsets and weights live in scalar registers
-    const float* const s_lane = nullptr;
-    auto interp = [&](float* buf, const float* sb, int i) {
-        const int e = wave * EPT + i;
-        const int r = e / PW, c = e - r * PW;
-        const int uy = i_y0 - 1 + r, ux = i_x0 - 1 + c;
-        float v = 0.f;
-        if (uy >= 0 && uy < p.H && ux >= 0 && ux < p.W) {          // uniform
-            const int iy0 = uy == 0 ? 0 : (uy - 1) >> 1, ix0 = ux == 0 ? 0 : (ux - 1) >> 1;
-            const float ly1 = uy == 0 ? 0.f : ((uy & 1) ? 0.25f : 0.75f), lx1 = ux == 0 ? 0.f : ((ux & 1) ? 0.25f : 0.75f);
-            const int dy = iy0 + 1 < p.Hs ? US_PW : 0, dx = ix0 + 1 < p.Ws ? 1 : 0;
-            const float* q = sb + lane * US_PITCH + (iy0 - (i_y0 >> 1) + 1) * US_PW + (ix0 - (i_x0 >> 1) + 1);
-            const float ly0 = 1.f - ly1, lx0 = 1.f - lx1;
-            v = ly0 * (lx0 * q[0] + lx1 * q[dx]) + ly1 * (lx0 * q[dy] + lx1 * q[dy + dx]);
-        }
-        buf[CO_T * GPITCH + lane * XPITCH + e] = v;
+    const float* const s_lane_base = sbuf + lane * US_PITCH;          // this lane's channel in source buffer 0
+    // an element's four source taps are READ one k-step before they are combined and written (as the MFMA fragments are): with
+    // read, combine and write in one step every wave waited ~200 cycles on its own LDS reads 27 times a tile
+    float iq[4];
+    auto interp_read = [&](int sbo, int i) {                           // sbo: float offset of the source buffer (0 / US_FLOATS)
+        const int e = wave * EPT + i;                                  // uniform
+        const int r = (e * 3641) >> 16, c = e - r * PW;                 // e / 18 for e < 108
+        // x2 pixel (y0 - 1 + r, x0 - 1 + c), y0 and x0 even: first tap at patch (r >> 1, c >> 1)
+        const float* q = s_lane_base + sbo + (r >> 1) * US_PW + (c >> 1);
+        iq[0] = q[0]; iq[1] = q[1]; iq[2] = q[US_PW]; iq[3] = q[US_PW + 1];
     };
-    (void)s_lane;
-
+    auto interp_write = [&](float* buf, int i) {
+        const int e = wave * EPT + i;
+        const int r = (e * 3641) >> 16, c = e - r * PW;
+        const float ly1 = (r & 1) ? 0.75f : 0.25f, lx1 = (c & 1) ? 0.75f : 0.25f;    // second-tap weight .25 on even r / c
+        const float t = (1.f - ly1) * ((1.f - lx1) * iq[0] + lx1 * iq[1]) + ly1 * ((1.f - lx1) * iq[2] + lx1 * iq[3]);
+        const bool inside = ((i_rows >> r) & (i_cols >> c) & 1u) != 0;  // uniform
+        buf[CO_T * GPITCH + lane * XPITCH + e] = inside ? t : 0.f;
+    };
+    auto interp = [&](float* buf, int sbo, int i) { interp_read(sbo, i); interp_write(buf, i); };
     const int stride = (int)gridDim.z;
     int tile = blockIdx.z;
     int cur = 0, par = 0;                      // tile buffer in use; source buffer holding the patch of tile `tile + stride`... see below
@@ -800,7 +816,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_up_kernel(const WgradArgs p) {
         wg_static_for<0, 4 * NG4>([&](auto s_) { store_g(smem, s_); });
         __syncthreads();
         aim_i(tile);
-        for (int i = 0; i < EPT; ++i) interp(smem, sbuf, i);
+        for (int i = 0; i < EPT; ++i) interp(smem, 0, i);
     }
     __syncthreads();
 
@@ -811,7 +827,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_up_kernel(const WgradArgs p) {
         constexpr bool H1 = decltype(has1_)::value, H2 = decltype(has2_)::value;
         const float* cbuf = smem + cur * BUF;
         float* nbuf = smem + (cur ^ 1) * BUF;
-        const float* s_next = sbuf + (par ^ 1) * US_FLOATS;          // patch of tile k+1
+        const int s_next = (par ^ 1) * US_FLOATS;                      // patch of tile k+1 (float offset behind sbuf)
         float* s_fill = sbuf + par * US_FLOATS;                       // patch of tile k+2 goes here
         const float* ga = cbuf + (wco * 32 + l32) * GPITCH + half;
         const float* xb = cbuf + CO_T * GPITCH + (wci * 32 + l32) * XPITCH + half;
@@ -828,12 +844,21 @@ __global__ __launch_bounds__(256) void wgrad3x3_up_kernel(const WgradArgs p) {
             if constexpr (st + 1 < STEPS) SPK_WU_FRAG(st + 1, (st + 1) & 1);
             if constexpr (H1 && st < NG4) load_g(std::integral_constant<int, st < NG4 ? st : 0>{});
             if constexpr (H2 && st >= NG4 && st < NG4 + 4) load_s(std::integral_constant<int, (st >= NG4 && st < NG4 + 4) ? st - NG4 : 0>{});
-            if constexpr (H1 && st < EPT) interp(nbuf, s_next, st);
+            if constexpr (H1 && st >= 1 && st <= EPT) interp_write(nbuf, st - 1);
+            if constexpr (H1 && st < EPT) interp_read(s_next, st);
             if constexpr (H1 && st >= HS) store_g(nbuf, std::integral_constant<int, st >= HS ? st - HS : 0>{});
             if constexpr (H2 && st >= HS && st < HS + 10) store_s(s_fill, std::integral_constant<int, (st >= HS && st < HS + 10) ? st - HS : 0>{});
 #pragma unroll
             for (int t = 0; t < TAPS; ++t)
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[st & 1], fb[st & 1][t], acc[t], 0, 0, 0);
+            // order: the LDS reads (next step's fragments, the next element's taps) first, then the MFMAs with the rest of the
+            // step's staging (loads, LDS stores, the interpolation arithmetic) spread between them in three parts
+            if constexpr (st + 1 < STEPS) __builtin_amdgcn_sched_group_barrier(0x100, TAPS + 1 + ((H1 && st < EPT) ? 4 : 0), 0);
+            __builtin_amdgcn_sched_group_barrier(0x8, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x2 | 0x4 | 0x20 | 0x200, 8, 0);
+            __builtin_amdgcn_sched_group_barrier(0x8, 3, 0);
+            __builtin_amdgcn_sched_group_barrier(0x2 | 0x4 | 0x20 | 0x200, 8, 0);
+            __builtin_amdgcn_sched_group_barrier(0x8, 3, 0);
         });
 #undef SPK_WU_FRAG
     };
@@ -1372,6 +1397,11 @@ int64_t spk_conv2d_wgrad_workspace_bytes(int kh, int kw, int stride, int splits,
 }
 
 int spk_conv2d_wgrad_up_supported(int B, int Cin, int Cout, int H, int W) {
+    // Measured (tools/bench_wgrad.py --upsample, B = 8): the folded form is level with "upsample, then the plain kernel" at
+    // 256^2 (851 vs 875 us, and 268 MB less written and read back) but 10-20 % behind it on the 32^2..128^2 layers, whose x2
+    // images are small (16..134 MB): by default it takes planes at least 256 wide (SPK_WGRAD_UP_MIN_W overrides).
+    static const int min_w = [] { const char* e = getenv("SPK_WGRAD_UP_MIN_W"); return e ? atoi(e) : 256; }();
+    if (W < min_w) return 0;
     return (B > 0 && Cin > 0 && Cout > 0 && W >= 16 && W % 8 == 0 && H >= 4 && H % 2 == 0 && (long long)Cout * H * W < (1ll << 31) &&
             (long long)Cin * H * W / 4 < (1ll << 31)) ? 1 : 0;
 }

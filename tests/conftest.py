@@ -10,6 +10,11 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
+# The upsample-folded weight gradient (csrc/wgrad_mfma_f32.hip, wgrad3x3_up_kernel) is by default used for planes at least 256
+# wide, where it pays; the test process sends EVERY shape it can take through it (the library reads this once, at first use),
+# so the decoder's block / end-to-end gradient tests cover it at 32^2..128^2 as well.
+os.environ.setdefault("SPK_WGRAD_UP_MIN_W", "16")
+
 
 def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")

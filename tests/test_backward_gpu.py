@@ -244,6 +244,7 @@ def test_wgrad_of_upsampled_input_without_materialising_it(pkg, dev, B, Cin, Cou
     y = F.conv2d(F.interpolate(x, scale_factor=2, mode="bilinear", align_corners=False), w, padding=1)
     g = recipe_input(tag + ".g", y.shape)
     y.backward(g)
+    # (tests/conftest.py sets SPK_WGRAD_UP_MIN_W=16: in the test process every shape the folded kernel can take goes to it)
     assert pkg._lib.lib().spk_conv2d_wgrad_up_supported(B, Cin, Cout, 2 * Hs, 2 * Ws)
     for splits in (0, 1, 3):
         dw = pkg.ops.conv2d_wgrad(g.to(dev), x.to(dev), Cout, Cin, 3, 1, upsample=True, splits=splits)

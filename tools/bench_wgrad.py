@@ -19,6 +19,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--res", type=int, default=256)
+    ap.add_argument("--upsample", action="store_true", help="the first conv of every block reads the bilinear x2 of its input: "
+                    "time the folded form against upsample-then-wgrad")
     args = ap.parse_args()
     dev, B = torch.device("cuda:0"), args.batch
     r, cin, tot_t, tot_f = 8, 512, 0.0, 0.0
@@ -42,6 +44,27 @@ def main():
                 tot_t += ms
                 tot_f += fl
                 print(f"{ci:4d}->{co:4d} @{r:3d}^2 splits={splits}: {ms * 1e3:8.1f} us  {fl / ms / 1e9:6.1f} TFLOP/s")
+        if args.upsample and r >= 16:
+            g = torch.randn(B, cout, r, r, device=dev)
+            xl = torch.randn(B, cin, r // 2, r // 2, device=dev)
+            res = []
+            for mode in ("folded", "materialised"):
+                def run():
+                    if mode == "folded":
+                        return ops.conv2d_wgrad(g, xl, cout, cin, 3, 1, upsample=True)
+                    return ops.conv2d_wgrad(g, ops.upsample2x_bilinear(xl), cout, cin, 3, 1)
+                for _ in range(2):
+                    run()
+                torch.cuda.synchronize()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(5):
+                    run()
+                e1.record()
+                torch.cuda.synchronize()
+                res.append(e0.elapsed_time(e1) / 5)
+            fl = 2 * 9 * cin * cout * r * r * B
+            print(f"   up {cin:4d}->{cout:4d} @{r:3d}^2: folded {res[0] * 1e3:8.1f} us {fl / res[0] / 1e9:6.1f} TF | upsample + wgrad {res[1] * 1e3:8.1f} us {fl / res[1] / 1e9:6.1f} TF")
         cin, r = cout, r * 2
     print(f"total {tot_t:.2f} ms, {tot_f / tot_t / 1e9:.1f} TFLOP/s")
 
