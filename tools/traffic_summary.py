@@ -1,0 +1,70 @@
+#!/usr/bin/env python3
+"""HBM traffic of the decoder step's conv launches from two rocprofv3 PMC passes over tools/pmc_decoder.py
+(--pmc FETCH_SIZE and --pmc WRITE_SIZE, separate runs, each with --kernel-trace).
+
+    python tools/traffic_summary.py gpurun_out/r2/pmc_fetch gpurun_out/r2/pmc_write [--json profiles/conv_traffic.json]
+
+Calls are told apart by their toRGB launch (the last kernel of a decoder forward); the first call of each precision builds
+the launch plan and is dropped.  FETCH_SIZE / WRITE_SIZE are in KiB (MI355X_MICROARCH.md, HBM section).
+"""
+import csv
+import glob
+import json
+import sys
+from collections import defaultdict
+
+
+def calls(d, counter):
+    f = glob.glob(f"{d}/**/*_counter_collection.csv", recursive=True)[0]
+    rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
+    rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    out, cur = [], []
+    for r in rows:
+        n = r["Kernel_Name"]
+        if "conv_kernel<" in n and ", 3, 3, 1, " in n or "conv3x3_bf16x3_kernel" in n:
+            cur.append((n, float(r["Counter_Value"]) * 1024.0))
+        if "conv1x1_small" in n:
+            out.append(cur)
+            cur = []
+    return out
+
+
+def main():
+    fetch, write = calls(sys.argv[1], "FETCH_SIZE"), calls(sys.argv[2], "WRITE_SIZE")
+    res = {}
+    for tag, pred in (("f32", lambda c: not any("bf16x3" in n for n, _ in c)), ("bf16x3", lambda c: any("bf16x3" in n for n, _ in c))):
+        fc = [c for c in fetch if pred(c) and len(c) == 12][1:]
+        wc = [c for c in write if pred(c) and len(c) == 12][1:]
+        fb = sum(v for c in fc for _, v in c) / len(fc)
+        wb = sum(v for c in wc for _, v in c) / len(wc)
+        res[tag] = (fb, wb, len(fc))
+        print(f"{tag:7s}: {len(fc)} steps counted; per step: FETCH {fb / 1e6:8.1f} MB, WRITE {wb / 1e6:8.1f} MB, "
+              f"sum {(fb + wb) / 1e6:8.1f} MB = {(fb + wb) / 12 / 1e6:6.1f} MB per conv launch")
+        per = defaultdict(lambda: [0.0, 0.0, 0])
+        for c in fc:
+            for n, v in c:
+                per[n][0] += v / len(fc)
+                per[n][2] += 1
+        for c in wc:
+            for n, v in c:
+                per[n][1] += v / len(wc)
+        for n, (f, w, k) in sorted(per.items(), key=lambda kv: -(kv[1][0] + kv[1][1])):
+            print(f"    {n.replace('void ', '')[:86]:86s} launches/step {k // len(fc):2d}  fetch {f / 1e6:8.1f} MB  write {w / 1e6:8.1f} MB")
+    if "--json" in sys.argv:
+        fb, wb, n = res["f32"]
+        out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python3 tools/pmc_decoder.py` "
+                         "(the headline decoder step launched eagerly through its launch plan, round 2 final kernels); summary in "
+                         "profiles/r02_c_conv_traffic.txt",
+               "kernel": "spkconv::conv_kernel<Cfg,3,3,1,MODE 0|1>", "launches_per_step": 12, "steps_counted": n,
+               "fetch_bytes_per_step": int(fb), "write_bytes_per_step": int(wb), "bytes_per_launch": int((fb + wb) / 12),
+               "bf16x3_fetch_bytes_per_step": int(res["bf16x3"][0]), "bf16x3_write_bytes_per_step": int(res["bf16x3"][1]),
+               "correction": "FETCH_SIZE / WRITE_SIZE are KiB.  The input gathers are 4-byte-per-lane loads, which FETCH_SIZE counts in full "
+                             "(calibrated in round 1 on the 64->64@256^2 layer: 1.37x the input bytes = the (10*34)/(8*32) halo factor + "
+                             "weights); the 16-byte weight loads are L2 hits; the gfx950 x2 correction for 16-B/lane streams is therefore NOT "
+                             "applied.  WRITE_SIZE = output bytes + the split-K partial slabs of the <= 32^2 layers."}
+        with open(sys.argv[sys.argv.index("--json") + 1], "w") as f:
+            json.dump(out, f, indent=1)
+
+
+if __name__ == "__main__":
+    main()
