@@ -327,10 +327,11 @@ __global__ __launch_bounds__(256) void wgrad3x3_pipe_kernel(const WgradArgs p) {
         const int q = tile / p.tiles_x;
         const int ty = q % p.tiles_y, b = q / p.tiles_y;
         const int yy = ty * 4 + gpy, xx = tx * TW + gpx;
-        g_ok = yy < p.H && xx < p.W;
+        const bool live = tile < p.n_tiles;
+        g_ok = live && yy < p.H && xx < p.W;
         g_ptr = p.g + (g_ok ? (size_t)b * p.Cy * HW + (size_t)yy * p.W + xx : 0);
         const int uy = ty * 4 + xr - 1, ux = tx * TW + xc - 1;
-        x_ok = xpos_ok && uy >= 0 && uy < p.Hs && ux >= 0 && ux < p.Ws;
+        x_ok = live && xpos_ok && uy >= 0 && uy < p.Hs && ux >= 0 && ux < p.Ws;
         x_ptr = p.x + (x_ok ? ((size_t)b * p.Cx + cx0 + ci0) * src_plane + (size_t)uy * p.Ws + ux : 0);
     };
     // staging pieces (j static): 0..15 the gradient element j, 16..47 the input channel j - 16
@@ -382,6 +383,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_pipe_kernel(const WgradArgs p) {
         SPK_WP_FRAG(0, 0);
         wg_static_for<0, STEPS>([&](auto s_) {
             constexpr int st = decltype(s_)::value;
+            if constexpr (PIPE && st == STEPS / 2) __builtin_amdgcn_sched_barrier(0);      // see wgrad3x3_wide_kernel
             if constexpr (st + 1 < STEPS) SPK_WP_FRAG(st + 1, (st + 1) & 1);
             if constexpr (PIPE && st < STEPS / 2)
                 wg_static_for<PPS * st, PPS * st + PPS>([&](auto j_) { load_piece(j_); });
@@ -405,14 +407,13 @@ __global__ __launch_bounds__(256) void wgrad3x3_pipe_kernel(const WgradArgs p) {
 #undef SPK_WP_FRAG
     };
 
+    // ONE loop body: after the last tile the staging still runs, with every piece masked off (it reads the tensors' first
+    // floats and fills the idle buffer with zeros).  With a second, staging-free copy of the tile for that case the
+    // accumulators cross the if / else merge in VGPRs: 144 v_accvgpr_write before and 144 v_accvgpr_read after EVERY tile's
+    // 288 MFMAs (and twice the code).
     for (; tile < p.n_tiles; tile += gridDim.z) {
-        const int next = tile + (int)gridDim.z;
-        if (next < p.n_tiles) {               // uniform
-            aim(next);
-            run_tile(std::true_type{});
-        } else {
-            run_tile(std::false_type{});
-        }
+        aim(tile + (int)gridDim.z);
+        run_tile(std::true_type{});
         __syncthreads();                      // every wave is done with `cur`, and the other buffer is complete
         cur ^= 1;
     }
@@ -538,9 +539,10 @@ __global__ __launch_bounds__(256) void wgrad3x3_wide_kernel(const WgradArgs p) {
         ty0 = y0;
         gbase = p.g + ((size_t)b * p.Cy * p.H + y0) * p.W + x0;
         xbase = p.x + ((size_t)b * p.Cx * p.Hs + y0) * p.Ws + x0;
-        g_ok = y0 + grow < p.H && x0 + 4 * gk < p.W;
-        xcol_ok = x0 + 4 * xk < p.Ws;
-        hcol_ok = (unsigned)(x0 + (hs ? 16 : -1)) < (unsigned)p.Ws;
+        const bool live = tile < p.n_tiles;
+        g_ok = live && y0 + grow < p.H && x0 + 4 * gk < p.W;
+        xcol_ok = live && x0 + 4 * xk < p.Ws;
+        hcol_ok = live && (unsigned)(x0 + (hs ? 16 : -1)) < (unsigned)p.Ws;
     };
     auto x_row_ok = [&](int r) { return (unsigned)(ty0 + r - 1) < (unsigned)p.Hs; };    // plane row r of the tile being staged
     auto load_piece = [&](auto j_) {
@@ -604,6 +606,10 @@ __global__ __launch_bounds__(256) void wgrad3x3_wide_kernel(const WgradArgs p) {
         SPK_WW_FRAG(0, 0);
         wg_static_for<0, STEPS>([&](auto s_) {
             constexpr int st = decltype(s_)::value;
+            // Nothing may be scheduled across the load / store boundary: left alone, the scheduler hoists the stores' VALU
+            // halves (the zero-select of out-of-image pieces, the folded BatchNorm affine) up to the loads they consume -- and
+            // every load is then followed by s_waitcnt vmcnt(0), a full memory latency with the MFMA pipe idle (one wave per SIMD).
+            if constexpr (PIPE && st == HS) __builtin_amdgcn_sched_barrier(0);
             if constexpr (st + 1 < STEPS) SPK_WW_FRAG(st + 1, (st + 1) & 1);
             constexpr int nl = (PIPE && st < HS) ? ((PL * st + PL <= NL) ? PL : (PL * st < NL ? NL - PL * st : 0)) : 0;
             constexpr int s0 = PS * (st - HS);
@@ -634,14 +640,13 @@ __global__ __launch_bounds__(256) void wgrad3x3_wide_kernel(const WgradArgs p) {
 #undef SPK_WW_FRAG
     };
 
+    // ONE loop body: after the last tile the staging still runs, with every piece masked off (it reads the tensors' first
+    // floats and fills the idle buffer with zeros).  With a second, staging-free copy of the tile for that case the
+    // accumulators cross the if / else merge in VGPRs: 144 v_accvgpr_write before and 144 v_accvgpr_read after EVERY tile's
+    // 288 MFMAs (and twice the code).
     for (; tile < p.n_tiles; tile += gridDim.z) {
-        const int next = tile + (int)gridDim.z;
-        if (next < p.n_tiles) {               // uniform
-            aim(next);
-            run_tile(std::true_type{});
-        } else {
-            run_tile(std::false_type{});
-        }
+        aim(tile + (int)gridDim.z);
+        run_tile(std::true_type{});
         __syncthreads();                      // every wave is done with `cur`, and the other buffer is complete
         cur ^= 1;
     }
@@ -660,6 +665,234 @@ __global__ __launch_bounds__(256) void wgrad3x3_wide_kernel(const WgradArgs p) {
                     const int co = co0 + (wco * MCO + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                     if (co < co_end && ci < p.Cin) out[((size_t)co * TAPS + t) * p.Cin + ci] = acc[m][n][t][r];
                 }
+        }
+}
+
+// ---- 3x3 STRIDE-2 weight gradient (the trunk's downsampling convs, the discriminator's conv2 of every block) -----------
+// dW[co][ci][ky][kx] = sum g[b,co,y,x] * in(x)[b,ci,2y+ky-1,2x+kx-1].  A stride-2 conv reads 4.6 input values per output pixel
+// and channel where a stride-1 one reads 1.7, so the generic kernel above (64co x 32ci block, 64 dword gathers + 16 loads per
+// thread for 144 MFMAs per wave, staged serially) spends its time issuing loads: 33-42 TFLOP/s on the trunk, 65 on the
+// discriminator.  Here the input tile serves FOUR co tiles: block = 128co x 32ci, wave w owns co rows [32w, 32w+32) and all 64
+// pixels of the tile (288 MFMAs per wave and tile), the (2 TH + 1) x (2 TW + 1) input plane is loaded as 16-byte row
+// segments (columns 2 x0 .. 2 x0 + 2 TW - 1 are aligned; the left halo column is one dword per row), and -- as in
+// wgrad3x3_wide_kernel -- the LDS tile is double-buffered with the next tile's loads behind k-steps 0-15 and its LDS stores
+// behind k-steps 16-31: 19 load + 70 store instructions per thread against 288 MFMAs.
+// TW = 16 (16 x 4 output pixels, 9 x 33 plane) or 8 (8 x 8, 17 x 17: the 8^2 outputs).  Needs W % 4 == 0, W >= TW / 2,
+// Hin = 2 H, Win = 2 W, 16-byte aligned tensors (host-checked: s2_takes).
+template <int TW_>
+struct S2Shape {
+    static constexpr int CO_T = 128, CI_T = 32, TW = TW_, TH = 64 / TW, PW = 2 * TW + 1, PH = 2 * TH + 1, PLANE = PH * PW;
+    static constexpr int GPITCH = 65, XPITCH = PLANE | 1;
+    static constexpr int BUF = (CO_T * GPITCH + CI_T * XPITCH + 1 + 3) & ~3;        // floats per buffer (+ a dump slot: BUF - 1)
+    static constexpr int NG4 = CO_T / 16;                 // float4 pieces of the gradient tile per thread (16 channels per piece)
+    static constexpr int NXK = 2 * TW / 4;                // float4 per plane row
+    static constexpr int RS = 256 / (CI_T * NXK);         // plane rows covered by one piece (1 or 2)
+    static constexpr int NX4 = (PH + RS - 1) / RS;        // float4 pieces of the input tile
+    static constexpr int NXH = (PH + 7) / 8;              // halo-dword pieces (piece = 8 plane rows x 32 channels)
+    static constexpr int NL = NG4 + NX4 + NXH, NS = 4 * NG4 + 4 * NX4 + NXH;
+    static constexpr int STEPS = 32, HS = STEPS / 2;
+    static constexpr int PL = (NL + HS - 1) / HS, PS = (NS + HS - 1) / HS;
+    static_assert(XPITCH % 2 == 1, "odd pitch: the 32 channels of a fragment hit 32 banks");
+};
+
+// LAB (builds with -DSPK_WGRAD_S2_LAB only): knock-outs for timing -- 1 = no global loads, 2 = no LDS stores of the staging,
+// 4 = no MFMAs, 8 = no fragment reads
+template <int TW_, int MODE, int LAB = 0>
+__global__ __launch_bounds__(256) void wgrad3x3_s2_kernel(const WgradArgs p) {
+    using SH = S2Shape<TW_>;
+    constexpr int TAPS = 9, CO_T = SH::CO_T, CI_T = SH::CI_T, TW = SH::TW, TH = SH::TH, PW = SH::PW, PH = SH::PH;
+    constexpr int GPITCH = SH::GPITCH, XPITCH = SH::XPITCH, BUF = SH::BUF;
+    constexpr int NG4 = SH::NG4, NXK = SH::NXK, RS = SH::RS, NX4 = SH::NX4, NXH = SH::NXH, NL = SH::NL, NS = SH::NS;
+    constexpr int STEPS = SH::STEPS, HS = SH::HS, PL = SH::PL, PS = SH::PS;
+    constexpr bool AFF = MODE == WG_AFFINE_RELU;
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l32 = lane & 31;
+
+    const int co0 = blockIdx.x * CO_T;
+    const int grp = co0 / p.Cout;
+    const int co_end = (grp + 1) * p.Cout;
+    const int cx0 = grp * p.gin;
+    const int ci0 = blockIdx.y * CI_T;
+    const int nci = min(CI_T, p.Cin - ci0);
+
+    // ---- staging roles (launch constants; only the tile origin moves) ----
+    // gradient piece i: float4 gk of tile row grow of channel (tid >> 4) + 16 i
+    const int gk = tid & (TW / 4 - 1), grow = (tid / (TW / 4)) & (TH - 1);
+    int g_off[NG4];
+#pragma unroll
+    for (int i = 0; i < NG4; ++i)
+        g_off[i] = (min(co0 + (tid >> 4) + 16 * i, co_end - 1) * p.H + grow) * p.W + 4 * gk;     // rows past the last channel: clamped (never written out)
+    const int g_dst = (tid >> 4) * GPITCH + grow * TW + 4 * gk;                                    // + 16 i GPITCH + j
+    // input piece i: float4 xk of plane row RS i + xr of channel xc
+    const int xk = tid & (NXK - 1), xc = (tid / NXK) & (CI_T - 1), xr = tid / (NXK * CI_T);
+    const int x_chan = cx0 + ci0 + min(xc, nci - 1);
+    const int x_base = (x_chan * p.Hs + xr - 1) * p.Ws + 4 * xk;                                   // + RS i Ws
+    const int x_dst = CO_T * GPITCH + xc * XPITCH + xr * PW + 1 + 4 * xk;                          // + RS i PW + j
+    float x_sc = 1.f, x_sh = 0.f;
+    if (AFF) { x_sc = p.in_scale[x_chan]; x_sh = p.in_shift[x_chan]; }
+    // halo piece i: plane column 0 of plane row hr + 8 i of channel hc
+    const int hc = tid & (CI_T - 1), hr = tid >> 5;
+    const int h_chan = cx0 + ci0 + min(hc, nci - 1);
+    const int h_base = (h_chan * p.Hs + hr - 1) * p.Ws - 1;                                        // + 8 i Ws
+    const int h_dst = CO_T * GPITCH + hc * XPITCH + hr * PW;                                       // + 8 i PW
+    float h_sc = 1.f, h_sh = 0.f;
+    if (AFF) { h_sc = p.in_scale[h_chan]; h_sh = p.in_shift[h_chan]; }
+
+    f32x16 acc[TAPS];
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
+
+    f32x4 gq[NG4], xq[NX4];
+    float hq[NXH];
+    if constexpr (LAB & 1) {
+#pragma unroll
+        for (int i = 0; i < NG4; ++i) gq[i] = f32x4{1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+        for (int i = 0; i < NX4; ++i) xq[i] = f32x4{1.f, 1.f, 1.f, 1.f};
+#pragma unroll
+        for (int i = 0; i < NXH; ++i) hq[i] = 1.f;
+    }
+    const float* gbase = p.g;
+    const float* xbase = p.x;
+    int sy0 = 0;                       // first input row of the tile being staged (2 y0)
+    bool g_ok = false, xcol_ok = false, hcol_ok = false;
+    auto aim = [&](int tile) {
+        const int tx = tile % p.tiles_x;
+        const int q = tile / p.tiles_x;
+        const int ty = q % p.tiles_y, b = q / p.tiles_y;
+        const int y0 = ty * TH, x0 = tx * TW;
+        sy0 = 2 * y0;
+        gbase = p.g + ((size_t)b * p.Cy * p.H + y0) * p.W + x0;
+        xbase = p.x + ((size_t)b * p.Cx * p.Hs + 2 * y0) * p.Ws + 2 * x0;
+        const bool live = tile < p.n_tiles;
+        g_ok = live && y0 + grow < p.H && x0 + 4 * gk < p.W;
+        xcol_ok = live && 2 * x0 + 4 * xk < p.Ws;
+        hcol_ok = live && x0 > 0;
+    };
+    // plane row r of the tile being staged lies inside the image (and inside the plane: the last piece of a two-row role)
+    auto row_ok = [&](int r) { return r < PH && (unsigned)(sy0 + r - 1) < (unsigned)p.Hs; };
+    auto load_piece = [&](auto j_) {
+        constexpr int j = decltype(j_)::value;
+        if constexpr (LAB & 1) return;
+        if constexpr (j < NG4) {
+            gq[j] = *reinterpret_cast<const f32x4*>(g_ok ? gbase + g_off[j] : p.g);
+        } else if constexpr (j < NG4 + NX4) {
+            constexpr int i = j - NG4;
+            const bool ok = xcol_ok && row_ok(RS * i + xr);
+            xq[i] = *reinterpret_cast<const f32x4*>(ok ? xbase + (x_base + RS * i * p.Ws) : p.x);
+        } else if constexpr (j < NL) {
+            constexpr int i = j - NG4 - NX4;
+            const bool ok = hcol_ok && row_ok(hr + 8 * i);
+            hq[i] = *(ok ? xbase + (h_base + 8 * i * p.Ws) : p.x);
+        }
+    };
+    auto store_piece = [&](float* buf, auto s_) {
+        constexpr int s = decltype(s_)::value;
+        if constexpr (LAB & 2) return;
+        if constexpr (s < 4 * NG4) {
+            constexpr int i = s / 4, j = s % 4;
+            buf[g_dst + 16 * i * GPITCH + j] = g_ok ? gq[i][j] : 0.f;         // only the PIXEL axis (the contraction) needs zeros
+        } else if constexpr (s < 4 * NG4 + 4 * NX4) {
+            constexpr int i = (s - 4 * NG4) / 4, j = (s - 4 * NG4) % 4;
+            float v = xq[i][j];
+            if (AFF) v = fmaxf(v * x_sc + x_sh, 0.f);
+            // (a two-row role's last piece: plane row PH does not exist -- those lanes hit the dump slot, no branch)
+            const int dst = (RS * i + RS - 1 < PH || RS * i + xr < PH) ? x_dst + RS * i * PW + j : BUF - 1;
+            buf[dst] = (xcol_ok && row_ok(RS * i + xr)) ? v : 0.f;
+        } else if constexpr (s < NS) {
+            constexpr int i = s - 4 * NG4 - 4 * NX4;
+            float v = hq[i];
+            if (AFF) v = fmaxf(v * h_sc + h_sh, 0.f);
+            const int dst = (8 * i + 7 < PH || hr + 8 * i < PH) ? h_dst + 8 * i * PW : BUF - 1;
+            buf[dst] = (hcol_ok && row_ok(hr + 8 * i)) ? v : 0.f;
+        }
+    };
+
+    int tile = blockIdx.z;
+    int cur = 0;
+    if (tile < p.n_tiles) {                  // first tile: staged the serial way
+        aim(tile);
+        wg_static_for<0, NL>([&](auto j_) { load_piece(j_); });
+        wg_static_for<0, NS>([&](auto s_) { store_piece(smem, s_); });
+    }
+    __syncthreads();
+
+    auto run_tile = [&](auto pipe_) {
+        constexpr bool PIPE = decltype(pipe_)::value;
+        const float* cbuf = smem + cur * BUF;
+        float* nbuf = smem + (cur ^ 1) * BUF;
+        const float* ga = cbuf + (wave * 32 + l32) * GPITCH + half;
+        const float* xb = cbuf + CO_T * GPITCH + l32 * XPITCH + 2 * half;
+        float fa[2], fb[2][TAPS];
+#define SPK_W2_FRAG(st_, slot_)                                                                               \
+    {                                                                                                         \
+        constexpr int px_ = (2 * (st_)) & (TW - 1), py_ = (2 * (st_)) / TW;                                   \
+        fa[slot_] = (LAB & 8) ? 1.f : ga[2 * (st_)];                                                          \
+        _Pragma("unroll") for (int t = 0; t < TAPS; ++t)                                                      \
+            fb[slot_][t] = (LAB & 8) ? 1.f : xb[(2 * py_ + t / 3) * PW + 2 * px_ + t % 3];                    \
+    }
+        SPK_W2_FRAG(0, 0);
+        wg_static_for<0, STEPS>([&](auto s_) {
+            constexpr int st = decltype(s_)::value;
+            if constexpr (PIPE && st == HS) __builtin_amdgcn_sched_barrier(0);             // see wgrad3x3_wide_kernel
+            if constexpr (st + 1 < STEPS) SPK_W2_FRAG(st + 1, (st + 1) & 1);
+            constexpr int nl = (PIPE && st < HS) ? ((PL * st + PL <= NL) ? PL : (PL * st < NL ? NL - PL * st : 0)) : 0;
+            constexpr int s0 = PS * (st - HS);
+            constexpr int ns = (PIPE && st >= HS) ? ((s0 + PS <= NS) ? PS : (s0 < NS ? NS - s0 : 0)) : 0;
+            if constexpr (nl > 0) wg_static_for<PL * st, PL * st + nl>([&](auto j_) { load_piece(j_); });
+            if constexpr (ns > 0) wg_static_for<s0, s0 + ns>([&](auto q_) { store_piece(nbuf, q_); });
+#pragma unroll
+            for (int t = 0; t < TAPS; ++t) {
+                if constexpr (LAB & 4) acc[t][st & 15] += fa[st & 1] * fb[st & 1][t];
+                else acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[st & 1], fb[st & 1][t], acc[t], 0, 0, 0);
+            }
+            if constexpr (LAB != 0 && LAB != 32) return;
+            if constexpr (st + 1 < STEPS) __builtin_amdgcn_sched_group_barrier(0x100, TAPS + 1, 0);
+            if constexpr (LAB == 32) return;
+            constexpr int np = nl > 0 ? nl : ns;
+            if constexpr (np > 0) {
+                constexpr int per = TAPS / (np + 1) > 0 ? TAPS / (np + 1) : 1;
+                constexpr int groups = np < TAPS ? np : TAPS - 1;
+                wg_static_for<0, groups>([&](auto k_) {
+                    constexpr int k = decltype(k_)::value;
+                    // pieces beyond the MFMA count share the last slots
+                    constexpr int cnt = (k + 1 == groups) ? np - (groups - 1) : 1;
+                    __builtin_amdgcn_sched_group_barrier(0x8, per, 0);
+                    __builtin_amdgcn_sched_group_barrier(nl > 0 ? 0x20 : 0x200, cnt, 0);
+                });
+                __builtin_amdgcn_sched_group_barrier(0x8, TAPS - per * groups, 0);
+            } else {
+                __builtin_amdgcn_sched_group_barrier(0x8, TAPS, 0);
+            }
+        });
+#undef SPK_W2_FRAG
+    };
+
+    // ONE loop body: after the last tile the staging still runs, with every piece masked off (it reads the tensors' first
+    // floats and fills the idle buffer with zeros).  With a second, staging-free copy of the tile for that case the
+    // accumulators cross the if / else merge in VGPRs: 144 v_accvgpr_write before and 144 v_accvgpr_read after EVERY tile's
+    // 288 MFMAs (and twice the code).
+    for (; tile < p.n_tiles; tile += gridDim.z) {
+        aim(tile + (int)gridDim.z);
+        run_tile(std::true_type{});
+        __syncthreads();                      // every wave is done with `cur`, and the other buffer is complete
+        cur ^= 1;
+    }
+
+    // ---- partial block -> slab [slab][co][tap][ci] (ci contiguous: 128-B stores per half wave) ----
+    float* out = p.slabs + (size_t)blockIdx.z * p.Cy * TAPS * p.Cin;
+    const int ci = ci0 + l32;
+#pragma unroll
+    for (int t = 0; t < TAPS; ++t)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (co < co_end && ci < p.Cin) out[((size_t)co * TAPS + t) * p.Cin + ci] = acc[t][r];
         }
 }
 
@@ -728,7 +961,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_up_kernel(const WgradArgs p) {
         int b, y0, x0;
         origin(tile, b, y0, x0);
         gbase = p.g + ((size_t)b * p.Cy * p.H + y0) * p.W + x0;
-        g_ok = y0 + grow < p.H && x0 + 4 * gk < p.W;
+        g_ok = tile < p.n_tiles && y0 + grow < p.H && x0 + 4 * gk < p.W;
     };
     // The source patch is REPLICATE-padded (rows / columns outside the image take the nearest edge pixel: loads with clamped
     // coordinates): torch's bilinear clamps its second tap at the border, which is the plain parity weights (.75, .25) applied
@@ -841,6 +1074,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_up_kernel(const WgradArgs p) {
         SPK_WU_FRAG(0, 0);
         wg_static_for<0, STEPS>([&](auto s_) {
             constexpr int st = decltype(s_)::value;
+            if constexpr (H1 && st == HS) __builtin_amdgcn_sched_barrier(0);               // see wgrad3x3_wide_kernel
             if constexpr (st + 1 < STEPS) SPK_WU_FRAG(st + 1, (st + 1) & 1);
             if constexpr (H1 && st < NG4) load_g(std::integral_constant<int, st < NG4 ? st : 0>{});
             if constexpr (H2 && st >= NG4 && st < NG4 + 4) load_s(std::integral_constant<int, (st >= NG4 && st < NG4 + 4) ? st - NG4 : 0>{});
@@ -864,12 +1098,12 @@ __global__ __launch_bounds__(256) void wgrad3x3_up_kernel(const WgradArgs p) {
     };
 
     for (; tile < p.n_tiles; tile += stride) {
-        const bool has1 = tile + stride < p.n_tiles, has2 = tile + 2 * stride < p.n_tiles;      // uniform
-        if (has1) { aim_g(tile + stride); aim_i(tile + stride); }
-        if (has2) aim_s(tile + 2 * stride);
-        if (has2) run_tile(std::true_type{}, std::true_type{});
-        else if (has1) run_tile(std::true_type{}, std::false_type{});
-        else run_tile(std::false_type{}, std::false_type{});
+        // one loop body (see wgrad3x3_wide_kernel): past the last tile the gradient pieces are masked off, the patch of the
+        // last tile is fetched again and the idle buffers are filled with values nobody reads
+        aim_g(tile + stride);
+        aim_i(tile + stride);
+        aim_s(min(tile + 2 * stride, p.n_tiles - 1));
+        run_tile(std::true_type{}, std::true_type{});
         __syncthreads();
         cur ^= 1;
         par ^= 1;
@@ -1057,6 +1291,73 @@ int run_wgrad_up(const spk_wgrad_desc* d, hipStream_t stream) {
     return spk::check_launch("wgrad_reduce_kernel");
 }
 
+// the stride-2 form: 128co x 32ci blocks, 16x4 or 8x8 output-pixel tiles
+inline bool s2_takes(const spk_wgrad_desc* d) {
+    static const bool allow = [] { const char* e = getenv("SPK_WGRAD_S2"); return !e || atoi(e) != 0; }();
+    const int G = d->groups > 1 ? d->groups : 1;
+    const auto aligned = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    return allow && d->kh == 3 && d->kw == 3 && d->stride == 2 && d->W >= 8 && d->W % 4 == 0 && d->H >= 2 && d->Hin == 2 * d->H &&
+           d->Win == 2 * d->W && aligned(d->g) && aligned(d->x) && d->Cout >= 96 && (G == 1 || d->Cout % 128 == 0) &&
+           (long long)G * d->Cout * d->H * d->W < (1ll << 31) &&
+           ((long long)d->group_in_stride * (G - 1) + d->Cin) * d->Hin * d->Win < (1ll << 31);
+}
+inline WideGeom s2_geom(int TW, int B, int Cin, int Cout_all, int H, int W, int want_splits) {
+    WideGeom g;
+    g.tiles_x = spk::ceil_div(W, TW);
+    g.tiles_y = spk::ceil_div(H, 64 / TW);
+    g.n_tiles = g.tiles_x * g.tiles_y * B;
+    const int blocks = spk::ceil_div(Cout_all, 128) * spk::ceil_div(Cin, 32);
+    static const int target = [] { const char* e = getenv("SPK_WGRAD_S2_TARGET"); return e ? atoi(e) : 256; }();
+    const int sp = want_splits > 0 ? want_splits : std::max(1, target / blocks);
+    g.splits = std::max(1, std::min(sp, g.n_tiles));
+    g.n_slabs = g.splits;
+    return g;
+}
+
+template <int TW, int MODE>
+int run_wgrad_s2(const spk_wgrad_desc* d, hipStream_t stream) {
+    using SH = S2Shape<TW>;
+    const int G = d->groups > 1 ? d->groups : 1;
+    const WideGeom g = s2_geom(TW, d->B, d->Cin, G * d->Cout, d->H, d->W, d->splits);
+    const size_t slab_floats = (size_t)G * d->Cout * d->Cin * 9;
+    SPK_REQUIRE(d->workspace && (size_t)d->workspace_bytes >= g.n_slabs * slab_floats * sizeof(float),
+                "wgrad: needs a %zu-byte workspace (see spk_conv2d_wgrad_workspace_bytes)", g.n_slabs * slab_floats * sizeof(float));
+    WgradArgs a;
+    a.g = d->g; a.x = d->x; a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.slabs = static_cast<float*>(d->workspace);
+    a.B = d->B; a.Cin = d->Cin; a.Cout = d->Cout; a.H = d->H; a.W = d->W; a.Hs = d->Hin; a.Ws = d->Win;
+    a.gin = G > 1 ? d->group_in_stride : d->Cin;
+    a.Cx = a.gin * (G - 1) + d->Cin;
+    a.Cy = G * d->Cout;
+    a.lgTW = spk::ilog2(TW); a.lgTH = spk::ilog2(64 / TW); a.lgTB = 0;
+    a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y; a.n_tiles = g.n_tiles;
+    auto kern = &wgrad3x3_s2_kernel<TW, MODE>;
+#ifdef SPK_WGRAD_S2_LAB
+    if constexpr (TW == 16 && MODE == WG_PLAIN) {
+        const char* e = getenv("SPK_WG_LAB");
+        switch (e ? atoi(e) : 0) {
+            case 16: kern = &wgrad3x3_s2_kernel<TW, MODE, 16>; break;
+            case 32: kern = &wgrad3x3_s2_kernel<TW, MODE, 32>; break;
+            default: break;
+        }
+        hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    }
+#endif
+    static bool raised = false;
+    if (!raised) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return spk::fail(SPK_ELAUNCH, "hipFuncSetAttribute(LDS): %s", hipGetErrorString(e));
+        raised = true;
+    }
+    dim3 grid((unsigned)spk::ceil_div(G * d->Cout, SH::CO_T), (unsigned)spk::ceil_div(d->Cin, SH::CI_T), (unsigned)g.splits);
+    hipLaunchKernelGGL(kern, grid, dim3(256), 2 * SH::BUF * sizeof(float), stream, a);
+    int rc = spk::check_launch("wgrad3x3_s2_kernel");
+    if (rc != SPK_OK) return rc;
+    const unsigned blocks = (unsigned)std::min<size_t>((slab_floats + 255) / 256, 2048);
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, a.slabs, d->dw, g.n_slabs, G * d->Cout, d->Cin, 9,
+                       d->scale, d->accumulate ? 1 : 0, d->fold > 1 ? d->fold : 1);
+    return spk::check_launch("wgrad_reduce_kernel");
+}
+
 template <int MODE>
 int run_wgrad_wide_any(const spk_wgrad_desc* d, hipStream_t stream) {
     return run_wgrad_wide<1, 1, MODE>(d, stream);
@@ -1068,6 +1369,9 @@ int run_wgrad(const spk_wgrad_desc* d, hipStream_t stream) {
     const int G = d->groups > 1 ? d->groups : 1;
     if constexpr (KH == 3 && S == 1 && (MODE == WG_PLAIN || MODE == WG_AFFINE_RELU)) {
         if (wide_takes(d)) return run_wgrad_wide_any<MODE>(d, stream);
+    }
+    if constexpr (KH == 3 && S == 2 && (MODE == WG_PLAIN || MODE == WG_AFFINE_RELU)) {
+        if (s2_takes(d)) return d->W >= 16 ? run_wgrad_s2<16, MODE>(d, stream) : run_wgrad_s2<8, MODE>(d, stream);
     }
     SPK_REQUIRE(!SH::PACK || KW * d->Cin <= 32, "wgrad: the %dx%d kernel packs (kx, ci) into 32 lanes: Cin <= %d", KH, KW, 32 / KW);
     SPK_REQUIRE(G == 1 || d->Cout % SH::CO_T == 0, "wgrad: grouped launches need Cout (per group) to be a multiple of %d", SH::CO_T);
@@ -1393,14 +1697,16 @@ int64_t spk_conv2d_wgrad_workspace_bytes(int kh, int kw, int stride, int splits,
         n_slabs = std::max(n_slabs, wide_geom(64, 128, B, Cin, Cout, H, W, splits).n_slabs);
         n_slabs = std::max(n_slabs, wide_geom(64, 64, B, Cin, Cout, H, W, splits).n_slabs);
     }
+    if (kh == 3 && stride == 2 && W >= 8) n_slabs = std::max(n_slabs, s2_geom(W >= 16 ? 16 : 8, B, Cin, Cout, H, W, splits).n_slabs);
     return (int64_t)n_slabs * Cout * Cin * kh * kw * (int64_t)sizeof(float);
 }
 
 int spk_conv2d_wgrad_up_supported(int B, int Cin, int Cout, int H, int W) {
-    // Measured (tools/bench_wgrad.py --upsample, B = 8): the folded form is level with "upsample, then the plain kernel" at
-    // 256^2 (851 vs 875 us, and 268 MB less written and read back) but 10-20 % behind it on the 32^2..128^2 layers, whose x2
-    // images are small (16..134 MB): by default it takes planes at least 256 wide (SPK_WGRAD_UP_MIN_W overrides).
-    static const int min_w = [] { const char* e = getenv("SPK_WGRAD_UP_MIN_W"); return e ? atoi(e) : 256; }();
+    // Measured (tools/bench_wgrad.py --upsample, B = 8): the folded form beats "upsample, then the plain kernel" at 256^2
+    // (744 vs 775 us, and 268 MB less written and read back), is level with it at 128^2 (668 vs 668, 134 MB less) and 2 %
+    // behind at 32^2..64^2, whose x2 images are small (8..67 MB): by default it takes planes at least 128 wide
+    // (SPK_WGRAD_UP_MIN_W overrides).
+    static const int min_w = [] { const char* e = getenv("SPK_WGRAD_UP_MIN_W"); return e ? atoi(e) : 128; }();
     if (W < min_w) return 0;
     return (B > 0 && Cin > 0 && Cout > 0 && W >= 16 && W % 8 == 0 && H >= 4 && H % 2 == 0 && (long long)Cout * H * W < (1ll << 31) &&
             (long long)Cin * H * W / 4 < (1ll << 31)) ? 1 : 0;

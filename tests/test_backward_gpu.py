@@ -75,6 +75,40 @@ def test_wgrad_with_upsampled_and_bn_folded_input(pkg, dev):
     assert rel_l2(dw, w2.grad) < TOL
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,W,groups,aff", [
+    (2, 32, 128, 16, 16, 1, False),      # 16 x 4 output tiles, whole blocks
+    (3, 40, 160, 10, 20, 1, True),       # ragged channels (8 live rows in the second ci block, 32 in the second co block), partial tiles
+    (2, 64, 128, 8, 8, 1, False),        # 8 x 8 tiles (the 16^2 -> 8^2 layers)
+    (3, 24, 96, 6, 8, 1, True),          # 8 x 8 tiles, partial in y, fewer channels than a block
+    (2, 32, 128, 12, 16, 3, True),       # grouped (the three encoders), BatchNorm-folded input
+    (2, 32, 256, 8, 8, 2, False),
+])
+def test_wgrad_stride2_wide_form(pkg, dev, B, Cin, Cout, H, W, groups, aff):
+    """wgrad3x3_s2_kernel (128co x 32ci blocks, 16-byte row loads, staging behind the MFMAs) against autograd; H, W = OUTPUT size."""
+    tag = f"wgs2.{B}.{Cin}.{Cout}.{H}.{W}.{groups}.{int(aff)}"
+    G = groups
+    x = recipe_input(tag + ".x", (B, G * Cin, 2 * H, 2 * W))
+    a = 1.0 + recipe_tensor(tag + ".a", (G * Cin,), 0.3)
+    b = recipe_tensor(tag + ".b", (G * Cin,), 0.3)
+    xin = F.relu(x * a.view(1, -1, 1, 1) + b.view(1, -1, 1, 1)) if aff else x
+    ws = [recipe_tensor(tag + f".weight{q}", (Cout, Cin, 3, 3)).requires_grad_(True) for q in range(G)]
+    y = torch.cat([F.conv2d(xin[:, q * Cin:(q + 1) * Cin], ws[q], stride=2, padding=1) for q in range(G)], 1)
+    g = recipe_input(tag + ".g", y.shape)
+    y.backward(g)
+    ref = torch.cat([w.grad for w in ws], 0)
+    kw = dict(in_affine=(a.to(dev), b.to(dev))) if aff else {}
+    for splits in (0, 1, 5):
+        dw = pkg.ops.conv2d_wgrad(g.to(dev), x.to(dev), Cout, Cin, 3, 2, splits=splits, groups=G, **kw)
+        assert rel_l2(dw, ref) < TOL, splits
+    if G > 1:     # the two images' gradients folded in the slab reduce
+        if G % 2 == 0:
+            dw = pkg.ops.conv2d_wgrad(g.to(dev), x.to(dev), Cout, Cin, 3, 2, groups=G, fold=2, **kw)
+            assert rel_l2(dw, ref[:Cout] + ref[Cout:]) < TOL
+    base = recipe_tensor(tag + ".base", ref.shape).to(dev)
+    acc = pkg.ops.conv2d_wgrad(g.to(dev), x.to(dev), Cout, Cin, 3, 2, scale=0.5, out=base.clone(), accumulate=True, groups=G, **kw)
+    assert rel_l2(acc, base.cpu() + 0.5 * ref) < TOL
+
+
 def test_pointwise_backward_kernels(pkg, dev, golden):
     # bilinear x2 adjoint, incl. odd sizes and 1x1
     g = golden("decoder_ops.npz")
