@@ -252,7 +252,10 @@ __global__ __launch_bounds__(NT) void conv3x3_bf16x3_kernel(const Args p) {
         *reinterpret_cast<u32x4*>(stage + it_dst[r] + hl_x) = lo;
     };
     // ---- UPS: source tile -> LDS (fp32, modulation applied here), then LDS -> LDS interpolation + split into the X image ----
-    float sga[UPS ? MAX_SR : 1][8];
+    // s_issue only LOADS (the pixel and, for a modulated conv, its channel scale): any arithmetic on the loaded values here
+    // gets an s_waitcnt vmcnt(0) in front of it -- 16 full memory latencies per chunk and wave before the first MFMA (ISA of
+    // the first version, which multiplied in place).  The product is formed in s_store, a chunk of MFMAs later.
+    float sga[UPS ? MAX_SR : 1][8], ssa[UPS ? MAX_SR : 1][8];
     auto s_issue = [&](int chunk, auto r_) {
         constexpr int r = decltype(r_)::value;
         const bool lastc = chunk == p.n_chunks - 1;
@@ -261,9 +264,14 @@ __global__ __launch_bounds__(NT) void conv3x3_bf16x3_kernel(const Args p) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const bool live = !lastc || h8 + j < ci_last;
-            float v = xc[si_off[r] + (ptrdiff_t)(live ? j : -h8) * (ptrdiff_t)src_plane];
-            if (bsc) v *= p.in_scale[si_sc[r] + chunk * CI_T + (live ? j : -h8)];
-            sga[r][j] = v;
+            sga[r][j] = xc[si_off[r] + (ptrdiff_t)(live ? j : -h8) * (ptrdiff_t)src_plane];
+        }
+        if (bsc) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const bool live = !lastc || h8 + j < ci_last;
+                ssa[r][j] = p.in_scale[si_sc[r] + chunk * CI_T + (live ? j : -h8)];
+            }
         }
     };
     auto s_store = [&](char* sbuf, int chunk, auto r_) {
@@ -271,11 +279,18 @@ __global__ __launch_bounds__(NT) void conv3x3_bf16x3_kernel(const Args p) {
         if (si_dst[r] == 0xffffffffu) return;
         const bool lastc = chunk == p.n_chunks - 1;
         const int h8 = 8 * si_h[r];
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = sga[r][j];
+        if (bsc) {
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] *= ssa[r][j];
+        }
         f32x4 a, b;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            a[j] = (!lastc || h8 + j < ci_last) ? sga[r][j] : 0.f;
-            b[j] = (!lastc || h8 + 4 + j < ci_last) ? sga[r][4 + j] : 0.f;
+            a[j] = (!lastc || h8 + j < ci_last) ? v[j] : 0.f;
+            b[j] = (!lastc || h8 + 4 + j < ci_last) ? v[4 + j] : 0.f;
         }
         *reinterpret_cast<f32x4*>(sbuf + si_dst[r]) = a;
         *reinterpret_cast<f32x4*>(sbuf + si_dst[r] + 16) = b;
@@ -412,6 +427,7 @@ __global__ __launch_bounds__(NT) void conv3x3_bf16x3_kernel(const Args p) {
         }
         if constexpr (UPS) {
             if (more2) {                                       // S(i) was last read while X(i) was built, a chunk ago
+                __builtin_amdgcn_sched_barrier(0);
                 s_store(s_nn, i + 2, I0{});
                 if (s_rounds > 1) s_store(s_nn, i + 2, I1{});
             }
