@@ -45,9 +45,11 @@ extern "C" {
 #define SPK_CONV_DGRAD_S2 1024u  /* kh = kw = 3, stride = 2: run the DATA GRADIENT of that conv instead: x = the output-side
                                   * gradient [B,Cin,Hin,Win], y = the input-side gradient [B,Cout,H,W] (H in {2Hin-1, 2Hin});
                                   * w_packed from spk_conv2d_pack_weights(w[Cin][Cout][3][3], transpose_flip = 2) for a
-                                  * tile config in 0-3 (spk_conv2d_pick_config(2, 2, 1, B, Cin, 4*Cout, Hin, Win));
+                                  * the tile config spk_conv2d_dgrad_s2_config(B, Cin, Cout, Hin, Win) names;
                                   * SPK_EPI_ACCUM is the only other flag.  Computed by output parity -- dx[2m+py, 2n+px]
-                                  * needs 1/2/2/4 of the 9 taps -- as four 2x2 kernels in one launch, stored interleaved. */
+                                  * needs 1/2/2/4 of the 9 taps.  Config 13: one kernel with exactly those taps (a wave owns
+                                  * the four classes of its channels and pixels; 9 MFMAs per contraction pair).  Configs 0-3:
+                                  * four zero-padded 2x2 kernels in one launch of the general kernel (16 taps executed). */
 #define SPK_CONV_TRANSPOSE4X4_S2 2048u /* kh = kw = 4, stride = 2: the FORWARD of nn.ConvTranspose2d(Cin, Cout, 4, stride=2,
                                   * padding=1) -- the fused upscale of the legacy GBlock, replaces: styleganv1.py:231,258 --
                                   * x [B,Cin,Hin,Win] -> y [B,Cout,2Hin,2Win]; w_packed from spk_conv2d_pack_weights(w[Cin][Cout]
@@ -135,6 +137,10 @@ int spk_conv2d_stats_slots(int config, int kh, int kw, int stride, int B, int Ci
 int spk_conv2d_config_valid(int config, int kh, int kw, int stride);
 /* tile config chosen by the heuristic for this problem (what `config = -1` resolves to); H, W = output size */
 int spk_conv2d_pick_config(int kh, int kw, int stride, int B, int Cin, int Cout, int H, int W);
+/* tile config for SPK_CONV_DGRAD_S2 (the data gradient of a 3x3 stride-2 conv with Cin -> Cout... seen from the gradient:
+ * Cin = channels of the output-side gradient, Cout = channels of the input-side one, Hin x Win = the gradient's size):
+ * 13 = the exact-tap kernel, else one of 0-3 */
+int spk_conv2d_dgrad_s2_config(int B, int Cin, int Cout, int Hin, int Win);
 /* CO_T / CI_T / PIX_T of a config (any out pointer may be NULL) */
 int spk_conv2d_config_info(int config, int* co_tile, int* ci_tile, int* pix_tile);
 /* number of floats of the packed image of a [Cout,Cin,kh,kw] weight for `config` (<0 = bad args) */
@@ -151,7 +157,8 @@ int64_t spk_conv2d_workspace_bytes_grouped(int config, int ksplit, int kh, int k
  * (then the packed image is that of a [Cin,Cout,kh,kw] weight).
  * transpose_flip = 2 (kh = kw = 3): the four output-parity 2x2 kernels of the STRIDE-2 data gradient
  * (SPK_CONV_DGRAD_S2), the image of a [4*Cin, Cout, 2, 2] weight: spk_conv2d_packed_floats(config, 2, 2, Cout, 4*Cin)
- * floats, config in 0-3.  2x2 is accepted by the size / config queries for that purpose only.
+ * floats, config in 0-3; config 13 (the exact-tap kernel) packs the transposed 3x3 operator itself,
+ * [co tile 64][chunk 8][tap][8][64].  2x2 is accepted by the size / config queries for that purpose only.
  * transpose_flip = 3 (kh = kw = 4, w is the [Cin,Cout,4,4] weight of a ConvTranspose2d): the four output-parity 2x2 kernels
  * of SPK_CONV_TRANSPOSE4X4_S2: spk_conv2d_packed_floats(config, 2, 2, Cin, 4*Cout) floats, config in 0-3.
  * replaces: nothing in the reference (layout change private to this library). */

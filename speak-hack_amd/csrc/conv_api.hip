@@ -198,7 +198,7 @@ static const CfgDims kDims[kNumConfigs] = {
     {Cfg3::CO_T, Cfg3::CI_T, Cfg3::PIX_T},   {Cfg4::CO_T, Cfg4::CI_T, Cfg4::PIX_T},   {Cfg5::CO_T, Cfg5::CI_T, Cfg5::PIX_T},
     {Cfg6::CO_T, Cfg6::CI_T, Cfg6::PIX_T},   {Cfg7::CO_T, Cfg7::CI_T, Cfg7::PIX_T},   {Cfg8::CO_T, Cfg8::CI_T, Cfg8::PIX_T},
     {Cfg9::CO_T, Cfg9::CI_T, Cfg9::PIX_T},   {Cfg10::CO_T, Cfg10::CI_T, Cfg10::PIX_T}, {Cfg11::CO_T, Cfg11::CI_T, Cfg11::PIX_T},
-    {128, 32, 128}};
+    {128, 32, 128}, {64, 8, 128}};
 
 static bool supported_kernel(int kh, int kw, int stride) {
     if (kh == 2 && kw == 2) return stride == 1;   // the parity form of the 3x3 stride-2 data gradient (SPK_CONV_DGRAD_S2)
@@ -208,6 +208,7 @@ static bool supported_kernel(int kh, int kw, int stride) {
 static bool config_valid(int cfg, int kh, int kw, int stride) {
     if (!supported_kernel(kh, kw, stride) || cfg < 0 || cfg >= kNumConfigs) return false;
     if (cfg == kGemmConfig) return kh == 1 && stride == 1;
+    if (cfg == kDgradS2Config) return kh == 2;
     if (kh == 1) return cfg >= 8;
     if (kh == 2) return cfg <= 3;
     if (kh == 3 && stride == 1) return cfg <= 7;
@@ -241,6 +242,15 @@ static Geometry geometry_any(int kh, int stride, int cfg, int B, int Cin, int Co
         g.tiles_x = (int)gemm1x1_pixel_tiles(B, H, W); g.tiles_y = g.tiles_b = 1;
         g.n_chunks = 1;                  // never splits K
         g.co_tiles = spk::ceil_div(Cout, 128);
+        g.lds_bytes = 0;
+        return g;
+    }
+    if (cfg == kDgradS2Config) {         // Cout = 4 x the input-side channels (the four classes); everything ragged is masked
+        g.ok = Cout % 4 == 0 && dgrad_s2_fused_takes(B, Cin, Cout / 4, H, W);
+        g.TW = 16; g.TH = 8; g.TB = 1; g.PLANE = 9 * 17;
+        g.tiles_x = spk::ceil_div(W, 16); g.tiles_y = spk::ceil_div(H, 8); g.tiles_b = B;
+        g.n_chunks = 1;                  // never splits K
+        g.co_tiles = spk::ceil_div(Cout / 4, 64);
         g.lds_bytes = 0;
         return g;
     }
@@ -306,6 +316,16 @@ int spk_conv2d_pick_config(int kh, int kw, int stride, int B, int Cin, int Cout,
     return pick_config(kh, stride, B, Cin, Cout, H, W);
 }
 
+int spk_conv2d_dgrad_s2_config(int B, int Cin, int Cout, int Hin, int Win) {
+    SPK_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && Hin > 0 && Win > 0, "conv2d: bad shape");
+    // the exact-tap kernel everywhere it applies (SPK_DGRAD_S2_FUSED=0: the four zero-padded 2x2 kernels of the general kernel)
+    static const bool fused_on = [] { const char* e = getenv("SPK_DGRAD_S2_FUSED"); return !e || atoi(e) != 0; }();
+    // (its pixel tile is 16 x 8: on the trunk's 8 x 8 gradients, 512 -> 512 x 6 groups, half of every tile is empty and it
+    // measured 308 us against 228 for the 2x2 form; 138 against 277 at 32 x 32, 165 against 246 at 16 x 16)
+    if (fused_on && Win > 8 && dgrad_s2_fused_takes(B, Cin, Cout, Hin, Win)) return kDgradS2Config;
+    return pick_config(2, 1, B, Cin, 4 * Cout, Hin, Win);
+}
+
 int spk_conv2d_config_info(int config, int* co_tile, int* ci_tile, int* pix_tile) {
     SPK_REQUIRE(config >= 0 && config < kNumConfigs, "conv2d: bad config %d", config);
     if (co_tile) *co_tile = kDims[config].co_t;
@@ -317,6 +337,7 @@ int spk_conv2d_config_info(int config, int* co_tile, int* ci_tile, int* pix_tile
 int64_t spk_conv2d_packed_floats(int config, int kh, int kw, int Cin, int Cout) {
     if (config < 0 || config >= kNumConfigs || Cin <= 0 || Cout <= 0 || kh <= 0 || kw <= 0) return -1;
     if (config == kGemmConfig) return kh == 1 && kw == 1 ? (int64_t)Cout * Cin : -1;      // plain [Cout][Cin]
+    if (config == kDgradS2Config) return (kh == 2 && kw == 2 && Cout % 4 == 0) ? (int64_t)dgrad_s2_fused_packed_floats(Cin, Cout / 4) : -1;
     const CfgDims& c = kDims[config];
     return (int64_t)spk::ceil_div(Cout, c.co_t) * spk::ceil_div(Cin, c.ci_t) * kh * kw * c.ci_t * c.co_t;
 }
@@ -359,6 +380,10 @@ int spk_conv2d_pack_weights(const float* w, float* w_packed, int kh, int kw, int
         hipLaunchKernelGGL(pack_rowmajor_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, w_packed,
                            Cin, Cout, transpose_flip, n);
         return spk::check_launch("pack_rowmajor_kernel");
+    }
+    if (config == kDgradS2Config) {     // the transposed 3x3 operator itself, in 64-channel x 8-channel tiles (kDims[13])
+        SPK_REQUIRE(transpose_flip == 2, "pack_weights: config %d packs the stride-2 data-gradient form (transpose_flip = 2)", kDgradS2Config);
+        transpose_flip = 1;
     }
     const CfgDims& c = kDims[config];
     const int opCin = (transpose_flip == 1 || transpose_flip == 2) ? Cout : Cin;
@@ -410,8 +435,9 @@ int spk_conv2d_fwd(const spk_conv2d_desc* d, void* stream) {
         spk_conv2d_desc dd = *d;
         dd.kh = dd.kw = 2; dd.stride = 1; dd.Cout = 4 * d->Cout; dd.H = d->Hin; dd.W = d->Win; dd.ksplit = 1;
         dd.flags = d->flags & SPK_EPI_ACCUM; dd.out_scale = d->out_scale;
-        if (dd.config < 0) dd.config = pick_config(2, 1, dd.B, dd.Cin, dd.Cout, dd.H, dd.W);
-        SPK_REQUIRE(config_valid(dd.config, 2, 2, 1), "conv2d: DGRAD_S2 runs tile configs 0-3 (got %d)", dd.config);
+        if (dd.config < 0) dd.config = spk_conv2d_dgrad_s2_config(d->B, d->Cin, d->Cout, d->Hin, d->Win);
+        SPK_REQUIRE(config_valid(dd.config, 2, 2, 1), "conv2d: DGRAD_S2 runs tile configs 0-3 and %d (got %d)", kDgradS2Config, dd.config);
+        if (dd.config == kDgradS2Config) return run_dgrad_s2_fused(d, (hipStream_t)stream);
         return run_2x2_parity(dd.config, &dd, d->H, d->W, 0, (hipStream_t)stream);
     }
     const bool ups = d->flags & SPK_CONV_UPSAMPLE2X, aff = d->flags & SPK_CONV_IN_AFFINE_RELU;

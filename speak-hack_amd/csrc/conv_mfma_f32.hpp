@@ -850,8 +850,9 @@ typedef Cfg<2, 2, 2, 2, 16> Cfg8;  //  128   128   1x1 s1/s2   (16-channel chunk
 typedef Cfg<1, 4, 2, 2, 16> Cfg9;  //   64   256   1x1 s1/s2
 typedef Cfg<2, 2, 1, 1, 16> Cfg10; //   64    64   1x1 s1/s2
 typedef Cfg<1, 4, 1, 1, 16> Cfg11; //   32   128   1x1 s1/s2
-constexpr int kNumConfigs = 13;   // 12 = the GEMM form of a stride-1 1x1 (conv1x1_gemm.hip): 128co x 128px block, 32-channel k-tiles
+constexpr int kNumConfigs = 14;   // 12 = the GEMM form of a stride-1 1x1 (conv1x1_gemm.hip): 128co x 128px block, 32-channel k-tiles
 constexpr int kGemmConfig = 12;
+constexpr int kDgradS2Config = 13;   // the exact-tap data gradient of a 3x3 stride-2 conv (dgrad3x3s2.hip): 64co x 128px block, 8-channel chunks
 
 // per-family dispatchers, one translation unit each (parallel compilation)
 int run_3x3s1_a(int cfg, int mode, const spk_conv2d_desc* d, hipStream_t s);  // ids 0-3
@@ -860,6 +861,9 @@ int run_3x3s2_7x7s2(int kh, int cfg, int mode, const spk_conv2d_desc* d, hipStre
 int run_1x1(int stride, int cfg, int mode, const spk_conv2d_desc* d, hipStream_t s);      // ids 8-11
 int run_2x2_parity(int cfg, const spk_conv2d_desc* d, int Hd, int Wd, int pshift, hipStream_t s);     // ids 0-3
 int run_1x1_gemm(const spk_conv2d_desc* d, hipStream_t s);                                // id 12
+int run_dgrad_s2_fused(const spk_conv2d_desc* d, hipStream_t s);                          // id 13
+bool dgrad_s2_fused_takes(int B, int K, int Cc, int Hg, int Wg);
+long long dgrad_s2_fused_packed_floats(int K, int Cc);
 bool gemm1x1_takes(int kh, int stride, int Cin, int H, int W);
 long long gemm1x1_pixel_tiles(int B, int H, int W);
 

@@ -707,8 +707,11 @@ def dgrad_at_output_size(k, stride, out=None, accumulate=False):
 
 def dgrad_plan(k, stride, B, Cout, Cin, in_hw, g_hw, out=None, accumulate=False):
     """-> (tile config, ``transpose_flip`` mode of ``pack_conv_weight``) for ``conv2d_dgrad`` of this conv."""
-    if k == 3 and stride == 2:       # four output-parity 2x2 kernels over the gradient's own pixels
-        return conv2d_pick_config(2, 1, B, Cout, 4 * Cin, g_hw[0], g_hw[1]), 2
+    if k == 3 and stride == 2:       # by output parity over the gradient's own pixels: the exact-tap kernel (config 13)
+        cfg = L.lib().spk_conv2d_dgrad_s2_config(B, Cout, Cin, g_hw[0], g_hw[1])
+        if cfg < 0:
+            raise L.SpkError(f"spk_conv2d_dgrad_s2_config: {L.lib().spk_last_error().decode()}")
+        return cfg, 2
     hw = g_hw if dgrad_at_output_size(k, stride, out, accumulate) else in_hw
     return conv2d_pick_config(k, 1, B, Cout, Cin, hw[0], hw[1]), 1
 

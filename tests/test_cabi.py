@@ -46,6 +46,12 @@ def test_host_side_queries_and_argument_errors(pkg):
             # the GEMM form of a stride-1 1x1: its packed image is the plain [Cout][Cin] matrix
             assert lib.spk_conv2d_packed_floats(cfg, 1, 1, 8, 5) == 40 and lib.spk_conv2d_packed_floats(cfg, 3, 3, 3, 5) == -1
             continue
+        if lib.spk_conv2d_config_valid(cfg, 2, 2, 1) and not lib.spk_conv2d_config_valid(cfg, 3, 3, 1):
+            # the exact-tap data gradient of a 3x3 stride-2 conv: the transposed 3x3 operator in 64 x 8 channel tiles
+            assert (co, ci) == (64, 8) and lib.spk_conv2d_packed_floats(cfg, 2, 2, 3, 4 * 128) == 2 * 1 * 9 * 8 * 64
+            assert lib.spk_conv2d_dgrad_s2_config(2, 3, 128, 8, 16) == cfg and lib.spk_conv2d_dgrad_s2_config(2, 3, 128, 8, 8) < 4
+            assert lib.spk_conv2d_packed_floats(cfg, 3, 3, 3, 5) == -1
+            continue
         # packed image is zero-padded up to whole tiles
         assert lib.spk_conv2d_packed_floats(cfg, 3, 3, 3, 5) == -(-5 // co) * -(-3 // ci) * 9 * ci * co
     assert lib.spk_conv2d_packed_floats(99, 3, 3, 3, 5) < 0

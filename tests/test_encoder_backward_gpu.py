@@ -129,13 +129,46 @@ def test_stride2_data_gradient_grouped(pkg, dev, groups, B, Cin, Cout, Hin):
     assert rel_l2(dx2, base.cpu() + x.grad) < TOL
 
 
+@pytest.mark.parametrize("groups,B,Cin,Cout,Hin,Win", [
+    (1, 2, 128, 64, 128, 128),     # 128-channel classes (128 x 128 tiles), the shape pick_config sends here by itself
+    (1, 2, 64, 128, 64, 64),       # 64-channel classes: the 64co x 256px tiles
+    (1, 3, 40, 24, 31, 45),        # ragged channels on both sides, odd input (the last row / column belongs to no class-1 pixel)
+    (3, 2, 32, 48, 32, 32),        # grouped: a group's four class images are packed together
+    (1, 1, 160, 136, 16, 24),      # three co tiles, a ragged last one; 17 chunks
+    (1, 2, 5, 3, 2, 2),            # a 1x1 gradient
+    (2, 2, 70, 12, 9, 40),         # odd height, a ragged chunk, groups
+])
+def test_stride2_data_gradient_exact_taps(pkg, dev, groups, B, Cin, Cout, Hin, Win):
+    """Tile config 13 (dgrad3x3s2.hip): one kernel with exactly the 9 taps -- a wave owns the four output-parity classes of its
+    channels and pixels -- against autograd and against the zero-padded one-launch form of the general kernel."""
+    PAR = 13
+    tag = f"s2e.{groups}.{B}.{Cin}.{Cout}.{Hin}.{Win}"
+    x = recipe_input(tag + ".x", (B, groups * Cin, Hin, Win)).requires_grad_(True)
+    ws = [recipe_tensor(tag + f".w{q}", (Cout, Cin, 3, 3)) for q in range(groups)]
+    y = torch.cat([F.conv2d(x[:, q * Cin:(q + 1) * Cin], ws[q], stride=2, padding=1) for q in range(groups)], 1)
+    g = recipe_input(tag + ".g", y.shape)
+    y.backward(g)
+    assert pkg.ops.conv2d_config_fits(PAR, 2, 1, B, Cout, 4 * Cin, *y.shape[-2:])
+    assert pkg.ops.dgrad_plan(3, 2, B, Cout, Cin, (Hin, Win), y.shape[-2:]) == ((PAR if y.shape[-1] > 8 else 2), 2) or y.shape[-1] <= 8
+    wp = torch.cat([pkg.ops.pack_conv_weight(w.to(dev), PAR, transpose_flip=2) for w in ws])
+    dx = pkg.ops.conv2d_dgrad(g.to(dev), wp, Cin, 3, 2, (Hin, Win), PAR, groups=groups)
+    assert dx.shape == x.shape and rel_l2(dx, x.grad) < TOL
+    # the one-launch form computes the same sums in the same order, zero taps aside
+    wp0 = torch.cat([pkg.ops.pack_conv_weight(w.to(dev), 0, transpose_flip=2) for w in ws])
+    if pkg.ops.conv2d_config_fits(0, 2, 1, B, Cout, 4 * Cin, *y.shape[-2:]):
+        assert rel_l2(dx, pkg.ops.conv2d_dgrad(g.to(dev), wp0, Cin, 3, 2, (Hin, Win), 0, groups=groups)) < 1e-6
+    base = recipe_input(tag + ".base", x.shape).to(dev)
+    dx2 = pkg.ops.conv2d_dgrad(g.to(dev), wp, Cin, 3, 2, (Hin, Win), PAR, out=base.clone(), accumulate=True, groups=groups)
+    assert rel_l2(dx2, base.cpu() + x.grad) < TOL
+
+
 def test_stride2_data_gradient_flag_is_validated(pkg, dev):
     L = pkg._lib
     g = torch.zeros(1, 8, 4, 4, device=dev)
     wp = pkg.ops.pack_conv_weight(torch.zeros(8, 4, 3, 3, device=dev), 0, transpose_flip=2)
     with pytest.raises(L.SpkError):          # 9x9 is not the input size of a stride-2 conv with a 4x4 output
         pkg.ops.conv2d_dgrad(g, wp, 4, 3, 2, (9, 9), 0)
-    with pytest.raises(L.SpkError):          # tile configs 0-3 only
+    with pytest.raises(L.SpkError):          # tile configs 0-3 and 13 only
         pkg.ops.conv2d_dgrad(g, wp, 4, 3, 2, (8, 8), 5)
 
 
