@@ -149,7 +149,8 @@ def test_stride2_data_gradient_exact_taps(pkg, dev, groups, B, Cin, Cout, Hin, W
     g = recipe_input(tag + ".g", y.shape)
     y.backward(g)
     assert pkg.ops.conv2d_config_fits(PAR, 2, 1, B, Cout, 4 * Cin, *y.shape[-2:])
-    assert pkg.ops.dgrad_plan(3, 2, B, Cout, Cin, (Hin, Win), y.shape[-2:]) == ((PAR if y.shape[-1] > 8 else 2), 2) or y.shape[-1] <= 8
+    auto_cfg, auto_tf = pkg.ops.dgrad_plan(3, 2, B, Cout, Cin, (Hin, Win), y.shape[-2:])
+    assert auto_tf == 2 and (auto_cfg == PAR if y.shape[-1] > 8 else auto_cfg < 4)     # narrow planes stay on the 2x2 form
     wp = torch.cat([pkg.ops.pack_conv_weight(w.to(dev), PAR, transpose_flip=2) for w in ws])
     dx = pkg.ops.conv2d_dgrad(g.to(dev), wp, Cin, 3, 2, (Hin, Win), PAR, groups=groups)
     assert dx.shape == x.shape and rel_l2(dx, x.grad) < TOL
