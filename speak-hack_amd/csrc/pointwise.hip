@@ -126,59 +126,72 @@ __global__ __launch_bounds__(256) void conv1x1_small_kernel(const float* __restr
     }
 }
 
-// Same op for small images with many channels (StyleGAN2's toRGB at 4^2..64^2 with 256-512 channels): too few pixels to
-// fill the chip with one thread per 4 pixels, so the channel range is split over the 4 waves of a workgroup (64 pixel
-// quads x 4 channel slices) and the partial sums meet in LDS.
+// Same op for small images with many channels (StyleGAN2's toRGB at 4^2..128^2 with 128-512 channels): too few pixels to fill
+// the chip with one thread per 4 pixels, and a thread that walks all C channels alone is bound by the LATENCY of its C
+// dependent-looking loads (the first form: 64 pixel quads x 4 channel slices per workgroup, 128 channels per thread -- 48 us
+// for a 4 x 4 image).  Here a workgroup takes Q <= 16 pixel quads and splits the channels 256 / Q ways (16 ... 64 slices,
+// 8 ... 32 channels per thread, all of a thread's loads issued before the first FMA); the partial sums meet in LDS.
+constexpr int CS_BATCH = 16;
 __global__ __launch_bounds__(256) void conv1x1_small_csplit_kernel(const float* __restrict__ x, const float* __restrict__ w,
                                                                   const float* __restrict__ bias, float* __restrict__ y, int C,
                                                                   int O, long long HW, float in_scale,
-                                                                  const float* __restrict__ mod, const float* __restrict__ skip, int W) {
-    extern __shared__ float sm[];           // [O][C] weights, then [4 waves][4 outputs][64 lanes] float4 partials
+                                                                  const float* __restrict__ mod, const float* __restrict__ skip, int W,
+                                                                  int lgQ) {
+    extern __shared__ float sm[];           // [O][C] weights, then [slices][4 outputs][Q] float4 partials
     float* w_s = sm;
     float4* part = reinterpret_cast<float4*>(sm + ((O * C + 3) & ~3));
-    const int b = blockIdx.y, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int Q = 1 << lgQ, NS = 256 >> lgQ;
+    const int b = blockIdx.y, q = threadIdx.x & (Q - 1), slice = threadIdx.x >> lgQ;
     for (int i = threadIdx.x; i < O * C; i += 256) w_s[i] = w[i] * in_scale * (mod ? mod[(size_t)b * C + (i % C)] : 1.f);
     __syncthreads();
     const float* xb = x + (size_t)b * C * HW;
     float* yb = y + (size_t)b * O * HW;
     const long long n4 = HW / 4;
-    const long long p4 = (long long)blockIdx.x * 64 + lane;
-    const int c0 = (int)((long long)C * wave / 4), c1 = (int)((long long)C * (wave + 1) / 4);
+    const long long p4 = (long long)blockIdx.x * Q + q;
+    const int c0 = (int)((long long)C * slice / NS), c1 = (int)((long long)C * (slice + 1) / NS);
     float4 acc[4];
 #pragma unroll
     for (int o = 0; o < 4; ++o) acc[o] = make_float4(0.f, 0.f, 0.f, 0.f);
     if (p4 < n4) {
-#pragma unroll 8
-        for (int c = c0; c < c1; ++c) {
-            const float4 xv = reinterpret_cast<const float4*>(xb + (size_t)c * HW)[p4];
+        for (int cb = c0; cb < c1; cb += CS_BATCH) {
+            float4 xv[CS_BATCH];
 #pragma unroll
-            for (int o = 0; o < 4; ++o) {
-                if (o < O) {
-                    const float wv = w_s[o * C + c];
-                    acc[o].x += wv * xv.x; acc[o].y += wv * xv.y; acc[o].z += wv * xv.z; acc[o].w += wv * xv.w;
+            for (int k = 0; k < CS_BATCH; ++k)          // every load of the batch is in flight before the first use
+                xv[k] = reinterpret_cast<const float4*>(xb + (size_t)min(cb + k, c1 - 1) * HW)[p4];
+#pragma unroll
+            for (int k = 0; k < CS_BATCH; ++k) {
+                if (cb + k < c1) {
+#pragma unroll
+                    for (int o = 0; o < 4; ++o) {
+                        if (o < O) {
+                            const float wv = w_s[o * C + cb + k];
+                            acc[o].x += wv * xv[k].x; acc[o].y += wv * xv[k].y; acc[o].z += wv * xv[k].z; acc[o].w += wv * xv[k].w;
+                        }
+                    }
                 }
             }
         }
     }
 #pragma unroll
-    for (int o = 0; o < 4; ++o) part[(wave * 4 + o) * 64 + lane] = acc[o];
+    for (int o = 0; o < 4; ++o) part[(slice * 4 + o) * Q + q] = acc[o];
     __syncthreads();
-    if (wave < O && p4 < n4) {              // wave o finishes output channel o
-        const int o = wave;
-        const float bo = bias ? bias[o] : 0.f;
+    // thread t < O * Q finishes output channel t / Q of quad t % Q: the slices in a fixed order
+    const int fo = threadIdx.x >> lgQ, fq = threadIdx.x & (Q - 1);
+    const long long fp4 = (long long)blockIdx.x * Q + fq;
+    if (fo < O && fp4 < n4) {
+        const float bo = bias ? bias[fo] : 0.f;
         float4 r = make_float4(bo, bo, bo, bo);
-#pragma unroll
-        for (int k = 0; k < 4; ++k) {
-            const float4 t = part[(k * 4 + o) * 64 + lane];
+        for (int k = 0; k < NS; ++k) {
+            const float4 t = part[(k * 4 + fo) * Q + fq];
             r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
         }
         if (skip) {
             const int Hs = (int)(HW / W) >> 1, Ws = W >> 1;
-            const long long p = 4 * p4;
-            const float4 u = upfir2x_4(skip + ((size_t)b * O + o) * Hs * Ws, Hs, Ws, (int)(p / W), (int)(p % W));
+            const long long p = 4 * fp4;
+            const float4 u = upfir2x_4(skip + ((size_t)b * O + fo) * Hs * Ws, Hs, Ws, (int)(p / W), (int)(p % W));
             r.x += u.x; r.y += u.y; r.z += u.z; r.w += u.w;
         }
-        reinterpret_cast<float4*>(yb + (size_t)o * HW)[p4] = r;
+        reinterpret_cast<float4*>(yb + (size_t)fo * HW)[fp4] = r;
     }
 }
 
@@ -248,10 +261,13 @@ static int conv1x1_small_launch(const float* x, const float* w, const float* mod
     const bool vec = (HW % 4 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)y % 16 == 0) && (!skip || W % 4 == 0);
     const size_t lds = (size_t)O * C * sizeof(float);
     if (vec && C >= 64 && (HW / 4 + 255) / 256 * B < 512) {   // too few pixel quads for one thread each: split the channels
-        dim3 grid((unsigned)((HW / 4 + 63) / 64), (unsigned)B);
-        const size_t lds2 = ((size_t)((O * C + 3) & ~3) + 4 * 4 * 64 * 4) * sizeof(float);
+        const long long n4 = HW / 4;
+        const int lgQ = n4 >= 16 ? 4 : (n4 >= 8 ? 3 : (n4 >= 4 ? 2 : (n4 >= 2 ? 1 : 0)));      // Q = min(16, pow2 <= n4 ...)
+        const int Q = 1 << lgQ, NS = 256 >> lgQ;
+        dim3 grid((unsigned)((n4 + Q - 1) / Q), (unsigned)B);
+        const size_t lds2 = ((size_t)((O * C + 3) & ~3) + (size_t)NS * 4 * Q * 4) * sizeof(float);
         hipLaunchKernelGGL(conv1x1_small_csplit_kernel, grid, dim3(256), lds2, (hipStream_t)stream, x, w, bias, y, C, O,
-                           (long long)HW, in_scale, mod, skip, W);
+                           (long long)HW, in_scale, mod, skip, W, lgQ);
         return spk::check_launch("conv1x1_small_csplit_kernel");
     }
     if (vec) {

@@ -18,10 +18,24 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--sg2", action="store_true", help="the StyleGAN2 variant's step instead (exact fp32 only)")
     args = ap.parse_args()
     pkg = importlib.import_module("speak-hack_amd")
     dev = torch.device("cuda:0")
     torch.manual_seed(1)
+    if args.sg2:
+        sg2 = importlib.import_module("speak-hack_amd.stylegan2")
+        gen = sg2.StyleGAN2Generator(6144).eval().to(dev)
+        with torch.no_grad():
+            for n, p in gen.named_parameters():
+                if n.endswith("noise.weight"):
+                    p.fill_(0.1)
+            z = torch.randn(args.batch, 6144, device=dev)
+            for _ in range(args.steps + 1):
+                gen(z)
+            torch.cuda.synchronize()
+        print("done")
+        return
     gen = pkg.StyleGenerator(6144).eval().to(dev)
     with torch.no_grad():
         for n, p in gen.named_parameters():
