@@ -446,27 +446,35 @@ __global__ __launch_bounds__(256) void wgrad3x3_pipe_kernel(const WgradArgs p) {
 // accumulation order and slab layout as the kernels above: results are bitwise equal to theirs for equal pixel splits.
 // MCO = MCI = 1 is the 64co x 64ci block of wgrad3x3_pipe_kernel with the wide loads.
 // Needs W % 4 == 0, W >= 16 and 16-byte aligned tensors (host-checked).
-template <int MCO, int MCI>
-struct WideShape {
-    static constexpr int CO_T = 64 * MCO, CI_T = 64 * MCI, NT = 256;
-    static constexpr int TW = 16, TH = 4, PW = TW + 2, PH = TH + 2, PLANE = PH * PW;
+template <int TW_>
+struct WideShapeT {
+    static constexpr int CO_T = 64, CI_T = 64, NT = 256;
+    static constexpr int TW = TW_, TH = 64 / TW, PW = TW + 2, PH = TH + 2, PLANE = PH * PW;
     static constexpr int GPITCH = TW * TH + 1, XPITCH = PLANE | 1;
-    static constexpr int BUF = (CO_T * GPITCH + CI_T * XPITCH + 3) & ~3;           // floats per buffer
+    static constexpr int BUF = (CO_T * GPITCH + CI_T * XPITCH + 1 + 3) & ~3;       // floats per buffer (+ a dump slot: BUF - 1)
     static constexpr int NG4 = CO_T / 16;            // float4 pieces of the gradient tile per thread (16 channels per piece)
-    static constexpr int NX4 = 6 * MCI;              // float4 pieces of the input tile (piece = one plane row of 64 channels)
-    static constexpr int NXH = 3 * MCI;              // halo-dword pieces (piece = two plane rows x 2 sides of 64 channels)
+    static constexpr int NXK = TW / 4;               // float4 per plane row (the aligned columns 0 .. TW-1)
+    static constexpr int RS = 256 / (CI_T * NXK);    // plane rows covered by one float4 piece (1 or 2)
+    static constexpr int NX4 = (PH + RS - 1) / RS;   // float4 pieces of the input tile
+    static constexpr int NXH = (PH + 1) / 2;         // halo-dword pieces (piece = two plane rows x 2 sides of 64 channels)
     static constexpr int NL = NG4 + NX4 + NXH, NS = 4 * NG4 + 4 * NX4 + NXH;
     static constexpr int STEPS = 32, HS = STEPS / 2;
     static constexpr int PL = (NL + HS - 1) / HS, PS = (NS + HS - 1) / HS;
-    static constexpr int NMFMA = MCO * MCI * 9, NFRAG = MCO + 9 * MCI;
+    static constexpr int NMFMA = 9, NFRAG = 10;
+    static_assert(XPITCH % 2 == 1, "odd pitch");
 };
+// (the shape the folded-upsample kernel below shares: the 16 x 4 tile)
+template <int MCO, int MCI>
+struct WideShape : WideShapeT<16> { static_assert(MCO == 1 && MCI == 1, "one accumulator tile set per wave"); };
 
-template <int MCO, int MCI, int MODE>
+// TW = 16: 16 x 4 pixel tiles (18 x 6 plane); TW = 8: 8 x 8 tiles (10 x 10 plane) for the 8^2 layers, one tile per image.
+template <int TW_, int MODE>
 __global__ __launch_bounds__(256) void wgrad3x3_wide_kernel(const WgradArgs p) {
-    using SH = WideShape<MCO, MCI>;
-    constexpr int TAPS = 9, CO_T = SH::CO_T, CI_T = SH::CI_T, PW = SH::PW, GPITCH = SH::GPITCH, XPITCH = SH::XPITCH, BUF = SH::BUF;
-    constexpr int NG4 = SH::NG4, NX4 = SH::NX4, NXH = SH::NXH, NL = SH::NL, NS = SH::NS, STEPS = SH::STEPS, HS = SH::HS;
-    constexpr int PL = SH::PL, PS = SH::PS, NMFMA = SH::NMFMA;
+    using SH = WideShapeT<TW_>;
+    constexpr int TAPS = 9, CO_T = SH::CO_T, CI_T = SH::CI_T, TW = SH::TW, TH = SH::TH, PW = SH::PW, PH = SH::PH;
+    constexpr int GPITCH = SH::GPITCH, XPITCH = SH::XPITCH, BUF = SH::BUF;
+    constexpr int NG4 = SH::NG4, NXK = SH::NXK, RS = SH::RS, NX4 = SH::NX4, NXH = SH::NXH, NL = SH::NL, NS = SH::NS;
+    constexpr int STEPS = SH::STEPS, HS = SH::HS, PL = SH::PL, PS = SH::PS;
     constexpr bool AFF = MODE == WG_AFFINE_RELU;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
@@ -481,48 +489,35 @@ __global__ __launch_bounds__(256) void wgrad3x3_wide_kernel(const WgradArgs p) {
     const int cx0 = grp * p.gin;
     const int ci0 = blockIdx.y * CI_T;
     const int nci = min(CI_T, p.Cin - ci0);
-    const int HW = p.H * p.W;                    // host: every tensor has < 2^31 elements
 
     // ---- staging roles (launch constants; only the tile origin moves) ----
     // gradient piece i: float4 gk of tile row grow of channel (tid >> 4) + 16 i
-    const int gk = tid & 3, grow = (tid >> 2) & 3;
+    const int gk = tid & (TW / 4 - 1), grow = (tid / (TW / 4)) & (TH - 1);
     int g_off[NG4];
 #pragma unroll
     for (int i = 0; i < NG4; ++i)
         g_off[i] = (min(co0 + (tid >> 4) + 16 * i, co_end - 1) * p.H + grow) * p.W + 4 * gk;    // rows past the last channel: clamped (never written out)
-    const int g_dst = (tid >> 4) * GPITCH + grow * 16 + 4 * gk;                                   // + 16 i GPITCH + j
-    // input piece i: float4 xk of plane row i % 6 of channel (tid >> 2) + 64 (i / 6)
-    const int xk = tid & 3, xc = tid >> 2;
-    int x_base[MCI];
-    float x_sc[AFF ? MCI : 1], x_sh[AFF ? MCI : 1];
-#pragma unroll
-    for (int m = 0; m < MCI; ++m) {
-        const int c = cx0 + ci0 + min(xc + 64 * m, nci - 1);
-        x_base[m] = (c * p.Hs - 1) * p.Ws + 4 * xk;                                               // + (i % 6) Ws
-        if (AFF) { x_sc[m] = p.in_scale[c]; x_sh[m] = p.in_shift[c]; }
-    }
-    const int x_dst = CO_T * GPITCH + xc * XPITCH + 1 + 4 * xk;                                   // + 64 (i / 6) XPITCH + (i % 6) PW + j
-    // halo piece i: column -1 / 16 (hs) of plane row 2 (i % 3) + hr of channel ((tid >> 1) & 63) + 64 (i / 3)
-    const int hs = tid & 1, hc = (tid >> 1) & 63, hr = tid >> 7;
-    int h_base[MCI];
-    float h_sc[AFF ? MCI : 1], h_sh[AFF ? MCI : 1];
-#pragma unroll
-    for (int m = 0; m < MCI; ++m) {
-        const int c = cx0 + ci0 + min(hc + 64 * m, nci - 1);
-        h_base[m] = (c * p.Hs + hr - 1) * p.Ws + (hs ? 16 : -1);                                  // + 2 (i % 3) Ws
-        if (AFF) { h_sc[m] = p.in_scale[c]; h_sh[m] = p.in_shift[c]; }
-    }
-    const int h_dst = CO_T * GPITCH + hc * XPITCH + hr * PW + (hs ? 17 : 0);                      // + 64 (i / 3) XPITCH + 2 (i % 3) PW
+    const int g_dst = (tid >> 4) * GPITCH + grow * TW + 4 * gk;                                   // + 16 i GPITCH + j
+    // input piece i: float4 xk of plane row RS i + xr of channel xc
+    const int xk = tid & (NXK - 1), xc = (tid / NXK) & (CI_T - 1), xr = tid / (NXK * CI_T);
+    const int x_chan = cx0 + ci0 + min(xc, nci - 1);
+    const int x_base = (x_chan * p.Hs + xr - 1) * p.Ws + 4 * xk;                                  // + RS i Ws
+    const int x_dst = CO_T * GPITCH + xc * XPITCH + xr * PW + 1 + 4 * xk;                         // + RS i PW + j
+    float x_sc = 1.f, x_sh = 0.f;
+    if (AFF) { x_sc = p.in_scale[x_chan]; x_sh = p.in_shift[x_chan]; }
+    // halo piece i: column -1 / TW (hs) of plane row 2 i + hr of channel hc
+    const int hs = tid & 1, hc = (tid >> 1) & (CI_T - 1), hr = tid >> 7;
+    const int h_chan = cx0 + ci0 + min(hc, nci - 1);
+    const int h_base = (h_chan * p.Hs + hr - 1) * p.Ws + (hs ? TW : -1);                          // + 2 i Ws
+    const int h_dst = CO_T * GPITCH + hc * XPITCH + hr * PW + (hs ? TW + 1 : 0);                  // + 2 i PW
+    float h_sc = 1.f, h_sh = 0.f;
+    if (AFF) { h_sc = p.in_scale[h_chan]; h_sh = p.in_shift[h_chan]; }
 
-    f32x16 acc[MCO][MCI][TAPS];
+    f32x16 acc[TAPS];
 #pragma unroll
-    for (int m = 0; m < MCO; ++m)
+    for (int t = 0; t < TAPS; ++t)
 #pragma unroll
-        for (int n = 0; n < MCI; ++n)
-#pragma unroll
-            for (int t = 0; t < TAPS; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) acc[m][n][t][r] = 0.f;
+        for (int r = 0; r < 16; ++r) acc[t][r] = 0.f;
 
     // prefetch registers and, for the tile being staged: its base pointers, origin row and which of this thread's columns exist
     f32x4 gq[NG4], xq[NX4];
@@ -535,28 +530,29 @@ __global__ __launch_bounds__(256) void wgrad3x3_wide_kernel(const WgradArgs p) {
         const int tx = tile % p.tiles_x;
         const int q = tile / p.tiles_x;
         const int ty = q % p.tiles_y, b = q / p.tiles_y;
-        const int y0 = ty * 4, x0 = tx * 16;
+        const int y0 = ty * TH, x0 = tx * TW;
         ty0 = y0;
         gbase = p.g + ((size_t)b * p.Cy * p.H + y0) * p.W + x0;
         xbase = p.x + ((size_t)b * p.Cx * p.Hs + y0) * p.Ws + x0;
         const bool live = tile < p.n_tiles;
         g_ok = live && y0 + grow < p.H && x0 + 4 * gk < p.W;
         xcol_ok = live && x0 + 4 * xk < p.Ws;
-        hcol_ok = live && (unsigned)(x0 + (hs ? 16 : -1)) < (unsigned)p.Ws;
+        hcol_ok = live && (unsigned)(x0 + (hs ? TW : -1)) < (unsigned)p.Ws;
     };
-    auto x_row_ok = [&](int r) { return (unsigned)(ty0 + r - 1) < (unsigned)p.Hs; };    // plane row r of the tile being staged
+    // plane row r of the tile being staged lies inside the image (and inside the plane: the last piece of a two-row role)
+    auto row_ok = [&](int r) { return r < PH && (unsigned)(ty0 + r - 1) < (unsigned)p.Hs; };
     auto load_piece = [&](auto j_) {
         constexpr int j = decltype(j_)::value;
         if constexpr (j < NG4) {
             gq[j] = *reinterpret_cast<const f32x4*>(g_ok ? gbase + g_off[j] : p.g);
         } else if constexpr (j < NG4 + NX4) {
-            constexpr int i = j - NG4, m = i / 6, r = i % 6;
-            const bool ok = xcol_ok && x_row_ok(r);
-            xq[i] = *reinterpret_cast<const f32x4*>(ok ? xbase + (x_base[m] + r * p.Ws) : p.x);
+            constexpr int i = j - NG4;
+            const bool ok = xcol_ok && row_ok(RS * i + xr);
+            xq[i] = *reinterpret_cast<const f32x4*>(ok ? xbase + (x_base + RS * i * p.Ws) : p.x);
         } else if constexpr (j < NL) {
-            constexpr int i = j - NG4 - NX4, m = i / 3, r2 = 2 * (i % 3);
-            const bool ok = hcol_ok && x_row_ok(r2 + hr);
-            hq[i] = *(ok ? xbase + (h_base[m] + r2 * p.Ws) : p.x);
+            constexpr int i = j - NG4 - NX4;
+            const bool ok = hcol_ok && row_ok(2 * i + hr);
+            hq[i] = *(ok ? xbase + (h_base + 2 * i * p.Ws) : p.x);
         }
     };
     auto store_piece = [&](float* buf, auto s_) {
@@ -565,15 +561,18 @@ __global__ __launch_bounds__(256) void wgrad3x3_wide_kernel(const WgradArgs p) {
             constexpr int i = s / 4, j = s % 4;
             buf[g_dst + 16 * i * GPITCH + j] = g_ok ? gq[i][j] : 0.f;        // only the PIXEL axis (the contraction) needs zeros
         } else if constexpr (s < 4 * NG4 + 4 * NX4) {
-            constexpr int i = (s - 4 * NG4) / 4, j = (s - 4 * NG4) % 4, m = i / 6, r = i % 6;
+            constexpr int i = (s - 4 * NG4) / 4, j = (s - 4 * NG4) % 4;
             float v = xq[i][j];
-            if (AFF) v = fmaxf(v * x_sc[m] + x_sh[m], 0.f);
-            buf[x_dst + 64 * m * XPITCH + r * PW + j] = (xcol_ok && x_row_ok(r)) ? v : 0.f;
+            if (AFF) v = fmaxf(v * x_sc + x_sh, 0.f);
+            // (a two-row role's last piece: plane row PH does not exist -- those lanes hit the dump slot, no branch)
+            const int dst = (RS * i + RS - 1 < PH || RS * i + xr < PH) ? x_dst + RS * i * PW + j : BUF - 1;
+            buf[dst] = (xcol_ok && row_ok(RS * i + xr)) ? v : 0.f;
         } else if constexpr (s < NS) {
-            constexpr int i = s - 4 * NG4 - 4 * NX4, m = i / 3, r2 = 2 * (i % 3);
+            constexpr int i = s - 4 * NG4 - 4 * NX4;
             float v = hq[i];
-            if (AFF) v = fmaxf(v * h_sc[m] + h_sh[m], 0.f);
-            buf[h_dst + 64 * m * XPITCH + r2 * PW] = (hcol_ok && x_row_ok(r2 + hr)) ? v : 0.f;
+            if (AFF) v = fmaxf(v * h_sc + h_sh, 0.f);
+            const int dst = (2 * i + 1 < PH || 2 * i + hr < PH) ? h_dst + 2 * i * PW : BUF - 1;
+            buf[dst] = (hcol_ok && row_ok(2 * i + hr)) ? v : 0.f;
         }
     };
 
@@ -586,22 +585,20 @@ __global__ __launch_bounds__(256) void wgrad3x3_wide_kernel(const WgradArgs p) {
     }
     __syncthreads();
 
-    // one tile's 32 k-steps out of buffer `cur`; PIPE: the next tile is staged into the other buffer on the way (its loads
-    // behind the first half of the k-steps, its LDS stores behind the second half)
-    auto run_tile = [&](auto pipe_) {
-        constexpr bool PIPE = decltype(pipe_)::value;
+    // one tile's 32 k-steps out of buffer `cur`; the next tile is staged into the other buffer on the way (its loads behind the
+    // first half of the k-steps, its LDS stores behind the second half)
+    auto run_tile = [&]() {
         const float* cbuf = smem + cur * BUF;
         float* nbuf = smem + (cur ^ 1) * BUF;
-        const float* ga = cbuf + (wco * 32 * MCO + l32) * GPITCH + half;
-        const float* xb = cbuf + CO_T * GPITCH + (wci * 32 * MCI + l32) * XPITCH + half;
-        float fa[2][MCO], fb[2][MCI][TAPS];
+        const float* ga = cbuf + (wco * 32 + l32) * GPITCH + half;
+        const float* xb = cbuf + CO_T * GPITCH + (wci * 32 + l32) * XPITCH + half;
+        float fa[2], fb[2][TAPS];
 #define SPK_WW_FRAG(st_, slot_)                                                                               \
     {                                                                                                         \
-        constexpr int px_ = (2 * (st_)) & 15, py_ = (2 * (st_)) >> 4;                                         \
-        _Pragma("unroll") for (int m = 0; m < MCO; ++m) fa[slot_][m] = ga[m * 32 * GPITCH + 2 * (st_)];       \
-        _Pragma("unroll") for (int n = 0; n < MCI; ++n)                                                       \
-            _Pragma("unroll") for (int t = 0; t < TAPS; ++t)                                                  \
-                fb[slot_][n][t] = xb[n * 32 * XPITCH + (py_ + t / 3) * PW + px_ + t % 3];                     \
+        constexpr int px_ = (2 * (st_)) & (TW - 1), py_ = (2 * (st_)) / TW;                                   \
+        fa[slot_] = ga[2 * (st_)];                                                                            \
+        _Pragma("unroll") for (int t = 0; t < TAPS; ++t)                                                      \
+            fb[slot_][t] = xb[(py_ + t / 3) * PW + px_ + t % 3];                                              \
     }
         SPK_WW_FRAG(0, 0);
         wg_static_for<0, STEPS>([&](auto s_) {
@@ -609,32 +606,28 @@ __global__ __launch_bounds__(256) void wgrad3x3_wide_kernel(const WgradArgs p) {
             // Nothing may be scheduled across the load / store boundary: left alone, the scheduler hoists the stores' VALU
             // halves (the zero-select of out-of-image pieces, the folded BatchNorm affine) up to the loads they consume -- and
             // every load is then followed by s_waitcnt vmcnt(0), a full memory latency with the MFMA pipe idle (one wave per SIMD).
-            if constexpr (PIPE && st == HS) __builtin_amdgcn_sched_barrier(0);
+            if constexpr (st == HS) __builtin_amdgcn_sched_barrier(0);
             if constexpr (st + 1 < STEPS) SPK_WW_FRAG(st + 1, (st + 1) & 1);
-            constexpr int nl = (PIPE && st < HS) ? ((PL * st + PL <= NL) ? PL : (PL * st < NL ? NL - PL * st : 0)) : 0;
+            constexpr int nl = st < HS ? ((PL * st + PL <= NL) ? PL : (PL * st < NL ? NL - PL * st : 0)) : 0;
             constexpr int s0 = PS * (st - HS);
-            constexpr int ns = (PIPE && st >= HS) ? ((s0 + PS <= NS) ? PS : (s0 < NS ? NS - s0 : 0)) : 0;
+            constexpr int ns = st >= HS ? ((s0 + PS <= NS) ? PS : (s0 < NS ? NS - s0 : 0)) : 0;
             if constexpr (nl > 0) wg_static_for<PL * st, PL * st + nl>([&](auto j_) { load_piece(j_); });
             if constexpr (ns > 0) wg_static_for<s0, s0 + ns>([&](auto q_) { store_piece(nbuf, q_); });
 #pragma unroll
-            for (int m = 0; m < MCO; ++m)
-#pragma unroll
-                for (int n = 0; n < MCI; ++n)
-#pragma unroll
-                    for (int t = 0; t < TAPS; ++t)
-                        acc[m][n][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[st & 1][m], fb[st & 1][n][t], acc[m][n][t], 0, 0, 0);
+            for (int t = 0; t < TAPS; ++t)
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[st & 1], fb[st & 1][t], acc[t], 0, 0, 0);
             // order: next step's fragments first, then the MFMAs with the staging accesses spread between them
             if constexpr (st + 1 < STEPS) __builtin_amdgcn_sched_group_barrier(0x100, SH::NFRAG, 0);
             constexpr int np = nl > 0 ? nl : ns;
             if constexpr (np > 0) {
-                constexpr int per = NMFMA / (np + 1);
+                constexpr int per = TAPS / (np + 1);
                 wg_static_for<0, np>([&](auto k_) {
                     __builtin_amdgcn_sched_group_barrier(0x8, per, 0);
                     __builtin_amdgcn_sched_group_barrier(nl > 0 ? 0x20 : 0x200, 1, 0);
                 });
-                __builtin_amdgcn_sched_group_barrier(0x8, NMFMA - per * np, 0);
+                __builtin_amdgcn_sched_group_barrier(0x8, TAPS - per * np, 0);
             } else {
-                __builtin_amdgcn_sched_group_barrier(0x8, NMFMA, 0);
+                __builtin_amdgcn_sched_group_barrier(0x8, TAPS, 0);
             }
         });
 #undef SPK_WW_FRAG
@@ -646,25 +639,20 @@ __global__ __launch_bounds__(256) void wgrad3x3_wide_kernel(const WgradArgs p) {
     // 288 MFMAs (and twice the code).
     for (; tile < p.n_tiles; tile += gridDim.z) {
         aim(tile + (int)gridDim.z);
-        run_tile(std::true_type{});
+        run_tile();
         __syncthreads();                      // every wave is done with `cur`, and the other buffer is complete
         cur ^= 1;
     }
 
     // ---- partial block -> slab [slab][co][tap][ci] (ci contiguous: 128-B stores per half wave) ----
     float* out = p.slabs + (size_t)blockIdx.z * p.Cy * TAPS * p.Cin;
+    const int ci = ci0 + wci * 32 + l32;
 #pragma unroll
-    for (int m = 0; m < MCO; ++m)
+    for (int t = 0; t < TAPS; ++t)
 #pragma unroll
-        for (int n = 0; n < MCI; ++n) {
-            const int ci = ci0 + (wci * MCI + n) * 32 + l32;
-#pragma unroll
-            for (int t = 0; t < TAPS; ++t)
-#pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int co = co0 + (wco * MCO + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-                    if (co < co_end && ci < p.Cin) out[((size_t)co * TAPS + t) * p.Cin + ci] = acc[m][n][t][r];
-                }
+        for (int r = 0; r < 16; ++r) {
+            const int co = co0 + wco * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+            if (co < co_end && ci < p.Cin) out[((size_t)co * TAPS + t) * p.Cin + ci] = acc[t][r];
         }
 }
 
@@ -1186,12 +1174,12 @@ WGeom wgeom(int B, int Cin, int Cout, int H, int W, int want_splits) {
     return g;
 }
 
-// geometry of the wide form: 16 x 4 pixel tiles, one workgroup per CU
+// geometry of the wide form: 16 x 4 (or, tw = 8, 8 x 8) pixel tiles, one workgroup per CU
 struct WideGeom { int tiles_x, tiles_y, n_tiles, splits, n_slabs; };
-inline WideGeom wide_geom(int co_t, int ci_t, int B, int Cin, int Cout_all, int H, int W, int want_splits) {
+inline WideGeom wide_geom(int co_t, int ci_t, int B, int Cin, int Cout_all, int H, int W, int want_splits, int tw = 16) {
     WideGeom g;
-    g.tiles_x = spk::ceil_div(W, 16);
-    g.tiles_y = spk::ceil_div(H, 4);
+    g.tiles_x = spk::ceil_div(W, tw);
+    g.tiles_y = spk::ceil_div(H, 64 / tw);
     g.n_tiles = g.tiles_x * g.tiles_y * B;
     const int blocks = spk::ceil_div(Cout_all, co_t) * spk::ceil_div(Cin, ci_t);
     static const int target = [] { const char* e = getenv("SPK_WGRAD_WIDE_TARGET"); return e ? atoi(e) : 256; }();
@@ -1213,16 +1201,16 @@ inline bool wide_takes(const spk_wgrad_desc* d) {
     static const bool allow = [] { const char* e = getenv("SPK_WGRAD_WIDE"); return !e || atoi(e) != 0; }();
     const int G = d->groups > 1 ? d->groups : 1;
     const auto aligned = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-    return allow && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->W >= 16 && d->W % 4 == 0 && d->H >= 4 && aligned(d->g) && aligned(d->x) &&
+    return allow && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->W >= 8 && d->W % 4 == 0 && d->H >= 4 && aligned(d->g) && aligned(d->x) &&
            (long long)G * d->Cout * d->H * d->W < (1ll << 31) && ((long long)d->group_in_stride * (G - 1) + d->Cin) * d->H * d->W < (1ll << 31) &&
            wide_variant(d->groups, d->Cout, d->Cin) >= 0;
 }
 
-template <int MCO, int MCI, int MODE>
+template <int TW, int MODE>
 int run_wgrad_wide(const spk_wgrad_desc* d, hipStream_t stream) {
-    using SH = WideShape<MCO, MCI>;
+    using SH = WideShapeT<TW>;
     const int G = d->groups > 1 ? d->groups : 1;
-    const WideGeom g = wide_geom(SH::CO_T, SH::CI_T, d->B, d->Cin, G * d->Cout, d->H, d->W, d->splits);
+    const WideGeom g = wide_geom(SH::CO_T, SH::CI_T, d->B, d->Cin, G * d->Cout, d->H, d->W, d->splits, TW);
     const size_t slab_floats = (size_t)G * d->Cout * d->Cin * 9;
     SPK_REQUIRE(d->workspace && (size_t)d->workspace_bytes >= g.n_slabs * slab_floats * sizeof(float),
                 "wgrad: needs a %zu-byte workspace (see spk_conv2d_wgrad_workspace_bytes)", g.n_slabs * slab_floats * sizeof(float));
@@ -1232,9 +1220,9 @@ int run_wgrad_wide(const spk_wgrad_desc* d, hipStream_t stream) {
     a.gin = G > 1 ? d->group_in_stride : d->Cin;
     a.Cx = a.gin * (G - 1) + d->Cin;
     a.Cy = G * d->Cout;
-    a.lgTW = 4; a.lgTH = 2; a.lgTB = 0;
+    a.lgTW = spk::ilog2(TW); a.lgTH = spk::ilog2(64 / TW); a.lgTB = 0;
     a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y; a.n_tiles = g.n_tiles;
-    auto kern = &wgrad3x3_wide_kernel<MCO, MCI, MODE>;
+    auto kern = &wgrad3x3_wide_kernel<TW, MODE>;
     static bool raised = false;
     if (!raised) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -1360,7 +1348,7 @@ int run_wgrad_s2(const spk_wgrad_desc* d, hipStream_t stream) {
 
 template <int MODE>
 int run_wgrad_wide_any(const spk_wgrad_desc* d, hipStream_t stream) {
-    return run_wgrad_wide<1, 1, MODE>(d, stream);
+    return d->W >= 16 ? run_wgrad_wide<16, MODE>(d, stream) : run_wgrad_wide<8, MODE>(d, stream);
 }
 
 template <int KH, int KW, int S, int MODE>
@@ -1693,9 +1681,7 @@ int64_t spk_conv2d_wgrad_workspace_bytes(int kh, int kw, int stride, int splits,
     else g = wgeom<7, 7, 2>(B, Cin, Cout, H, W, splits);
     int n_slabs = g.n_slabs;
     if (kh == 3 && stride == 1) {     // the 8-wave form may take the problem (the group count is not known here: the largest of its shapes)
-        n_slabs = std::max(n_slabs, wide_geom(128, 64, B, Cin, Cout, H, W, splits).n_slabs);
-        n_slabs = std::max(n_slabs, wide_geom(64, 128, B, Cin, Cout, H, W, splits).n_slabs);
-        n_slabs = std::max(n_slabs, wide_geom(64, 64, B, Cin, Cout, H, W, splits).n_slabs);
+        n_slabs = std::max(n_slabs, wide_geom(64, 64, B, Cin, Cout, H, W, splits, W >= 16 ? 16 : 8).n_slabs);
     }
     if (kh == 3 && stride == 2 && W >= 8) n_slabs = std::max(n_slabs, s2_geom(W >= 16 ? 16 : 8, B, Cin, Cout, H, W, splits).n_slabs);
     return (int64_t)n_slabs * Cout * Cin * kh * kw * (int64_t)sizeof(float);

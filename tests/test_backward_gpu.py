@@ -76,6 +76,35 @@ def test_wgrad_with_upsampled_and_bn_folded_input(pkg, dev):
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W,groups,aff", [
+    (2, 64, 64, 8, 8, 1, False),         # 8 x 8 tiles: one per image (the 8^2 layers)
+    (3, 70, 130, 12, 12, 1, True),       # 8 x 8 tiles, partial in both directions, ragged channel blocks, folded BatchNorm
+    (2, 64, 64, 8, 8, 3, True),          # grouped (the trunk's layer4 convs)
+    (2, 40, 72, 6, 8, 1, False),
+    (2, 64, 128, 20, 16, 2, True),       # 16 x 4 tiles, grouped, folded BatchNorm
+])
+def test_wgrad_stride1_wide_form(pkg, dev, B, Cin, Cout, H, W, groups, aff):
+    """wgrad3x3_wide_kernel<16 | 8> (64co x 64ci blocks, 16-byte row loads, staging behind the MFMAs) against autograd."""
+    tag = f"wgw.{B}.{Cin}.{Cout}.{H}.{W}.{groups}.{int(aff)}"
+    G = groups
+    x = recipe_input(tag + ".x", (B, G * Cin, H, W))
+    a = 1.0 + recipe_tensor(tag + ".a", (G * Cin,), 0.3)
+    b = recipe_tensor(tag + ".b", (G * Cin,), 0.3)
+    xin = F.relu(x * a.view(1, -1, 1, 1) + b.view(1, -1, 1, 1)) if aff else x
+    ws = [recipe_tensor(tag + f".weight{q}", (Cout, Cin, 3, 3)).requires_grad_(True) for q in range(G)]
+    y = torch.cat([F.conv2d(xin[:, q * Cin:(q + 1) * Cin], ws[q], padding=1) for q in range(G)], 1)
+    g = recipe_input(tag + ".g", y.shape)
+    y.backward(g)
+    ref = torch.cat([w.grad for w in ws], 0)
+    kw = dict(in_affine=(a.to(dev), b.to(dev))) if aff else {}
+    for splits in (0, 1, 3):
+        dw = pkg.ops.conv2d_wgrad(g.to(dev), x.to(dev), Cout, Cin, 3, 1, splits=splits, groups=G, **kw)
+        assert rel_l2(dw, ref) < TOL, splits
+    base = recipe_tensor(tag + ".base", ref.shape).to(dev)
+    acc = pkg.ops.conv2d_wgrad(g.to(dev), x.to(dev), Cout, Cin, 3, 1, scale=0.5, out=base.clone(), accumulate=True, groups=G, **kw)
+    assert rel_l2(acc, base.cpu() + 0.5 * ref) < TOL
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,groups,aff", [
     (2, 32, 128, 16, 16, 1, False),      # 16 x 4 output tiles, whole blocks
     (3, 40, 160, 10, 20, 1, True),       # ragged channels (8 live rows in the second ci block, 32 in the second co block), partial tiles
     (2, 64, 128, 8, 8, 1, False),        # 8 x 8 tiles (the 16^2 -> 8^2 layers)
