@@ -260,6 +260,25 @@ typedef struct spk_fc_group {
     int32_t reserved;
 } spk_fc_group;
 int spk_fc_grouped_fwd(const spk_fc_group* groups, int n_groups, int B, void* stream);
+/* The backward of up to SPK_FC_MAX_GROUPS independent FCs in two launches (spk_fc_bwd's two kernels over the groups): per group
+ * dz = dout * act'(out); dx[b, :] (row stride dx_stride; NULL to skip) = wmul * dz @ w; dw = wmul * dz^T @ x, db = bmul * sum_b dz
+ * (dw NULL to skip both).  replaces: autograd's backward of the 13 ApplyStyle.linear FCs of a synthesis pass
+ * (styleganv1.py:463-468), whose input gradients are the rows of one [B, 13, 512] latent gradient. */
+typedef struct spk_fc_bwd_group {
+    const float* dout;   /* [B, O] */
+    const float* out;    /* [B, O] the saved forward output */
+    const float* x;      /* [B, I], row stride x_stride (for dw) */
+    int64_t x_stride;
+    const float* w;      /* [O, I] (for dx) */
+    float* dx;           /* [B, I], row stride dx_stride, or NULL */
+    int64_t dx_stride;
+    float* dw;           /* [O, I] or NULL */
+    float* db;           /* [O] or NULL */
+    int32_t I, O;
+    float wmul, bmul, slope;
+    int32_t reserved;
+} spk_fc_bwd_group;
+int spk_fc_grouped_bwd(const spk_fc_bwd_group* groups, int n_groups, int B, void* stream);
 
 /* ---- bias + noise + style (decoder prologue; stand-alone ApplyNoise / ApplyStyle) ------------------
  * y[b,c,p] = (x[b*x_batch_stride + c*HW + p] + bias[c] + noise_w[c]*noise[b,p]) * (s0[b,c]+1) + s1[b,c]

@@ -53,6 +53,13 @@ class FcGroup(C.Structure):
                 ("slope", C.c_float), ("reserved", C.c_int32)]
 
 
+class FcBwdGroup(C.Structure):
+    """``spk_fc_bwd_group`` (include/spk.h)."""
+    _fields_ = [("dout", C.c_void_p), ("out", C.c_void_p), ("x", C.c_void_p), ("x_stride", C.c_int64), ("w", C.c_void_p),
+                ("dx", C.c_void_p), ("dx_stride", C.c_int64), ("dw", C.c_void_p), ("db", C.c_void_p), ("I", C.c_int32),
+                ("O", C.c_int32), ("wmul", C.c_float), ("bmul", C.c_float), ("slope", C.c_float), ("reserved", C.c_int32)]
+
+
 class DemodGroup(C.Structure):
     """``spk_demod_group`` (include/spk.h)."""
     _fields_ = [("w", C.c_void_p), ("s", C.c_void_p), ("d", C.c_void_p), ("Cin", C.c_int32), ("Cout", C.c_int32),
@@ -186,6 +193,7 @@ _PROTOTYPES = {
     "spk_fc_fwd": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int,
                              C.c_int, C.c_float, C.c_float, C.c_float, C.c_void_p]),
     "spk_fc_grouped_fwd": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "spk_fc_grouped_bwd": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "spk_bias_noise_style_fwd": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "spk_conv1x1_small_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,

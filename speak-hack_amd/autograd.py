@@ -109,6 +109,49 @@ class FCFn(torch.autograd.Function):
         return dx, dw, db, None, None, None, None
 
 
+class StyleFCGroupFn(torch.autograd.Function):
+    """The style affines of a synthesis pass -- ``ApplyStyle.linear`` of every layer (styleganv1.py:463-468) applied to its row
+    of the latent ``w`` [B, L, 512] -- as ONE grouped launch, and their backward as two: the input gradients are written
+    straight into the rows of one [B, L, 512] latent gradient (13 FCFn nodes cost 13 + 26 launches and 13 row scatters)."""
+
+    @staticmethod
+    def forward(ctx, w, confs, grad_mode, *params):
+        # confs: per layer (wmul, bmul, slope, has_bias); params: weight_0, bias_0 | None, weight_1, ...
+        n = len(confs)
+        ws, bs = params[0::2], params[1::2]
+        outs = ops.fc_grouped((w[:, j], ws[j], bs[j], confs[j][0], confs[j][1], confs[j][2]) for j in range(n))
+        if _needs(ctx, grad_mode):
+            ctx.save_for_backward(w, *ws, *outs)
+            ctx.confs = confs
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, *douts):
+        confs = ctx.confs
+        n = len(confs)
+        saved = ctx.saved_tensors
+        w, ws, outs = saved[0], saved[1:1 + n], saved[1 + n:1 + 2 * n]
+        B = w.size(0)
+        need_dx = ctx.needs_input_grad[0]
+        # rows of w that feed no layer (or whose layer got no gradient) keep a zero gradient
+        live = [j for j in range(n) if douts[j] is not None]
+        dwl = (torch.zeros_like(w) if (w.size(1) > n or len(live) < n) else torch.empty_like(w)) if need_dx else None
+        res = ops.fc_grouped_bwd(((douts[j], outs[j], w[:, j], ws[j], dwl[:, j] if need_dx else None,
+                                   ctx.needs_input_grad[3 + 2 * j] or (confs[j][3] and ctx.needs_input_grad[4 + 2 * j]),
+                                   confs[j][3], confs[j][0], confs[j][1], confs[j][2]) for j in live), B) if live else []
+        grads = [None] * (2 * n)
+        for j, (dw, db) in zip(live, res):
+            grads[2 * j], grads[2 * j + 1] = dw, db
+        return (dwl, None, None, *grads)
+
+
+def style_fc_group(w, linears, slope):
+    """``linears``: the FC modules (decoder.FC) of the style affines, layer j reading ``w[:, j]`` -> tuple of [B, 2C] styles."""
+    confs = tuple((float(m.w_lrmul), float(m.b_lrmul), float(slope), m.bias is not None) for m in linears)
+    params = [t for m in linears for t in (m.weight, m.bias)]
+    return StyleFCGroupFn.apply(w, confs, torch.is_grad_enabled(), *params)
+
+
 class ToRGBFn(torch.autograd.Function):
     """1x1 conv to <= 4 channels -- styleganv1.py:607."""
 

@@ -465,6 +465,11 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
                     if constexpr (DMA) __builtin_amdgcn_s_waitcnt(0x0f70);   // vmcnt(0): the DMA blocks of slot (i+1)%3 have landed
                     __syncthreads();
                 }
+                // A store piece's VALU half (the zero-select of padding elements, the folded affine) must stay in its own step:
+                // unfenced, the scheduler gathers the selects of ALL pieces behind the first MFMAs of the chunk, and the
+                // s_waitcnt vmcnt(0) in front of them makes step 0 wait for the gather issued two steps earlier (a full memory
+                // latency) instead of each step waiting for a load that has been in flight for half a chunk.
+                if constexpr (st < NST_S) __builtin_amdgcn_sched_barrier(0);
 #ifdef SPK_LAB_STEPTIME
                 if (i == 10) lab_ts[st] = __builtin_readcyclecounter();
 #endif

@@ -292,6 +292,84 @@ __global__ __launch_bounds__(256) void fc_bwd_weight_kernel(const float* __restr
     }
 }
 
+// ---- the same two kernels over up to SPK_FC_MAX_GROUPS independent FCs (the 13 style affines of a training pass:
+// one launch each instead of 13 pairs; the groups share B) ----
+struct FcBwdGroups { spk_fc_bwd_group g[SPK_FC_MAX_GROUPS]; int n; };
+
+__global__ __launch_bounds__(256) void fc_grouped_bwd_input_kernel(const FcBwdGroups a, int B) {
+    extern __shared__ float dz_s[];            // [FCB_BT][O]
+    __shared__ float red[4][FCB_BT][64];
+    const spk_fc_bwd_group& g = a.g[blockIdx.y];
+    const int I = g.I, O = g.O;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int i = blockIdx.x * 64 + lane;
+    if (!g.dx || (int)blockIdx.x * 64 >= I) return;          // uniform
+    for (int b0 = 0; b0 < B; b0 += FCB_BT) {
+        __syncthreads();
+        for (int e = tid; e < FCB_BT * O; e += 256) {
+            const int b = e / O, o = e - b * O;
+            float v = 0.f;
+            if (b0 + b < B) {
+                const size_t idx = (size_t)(b0 + b) * O + o;
+                v = g.dout[idx] * (g.out[idx] > 0.f ? 1.f : g.slope);
+            }
+            dz_s[e] = v;
+        }
+        __syncthreads();
+        float acc[FCB_BT];
+#pragma unroll
+        for (int b = 0; b < FCB_BT; ++b) acc[b] = 0.f;
+        if (i < I) {
+            int o = wave;
+            for (; o + 28 < O; o += 32) {            // 8 independent row loads in flight
+                float wv[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) wv[u] = g.w[(size_t)(o + 4 * u) * I + i];
+#pragma unroll
+                for (int u = 0; u < 8; ++u)
+#pragma unroll
+                    for (int b = 0; b < FCB_BT; ++b) acc[b] += dz_s[b * O + o + 4 * u] * wv[u];
+            }
+            for (; o < O; o += 4) {
+                const float wv = g.w[(size_t)o * I + i];
+#pragma unroll
+                for (int b = 0; b < FCB_BT; ++b) acc[b] += dz_s[b * O + o] * wv;
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < FCB_BT; ++b) red[wave][b][lane] = acc[b];
+        __syncthreads();
+        if (wave == 0 && i < I) {
+#pragma unroll
+            for (int b = 0; b < FCB_BT; ++b)
+                if (b0 + b < B)
+                    g.dx[(size_t)(b0 + b) * g.dx_stride + i] = (red[0][b][lane] + red[1][b][lane] + red[2][b][lane] + red[3][b][lane]) * g.wmul;
+        }
+    }
+}
+
+__global__ __launch_bounds__(256) void fc_grouped_bwd_weight_kernel(const FcBwdGroups a, int B) {
+    const spk_fc_bwd_group& g = a.g[blockIdx.z];
+    const int o = blockIdx.y, I = g.I, O = g.O;
+    if (!g.dw || o >= O) return;                              // uniform
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < I; i += gridDim.x * 256) {
+        float acc = 0.f;
+        for (int b = 0; b < B; ++b) {
+            const float ov = g.out[(size_t)b * O + o];
+            acc += g.dout[(size_t)b * O + o] * (ov > 0.f ? 1.f : g.slope) * g.x[(size_t)b * g.x_stride + i];
+        }
+        g.dw[(size_t)o * I + i] = acc * g.wmul;
+    }
+    if (g.db && blockIdx.x == 0 && threadIdx.x == 0) {
+        float dzs = 0.f;
+        for (int b = 0; b < B; ++b) {
+            const float ov = g.out[(size_t)b * O + o];
+            dzs += g.dout[(size_t)b * O + o] * (ov > 0.f ? 1.f : g.slope);
+        }
+        g.db[o] = dzs * g.bmul;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -358,6 +436,40 @@ int spk_fc_bwd(const float* dout, const float* out, const float* x, int64_t x_st
         hipLaunchKernelGGL(fc_bwd_weight_kernel, dim3((unsigned)std::min(spk::ceil_div(I, 256), 8), (unsigned)O), dim3(256), 0,
                            s, dout, out, x, (long long)x_stride, dw, db, B, I, O, wmul, bmul, slope);
         return spk::check_launch("fc_bwd_weight_kernel");
+    }
+    return SPK_OK;
+}
+
+int spk_fc_grouped_bwd(const spk_fc_bwd_group* groups, int n_groups, int B, void* stream) {
+    SPK_REQUIRE(groups && n_groups > 0 && n_groups <= SPK_FC_MAX_GROUPS && B > 0, "fc_grouped_bwd: bad arguments (1..%d groups)",
+                SPK_FC_MAX_GROUPS);
+    FcBwdGroups a;
+    a.n = n_groups;
+    int maxI = 0, maxO = 0;
+    bool any_dx = false, any_dw = false;
+    for (int i = 0; i < n_groups; ++i) {
+        const spk_fc_bwd_group& g = groups[i];
+        SPK_REQUIRE(g.dout && g.out && g.I > 0 && g.O > 0, "fc_grouped_bwd: group %d: bad shape", i);
+        SPK_REQUIRE(!g.dx || (g.w && g.dx_stride >= g.I), "fc_grouped_bwd: group %d: dx needs w and dx_stride >= I", i);
+        SPK_REQUIRE(!g.dw || (g.x && g.x_stride >= g.I), "fc_grouped_bwd: group %d: dw needs x and x_stride >= I", i);
+        SPK_REQUIRE(!g.db || g.dw, "fc_grouped_bwd: group %d: db comes with dw", i);
+        SPK_REQUIRE((size_t)FCB_BT * g.O * sizeof(float) <= 60 * 1024, "fc_grouped_bwd: group %d: O too large for the LDS tile", i);
+        a.g[i] = g;
+        maxI = std::max(maxI, g.I); maxO = std::max(maxO, g.O);
+        any_dx = any_dx || g.dx; any_dw = any_dw || g.dw;
+    }
+    hipStream_t s = (hipStream_t)stream;
+    if (any_dx) {
+        hipLaunchKernelGGL(fc_grouped_bwd_input_kernel, dim3((unsigned)spk::ceil_div(maxI, 64), (unsigned)n_groups), dim3(256),
+                           (size_t)FCB_BT * maxO * sizeof(float), s, a, B);
+        int rc = spk::check_launch("fc_grouped_bwd_input_kernel");
+        if (rc != SPK_OK) return rc;
+    }
+    if (any_dw) {
+        SPK_REQUIRE(maxO < 65536, "fc_grouped_bwd: O too large for the grid");
+        hipLaunchKernelGGL(fc_grouped_bwd_weight_kernel, dim3((unsigned)std::min(spk::ceil_div(maxI, 256), 8), (unsigned)maxO, (unsigned)n_groups),
+                           dim3(256), 0, s, a, B);
+        return spk::check_launch("fc_grouped_bwd_weight_kernel");
     }
     return SPK_OK;
 }

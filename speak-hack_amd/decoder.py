@@ -171,10 +171,13 @@ class SynthesisNetwork(nn.Module):
         elif len(noises) != 2 * len(self.layers) + 1:
             raise ValueError(f"expected {2 * len(self.layers) + 1} noise tensors, got {len(noises)}")
         styles = None
-        if not (torch.is_grad_enabled() and (w.requires_grad or any(p.requires_grad for p in self.parameters()))):
-            # inference: the 13 style affines depend only on w -> one grouped launch instead of 13
-            mods = [self.style_mod] + [m for layer in self.layers for m in (layer.style_mod1, layer.style_mod2)]
-            if len(mods) <= ops.L.FC_MAX_GROUPS and w.size(1) >= len(mods):
+        # the 13 style affines depend only on w -> one grouped launch instead of 13 (and, under autograd, one node whose
+        # backward is two launches writing the rows of a single [B, L, 512] latent gradient)
+        mods = [self.style_mod] + [m for layer in self.layers for m in (layer.style_mod1, layer.style_mod2)]
+        if w.is_cuda and len(mods) <= ops.L.FC_MAX_GROUPS and w.size(1) >= len(mods):
+            if torch.is_grad_enabled() and (w.requires_grad or any(p.requires_grad for p in self.parameters())):
+                styles = AG.style_fc_group(w, [m.linear for m in mods], LRELU)
+            else:
                 styles = ops.fc_grouped((w[:, j], m.linear.weight, m.linear.bias, m.linear.w_lrmul, m.linear.b_lrmul, LRELU)
                                         for j, m in enumerate(mods))
         x = AG.bias_noise_style(self.const_input, self.bias, self.noise_input1.weight, noises[0],

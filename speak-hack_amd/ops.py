@@ -310,6 +310,29 @@ def fc_grouped(items):
     return outs
 
 
+def fc_grouped_bwd(items, B):
+    """Backward of up to 16 independent FCs in two launches.  ``items``: iterable of (dout [B,O], out [B,O] saved output,
+    x [B,I] row-strided view, weight [O,I], dx [B,I] row-strided view | None, need_dw, has_bias, wmul, bmul, slope);
+    returns the list of (dw | None, db | None)."""
+    items = list(items)
+    groups, res, keep = (L.FcBwdGroup * len(items))(), [], []
+    for g, (dout, out, x, weight, dx, need_dw, has_bias, wmul, bmul, slope) in zip(groups, items):
+        O, I = weight.shape
+        dout = dout.contiguous()
+        keep.append(dout)
+        if x.stride(1) != 1 or (dx is not None and dx.stride(1) != 1):
+            raise L.SpkError("fc_grouped_bwd: x / dx must have unit inner stride")
+        dw = torch.empty((O, I), device=weight.device, dtype=torch.float32) if need_dw else None
+        db = torch.empty(O, device=weight.device, dtype=torch.float32) if (need_dw and has_bias) else None
+        res.append((dw, db))
+        g.dout, g.out, g.x, g.x_stride = L.dptr(dout, "dout"), L.dptr(out, "out"), x.data_ptr(), x.stride(0)
+        g.w, g.dx, g.dx_stride = L.dptr(weight, "weight"), (dx.data_ptr() if dx is not None else None), (dx.stride(0) if dx is not None else 0)
+        g.dw, g.db, g.I, g.O = L.dptr(dw), L.dptr(db), I, O
+        g.wmul, g.bmul, g.slope = float(wmul), float(bmul), float(slope)
+    L.check(L.lib().spk_fc_grouped_bwd(C.cast(groups, C.c_void_p), len(items), B, L.stream_ptr()), "spk_fc_grouped_bwd")
+    return res
+
+
 def bias_noise_style(x, B: int, bias=None, noise_w=None, noise=None, style=None):
     """y = (x + bias + noise_w*noise) * (s0+1) + s1 -> [B,C,H,W]; x is [B,C,H,W] or a [1,C,H,W]
     constant broadcast over the batch.  Any of bias / noise / style may be None."""
