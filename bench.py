@@ -18,7 +18,7 @@ Extra objects in the line (headline fields unchanged):
                     on this box's host cores on the same B=8 workload (rank 0, N=1 only).
   eager          -- the same step WITHOUT the hipGraph: what an unchanged ``model.Gd(x)`` caller gets (one
                     launch list per call, plan.DecoderPlan).
-  bf16x3         -- the OPT-IN split-precision speed path on the headline workload (3x3 convs of the >= 32^2 layers on the bf16
+  bf16x3         -- the OPT-IN split-precision speed path on the headline workload (3x3 convs of the >= 16^2 layers on the bf16
                     matrix pipe, operands split hi + lo, three MFMAs per product; ~2e-5 rel-L2 against the reference, asserted in
                     tests/test_bf16x3_gpu.py); roofline against the dense bf16 MFMA peak.  The headline stays exact fp32.
   stylegan2_variant -- the build-defined StyleGAN2 decoder (A11) on the same workload, with its own roofline.
@@ -318,7 +318,7 @@ def main():
                 gen.synthesis.precision = "f32"
             fl_all = decoder_conv_flops(BATCH)
             extras["bf16x3"] = {
-                "what": "OPT-IN: the headline workload with SynthesisNetwork.precision = 'bf16x3' -- the 3x3 convs of the layers with >= 8192 "
+                "what": "OPT-IN: the headline workload with SynthesisNetwork.precision = 'bf16x3' -- the 3x3 convs of the layers with >= 2048 "
                         "output pixels run on the bf16 matrix pipe with fp32 operands split into bf16 hi + lo (3 MFMAs per product, fp32 "
                         "accumulate); parity 1.5e-5 rel-L2 vs the reference golden / the oracle at B=8 (tests/test_bf16x3_gpu.py, bound 1e-3)",
                 "frames_per_s_per_gpu": round(BATCH / bf_ms * 1e3, 2), "ms_per_step": round(bf_ms, 4),
@@ -326,7 +326,7 @@ def main():
                 "conv_launches": nb, "conv_launches_on_bf16_pipe": len(fast), "conv_ms_per_step": round(cb_ms, 4),
                 "algorithmic_conv_tflops": round(fl_all / (cb_ms * 1e-3) / 1e12, 1),
                 "roofline": {"bound": "mfma", "kernel": "spkbf::conv3x3_bf16x3_kernel (v_mfma_f32_32x32x16_bf16 x3 per product) + the f32 kernel on the "
-                                                        "<= 16^2 layers", "achieved": round((3 * fl_fast + (fl_all - fl_fast)) / (cb_ms * 1e-3) / 1e12, 1),
+                                                        "8^2 layers", "achieved": round((3 * fl_fast + (fl_all - fl_fast)) / (cb_ms * 1e-3) / 1e12, 1),
                              "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s (executed: 3 bf16 MFMA FLOPs per algorithmic FLOP on the split layers)",
                              "frac": round((3 * fl_fast + (fl_all - fl_fast)) / (cb_ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None}}
 

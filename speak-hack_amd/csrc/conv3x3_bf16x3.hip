@@ -18,9 +18,16 @@
 //      conflict-free ds_read_b128.
 //   D: 32x32 tiles, col = lane & 31 = pixel, row = output channel -- the same accumulator layout as the f32 kernel, so the
 //      epilogue (out_scale, demodulation, bias, noise, LeakyReLU, style) is that kernel's, element for element.
-// Block = 64 co x 256 pixels, 4 waves side by side along the pixels, each 2 x 2 MFMA tiles; 108 MFMAs per wave and chunk
-// (3456 cycles) over a two-stage LDS ring (58 KB per stage: one workgroup per CU), one barrier per chunk; the next chunk's
-// gathers are issued before each tap row and converted / stored after it.
+// Block = 64 co x 256 pixels over a two-stage LDS ring (58 KB per stage: ONE workgroup per CU), one barrier per chunk, and
+// EIGHT waves in two roles (two per SIMD):
+//   * waves 0-3, the consumers: side by side along the pixels, each 2 x 2 MFMA tiles -- nothing but fragment reads and the
+//     108 MFMAs per chunk (3456 cycles);
+//   * waves 4-7, the producers: everything that fills the other stage -- the LDS-DMA of the next chunk's weights, the gathers
+//     (issued a chunk ahead of their use), the split into hi / lo and the LDS stores, the x2 interpolation.
+// With four do-everything waves (one per SIMD) nothing overlapped: knock-out timing gave MFMA + fragments 79 us, staging 46,
+// epilogue 13 for 256 -> 256 @ 64^2 and the whole kernel took their SUM, 137 (the compiler keeps the 108 MFMAs of a chunk in one
+// block and the staging in another).  Two waves of different roles on a SIMD overlap by themselves.  The roles run separate
+// loops (the same number of barriers), so the consumers' registers hold no staging state and the producers' no accumulators.
 #include "spk_common.hpp"
 
 #include <algorithm>
@@ -34,7 +41,8 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int CO_T = 64, PIX_T = 256, CI_T = 16, NT = 256, TAPS = 9;
+constexpr int CO_T = 64, PIX_T = 256, CI_T = 16, NT = 256, TAPS = 9;      // NT: threads per ROLE
+constexpr int NTB = 2 * NT;                                                  // threads per workgroup (consumers + producers)
 constexpr int W_BYTES = 2 * TAPS * 2 * CO_T * 16;        // one chunk's weight image: [hi/lo][tap][h][co][8 bf16]
 constexpr int W_DMA = W_BYTES / (NT * 16);                // LDS-DMA instructions per thread and chunk (9)
 constexpr int MAX_ROUNDS = 3;                             // gather rounds per chunk: 2 * NPOS items <= 768
@@ -78,10 +86,11 @@ __device__ __forceinline__ void split8(const float (&v)[8], u32x4& hi, u32x4& lo
 }
 
 template <bool UPS>
-__global__ __launch_bounds__(NT) void conv3x3_bf16x3_kernel(const Args p) {
+__global__ __launch_bounds__(NTB) void conv3x3_bf16x3_kernel(const Args p) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    const int tid = threadIdx.x, lane = tid & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int tid_all = threadIdx.x, tid = tid_all & (NT - 1), lane = tid & 63;     // tid: index within the role
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);                       // wave within the role (0-3)
+    const bool producer = __builtin_amdgcn_readfirstlane(tid_all >> 8) != 0;
     const int half = lane >> 5, l32 = lane & 31;
 
     const int TW = 1 << p.lgTW, TH = 1 << p.lgTH, TB = 1 << p.lgTB;
@@ -327,41 +336,118 @@ __global__ __launch_bounds__(NT) void conv3x3_bf16x3_kernel(const Args p) {
         }
     };
 
-    // ---- prologue: chunk 0 -> stage 0 ----
     using I0 = std::integral_constant<int, 0>;
     using I1 = std::integral_constant<int, 1>;
     using I2 = std::integral_constant<int, 2>;
     char* const sb0 = smem + 2 * STAGE;                     // UPS: the two source-tile buffers sit behind the stages
-    dma_weights(smem, 0);
+    const int n_chunks = p.n_chunks;
+    // vmcnt(N): the producers' LDS-DMA blocks are issued BEFORE the gathers of a later chunk, and loads return in order, so
+    // waiting until only the N gather instructions are outstanding means the weight image has landed
+    auto wait_dma = [&](int gathers) {
+        switch (gathers) {                                  // simm16: vmcnt[3:0] | expcnt 7 << 4 | lgkmcnt 15 << 8 | vmcnt[5:4] << 14
+            case 0: __builtin_amdgcn_s_waitcnt(0x0f70); break;
+            case 8: __builtin_amdgcn_s_waitcnt(0x0f78); break;
+            case 16: __builtin_amdgcn_s_waitcnt(0x4f70); break;
+            case 24: __builtin_amdgcn_s_waitcnt(0x4f78); break;
+            case 32: __builtin_amdgcn_s_waitcnt(0x8f70); break;
+            case 48: __builtin_amdgcn_s_waitcnt(0xcf70); break;
+            default: __builtin_amdgcn_s_waitcnt(0x0f70); break;
+        }
+    };
+
+    // ---- prologue (producers): chunk 0 -> stage 0; the gathers of the chunk after the next one into the registers ----
+    if (producer) dma_weights(smem, 0);
     if constexpr (UPS) {
-        // source tiles of chunks 0 and 1, then X(0) by interpolation out of S(0)
-        s_issue(0, I0{});
-        if (s_rounds > 1) s_issue(0, I1{});
-        s_store(sb0, 0, I0{});
-        if (s_rounds > 1) s_store(sb0, 0, I1{});
-        if (p.n_chunks > 1) {
-            s_issue(1, I0{});
-            if (s_rounds > 1) s_issue(1, I1{});
-            s_store(sb0 + S_BYTES, 1, I0{});
-            if (s_rounds > 1) s_store(sb0 + S_BYTES, 1, I1{});
+        if (producer) {
+            // source tiles of chunks 0 and 1, then X(0) by interpolation out of S(0); S(2) stays in the registers
+            s_issue(0, I0{});
+            if (s_rounds > 1) s_issue(0, I1{});
+            s_store(sb0, 0, I0{});
+            if (s_rounds > 1) s_store(sb0, 0, I1{});
+            if (n_chunks > 1) {
+                s_issue(1, I0{});
+                if (s_rounds > 1) s_issue(1, I1{});
+                s_store(sb0 + S_BYTES, 1, I0{});
+                if (s_rounds > 1) s_store(sb0 + S_BYTES, 1, I1{});
+            }
         }
         __syncthreads();
-        interp_store(smem, sb0, I0{});
-        if (rounds > 1) interp_store(smem, sb0, I1{});
-        if (rounds > 2) interp_store(smem, sb0, I2{});
+        if (producer) {
+            interp_store(smem, sb0, I0{});
+            if (rounds > 1) interp_store(smem, sb0, I1{});
+            if (rounds > 2) interp_store(smem, sb0, I2{});
+        }
     } else {
-        issue_loads(0, I0{});
-        if (rounds > 1) issue_loads(0, I1{});
-        if (rounds > 2) issue_loads(0, I2{});
-        convert_store(smem, 0, I0{});
-        if (rounds > 1) convert_store(smem, 0, I1{});
-        if (rounds > 2) convert_store(smem, 0, I2{});
+        if (producer) {
+            issue_loads(0, I0{});
+            if (rounds > 1) issue_loads(0, I1{});
+            if (rounds > 2) issue_loads(0, I2{});
+            convert_store(smem, 0, I0{});
+            if (rounds > 1) convert_store(smem, 0, I1{});
+            if (rounds > 2) convert_store(smem, 0, I2{});
+        }
     }
     __builtin_amdgcn_s_waitcnt(0x0f70);                    // vmcnt(0): this wave's LDS-DMA blocks have landed
     __syncthreads();
 
-    // ---- main loop: MFMAs of chunk i out of stage i & 1; chunk i + 1 staged into the other stage on the way ----
-    bf16x8 fa[2][2][2], fb[2][2][2];                        // [slot][hi/lo][tile]
+    if (producer) {
+        // ---- producers: during chunk i (the consumers' MFMAs out of stage i & 1) stage (i + 1) & 1 is filled ----
+        if constexpr (UPS) {
+            if (n_chunks > 2) {                             // S(2) -> registers
+                s_issue(2, I0{});
+                if (s_rounds > 1) s_issue(2, I1{});
+            }
+        } else {
+            if (n_chunks > 1) {                             // the gathers of chunk 1 -> registers
+                issue_loads(1, I0{});
+                if (rounds > 1) issue_loads(1, I1{});
+                if (rounds > 2) issue_loads(1, I2{});
+            }
+        }
+        for (int i = 0; i < n_chunks; ++i) {
+            char* nxt = smem + ((i + 1) & 1) * STAGE;
+            const bool more = i + 1 < n_chunks;             // uniform
+            int pending = 0;                                // gather instructions issued after the DMA in this iteration
+            if (more) dma_weights(nxt, i + 1);
+            __builtin_amdgcn_sched_barrier(0);              // the DMA stays in front of this iteration's gathers (wait_dma counts on it)
+            if constexpr (UPS) {
+                char* const s_nxt = sb0 + ((i + 1) & 1) * S_BYTES;       // holds S(i + 1) since the previous barrier
+                char* const s_nn = sb0 + (i & 1) * S_BYTES;              // S(i) was last read while X(i) was built: free
+                if (i + 2 < n_chunks) {                     // registers (S(i + 2), loaded a chunk ago) -> LDS
+                    __builtin_amdgcn_sched_barrier(0);
+                    s_store(s_nn, i + 2, I0{});
+                    if (s_rounds > 1) s_store(s_nn, i + 2, I1{});
+                }
+                if (more) {                                 // X(i + 1) out of S(i + 1)
+                    interp_store(nxt, s_nxt, I0{});
+                    if (rounds > 1) interp_store(nxt, s_nxt, I1{});
+                    if (rounds > 2) interp_store(nxt, s_nxt, I2{});
+                }
+                if (i + 3 < n_chunks) {
+                    s_issue(i + 3, I0{});
+                    if (s_rounds > 1) s_issue(i + 3, I1{});
+                    pending = 8 * s_rounds;         // (the pixel gathers alone: a conservative count if scale loads get merged)
+                }
+            } else {
+                if (more) {                                 // registers (chunk i + 1, loaded a chunk ago) -> split -> LDS
+                    __builtin_amdgcn_sched_barrier(0);
+                    convert_store(nxt, i + 1, I0{});
+                    if (rounds > 1) convert_store(nxt, i + 1, I1{});
+                    if (rounds > 2) convert_store(nxt, i + 1, I2{});
+                }
+                if (i + 2 < n_chunks) {
+                    issue_loads(i + 2, I0{});
+                    if (rounds > 1) issue_loads(i + 2, I1{});
+                    if (rounds > 2) issue_loads(i + 2, I2{});
+                    pending = 8 * rounds;
+                }
+            }
+            wait_dma(pending);                              // the next stage's weight image has landed (the gathers fly on)
+            __syncthreads();
+        }
+    } else {
+        // ---- consumers: MFMAs of chunk i out of stage i & 1 ----
+        bf16x8 fa[2][2][2], fb[2][2][2];                    // [slot][hi/lo][tile]
 #define SPK_BF_FRAG(stage_, tap_, slot_)                                                                        \
     {                                                                                                          \
         const unsigned ta_ = a_base + (unsigned)((tap_) * 2 * CO_T * 16);                                      \
@@ -380,66 +466,21 @@ __global__ __launch_bounds__(NT) void conv3x3_bf16x3_kernel(const Args p) {
             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[slot_][0][m], fb[slot_][1][n], acc[m][n], 0, 0, 0); \
             acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[slot_][0][m], fb[slot_][0][n], acc[m][n], 0, 0, 0); \
         }
-
-    const bool lab_nostage = p.flags & (1u << 29), lab_noepi = p.flags & (1u << 30), lab_nomfma = p.flags & (1u << 28);
-    for (int i = 0; i < p.n_chunks; ++i) {
-        char* cur = smem + (i & 1) * STAGE;
-        char* nxt = smem + ((i + 1) & 1) * STAGE;
-        const bool more = i + 1 < p.n_chunks && !lab_nostage;               // uniform
-        const bool more2 = i + 2 < p.n_chunks && !lab_nostage;   // UPS: the source tile runs two chunks ahead
-        char* const s_nxt = sb0 + ((i + 1) & 1) * S_BYTES;       // holds S(i + 1); S(i + 2) goes where S(i) was
-        char* const s_nn = sb0 + (i & 1) * S_BYTES;
-        if (more) {
-            dma_weights(nxt, i + 1);
-            if constexpr (!UPS) {
-                issue_loads(i + 1, I0{});
-                if (rounds > 1) issue_loads(i + 1, I1{});
-                if (rounds > 2) issue_loads(i + 1, I2{});
-            }
-        }
-        if constexpr (UPS) {
-            if (more2) {
-                s_issue(i + 2, I0{});
-                if (s_rounds > 1) s_issue(i + 2, I1{});
-            }
-        }
-        SPK_BF_FRAG(cur, 0, 0);
+        for (int i = 0; i < n_chunks; ++i) {
+            const char* cur = smem + (i & 1) * STAGE;
+            SPK_BF_FRAG(cur, 0, 0);
 #pragma unroll
-        for (int row = 0; row < 3; ++row) {
-#pragma unroll
-            for (int k = 0; k < 3; ++k) {
-                const int tap = row * 3 + k;
+            for (int tap = 0; tap < TAPS; ++tap) {
                 if (tap + 1 < TAPS) SPK_BF_FRAG(cur, tap + 1, (tap + 1) & 1);
-                if (!lab_nomfma) SPK_BF_MFMA(tap & 1);
+                SPK_BF_MFMA(tap & 1);
             }
-            if constexpr (!UPS) {
-                if (more && row == 1) convert_store(nxt, i + 1, I0{});
-                if (more && row == 2) {
-                    if (rounds > 1) convert_store(nxt, i + 1, I1{});
-                    if (rounds > 2) convert_store(nxt, i + 1, I2{});
-                }
-            } else {
-                // X(i + 1) out of S(i + 1) (in LDS since the previous chunk's barrier): one round behind each tap row
-                if (more && row == 0) interp_store(nxt, s_nxt, I0{});
-                if (more && row == 1 && rounds > 1) interp_store(nxt, s_nxt, I1{});
-                if (more && row == 2 && rounds > 2) interp_store(nxt, s_nxt, I2{});
-            }
+            __syncthreads();
         }
-        if constexpr (UPS) {
-            if (more2) {                                       // S(i) was last read while X(i) was built, a chunk ago
-                __builtin_amdgcn_sched_barrier(0);
-                s_store(s_nn, i + 2, I0{});
-                if (s_rounds > 1) s_store(s_nn, i + 2, I1{});
-            }
-        }
-        __builtin_amdgcn_s_waitcnt(0x0f70);                // vmcnt(0): the next stage's weight image has landed
-        __syncthreads();
-    }
 #undef SPK_BF_FRAG
 #undef SPK_BF_MFMA
+    }
 
     // ---- epilogue (element for element the f32 kernel's): out_scale, demodulation, bias, noise, LeakyReLU * gain, style ----
-    if (lab_noepi && acc[0][0][0] != 123456.789f) return;      // measurement builds only (SPK_BF_LAB): see the host side
     const bool f_bias = p.flags & SPK_EPI_BIAS, f_noise = p.flags & SPK_EPI_NOISE;
     const bool f_lrelu = p.flags & SPK_EPI_LRELU, f_style = p.flags & SPK_EPI_STYLE;
     const size_t HW = (size_t)p.H * p.W;
@@ -448,17 +489,19 @@ __global__ __launch_bounds__(NT) void conv3x3_bf16x3_kernel(const Args p) {
         // accumulator order and read back as rows, so a thread finishes FOUR consecutive pixels of a channel per step --
         // 16 vector stores per thread instead of 64 dword stores, the per-channel / per-image operands loaded once per vector.
         // With the dword form the epilogue was HALF of the 256^2 layers' time (gpurun_out/r2/bf_lab.txt).
-        constexpr int OP = PIX_T + 4, F4 = PIX_T / 4, RPI = NT / F4;          // 4 rows per pass
+        constexpr int OP = PIX_T + 4, F4 = PIX_T / 4, RPI = NTB / F4;         // 8 rows per pass
         float* const ot = reinterpret_cast<float*>(smem);
+        if (!producer) {
 #pragma unroll
-        for (int m = 0; m < 2; ++m)
+            for (int m = 0; m < 2; ++m)
 #pragma unroll
-            for (int n = 0; n < 2; ++n)
+                for (int n = 0; n < 2; ++n)
 #pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    ot[(m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * OP + (wave * 2 + n) * 32 + l32] = acc[m][n][r];
+                    for (int r = 0; r < 16; ++r)
+                        ot[(m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * OP + (wave * 2 + n) * 32 + l32] = acc[m][n][r];
+        }
         __syncthreads();
-        const int f4 = tid % F4, row0 = tid / F4;
+        const int f4 = tid_all % F4, row0 = tid_all / F4;      // all eight waves store
         const int pt = 4 * f4;
         const int px = pt & (TW - 1), py = (pt >> p.lgTW) & (TH - 1), tb = pt >> (p.lgTW + p.lgTH);
         const int b = b0 + tb, yy = y0 + py, xx = x0 + px;
@@ -493,6 +536,7 @@ __global__ __launch_bounds__(NT) void conv3x3_bf16x3_kernel(const Args p) {
         }
         return;
     }
+    if (producer) return;
     bool pv[2];
     size_t poff[2];
     int pb[2];
@@ -599,7 +643,6 @@ int spk_conv2d_bf16x3_fwd(const spk_conv2d_desc* d, void* stream) {
     SPK_REQUIRE(d && d->x && d->w_packed && d->y, "conv2d bf16x3: null pointer");
     SPK_REQUIRE(d->kh == 3 && d->kw == 3 && d->stride == 1, "conv2d bf16x3: 3x3 stride-1 kernels only");
     SPK_REQUIRE(d->groups <= 1, "conv2d bf16x3: not grouped");
-    static const unsigned lab = [] { const char* e = getenv("SPK_BF_LAB"); return e ? (unsigned)atoi(e) << 28 : 0u; }();   // timing knock-outs
     const unsigned allowed = SPK_CONV_BF16X3 | SPK_EPI_BIAS | SPK_EPI_NOISE | SPK_EPI_LRELU | SPK_EPI_STYLE | SPK_CONV_UPSAMPLE2X |
                              SPK_CONV_UP_FIR1331 | SPK_CONV_IN_BATCH_SCALE;
     SPK_REQUIRE(!(d->flags & ~allowed) && !d->y_pre && !d->stats, "conv2d bf16x3: forward-only epilogue flags (bias, noise, lrelu, style, "
@@ -622,7 +665,7 @@ int spk_conv2d_bf16x3_fwd(const spk_conv2d_desc* d, void* stream) {
     a.lgTW = spk::ilog2(g.TW); a.lgTH = spk::ilog2(g.TH); a.lgTB = spk::ilog2(g.TB);
     a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y;
     a.n_chunks = spk::ceil_div(d->Cin, CI_T);
-    a.style_stride = d->style_stride; a.flags = d->flags | lab; a.slope = d->lrelu_slope; a.out_scale = d->out_scale;
+    a.style_stride = d->style_stride; a.flags = d->flags; a.slope = d->lrelu_slope; a.out_scale = d->out_scale;
     a.act_gain = d->act_gain != 0.f ? d->act_gain : 1.f;
     const auto aligned16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     a.staged = (d->W % 4 == 0 && g.TW >= 4 && aligned16(d->y) && aligned16(d->noise)) ? 1 : 0;
@@ -641,7 +684,7 @@ int spk_conv2d_bf16x3_fwd(const spk_conv2d_desc* d, void* stream) {
     const long long gx = (long long)g.tiles_x * g.tiles_y * g.tiles_b;
     SPK_REQUIRE(gx < (1ll << 31), "conv2d bf16x3: grid too large");
     dim3 grid((unsigned)gx, (unsigned)spk::ceil_div(d->Cout, CO_T));
-    hipLaunchKernelGGL(kern, grid, dim3(NT), lds, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(kern, grid, dim3(NTB), lds, (hipStream_t)stream, a);
     return spk::check_launch("conv3x3_bf16x3_kernel");
 }
 

@@ -58,8 +58,9 @@ class LaunchPlan:
         self._params.extend(params)
 
     # layers with at least this many output pixels (batch x H x W) take the split-precision path when the plan asks for it:
-    # below it the 64co x 256px blocks cannot fill 256 CUs without a split-K the bf16x3 kernel does not have
-    BF16X3_MIN_PIXELS = 8192
+    # below it the 64co x 256px blocks cannot fill 256 CUs without a split-K the bf16x3 kernel does not have (B = 8: the
+    # 16^2 layers up -- 93-96 us against 104-109 for the f32 kernel there, 83-88 against 40-43 at 8^2)
+    BF16X3_MIN_PIXELS = 2048
 
     def conv(self, x, weight, Cout, *, bias=None, noise_w=None, noise=None, style=None, upsample=False, up_fir=False, slope=None,
              out, out_scale=1.0, batch_scale=None, demod=None, act_gain=1.0, precision="f32"):
