@@ -346,10 +346,18 @@ def main():
             sg2_eager = (time.perf_counter() - t2) / 10 * 1e3
             fl = decoder_conv_flops(BATCH) + 2 * 9 * 16 * 512 * 512 * BATCH        # + the 4x4 styled conv the variant starts with
             a2 = fl / (c2_ms * 1e-3) / 1e12
+            gen2.precision = "bf16x3"                     # the same opt-in split-precision path (tests/test_bf16x3_gpu.py)
+            try:
+                g2b, _ = capture(lambda: gen2(feats))
+                sg2_bf_ms = event_ms(g2b.replay, max(10, args.steps // 2))
+                del g2b
+            finally:
+                gen2.precision = "f32"
             extras["stylegan2_variant"] = {
                 "what": "speak-hack_amd.stylegan2.StyleGAN2Generator (modulated 3x3 conv + demod, upfirdn2d [1,3,3,1] folded into "
                         "staging, skip toRGB with the skip upsample + add fused; same channel schedule; parity unpinned by the reference)",
                 "frames_per_s_per_gpu": round(BATCH / sg2_ms * 1e3, 2), "ms_per_step": round(sg2_ms, 4), "eager_ms_per_step": round(sg2_eager, 4),
+                "bf16x3_opt_in": {"ms_per_step": round(sg2_bf_ms, 4), "frames_per_s_per_gpu": round(BATCH / sg2_bf_ms * 1e3, 2)},
                 "roofline": {"bound": "mfma", "kernel": "spkconv::conv_kernel<Cfg,3,3,1,MODE_(UPSAMPLE_)BATCH_SCALE>", "achieved": round(a2, 2),
                              "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(a2 / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                              "launches_per_step": n2, "conv_ms_per_step": round(c2_ms, 4), "conv_share_of_step": round(c2_ms / sg2_ms, 3),
