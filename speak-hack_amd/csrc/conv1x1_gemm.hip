@@ -75,6 +75,10 @@ __global__ __launch_bounds__(256, 2) void conv1x1_gemm_kernel(const GemmArgs p) 
     // covers an HBM miss; the folded affine is applied at the store, so nothing waits on a load before the MFMAs.
     struct Stage { float4 a[4], b[4]; float sc[4], sh[4]; };
     Stage sA, sB;
+    // load() only LOADS (out-of-range rows / channels read a valid address); every select and the folded affine happen in
+    // store(), two compute phases later, behind a scheduling fence: with the zero-select right behind its load the compiler
+    // put an s_waitcnt in front of the MFMAs of the SAME phase (ISA: "Lx15 vmcnt(7) L vmcnt(1) MFMAx64") and the prefetch
+    // distance was nil.
     auto load = [&](Stage& st, int kt) {
         const int k0 = kt * GK;
 #pragma unroll
@@ -82,31 +86,34 @@ __global__ __launch_bounds__(256, 2) void conv1x1_gemm_kernel(const GemmArgs p) 
             const int r = arow + 32 * i, k = k0 + acol;
             const bool a_ok = co0 + r < p.Cout && k < p.Cin;
             st.a[i] = *reinterpret_cast<const float4*>(wb + (a_ok ? (size_t)r * p.Cin + k : 0));
-            if (!a_ok) st.a[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             const int ci = k0 + brow + 8 * i;
             const bool x_ok = b_ok && ci < p.Cin;
             st.b[i] = *reinterpret_cast<const float4*>(xb + (x_ok ? (size_t)ci * HW : 0));
             if (AFF) {
                 // channels past Cin (or pixels past the tensor): scale 0, shift 0 -> max(0, 0) = 0
-                st.sc[i] = x_ok ? p.in_scale[cx0 + ci] : 0.f;
-                st.sh[i] = x_ok ? p.in_shift[cx0 + ci] : 0.f;
-            } else if (!x_ok) {
-                st.b[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+                st.sc[i] = p.in_scale[cx0 + (x_ok ? ci : 0)];
+                st.sh[i] = p.in_shift[cx0 + (x_ok ? ci : 0)];
             }
         }
     };
-    auto store = [&](const Stage& st, int buf) {
+    auto store = [&](const Stage& st, int buf, int kt) {
+        __builtin_amdgcn_sched_barrier(0);
         float* as_ = smem + buf * GBUF;
         float* bs_ = as_ + A_FLOATS;
+        const int k0 = kt * GK;
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
+            const bool a_ok = co0 + arow + 32 * i < p.Cout && k0 + acol < p.Cin;
+            const bool x_ok = b_ok && k0 + brow + 8 * i < p.Cin;
             const int o = (arow + 32 * i) * APITCH + acol;
-            as_[o] = st.a[i].x; as_[o + 1] = st.a[i].y; as_[o + 2] = st.a[i].z; as_[o + 3] = st.a[i].w;
+            as_[o] = a_ok ? st.a[i].x : 0.f; as_[o + 1] = a_ok ? st.a[i].y : 0.f;
+            as_[o + 2] = a_ok ? st.a[i].z : 0.f; as_[o + 3] = a_ok ? st.a[i].w : 0.f;
             float4 v = st.b[i];
             if (AFF) {
                 v.x = fmaxf(v.x * st.sc[i] + st.sh[i], 0.f); v.y = fmaxf(v.y * st.sc[i] + st.sh[i], 0.f);
                 v.z = fmaxf(v.z * st.sc[i] + st.sh[i], 0.f); v.w = fmaxf(v.w * st.sc[i] + st.sh[i], 0.f);
             }
+            if (!x_ok) v = make_float4(0.f, 0.f, 0.f, 0.f);
             *reinterpret_cast<float4*>(bs_ + (brow + 8 * i) * BPITCH + bcol) = v;
         }
     };
@@ -147,20 +154,23 @@ __global__ __launch_bounds__(256, 2) void conv1x1_gemm_kernel(const GemmArgs p) 
 
     const int n_kt = (p.Cin + GK - 1) / GK;
     load(sA, 0);
-    store(sA, 0);
+    store(sA, 0, 0);
     __syncthreads();
-    if (n_kt > 1) load(sA, 1);
+    // Every phase issues its loads UNCONDITIONALLY (past the last k-tile: that tile again, never stored): with the loads under
+    // `if (kt + 2 < n_kt)` the compiler has to assume the short path and waits for vmcnt(0) before the stores -- i.e. for the
+    // loads issued a moment ago, not only for the ones issued a phase earlier.
+    load(sA, min(1, n_kt - 1));
     for (int kt = 0; kt < n_kt; kt += 2) {
         // tile kt out of buffer 0; sA = tile kt+1 (in flight since the previous phase); sB <- tile kt+2
-        if (kt + 2 < n_kt) load(sB, kt + 2);
+        load(sB, min(kt + 2, n_kt - 1));
         compute(0);
-        if (kt + 1 < n_kt) store(sA, 1);
+        store(sA, 1, min(kt + 1, n_kt - 1));
         __syncthreads();
         if (kt + 1 >= n_kt) break;
         // tile kt+1 out of buffer 1; sB = tile kt+2; sA <- tile kt+3
-        if (kt + 3 < n_kt) load(sA, kt + 3);
+        load(sA, min(kt + 3, n_kt - 1));
         compute(1);
-        if (kt + 2 < n_kt) store(sB, 0);
+        store(sB, 0, min(kt + 2, n_kt - 1));
         __syncthreads();
     }
 
