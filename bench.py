@@ -152,7 +152,7 @@ def conv_time_ms(module, feats, L):
     return ms, n
 
 
-def irfd_steps(pkg, dev, which, B, steps, warmup):
+def irfd_steps(pkg, dev, which, B, steps, warmup, precision="f32"):
     """The generator step (config 3) / discriminator step of train.py:150-210 on synthetic pairs -- tools/train_step_bench.py
     in brief.  Returns ms per step."""
     import model as M
@@ -185,14 +185,15 @@ def irfd_steps(pkg, dev, which, B, steps, warmup):
             red.clip_(1.0)
         opt.step()
 
-    for _ in range(warmup):
-        step()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(steps):
-        step()
-    torch.cuda.synchronize()
-    ms = (time.perf_counter() - t0) / steps * 1e3
+    with pkg.ops.train_conv_precision(precision):
+        for _ in range(warmup):
+            step()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step()
+        torch.cuda.synchronize()
+        ms = (time.perf_counter() - t0) / steps * 1e3
     red.remove()
     del net, opt, red
     torch.cuda.empty_cache()
@@ -387,10 +388,17 @@ def main():
                                 "ms_per_step": round(g_ms, 2), "pairs_per_s": round(16 / g_ms * 1e3, 1),
                                 "algorithmic_tflops": round(16 / g_ms * 1e3 * GFLOP_PER_PAIR / 1e3, 1),
                                 "frac_of_f32_mfma_peak": round(16 / g_ms * 1e3 * GFLOP_PER_PAIR / 1e3 / F32_MFMA_PEAK_TFLOPS, 4)}
+        g_bf = irfd_steps(pkg, dev, "g", 16, steps=5, warmup=2, precision="bf16x3")
+        extras["train_step"]["bf16x3_opt_in"] = {
+            "what": "OPT-IN ops.train_conv_precision('bf16x3'): the decoder's 3x3 convs forward and their data gradients on the bf16 pipe "
+                    "(operands split hi + lo, fp32 accumulation), weight gradients and the encoders exact; gradient parity in "
+                    "tests/test_bf16x3_gpu.py", "ms_per_step": round(g_bf, 2), "pairs_per_s": round(16 / g_bf * 1e3, 1)}
         d_ms = irfd_steps(pkg, dev, "d", 8, steps=5, warmup=2)
         extras["d_step"] = {"what": "discriminator step of train.py:155-183 (4 D fwd+bwd with instance noise + BCE, 2 R1 double backward, "
                                     "Adam on D), batch 8, fp32, eager launches", "ms_per_step": round(d_ms, 2),
                             "pairs_per_s": round(8 / d_ms * 1e3, 1)}
+        d_bf = irfd_steps(pkg, dev, "d", 8, steps=5, warmup=2, precision="bf16x3")
+        extras["d_step"]["bf16x3_opt_in"] = {"ms_per_step": round(d_bf, 2), "pairs_per_s": round(8 / d_bf * 1e3, 1)}
 
     if rank == 0:
         traffic = None

@@ -60,7 +60,7 @@ extern "C" {
                                   * (16 significant bits), three bf16 MFMAs per product into an fp32 accumulator -- 5.3x the
                                   * exact-f32 matrix rate at ~3e-5 rel-L2 through the whole decoder (csrc/conv3x3_bf16x3.hip).
                                   * w_packed from spk_conv2d_pack_weights_bf16x3; flags: BIAS / NOISE / LRELU / STYLE /
-                                  * UPSAMPLE2X (+ UP_FIR1331) / IN_BATCH_SCALE (+ out_scale_bc); config / ksplit ignored. */
+                                  * UPSAMPLE2X (+ UP_FIR1331) / IN_BATCH_SCALE (+ out_scale_bc), y_pre; config / ksplit ignored. */
 #define SPK_CONV_UP_FIR1331 512u     /* with UPSAMPLE2X: the x2 interpolation is upfirdn2d(up=2, FIR [1,3,3,1], pad (2,1)) --
                                       * the same (.75,.25) taps as bilinear, but neighbours outside the image are zero */
 
@@ -169,6 +169,10 @@ int spk_conv2d_fwd(const spk_conv2d_desc* desc, void* stream);
  * happens here, once per weight update) / whether a shape is served / the launch itself (spk_conv2d_fwd forwards to it). */
 int64_t spk_conv2d_packed_bytes_bf16x3(int Cin, int Cout);
 int spk_conv2d_pack_weights_bf16x3(const float* w, void* w_packed, int Cin, int Cout, void* stream);
+/* transpose_flip = 1: the data-gradient operator of the conv (w'[ci][co][ky][kx] = w[co][ci][2-ky][2-kx]): its image has
+ * spk_conv2d_packed_bytes_bf16x3(Cout, Cin) bytes and is run with Cin / Cout exchanged -- the opt-in reduced-precision TRAINING
+ * path (forward and data gradients on the bf16 pipe, weight gradients exact) */
+int spk_conv2d_pack_weights_bf16x3_tf(const float* w, void* w_packed, int Cin, int Cout, int transpose_flip, void* stream);
 int spk_conv2d_bf16x3_supported(int B, int Cin, int Cout, int H, int W);
 int spk_conv2d_bf16x3_fwd(const spk_conv2d_desc* desc, void* stream);
 

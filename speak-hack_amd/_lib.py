@@ -182,6 +182,7 @@ _PROTOTYPES = {
     "spk_conv2d_fwd": (C.c_int, [C.POINTER(Conv2dDesc), C.c_void_p]),
     "spk_conv2d_packed_bytes_bf16x3": (C.c_int64, [C.c_int, C.c_int]),
     "spk_conv2d_pack_weights_bf16x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
+    "spk_conv2d_pack_weights_bf16x3_tf": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "spk_conv2d_bf16x3_supported": (C.c_int, [C.c_int] * 5),
     "spk_conv2d_bf16x3_fwd": (C.c_int, [C.POINTER(Conv2dDesc), C.c_void_p]),
     "spk_conv2d_stats_slots": (C.c_int, [C.c_int] * 9),

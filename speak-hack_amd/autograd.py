@@ -50,11 +50,15 @@ class FusedConvFn(torch.autograd.Function):
         B, Cin, Hs, Ws = x.shape
         Cout = weight.shape[0]
         H, W = (2 * Hs, 2 * Ws) if upsample else (Hs, Ws)
-        cfg = ops.conv2d_pick_config(3, 1, B, Cin, Cout, H, W)
         keep = _needs(ctx, grad_mode)
         a = torch.empty((B, Cout, H, W), device=x.device, dtype=torch.float32) if keep else None
-        y = ops.conv2d_fused(x, packed.get(weight, cfg), Cout, 3, 1, bias=bias, noise_w=noise_w, noise=noise,
-                             style=style, upsample=upsample, lrelu_slope=slope, config=cfg, out_pre=a, out_scale=w_scale)
+        if ops.train_bf16x3(B, Cin, Cout, H, W):     # opt-in split-precision training (ops.train_conv_precision)
+            y = ops.conv3x3_bf16x3(x, packed.get_bf16x3(weight), Cout, bias=bias, noise_w=noise_w, noise=noise, style=style,
+                                   upsample=upsample, lrelu_slope=slope, out_pre=a, out_scale=w_scale)
+        else:
+            cfg = ops.conv2d_pick_config(3, 1, B, Cin, Cout, H, W)
+            y = ops.conv2d_fused(x, packed.get(weight, cfg), Cout, 3, 1, bias=bias, noise_w=noise_w, noise=noise,
+                                 style=style, upsample=upsample, lrelu_slope=slope, config=cfg, out_pre=a, out_scale=w_scale)
         if keep:
             ctx.save_for_backward(x, weight, a, noise, style)
             ctx.conf = (upsample, slope, packed, bias is not None, noise_w is not None, float(w_scale))
@@ -73,8 +77,11 @@ class FusedConvFn(torch.autograd.Function):
         dnw = sums[..., 3].sum(0) if has_noise else None
         dx = dw = None
         if ctx.needs_input_grad[0]:
-            cfg = ops.conv2d_pick_config(3, 1, B, Cout, Cin, H, W)
-            dx = ops.conv2d_fused(dt, packed.get(weight, cfg, transpose_flip=True), Cin, 3, 1, config=cfg, out_scale=w_scale)
+            if ops.train_bf16x3(B, Cout, Cin, H, W):
+                dx = ops.conv3x3_bf16x3(dt, packed.get_bf16x3(weight, transpose_flip=True), Cin, out_scale=w_scale)
+            else:
+                cfg = ops.conv2d_pick_config(3, 1, B, Cout, Cin, H, W)
+                dx = ops.conv2d_fused(dt, packed.get(weight, cfg, transpose_flip=True), Cin, 3, 1, config=cfg, out_scale=w_scale)
             if upsample:
                 dx = ops.upsample2x_bilinear_bwd(dx)
         if ctx.needs_input_grad[1]:
@@ -222,6 +229,8 @@ def _conv_plain(x, weight, k, stride):
     B, Cin, H, W = x.shape
     Cout = weight.shape[0]
     Ho, Wo = ops.conv_out_size(H, k, stride), ops.conv_out_size(W, k, stride)
+    if k == 3 and stride == 1 and ops.train_bf16x3(B, Cin, Cout, Ho, Wo):
+        return ops.conv3x3_bf16x3(x.contiguous(), ops.pack_conv_weight_bf16x3(weight), Cout)
     cfg = ops.conv2d_pick_config(k, stride, B, Cin, Cout, Ho, Wo)
     return ops.conv2d_fused(x, ops.pack_conv_weight(weight, cfg), Cout, k, stride, config=cfg)
 
@@ -229,6 +238,8 @@ def _conv_plain(x, weight, k, stride):
 def _conv_dgrad(dt, weight, k, stride, in_hw):
     B, Cout = dt.shape[:2]
     Cin = weight.shape[1]
+    if k == 3 and stride == 1 and ops.train_bf16x3(B, Cout, Cin, in_hw[0], in_hw[1]):
+        return ops.conv3x3_bf16x3(dt, ops.pack_conv_weight_bf16x3(weight, transpose_flip=True), Cin)
     cfg, tf = ops.dgrad_plan(k, stride, B, Cout, Cin, in_hw, dt.shape[-2:])
     return ops.conv2d_dgrad(dt, ops.pack_conv_weight(weight, cfg, transpose_flip=tf), Cin, k, stride, in_hw, cfg)
 
@@ -266,8 +277,11 @@ class ConvBiasLReLUFn(torch.autograd.Function):
         B, Cin, H, W = x.shape
         Cout = weight.shape[0]
         Ho, Wo = ops.conv_out_size(H, k, stride), ops.conv_out_size(W, k, stride)
-        cfg = ops.conv2d_pick_config(k, stride, B, Cin, Cout, Ho, Wo)
-        y = ops.conv2d_fused(x, ops.pack_conv_weight(weight, cfg), Cout, k, stride, bias=bias, lrelu_slope=slope, config=cfg)
+        if k == 3 and stride == 1 and ops.train_bf16x3(B, Cin, Cout, Ho, Wo):
+            y = ops.conv3x3_bf16x3(x.contiguous(), ops.pack_conv_weight_bf16x3(weight), Cout, bias=bias, lrelu_slope=slope)
+        else:
+            cfg = ops.conv2d_pick_config(k, stride, B, Cin, Cout, Ho, Wo)
+            y = ops.conv2d_fused(x, ops.pack_conv_weight(weight, cfg), Cout, k, stride, bias=bias, lrelu_slope=slope, config=cfg)
         if _needs(ctx, grad_mode):
             ctx.save_for_backward(x, weight, y)
             ctx.conf = (k, stride, slope, bias is not None)

@@ -58,6 +58,7 @@ struct Args {
     const float* in_scale;       // [B,Cin] modulation (SPK_CONV_IN_BATCH_SCALE) or null
     const float* out_scale_bc;   // [B,Cout] demodulation or null
     float* y;
+    float* y_pre;                // optional: the value before the style stage (kept for the backward pass of a training forward)
     int B, Cin, Cout, H, W, Hs, Ws;
     int lgTW, lgTH, lgTB;
     int tiles_x, tiles_y;
@@ -522,6 +523,7 @@ __global__ __launch_bounds__(NTB) void conv3x3_bf16x3_kernel(const Args p) {
             const float nwc = f_noise ? p.noise_w[co] : 0.f;
             float s0 = 1.f, s1 = 0.f;
             if (f_style) { s0 = stp[co] + 1.f; s1 = stp[p.Cout + co]; }
+            f32x4 pre;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
                 float t = v[k] * p.out_scale;
@@ -529,9 +531,11 @@ __global__ __launch_bounds__(NTB) void conv3x3_bf16x3_kernel(const Args p) {
                 t += bb;
                 if (f_noise) t += nwc * nzv[k];
                 if (f_lrelu) t = (t > 0.f ? t : t * p.slope) * p.act_gain;
+                pre[k] = t;
                 if (f_style) t = t * s0 + s1;
                 v[k] = t;
             }
+            if (p.y_pre) *reinterpret_cast<f32x4*>(p.y_pre + o0 + (size_t)co * HW) = pre;
             *reinterpret_cast<f32x4*>(p.y + o0 + (size_t)co * HW) = v;
         }
         return;
@@ -570,15 +574,17 @@ __global__ __launch_bounds__(NTB) void conv3x3_bf16x3_kernel(const Args p) {
                 v += bb;
                 if (f_noise) v += nwc * nz[n];
                 if (f_lrelu) v = (v > 0.f ? v : v * p.slope) * p.act_gain;
+                if (p.y_pre) p.y_pre[poff[n] + (size_t)co * HW] = v;
                 if (f_style) v = v * (st[n][co] + 1.f) + st[n][p.Cout + co];
                 p.y[poff[n] + (size_t)co * HW] = v;
             }
         }
 }
 
-// w[Cout][Cin][3][3] fp32 -> [co tile][chunk][hi/lo][tap][h][64 co][8 ci] bf16 (zero padded)
+// w[Cout][Cin][3][3] fp32 -> [co tile][chunk][hi/lo][tap][h][64 co][8 ci] bf16 (zero padded).  tf = 1 packs the data-gradient
+// operator instead: w'[ci][co][ky][kx] = w[co][ci][2-ky][2-kx] (then opCout = Cin rows, opCin = Cout contraction channels)
 __global__ __launch_bounds__(256) void pack_bf16x3_kernel(const float* __restrict__ w, unsigned short* __restrict__ out, int Cin,
-                                                         int Cout, int n_chunks, long long total) {
+                                                         int Cout, int opCin, int opCout, int tf, int n_chunks, long long total) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     long long t = idx;
@@ -591,7 +597,8 @@ __global__ __launch_bounds__(256) void pack_bf16x3_kernel(const float* __restric
     const int cot = (int)(t / n_chunks);
     const int co = cot * CO_T + col, ci = chunk * CI_T + 8 * h + j;
     float v = 0.f;
-    if (co < Cout && ci < Cin) v = w[((size_t)co * Cin + ci) * TAPS + tap];
+    if (co < opCout && ci < opCin)
+        v = tf ? w[((size_t)ci * Cin + co) * TAPS + (TAPS - 1 - tap)] : w[((size_t)co * Cin + ci) * TAPS + tap];
     const unsigned ph = pack_bf16(v, 0.f) & 0xffffu;
     const float hf = __uint_as_float(ph << 16);
     out[idx] = (unsigned short)(hl == 0 ? ph : (pack_bf16(v - hf, 0.f) & 0xffffu));
@@ -624,13 +631,18 @@ int64_t spk_conv2d_packed_bytes_bf16x3(int Cin, int Cout) {
     return (int64_t)spk::ceil_div(Cout, CO_T) * spk::ceil_div(Cin, CI_T) * W_BYTES;
 }
 
-int spk_conv2d_pack_weights_bf16x3(const float* w, void* w_packed, int Cin, int Cout, void* stream) {
-    SPK_REQUIRE(w && w_packed && Cin > 0 && Cout > 0, "pack_weights_bf16x3: bad arguments");
-    const int n_chunks = spk::ceil_div(Cin, CI_T);
-    const long long total = (long long)spk::ceil_div(Cout, CO_T) * n_chunks * (W_BYTES / 2);
+int spk_conv2d_pack_weights_bf16x3_tf(const float* w, void* w_packed, int Cin, int Cout, int transpose_flip, void* stream) {
+    SPK_REQUIRE(w && w_packed && Cin > 0 && Cout > 0 && (transpose_flip == 0 || transpose_flip == 1), "pack_weights_bf16x3: bad arguments");
+    const int opCin = transpose_flip ? Cout : Cin, opCout = transpose_flip ? Cin : Cout;
+    const int n_chunks = spk::ceil_div(opCin, CI_T);
+    const long long total = (long long)spk::ceil_div(opCout, CO_T) * n_chunks * (W_BYTES / 2);
     hipLaunchKernelGGL(pack_bf16x3_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w,
-                       static_cast<unsigned short*>(w_packed), Cin, Cout, n_chunks, total);
+                       static_cast<unsigned short*>(w_packed), Cin, Cout, opCin, opCout, transpose_flip, n_chunks, total);
     return spk::check_launch("pack_bf16x3_kernel");
+}
+
+int spk_conv2d_pack_weights_bf16x3(const float* w, void* w_packed, int Cin, int Cout, void* stream) {
+    return spk_conv2d_pack_weights_bf16x3_tf(w, w_packed, Cin, Cout, 0, stream);
 }
 
 int spk_conv2d_bf16x3_supported(int B, int Cin, int Cout, int H, int W) {
@@ -645,7 +657,7 @@ int spk_conv2d_bf16x3_fwd(const spk_conv2d_desc* d, void* stream) {
     SPK_REQUIRE(d->groups <= 1, "conv2d bf16x3: not grouped");
     const unsigned allowed = SPK_CONV_BF16X3 | SPK_EPI_BIAS | SPK_EPI_NOISE | SPK_EPI_LRELU | SPK_EPI_STYLE | SPK_CONV_UPSAMPLE2X |
                              SPK_CONV_UP_FIR1331 | SPK_CONV_IN_BATCH_SCALE;
-    SPK_REQUIRE(!(d->flags & ~allowed) && !d->y_pre && !d->stats, "conv2d bf16x3: forward-only epilogue flags (bias, noise, lrelu, style, "
+    SPK_REQUIRE(!(d->flags & ~allowed) && !d->stats, "conv2d bf16x3: forward-only epilogue flags (bias, noise, lrelu, style, "
                 "upsample, batch scale)");
     const bool ups = d->flags & SPK_CONV_UPSAMPLE2X;
     if (ups) SPK_REQUIRE(d->H == 2 * d->Hin && d->W == 2 * d->Win, "conv2d bf16x3: upsampled output must be 2x the input");
@@ -660,7 +672,7 @@ int spk_conv2d_bf16x3_fwd(const spk_conv2d_desc* d, void* stream) {
     SPK_REQUIRE((reinterpret_cast<uintptr_t>(d->w_packed) & 15) == 0, "conv2d bf16x3: packed weights must be 16-byte aligned");
     Args a;
     a.x = d->x; a.wp = reinterpret_cast<const char*>(d->w_packed); a.bias = d->bias; a.noise_w = d->noise_w; a.noise = d->noise;
-    a.style = d->style; a.in_scale = (d->flags & SPK_CONV_IN_BATCH_SCALE) ? d->in_scale : nullptr; a.out_scale_bc = d->out_scale_bc; a.y = d->y;
+    a.style = d->style; a.in_scale = (d->flags & SPK_CONV_IN_BATCH_SCALE) ? d->in_scale : nullptr; a.out_scale_bc = d->out_scale_bc; a.y = d->y; a.y_pre = d->y_pre;
     a.B = d->B; a.Cin = d->Cin; a.Cout = d->Cout; a.H = d->H; a.W = d->W; a.Hs = d->Hin; a.Ws = d->Win;
     a.lgTW = spk::ilog2(g.TW); a.lgTH = spk::ilog2(g.TH); a.lgTB = spk::ilog2(g.TB);
     a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y;
@@ -668,7 +680,7 @@ int spk_conv2d_bf16x3_fwd(const spk_conv2d_desc* d, void* stream) {
     a.style_stride = d->style_stride; a.flags = d->flags; a.slope = d->lrelu_slope; a.out_scale = d->out_scale;
     a.act_gain = d->act_gain != 0.f ? d->act_gain : 1.f;
     const auto aligned16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
-    a.staged = (d->W % 4 == 0 && g.TW >= 4 && aligned16(d->y) && aligned16(d->noise)) ? 1 : 0;
+    a.staged = (d->W % 4 == 0 && g.TW >= 4 && aligned16(d->y) && aligned16(d->y_pre) && aligned16(d->noise)) ? 1 : 0;
     const int snpos = g.TB * ((g.TH >> 1) + 2) * ((g.TW >> 1) + 2);          // UPS: source-tile positions
     SPK_REQUIRE(!ups || 2 * snpos <= 2 * NT, "conv2d bf16x3: source tile too large");
     const size_t lds = std::max(2 * (size_t)(W_BYTES + 4 * g.NPOS * 16) + (ups ? 2 * (size_t)(2 * snpos * 32) : (size_t)0),

