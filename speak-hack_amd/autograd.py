@@ -225,23 +225,42 @@ class _LReluMaskFn(torch.autograd.Function):
         return _LReluMaskFn.apply(g, y, ctx.slope), None, None
 
 
+def _packed(weight, cfg, tf=False):
+    """Packed image of a per-forward weight tensor (the discriminator's W / sigma: a fresh tensor every forward, so the
+    per-parameter cache of ``ops.PackedConvWeight`` cannot hold it).  The images ride on the tensor object itself and die with
+    it: the forward pack is reused by the R1 double backward, the data-gradient pack by both backward passes (64 of the 220
+    pack launches of a discriminator step)."""
+    cache = weight.__dict__.setdefault("_spk_packs", {}) if hasattr(weight, "__dict__") else {}
+    key = (cfg, tf, weight._version, weight.data_ptr())
+    hit = cache.get(key)
+    if hit is None:
+        if cache and next(iter(cache))[2:] != key[2:]:
+            cache.clear()                 # the tensor was updated in place (a Parameter after an optimizer step): drop old images
+        if cfg == "bf16x3":
+            hit = ops.pack_conv_weight_bf16x3(weight.detach(), transpose_flip=bool(tf))
+        else:
+            hit = ops.pack_conv_weight(weight.detach(), cfg, transpose_flip=tf)
+        cache[key] = hit
+    return hit
+
+
 def _conv_plain(x, weight, k, stride):
     B, Cin, H, W = x.shape
     Cout = weight.shape[0]
     Ho, Wo = ops.conv_out_size(H, k, stride), ops.conv_out_size(W, k, stride)
     if k == 3 and stride == 1 and ops.train_bf16x3(B, Cin, Cout, Ho, Wo):
-        return ops.conv3x3_bf16x3(x.contiguous(), ops.pack_conv_weight_bf16x3(weight), Cout)
+        return ops.conv3x3_bf16x3(x.contiguous(), _packed(weight, "bf16x3"), Cout)
     cfg = ops.conv2d_pick_config(k, stride, B, Cin, Cout, Ho, Wo)
-    return ops.conv2d_fused(x, ops.pack_conv_weight(weight, cfg), Cout, k, stride, config=cfg)
+    return ops.conv2d_fused(x, _packed(weight, cfg), Cout, k, stride, config=cfg)
 
 
 def _conv_dgrad(dt, weight, k, stride, in_hw):
     B, Cout = dt.shape[:2]
     Cin = weight.shape[1]
     if k == 3 and stride == 1 and ops.train_bf16x3(B, Cout, Cin, in_hw[0], in_hw[1]):
-        return ops.conv3x3_bf16x3(dt, ops.pack_conv_weight_bf16x3(weight, transpose_flip=True), Cin)
+        return ops.conv3x3_bf16x3(dt, _packed(weight, "bf16x3", True), Cin)
     cfg, tf = ops.dgrad_plan(k, stride, B, Cout, Cin, in_hw, dt.shape[-2:])
-    return ops.conv2d_dgrad(dt, ops.pack_conv_weight(weight, cfg, transpose_flip=tf), Cin, k, stride, in_hw, cfg)
+    return ops.conv2d_dgrad(dt, _packed(weight, cfg, tf), Cin, k, stride, in_hw, cfg)
 
 
 class ConvDgradFn(torch.autograd.Function):
@@ -278,10 +297,10 @@ class ConvBiasLReLUFn(torch.autograd.Function):
         Cout = weight.shape[0]
         Ho, Wo = ops.conv_out_size(H, k, stride), ops.conv_out_size(W, k, stride)
         if k == 3 and stride == 1 and ops.train_bf16x3(B, Cin, Cout, Ho, Wo):
-            y = ops.conv3x3_bf16x3(x.contiguous(), ops.pack_conv_weight_bf16x3(weight), Cout, bias=bias, lrelu_slope=slope)
+            y = ops.conv3x3_bf16x3(x.contiguous(), _packed(weight, "bf16x3"), Cout, bias=bias, lrelu_slope=slope)
         else:
             cfg = ops.conv2d_pick_config(k, stride, B, Cin, Cout, Ho, Wo)
-            y = ops.conv2d_fused(x, ops.pack_conv_weight(weight, cfg), Cout, k, stride, bias=bias, lrelu_slope=slope, config=cfg)
+            y = ops.conv2d_fused(x, _packed(weight, cfg), Cout, k, stride, bias=bias, lrelu_slope=slope, config=cfg)
         if _needs(ctx, grad_mode):
             ctx.save_for_backward(x, weight, y)
             ctx.conf = (k, stride, slope, bias is not None)

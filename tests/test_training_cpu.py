@@ -80,3 +80,28 @@ def test_training_iteration_constants_match_reference():
     torch.manual_seed(0)
     x = torch.zeros(64, 3, 32, 32)
     assert abs(float(T.add_instance_noise(x).std()) - 0.1) < 5e-3
+
+
+def test_train_conv_precision_switch_is_scoped():
+    """``ops.train_conv_precision`` (the opt-in reduced-precision training switch) restores the previous setting on exit and on
+    error, rejects unknown names, and never routes anything while it is off."""
+    import importlib
+    ops = importlib.import_module("speak-hack_amd").ops
+    assert ops.TRAIN_CONV_PRECISION == "f32"
+    with ops.train_conv_precision("bf16x3"):
+        assert ops.TRAIN_CONV_PRECISION == "bf16x3"
+        with ops.train_conv_precision("f32"):
+            assert ops.TRAIN_CONV_PRECISION == "f32"
+        assert ops.TRAIN_CONV_PRECISION == "bf16x3"
+    assert ops.TRAIN_CONV_PRECISION == "f32"
+    try:
+        with ops.train_conv_precision("bf16x3"):
+            raise RuntimeError("boom")
+    except RuntimeError:
+        pass
+    assert ops.TRAIN_CONV_PRECISION == "f32"
+    import pytest
+    with pytest.raises(ValueError):
+        with ops.train_conv_precision("fp8"):
+            pass
+    assert not ops.train_bf16x3(8, 64, 64, 256, 256)          # off: nothing takes the split-precision kernel
