@@ -380,6 +380,31 @@ def main():
                                         "conv_frac_of_f32_mfma_peak": round(fl5 / (c5_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4)}
             del s512, g5
         torch.cuda.empty_cache()
+        # ---- the weight-gradient kernel over the decoder's 12 conv layers (what a training step's backward runs), B = 8 ----
+        with torch.no_grad():
+            ops = pkg.ops
+            layers, r, cin = [], 8, 512
+            while r <= RES:
+                cout = min(int(8192 / (2.0 ** (r.bit_length() - 2))), 512)
+                layers += [(cin, cout, r, True), (cout, cout, r, False)]        # (Cin, Cout, output size, reads the x2 of its input)
+                cin, r = cout, r * 2
+            tens = [(torch.randn(BATCH, co, rr, rr, device=dev), torch.randn(BATCH, ci, rr // 2 if up else rr, rr // 2 if up else rr, device=dev), ci, co, up)
+                    for ci, co, rr, up in layers]
+
+            def wg_pass():
+                for g_, x_, ci, co, up in tens:
+                    ops.conv2d_wgrad(g_, x_, co, ci, 3, 1, upsample=up)
+            for _ in range(2):
+                wg_pass()
+            wg_ms = event_ms(wg_pass, 5)
+            wg_fl = sum(2 * 9 * ci * co * g_.shape[-1] * g_.shape[-2] * BATCH for g_, x_, ci, co, up in tens)
+            extras["wgrad_decoder_layers"] = {
+                "what": "spk_conv2d_wgrad over the decoder's conv layers at batch 8 (f32 MFMA, exact; the x2 layers read the "
+                        "low-resolution input and fold the bilinear upsampling where that is the faster form), kernel + slab reduce",
+                "layers": len(tens), "ms": round(wg_ms, 4), "tflops": round(wg_fl / (wg_ms * 1e-3) / 1e12, 1),
+                "frac_of_f32_mfma_peak": round(wg_fl / (wg_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4)}
+            del tens
+        torch.cuda.empty_cache()
         # ---- config 3: the IRFD generator step at batch 16; the discriminator step at batch 8 ----
         g_ms = irfd_steps(pkg, dev, "g", 16, steps=5, warmup=2)
         extras["train_step"] = {"what": "BASELINE config 3: IRFD generator step (3 ResNet-50 encoders x 2 images, train-mode BatchNorm, "
