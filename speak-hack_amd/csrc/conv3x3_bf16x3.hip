@@ -220,9 +220,8 @@ __global__ __launch_bounds__(NTB) void conv3x3_bf16x3_kernel(const Args p) {
 
     const char* wsrc = p.wp + (size_t)co_tile * p.n_chunks * W_BYTES;
 
-    // gather registers: per round 8 channels (x 4 bilinear taps).  All rounds of the next chunk are issued at the top of a
-    // chunk and consumed one to two tap rows (1 150 - 2 300 MFMA cycles) later: issued right before the tap row that precedes
-    // their use they came back late and every wave stalled on the same vmcnt (knock-out timing, gpurun_out/r2/bf_lab.txt)
+    // gather registers (producers): per round 8 channels of one plane position.  All rounds of a chunk are issued a whole chunk
+    // before they are converted and stored (see the producers' loop)
     constexpr int GXN = 8;                                  // (the UPS path stages a source tile instead: s_issue / interp_store)
     float gxa[MAX_ROUNDS][GXN];
     float gsa[MAX_ROUNDS][8];
@@ -489,7 +488,7 @@ __global__ __launch_bounds__(NTB) void conv3x3_bf16x3_kernel(const Args p) {
         // Through LDS (both stages are free now: every wave passed the last chunk's barrier): the 64 x 256 block is written in
         // accumulator order and read back as rows, so a thread finishes FOUR consecutive pixels of a channel per step --
         // 16 vector stores per thread instead of 64 dword stores, the per-channel / per-image operands loaded once per vector.
-        // With the dword form the epilogue was HALF of the 256^2 layers' time (gpurun_out/r2/bf_lab.txt).
+        // With the dword form the epilogue was HALF of the 256^2 layers' time (profiles/r02_f_bf16x3_layers.txt).
         constexpr int OP = PIX_T + 4, F4 = PIX_T / 4, RPI = NTB / F4;         // 8 rows per pass
         float* const ot = reinterpret_cast<float*>(smem);
         if (!producer) {

@@ -430,22 +430,18 @@ __global__ __launch_bounds__(256) void wgrad3x3_pipe_kernel(const WgradArgs p) {
         }
 }
 
-// ---- 3x3 stride-1 weight gradient, two accumulator tile sets per wave, 16-byte global loads ------------------------
+// ---- 3x3 stride-1 weight gradient with 16-byte global loads ---------------------------------------------------------------
 // The kernels above are bound by the ISSUE of their loads, not by the MFMA pipe (profiles/r01_k_wgrad_phases.txt: 48 dword
-// loads per thread and tile, ~1 000 line requests against 18.4K cycles of MFMA; a 64co x 64ci block needs 9.6 bytes per
-// cycle and CU from L2, which is all a CU takes in).  This form attacks both numbers:
-//   * each of the four waves owns MCO x MCI accumulator tiles of 32co x 32ci x 9 taps -- a 128co x 64ci (or, for the
-//     Cout = 64 layers, 64co x 128ci) block: 1.5x the FLOPs per staged byte, 18 MFMAs per k-step against 11 (19) fragment
-//     reads.  288 accumulator registers per lane: one wave per SIMD with the whole 512-entry file, as the kernels above;
-//   * rows are loaded 16 bytes per lane: a gradient row of the 16 x 4 tile is 4 aligned float4, an input row its 4 aligned
-//     float4 plus the two halo columns as single dwords: 17 (22) load instructions per thread and tile of 576 MFMAs,
-//     where the 64 x 64 form issues 48 per 288.
-// Staging roles make everything but the tile origin a launch constant: piece i of the input tile is plane ROW i % 6 of
-// 64 channels, so its global offset is a per-thread base plus a wave-uniform term, its LDS address an immediate offset
-// and its row test a scalar compare.  Same tile (16 x 4 pixels, 18 x 6 input plane), LDS images (odd row pitch), per-element
-// accumulation order and slab layout as the kernels above: results are bitwise equal to theirs for equal pixel splits.
-// MCO = MCI = 1 is the 64co x 64ci block of wgrad3x3_pipe_kernel with the wide loads.
-// Needs W % 4 == 0, W >= 16 and 16-byte aligned tensors (host-checked).
+// loads per thread and tile, ~1 000 line requests against 18.4K cycles of MFMA).  Here rows are loaded 16 bytes per lane: a
+// gradient row of the tile is TW / 4 aligned float4, an input row the same plus the two halo columns as single dwords --
+// 13 (TW = 16) load instructions per thread and tile of 288 MFMAs where the dword form issues 48.  (A second accumulator tile
+// set per wave -- 128co x 64ci blocks, 1.5x the FLOPs per staged byte -- was built and dropped: MFMA accumulators live in the
+// 256 AGPRs only, two 9-tap sets need 288.)
+// Staging roles make everything but the tile origin a launch constant: piece i of the input tile is a plane ROW of 64
+// channels, so its global offset is a per-thread base plus a wave-uniform term, its LDS address an immediate offset and its
+// row test a scalar compare.  Same 64co x 64ci block, LDS images (odd row pitch), per-element accumulation order and slab
+// layout as wgrad3x3_pipe_kernel: results are bitwise equal to its for equal pixel splits.
+// Needs W % 4 == 0, W >= 8 and 16-byte aligned tensors (host-checked: wide_takes).
 template <int TW_>
 struct WideShapeT {
     static constexpr int CO_T = 64, CI_T = 64, NT = 256;
@@ -1680,7 +1676,7 @@ int64_t spk_conv2d_wgrad_workspace_bytes(int kh, int kw, int stride, int splits,
     else if (kh == 3) g = stride == 1 ? wgeom<3, 3, 1>(B, Cin, Cout, H, W, splits) : wgeom<3, 3, 2>(B, Cin, Cout, H, W, splits);
     else g = wgeom<7, 7, 2>(B, Cin, Cout, H, W, splits);
     int n_slabs = g.n_slabs;
-    if (kh == 3 && stride == 1) {     // the 8-wave form may take the problem (the group count is not known here: the largest of its shapes)
+    if (kh == 3 && stride == 1) {     // the 16-byte-load form may take the problem
         n_slabs = std::max(n_slabs, wide_geom(64, 64, B, Cin, Cout, H, W, splits, W >= 16 ? 16 : 8).n_slabs);
     }
     if (kh == 3 && stride == 2 && W >= 8) n_slabs = std::max(n_slabs, s2_geom(W >= 16 ? 16 : 8, B, Cin, Cout, H, W, splits).n_slabs);
