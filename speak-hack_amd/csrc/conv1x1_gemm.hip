@@ -43,7 +43,16 @@ struct GemmArgs {
     int stats_slots;
     unsigned flags;
     float slope, out_scale, act_gain;
+#ifdef SPK_GEMM_LAB
+    int lab;                 // knock-outs (lab build only): 1 no MFMAs, 2 no x loads, 4 no y stores
+#endif
 };
+
+#ifdef SPK_GEMM_LAB
+#define SPK_GLAB(bit_) (p.lab & (bit_))
+#else
+#define SPK_GLAB(bit_) false
+#endif
 
 template <bool AFF>
 __global__ __launch_bounds__(256, 2) void conv1x1_gemm_kernel(const GemmArgs p) {
@@ -88,7 +97,8 @@ __global__ __launch_bounds__(256, 2) void conv1x1_gemm_kernel(const GemmArgs p) 
             st.a[i] = *reinterpret_cast<const float4*>(wb + (a_ok ? (size_t)r * p.Cin + k : 0));
             const int ci = k0 + brow + 8 * i;
             const bool x_ok = b_ok && ci < p.Cin;
-            st.b[i] = *reinterpret_cast<const float4*>(xb + (x_ok ? (size_t)ci * HW : 0));
+            if (!SPK_GLAB(2)) st.b[i] = *reinterpret_cast<const float4*>(xb + (x_ok ? (size_t)ci * HW : 0));
+            else st.b[i] = make_float4(1.f, 1.f, 1.f, 1.f);
             if (AFF) {
                 // channels past Cin (or pixels past the tensor): scale 0, shift 0 -> max(0, 0) = 0
                 st.sc[i] = p.in_scale[cx0 + (x_ok ? ci : 0)];
@@ -163,13 +173,13 @@ __global__ __launch_bounds__(256, 2) void conv1x1_gemm_kernel(const GemmArgs p) 
     for (int kt = 0; kt < n_kt; kt += 2) {
         // tile kt out of buffer 0; sA = tile kt+1 (in flight since the previous phase); sB <- tile kt+2
         load(sB, min(kt + 2, n_kt - 1));
-        compute(0);
+        if (!SPK_GLAB(1)) compute(0);
         store(sA, 1, min(kt + 1, n_kt - 1));
         __syncthreads();
         if (kt + 1 >= n_kt) break;
         // tile kt+1 out of buffer 1; sB = tile kt+2; sA <- tile kt+3
         load(sA, min(kt + 3, n_kt - 1));
-        compute(1);
+        if (!SPK_GLAB(1)) compute(1);
         store(sB, 0, min(kt + 2, n_kt - 1));
         __syncthreads();
     }
@@ -180,6 +190,15 @@ __global__ __launch_bounds__(256, 2) void conv1x1_gemm_kernel(const GemmArgs p) 
     constexpr int OPITCH = GN + 4;
     static_assert(GM * OPITCH <= 2 * GBUF, "the output tile reuses the staging buffers");
     float* const ot = smem;                                   // the last k-tile's barrier has passed
+    float* const red = smem + 2 * GBUF;                       // [2][GM] row sums / sums of squares
+#ifdef SPK_GEMM_LAB
+    if (SPK_GLAB(8)) {
+        float t = 0.f;
+        for (int m = 0; m < 2; ++m) for (int n = 0; n < 2; ++n) for (int r = 0; r < 16; ++r) t += acc[m][n][r];
+        if (t == 123.456f) p.y[tid] = t;
+        return;
+    }
+#endif
 #pragma unroll
     for (int m = 0; m < 2; ++m)
 #pragma unroll
@@ -189,7 +208,7 @@ __global__ __launch_bounds__(256, 2) void conv1x1_gemm_kernel(const GemmArgs p) 
                 ot[(wm * 64 + m * 32 + (r & 3) + 8 * (r >> 2) + 4 * half) * OPITCH + wn * 64 + n * 32 + l32] = acc[m][n][r];
     __syncthreads();
     const bool f_bias = p.flags & SPK_EPI_BIAS, f_lrelu = p.flags & SPK_EPI_LRELU;
-    const bool f_accum = p.flags & SPK_EPI_ACCUM, f_stats = p.flags & SPK_EPI_STATS;
+    const bool f_accum = p.flags & SPK_EPI_ACCUM, f_stats = (p.flags & SPK_EPI_STATS) && !SPK_GLAB(16);
     const int ocol = (tid & 31) * 4;
     const long long Po = P0 + ocol;
     const bool o_ok = Po < p.n_px;
@@ -220,25 +239,28 @@ __global__ __launch_bounds__(256, 2) void conv1x1_gemm_kernel(const GemmArgs p) 
                 const float4 old = *dst;
                 v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
             }
-            *dst = v;
+            if (!SPK_GLAB(4) || v.x == 123.456f) *dst = v;
             ssum = (v.x + v.y) + (v.z + v.w);
             ssq = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
         }
-        if (f_stats) {
-#pragma unroll
-            for (int off = 16; off >= 1; off >>= 1) {
-                ssum += __shfl_xor(ssum, off);
-                ssq += __shfl_xor(ssq, off);
+        if (f_stats) {                                         // uniform flag: every lane takes part
+            ssum = spk::half_wave_sum_hi(ssum);
+            ssq = spk::half_wave_sum_hi(ssq);
+            if (l32 == 31) {
+                red[cl] = ssum;
+                red[GM + cl] = ssq;
             }
-            if (l32 == 0 && cv) {
-                if (own_slot) {
-                    sp[cg] = (double)ssum;
-                    sp[p.Cy + cg] = (double)ssq;
-                } else {
-                    atomicAdd(sp + cg, (double)ssum);
-                    atomicAdd(sp + p.Cy + cg, (double)ssq);
-                }
-            }
+        }
+    }
+    if (f_stats) {
+        // the block's 128 + 128 row sums leave as two contiguous runs of doubles (one store instruction each)
+        __syncthreads();
+        const int cl = tid & (GM - 1), co = co0 + cl;
+        if (co < p.Cout) {
+            const int cg = grp * p.Cout + co;
+            double* dst = sp + (tid >= GM ? p.Cy : 0) + cg;
+            if (own_slot) *dst = (double)red[tid];
+            else atomicAdd(dst, (double)red[tid]);
         }
     }
 }
@@ -267,9 +289,12 @@ int run_1x1_gemm(const spk_conv2d_desc* d, hipStream_t stream) {
     a.co_tiles_g = spk::ceil_div(d->Cout, GM);
     a.stats_slots = d->stats_slots > 1 ? d->stats_slots : 1;
     a.flags = d->flags; a.slope = d->lrelu_slope; a.out_scale = d->out_scale; a.act_gain = d->act_gain != 0.f ? d->act_gain : 1.f;
+#ifdef SPK_GEMM_LAB
+    { const char* e = getenv("SPK_GEMM_LAB"); a.lab = e ? atoi(e) : 0; }
+#endif
     const long long gx = gemm1x1_pixel_tiles(d->B, d->H, d->W);
     SPK_REQUIRE(gx < (1ll << 31) && (long long)a.G * a.co_tiles_g < 65536, "conv2d: grid too large");
-    const size_t lds = 2 * (size_t)GBUF * sizeof(float);
+    const size_t lds = (2 * (size_t)GBUF + 2 * GM) * sizeof(float);
     const bool aff = d->flags & SPK_CONV_IN_AFFINE_RELU;
     auto kern = aff ? &conv1x1_gemm_kernel<true> : &conv1x1_gemm_kernel<false>;
     static bool raised[2] = {false, false};

@@ -518,6 +518,7 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
         constexpr bool CAN_HALVE = C::MT == 2;
         float* const ot = smem;
         const int rounds = (CAN_HALVE && p.staged == 2) ? 2 : 1;
+        float* const red_s = ot + (C::CO_T / rounds) * OP;    // [2][CO_T] row sums / sums of squares (SPK_EPI_STATS)
         const int f4 = tid % F4, row0 = tid / F4;
         const int pt = 4 * f4;
         const int px = pt & (TW - 1), py = (pt >> p.lgTW) & (TH - 1), tb = pt >> (p.lgTW + p.lgTH);
@@ -585,23 +586,27 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
                 ssum = (v.x + v.y) + (v.z + v.w);
                 ssq = (v.x * v.x + v.y * v.y) + (v.z * v.z + v.w * v.w);
             }
-            if (f_stats) {          // the F4 lanes of a row are consecutive: one butterfly finishes the row's sums
-#pragma unroll
-                for (int off = F4 / 2; off >= 1; off >>= 1) {
-                    ssum += __shfl_xor(ssum, off);
-                    ssq += __shfl_xor(ssq, off);
-                }
-                if (f4 == 0 && cv) {
-                    if (own_slot) {
-                        sp[cg] = (double)ssum;
-                        sp[p.Cy + cg] = (double)ssq;
-                    } else {
-                        atomicAdd(sp + cg, (double)ssum);
-                        atomicAdd(sp + p.Cy + cg, (double)ssq);
-                    }
+            if (f_stats) {          // the F4 lanes of a row are consecutive: DPP adds finish the row's sums in its last lane
+                ssum = spk::lane_group_sum_hi<F4>(ssum);
+                ssq = spk::lane_group_sum_hi<F4>(ssq);
+                if (f4 == F4 - 1) {
+                    red_s[co - co_tile0] = ssum;
+                    red_s[C::CO_T + co - co_tile0] = ssq;
                 }
             }
         }
+        }
+        if (f_stats) {
+            // the block's row sums leave as two contiguous runs of doubles instead of one 8-byte store per row and wave
+            __syncthreads();
+            for (int t = tid; t < 2 * C::CO_T; t += C::NTHREADS) {
+                const int cl = t % C::CO_T, co = co_tile0 + cl;
+                if (co < p.Cout) {
+                    double* dst = sp + (t >= C::CO_T ? p.Cy : 0) + grp * p.Cout + co;
+                    if (own_slot) *dst = (double)red_s[t];
+                    else atomicAdd(dst, (double)red_s[t]);
+                }
+            }
         }
         return;
     }
@@ -672,13 +677,10 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
                     ssq += v * v;
                 }
             }
-            if (f_stats) {  // wave-uniform flag: every lane takes part in the butterfly
-#pragma unroll
-                for (int off = 16; off >= 1; off >>= 1) {
-                    ssum += __shfl_xor(ssum, off);
-                    ssq += __shfl_xor(ssq, off);
-                }
-                if (l32 == 0) {
+            if (f_stats) {  // wave-uniform flag: every lane takes part
+                ssum = spk::half_wave_sum_hi(ssum);
+                ssq = spk::half_wave_sum_hi(ssq);
+                if (l32 == 31) {
                     float* rp = red + (wn * C::CO_T + (co - co_tile0)) * 2;
                     rp[0] = ssum;
                     rp[1] = ssq;
@@ -803,15 +805,16 @@ int run(const spk_conv2d_desc* d, hipStream_t stream, int Hd = 0, int Wd = 0, in
     {
         static const bool allow = [] { const char* e = getenv("SPK_CONV_STAGED_EPI"); return !e || atoi(e) != 0; }();
         const size_t tile_bytes = (size_t)C::CO_T * (C::PIX_T + 4) * sizeof(float);
+        const size_t red_bytes = (d->flags & SPK_EPI_STATS) ? 2 * (size_t)C::CO_T * sizeof(float) : 0;   // row sums behind the tile
         const size_t lds_now = g.lds_bytes;
         const auto aligned = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
         const auto same_slots = [&](size_t bytes) { return (160 * 1024) / std::max(bytes, lds_now) == (160 * 1024) / lds_now; };
         constexpr bool can_halve = C::MT == 2;
-        const int rounds = same_slots(tile_bytes) ? 1 : ((can_halve && same_slots(tile_bytes / 2)) ? 2 : 0);
+        const int rounds = same_slots(tile_bytes + red_bytes) ? 1 : ((can_halve && same_slots(tile_bytes / 2 + red_bytes)) ? 2 : 0);
         if (allow && rounds && KH != 2 && ksplit == 1 && g.TW >= 4 && d->W % 4 == 0 && C::NTHREADS % (C::PIX_T / 4) == 0 &&
             (C::CO_T / rounds) % (C::NTHREADS / (C::PIX_T / 4)) == 0 && aligned(d->y) && aligned(d->y_pre) && aligned(d->noise)) {
             a.staged = rounds;
-            g.lds_bytes = std::max(lds_now, tile_bytes / rounds);
+            g.lds_bytes = std::max(lds_now, tile_bytes / rounds + red_bytes);
         }
     }
     const size_t out_floats = (size_t)d->B * a.Cy * d->H * d->W;
