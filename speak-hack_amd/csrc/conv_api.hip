@@ -472,7 +472,13 @@ int spk_conv2d_fwd(const spk_conv2d_desc* d, void* stream) {
     hipStream_t s = (hipStream_t)stream;
     if (cfg == kGemmConfig) return run_1x1_gemm(&dd, s);
     if (d->kh == 1) return run_1x1(d->stride, cfg, mode, &dd, s);
-    if (d->kh == 3 && d->stride == 1) return cfg <= 3 ? run_3x3s1_a(cfg, mode, &dd, s) : run_3x3s1_b(cfg, mode, &dd, s);
+    if (d->kh == 3 && d->stride == 1) {
+        if ((d->flags & SPK_EPI_STATS) && mode != MODE_AFFINE_RELU) {
+            SPK_REQUIRE(mode == MODE_PLAIN, "conv2d: SPK_EPI_STATS on a 3x3 stride-1 conv goes with a plain or BatchNorm-folded input (not upsample / batch scale)");
+            return run_3x3s1_stats(cfg, &dd, s);
+        }
+        return cfg <= 3 ? run_3x3s1_a(cfg, mode, &dd, s) : run_3x3s1_b(cfg, mode, &dd, s);
+    }
     return run_3x3s2_7x7s2(d->kh, cfg, mode, &dd, s);
 }
 

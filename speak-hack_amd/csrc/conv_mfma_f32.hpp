@@ -35,7 +35,9 @@ namespace spkconv {
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-enum Mode { MODE_PLAIN = 0, MODE_UPSAMPLE = 1, MODE_AFFINE_RELU = 2, MODE_BATCH_SCALE = 3, MODE_UPSAMPLE_BATCH_SCALE = 4 };
+// MODE_PLAIN_STATS: MODE_PLAIN of a 3x3 stride-1 conv with the BatchNorm-statistics epilogue compiled in (see HAS_STATS in
+// the kernel); every other kernel shape carries that epilogue in all its modes.
+enum Mode { MODE_PLAIN = 0, MODE_UPSAMPLE = 1, MODE_AFFINE_RELU = 2, MODE_BATCH_SCALE = 3, MODE_UPSAMPLE_BATCH_SCALE = 4, MODE_PLAIN_STATS = 5 };
 
 template <int I, int N, class F>
 __device__ __forceinline__ void static_for(F&& f) {
@@ -503,7 +505,12 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
     const bool split = gridDim.z > 1;
     const bool f_bias = p.flags & SPK_EPI_BIAS, f_noise = p.flags & SPK_EPI_NOISE;
     const bool f_lrelu = p.flags & SPK_EPI_LRELU, f_style = p.flags & SPK_EPI_STYLE;
-    const bool f_accum = p.flags & SPK_EPI_ACCUM, f_stats = (p.flags & SPK_EPI_STATS) && !split;
+    // The statistics epilogue is compiled OUT of the 3x3 stride-1 plain / upsample / batch-scale instantiations -- the StyleGAN
+    // decoders' hot kernels, which never ask for it: with its (runtime-dead) code inside, the 64 -> 64 @256^2 layer ran 3 %
+    // slower (308 -> 318 us, +4 VGPRs; headline 3.71 -> 3.77 ms per step).  A plain 3x3 stride-1 conv that wants statistics
+    // is the separate instantiation MODE_PLAIN_STATS (conv_inst_3x3s1_stats.hip).
+    constexpr bool HAS_STATS = !(KH == 3 && KW == 3 && S == 1) || MODE == MODE_AFFINE_RELU || MODE == MODE_PLAIN_STATS;
+    const bool f_accum = p.flags & SPK_EPI_ACCUM, f_stats = HAS_STATS && (p.flags & SPK_EPI_STATS) && !split;
     const size_t HW = (size_t)p.H * p.W;
     if (p.staged) {
         // ---- staged form (host: no split-K, not the parity kernel, W % 4 == 0, 16-byte aligned tensors, TW >= 4, and an
@@ -865,6 +872,7 @@ constexpr int kDgradS2Config = 13;   // the exact-tap data gradient of a 3x3 str
 // per-family dispatchers, one translation unit each (parallel compilation)
 int run_3x3s1_a(int cfg, int mode, const spk_conv2d_desc* d, hipStream_t s);  // ids 0-3
 int run_3x3s1_b(int cfg, int mode, const spk_conv2d_desc* d, hipStream_t s);  // ids 4-7
+int run_3x3s1_stats(int cfg, const spk_conv2d_desc* d, hipStream_t s);      // ids 0-7, MODE_PLAIN_STATS
 int run_3x3s2_7x7s2(int kh, int cfg, int mode, const spk_conv2d_desc* d, hipStream_t s);  // ids 4-7
 int run_1x1(int stride, int cfg, int mode, const spk_conv2d_desc* d, hipStream_t s);      // ids 8-11
 int run_2x2_parity(int cfg, const spk_conv2d_desc* d, int Hd, int Wd, int pshift, hipStream_t s);     // ids 0-3
