@@ -110,7 +110,8 @@ typedef struct spk_conv2d_desc {
     /* StyleGAN2-style modulated convolution (build-defined variant): with
      * SPK_CONV_IN_BATCH_SCALE, in_scale is the modulation s[B,Cin]; out_scale_bc[B,Cout] (or NULL) multiplies the
      * contraction before bias/noise (the demodulation d[b,co] = rsqrt(sum (w*s)^2 + eps), spk_modconv_demod);
-     * act_gain (0 = 1) multiplies the LeakyReLU output (sqrt 2 of FusedLeakyReLU). */
+     * act_gain (0 = 1) multiplies the LeakyReLU output (sqrt 2 of FusedLeakyReLU).  out_scale_bc without
+     * SPK_CONV_IN_BATCH_SCALE is rejected (the plain kernels are built without the demodulation read). */
     const float* out_scale_bc;
     float act_gain;
     /* Grouped convolution: `groups` (0 or 1 = ordinary) independent convs of the same shape in one launch -- the three

@@ -465,6 +465,7 @@ int spk_conv2d_fwd(const spk_conv2d_desc* d, void* stream) {
     int cfg = d->config;
     if (cfg < 0) cfg = pick_config(d->kh, d->stride, d->B, d->Cin, d->Cout, d->H, d->W);
     SPK_REQUIRE(!bsc || cfg >= 4, "conv2d: IN_BATCH_SCALE is built for the half-depth configs (4-7)");
+    SPK_REQUIRE(!d->out_scale_bc || bsc, "conv2d: out_scale_bc (demodulation) goes with SPK_CONV_IN_BATCH_SCALE (the modulated convolution)");
     SPK_REQUIRE(config_valid(cfg, d->kh, d->kw, d->stride), "conv2d: config %d is not built for %dx%d stride %d", cfg, d->kh, d->kw, d->stride);
     spk_conv2d_desc dd = *d;
     dd.config = cfg;

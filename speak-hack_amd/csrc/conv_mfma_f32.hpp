@@ -564,7 +564,7 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
                 float4 v = *reinterpret_cast<const float4*>(ot + cl * OP + pt);
                 float sc = p.out_scale;
                 v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
-                if (p.out_scale_bc) {
+                if (BSC && p.out_scale_bc) {
                     const float d = p.out_scale_bc[(size_t)b * p.Cy + cg];
                     v.x *= d; v.y *= d; v.z *= d; v.w *= d;
                 }
@@ -672,7 +672,7 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
                         continue;
                     }
                     float v = acc[m][n][r] * p.out_scale;
-                    if (p.out_scale_bc) v *= p.out_scale_bc[(size_t)pb[n] * p.Cy + cg];   // demodulation d[b,co]
+                    if (BSC && p.out_scale_bc) v *= p.out_scale_bc[(size_t)pb[n] * p.Cy + cg];   // demodulation d[b,co]
                     v += bb;
                     if (f_noise) v += nwc * nz[n];
                     if (f_lrelu) v = (v > 0.f ? v : v * p.slope) * p.act_gain;
