@@ -165,6 +165,13 @@ int64_t spk_conv2d_workspace_bytes_grouped(int config, int ksplit, int kh, int k
  * replaces: nothing in the reference (layout change private to this library). */
 int spk_conv2d_pack_weights(const float* w, float* w_packed, int kh, int kw, int Cin, int Cout, int config,
                             int transpose_flip, void* stream);
+/* The same for `n` (1..SPK_PACK_LIST_MAX) weight tensors of one shape on ONE launch: their packed images one after another
+ * in w_packed (n x spk_conv2d_packed_floats floats) -- what a grouped launch (spk_conv2d_desc.groups) reads.  `ws` is a HOST
+ * array of device pointers.  replaces: the per-encoder weight reads of the three torchvision trunks Ei / Ee / Ep
+ * (model.py:60-62), whose convs of one position run as one grouped launch. */
+#define SPK_PACK_LIST_MAX 8
+int spk_conv2d_pack_weights_list(const float* const* ws, int n, float* w_packed, int kh, int kw, int Cin, int Cout, int config,
+                                 int transpose_flip, void* stream);
 int spk_conv2d_fwd(const spk_conv2d_desc* desc, void* stream);
 /* The SPK_CONV_BF16X3 path: packed image size in BYTES / packer (w is the fp32 [Cout,Cin,3,3] parameter; the hi / lo split
  * happens here, once per weight update) / whether a shape is served / the launch itself (spk_conv2d_fwd forwards to it). */

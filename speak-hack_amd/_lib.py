@@ -179,6 +179,8 @@ _PROTOTYPES = {
     "spk_conv2d_workspace_bytes_grouped": (C.c_int64, [C.c_int] * 11),
     "spk_conv2d_pack_weights": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int,
                                           C.c_void_p]),
+    "spk_conv2d_pack_weights_list": (C.c_int, [C.POINTER(C.c_void_p), C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int,
+                                               C.c_int, C.c_int, C.c_void_p]),
     "spk_conv2d_fwd": (C.c_int, [C.POINTER(Conv2dDesc), C.c_void_p]),
     "spk_conv2d_packed_bytes_bf16x3": (C.c_int64, [C.c_int, C.c_int]),
     "spk_conv2d_pack_weights_bf16x3": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_void_p]),

@@ -148,10 +148,16 @@ int launch_splitk_epilogue(const ConvArgs& a_in, const float* ws, int ksplit, hi
     return spk::check_launch("splitk_epilogue_kernel");
 }
 
-__global__ void pack_weights_kernel(const float* __restrict__ w, float* __restrict__ wp, int taps, int Cin_orig,
+// several weight tensors of one shape on one launch (blockIdx.y = which): their packed images one after another, as a
+// grouped conv launch reads them
+struct PackList { const float* w[SPK_PACK_LIST_MAX]; };
+
+__global__ void pack_weights_kernel(const PackList list, float* __restrict__ wp, int taps, int Cin_orig,
                                     int opCin, int opCout, int CO_T, int CI_T, int n_chunks, int tf, long long total) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= total) return;
+    const float* __restrict__ w = list.w[blockIdx.y];
+    wp += (size_t)blockIdx.y * total;
     long long t = idx;
     const int co_in = (int)(t % CO_T); t /= CO_T;
     const int ci = (int)(t % CI_T); t /= CI_T;
@@ -184,9 +190,11 @@ __global__ void pack_weights_kernel(const float* __restrict__ w, float* __restri
 }
 
 // config 12: w[Cout][Cin] -> itself (tf = 0) or its transpose [Cin][Cout] (tf = 1)
-__global__ void pack_rowmajor_kernel(const float* __restrict__ w, float* __restrict__ wp, int Cin, int Cout, int tf, long long n) {
+__global__ void pack_rowmajor_kernel(const PackList list, float* __restrict__ wp, int Cin, int Cout, int tf, long long n) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
     if (idx >= n) return;
+    const float* __restrict__ w = list.w[blockIdx.y];
+    wp += (size_t)blockIdx.y * n;
     if (!tf) { wp[idx] = w[idx]; return; }
     const int co = (int)(idx % Cout), ci = (int)(idx / Cout);       // wp[ci][co]
     wp[idx] = w[(size_t)co * Cin + ci];
@@ -368,7 +376,17 @@ int64_t spk_conv2d_workspace_bytes(int config, int ksplit, int kh, int kw, int s
 
 int spk_conv2d_pack_weights(const float* w, float* w_packed, int kh, int kw, int Cin, int Cout, int config,
                             int transpose_flip, void* stream) {
-    SPK_REQUIRE(w && w_packed, "pack_weights: null pointer");
+    return spk_conv2d_pack_weights_list(&w, 1, w_packed, kh, kw, Cin, Cout, config, transpose_flip, stream);
+}
+
+int spk_conv2d_pack_weights_list(const float* const* ws, int n, float* w_packed, int kh, int kw, int Cin, int Cout, int config,
+                                 int transpose_flip, void* stream) {
+    SPK_REQUIRE(ws && w_packed && n >= 1 && n <= SPK_PACK_LIST_MAX, "pack_weights: null pointer or bad list length (1..%d)", SPK_PACK_LIST_MAX);
+    PackList list;
+    for (int i = 0; i < SPK_PACK_LIST_MAX; ++i) {
+        list.w[i] = ws[i < n ? i : 0];
+        SPK_REQUIRE(list.w[i], "pack_weights: null pointer");
+    }
     SPK_REQUIRE(config >= 0 && config < kNumConfigs, "pack_weights: bad config %d", config);
     SPK_REQUIRE(Cin > 0 && Cout > 0 && kh > 0 && kw > 0, "pack_weights: bad shape");
     SPK_REQUIRE(transpose_flip >= 0 && transpose_flip <= 3, "pack_weights: transpose_flip is 0, 1, 2 or 3");
@@ -376,9 +394,9 @@ int spk_conv2d_pack_weights(const float* w, float* w_packed, int kh, int kw, int
     SPK_REQUIRE(transpose_flip != 3 || (kh == 4 && kw == 4), "pack_weights: the transposed-conv form packs a 4x4 kernel");
     if (config == kGemmConfig) {        // row-major [opCout][opCin]: the weight itself, or its transpose for the data gradient
         SPK_REQUIRE(kh == 1 && kw == 1 && transpose_flip < 2, "pack_weights: config %d packs 1x1 kernels", kGemmConfig);
-        const long long n = (long long)Cin * Cout;
-        hipLaunchKernelGGL(pack_rowmajor_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, w_packed,
-                           Cin, Cout, transpose_flip, n);
+        const long long nf = (long long)Cin * Cout;
+        hipLaunchKernelGGL(pack_rowmajor_kernel, dim3((unsigned)((nf + 255) / 256), (unsigned)n), dim3(256), 0, (hipStream_t)stream, list,
+                           w_packed, Cin, Cout, transpose_flip, nf);
         return spk::check_launch("pack_rowmajor_kernel");
     }
     if (config == kDgradS2Config) {     // the transposed 3x3 operator itself, in 64-channel x 8-channel tiles (kDims[13])
@@ -392,8 +410,8 @@ int spk_conv2d_pack_weights(const float* w, float* w_packed, int kh, int kw, int
     const int n_chunks = spk::ceil_div(opCin, c.ci_t);
     const long long total = (long long)spk::ceil_div(opCout, c.co_t) * n_chunks * taps * c.ci_t * c.co_t;
     const int threads = 256;
-    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((total + threads - 1) / threads)), dim3(threads), 0,
-                       (hipStream_t)stream, w, w_packed, taps, transpose_flip == 3 ? Cout : Cin, opCin, opCout, c.co_t, c.ci_t,
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((total + threads - 1) / threads), (unsigned)n), dim3(threads), 0,
+                       (hipStream_t)stream, list, w_packed, taps, transpose_flip == 3 ? Cout : Cin, opCin, opCout, c.co_t, c.ci_t,
                        n_chunks, transpose_flip, total);
     return spk::check_launch("pack_weights_kernel");
 }

@@ -156,7 +156,9 @@ class _GroupPacked:
         hit = self._cache.get(key)
         if hit is not None and hit[0] == stamp:
             return hit[1]
-        packed = torch.cat([ops.pack_conv_weight(w.detach(), config, transpose_flip) for w in weights])
+        # one launch into the previous image's storage (same key = same size): no per-tensor packs, no concatenation
+        packed = ops.pack_conv_weights_list([w.detach() for w in weights], config, transpose_flip,
+                                            out=hit[1] if hit is not None else None)
         self._cache[key] = (stamp, packed)
         return packed
 

@@ -100,6 +100,40 @@ def pack_conv_weight(weight: torch.Tensor, config: int, transpose_flip=False, ou
     return out
 
 
+PACK_LIST_MAX = 8
+
+
+def pack_conv_weights_list(weights, config: int, transpose_flip=False, out=None) -> torch.Tensor:
+    """The packed images of several same-shape weights one after another (what a grouped launch reads), ONE launch per
+    ``PACK_LIST_MAX`` tensors (``spk_conv2d_pack_weights_list``) instead of a pack per tensor and a concatenation."""
+    w0 = weights[0]
+    Cout, Cin, kh, kw = w0.shape
+    tf = int(transpose_flip)
+    if tf == 2:          # the stride-2 data-gradient form (see pack_conv_weight)
+        n1 = L.lib().spk_conv2d_packed_floats(config, 2, 2, Cout, 4 * Cin)
+    elif tf == 3:
+        raise L.SpkError("pack_conv_weights_list: transpose_flip 0, 1 or 2")
+    else:
+        n1 = L.lib().spk_conv2d_packed_floats(config, kh, kw, Cout if tf else Cin, Cin if tf else Cout)
+    if n1 <= 0:
+        raise L.SpkError("spk_conv2d_packed_floats: bad arguments")
+    if out is None:
+        out = torch.empty(n1 * len(weights), device=w0.device, dtype=torch.float32)
+    elif out.numel() != n1 * len(weights) or not out.is_contiguous() or out.device != w0.device:
+        raise L.SpkError(f"pack_conv_weights_list: out must be a contiguous buffer of {n1 * len(weights)} floats on {w0.device}")
+    ws = [w.contiguous() for w in weights]
+    for w in ws:
+        if w.shape != w0.shape or w.dtype != torch.float32 or w.device != w0.device:
+            raise L.SpkError("pack_conv_weights_list: the weights must share shape, dtype and device")
+    for i in range(0, len(ws), PACK_LIST_MAX):
+        part = ws[i:i + PACK_LIST_MAX]
+        arr = (C.c_void_p * len(part))(*[w.data_ptr() for w in part])
+        L.check(L.lib().spk_conv2d_pack_weights_list(arr, len(part), out.data_ptr() + 4 * n1 * i, kh, kw, Cin, Cout, config, tf,
+                                                     L.stream_ptr()),
+                "spk_conv2d_pack_weights_list")
+    return out
+
+
 _workspaces = {}
 _retired = []            # outgrown scratch buffers: never freed (a captured hipGraph may have their address baked in)
 

@@ -113,3 +113,19 @@ def test_grouped_weight_gradient_folded_over_images(ops, k, stride, B, Cin, Cout
     assert float((folded - want).abs().max()) <= 1e-5 * float(want.abs().max())
     with pytest.raises(Exception):
         ops.conv2d_wgrad(g, x, Cout, Cin, k, stride, groups=G, fold=4)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("k,Cin,Cout,cfg", [(1, 64, 256, 12), (1, 256, 64, 10), (3, 64, 64, 6), (3, 36, 40, 2), (7, 3, 64, 4), (3, 64, 48, 13)])
+@pytest.mark.parametrize("n", [1, 3, 6, 11])
+def test_pack_list_equals_separate_packs(ops, k, Cin, Cout, cfg, n):
+    """``spk_conv2d_pack_weights_list`` (several weights of a grouped launch on one launch, also past the 8 of one call)
+    writes exactly the images of the per-tensor entry point, forward and transposed; an ``out`` buffer is refilled in place."""
+    dev = torch.device("cuda:0")
+    ws = [torch.randn(Cout, Cin, k, k, device=dev) for _ in range(n)]
+    for tf in ([2] if cfg == 13 else [0, 1, 2] if (k == 3 and cfg < 4) else [0, 1] if k != 7 else [0]):
+        ref = torch.cat([ops.pack_conv_weight(w, cfg, tf) for w in ws])
+        got = ops.pack_conv_weights_list(ws, cfg, tf)
+        assert torch.equal(got, ref)
+        again = ops.pack_conv_weights_list([w * 2 for w in ws], cfg, tf, out=got)
+        assert again.data_ptr() == got.data_ptr() and torch.equal(again, ref * 2)
