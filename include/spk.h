@@ -226,8 +226,9 @@ int spk_conv2d_wgrad_up_supported(int B, int Cin, int Cout, int H, int W);
 /* Adjoint of the fused epilogue of spk_conv2d_fwd, one pass.  With y = a*(s0+1)+s1, a = lrelu(t),
  * t = conv + bias + noise_w*noise and dy = dL/dy:
  *   dt[b,c,p] = dy * (s0[b,c]+1) * (a > 0 ? 1 : slope)          (feeds the data / weight gradient)
- *   sums[b,c,:] = { sum_p dy, sum_p dy*a, sum_p dt, sum_p dt*noise[b,p] }
- * so d s1 = sums[..,0], d s0 = sums[..,1], d bias = sum_b sums[..,2], d noise_w = sum_b sums[..,3].
+ *   sums[b,:,c] = { sum_p dy*a, sum_p dy, sum_p dt, sum_p dt*noise[b,p] }          (layout [B][4][C])
+ * so d s0 = sums[b,0,:], d s1 = sums[b,1,:] -- rows 0-1 of an image are its style gradient [d s0 | d s1] as ApplyStyle's
+ * linear layer wants it, no copy -- and d bias = sum_b sums[b,2,:], d noise_w = sum_b sums[b,3,:].
  * a / noise / style may be NULL (stage absent).  dt may alias dy.
  * replaces: autograd's backward of styleganv1.py:626-628 / :631-633 (noise, leaky_relu, style_mod). */
 int spk_epilogue_bwd(const float* dy, const float* a, const float* noise, const float* style, int64_t style_stride,
@@ -277,7 +278,8 @@ int spk_fc_grouped_fwd(const spk_fc_group* groups, int n_groups, int B, void* st
  * (dw NULL to skip both).  replaces: autograd's backward of the 13 ApplyStyle.linear FCs of a synthesis pass
  * (styleganv1.py:463-468), whose input gradients are the rows of one [B, 13, 512] latent gradient. */
 typedef struct spk_fc_bwd_group {
-    const float* dout;   /* [B, O] */
+    const float* dout;   /* [B, O], row stride dout_stride (>= O: e.g. rows 0-1 of spk_epilogue_bwd's sums, O = 2C, stride 4C) */
+    int64_t dout_stride;
     const float* out;    /* [B, O] the saved forward output */
     const float* x;      /* [B, I], row stride x_stride (for dw) */
     int64_t x_stride;

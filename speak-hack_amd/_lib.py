@@ -55,7 +55,8 @@ class FcGroup(C.Structure):
 
 class FcBwdGroup(C.Structure):
     """``spk_fc_bwd_group`` (include/spk.h)."""
-    _fields_ = [("dout", C.c_void_p), ("out", C.c_void_p), ("x", C.c_void_p), ("x_stride", C.c_int64), ("w", C.c_void_p),
+    _fields_ = [("dout", C.c_void_p), ("dout_stride", C.c_int64), ("out", C.c_void_p), ("x", C.c_void_p), ("x_stride", C.c_int64),
+                ("w", C.c_void_p),
                 ("dx", C.c_void_p), ("dx_stride", C.c_int64), ("dw", C.c_void_p), ("db", C.c_void_p), ("I", C.c_int32),
                 ("O", C.c_int32), ("wmul", C.c_float), ("bmul", C.c_float), ("slope", C.c_float), ("reserved", C.c_int32)]
 

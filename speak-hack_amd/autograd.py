@@ -36,6 +36,22 @@ def _needs(ctx, grad_mode):
     return bool(grad_mode) and any(ctx.needs_input_grad)
 
 
+def _epilogue_param_grads(sums, has_style, has_bias, has_noise):
+    """(d style [B,2C] = [d s0 | d s1], d bias [C], d noise_w [C]) from ``ops.epilogue_bwd``'s sums [B,4,C]: the style
+    gradient is a view of rows 0-1, bias and noise weight come out of ONE reduction over the batch."""
+    B, _, Cc = sums.shape
+    dstyle = sums[:, :2].reshape(B, 2 * Cc) if has_style else None
+    dbias = dnw = None
+    if has_bias and has_noise:
+        red = sums[:, 2:].sum(0)
+        dbias, dnw = red[0], red[1]
+    elif has_bias:
+        dbias = sums[:, 2].sum(0)
+    elif has_noise:
+        dnw = sums[:, 3].sum(0)
+    return dstyle, dbias, dnw
+
+
 class FusedConvFn(torch.autograd.Function):
     """y = style(lrelu(conv3x3(up?(x)) + bias + noise_w*noise)) -- styleganv1.py:624-628 / :630-633.
 
@@ -72,9 +88,7 @@ class FusedConvFn(torch.autograd.Function):
         Cout, H, W = a.shape[1:]
         dt, sums = ops.epilogue_bwd(dy.contiguous(), a, noise if has_noise else None, style,
                                     slope if slope is not None else 1.0)
-        dstyle = torch.cat([sums[..., 1], sums[..., 0]], dim=1) if style is not None else None   # [ds0 | ds1]
-        dbias = sums[..., 2].sum(0) if has_bias else None
-        dnw = sums[..., 3].sum(0) if has_noise else None
+        dstyle, dbias, dnw = _epilogue_param_grads(sums, style is not None, has_bias, has_noise)
         dx = dw = None
         if ctx.needs_input_grad[0]:
             if ops.train_bf16x3(B, Cout, Cin, H, W):
@@ -199,9 +213,7 @@ class BiasNoiseStyleFn(torch.autograd.Function):
         pre, noise, style = ctx.saved_tensors
         broadcast, has_bias, has_noise = ctx.conf
         dt, sums = ops.epilogue_bwd(dy.contiguous(), pre, noise if has_noise else None, style, 1.0)
-        dstyle = torch.cat([sums[..., 1], sums[..., 0]], dim=1) if style is not None else None
-        dbias = sums[..., 2].sum(0) if has_bias else None
-        dnw = sums[..., 3].sum(0) if has_noise else None
+        dstyle, dbias, dnw = _epilogue_param_grads(sums, style is not None, has_bias, has_noise)
         dx = None
         if ctx.needs_input_grad[0]:
             dx = dt.sum(0, keepdim=True) if broadcast else dt      # [1,C,4,4] constant: B tiny planes
@@ -330,7 +342,7 @@ class ConvBiasLReLUFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             dw = ops.conv2d_wgrad(dt, x, Cout, Cin, k, stride)
         if has_bias and ctx.needs_input_grad[2]:
-            db = sums[..., 2].sum(0)
+            db = sums[:, 2].sum(0)
         return dx, dw, db, None, None, None, None
 
 
@@ -384,7 +396,7 @@ class ModConvFn(torch.autograd.Function):
         B, Cin = x.shape[:2]
         Cout, H, W = y.shape[1:]
         dt, sums = ops.epilogue_bwd(dy.contiguous(), y, noise, None, slope if slope is not None else 1.0)   # dz = gain * dt
-        s_dyy, s_dt, s_dtn = sums[..., 1], sums[..., 2], sums[..., 3]
+        s_dyy, s_dt, s_dtn = sums[:, 0], sums[:, 2], sums[:, 3]
         dbias = gain * s_dt.sum(0) if bias is not None else None
         dnw = gain * s_dtn.sum(0) if noise_w is not None else None
         dd = None
@@ -404,7 +416,7 @@ class ModConvFn(torch.autograd.Function):
             dxt = ops.conv2d_fused(dt, packed.get(weight, cfg, transpose_flip=True), Cin, 3, 1, out_scale=scale,
                                    batch_scale=dprime, config=cfg)                     # d (up(x) * s)
             dxu, sums2 = ops.epilogue_bwd(dxt, x_up, None, _scale_rows(s), 1.0)       # x s on the way out; <dx~, up(x)> per plane
-            ds = sums2[..., 1]
+            ds = sums2[:, 0]
             if ctx.needs_input_grad[0]:
                 dx = ops.upfirdn2d(dxu, torch.flip(fir, [0, 1]), up=1, down=2, pad=(1, 1)) if upsample else dxu
         if ctx.needs_input_grad[1]:
@@ -439,7 +451,7 @@ class ModToRGBFn(torch.autograd.Function):
         dskip = None
         if has_skip and ctx.needs_input_grad[5]:      # adjoint of upfirdn2d(up=2, pad (2,1)): down=2 with the flipped FIR, pad (1,1)
             dskip = ops.upfirdn2d(dy, torch.flip(fir, [0, 1]), up=1, down=2, pad=(1, 1))
-        return dx, dw, sums[..., 1], (db if has_bias else None), None, dskip, None, None
+        return dx, dw, sums[:, 0], (db if has_bias else None), None, dskip, None, None
 
 
 class UpFirDnFn(torch.autograd.Function):

@@ -69,8 +69,9 @@ __global__ __launch_bounds__(256) void epilogue_bwd_kernel(const float* __restri
     s_dt = block_sum(s_dt, red);
     s_dtn = block_sum(s_dtn, red);
     if (threadIdx.x == 0) {
-        float* o = sums + plane * 4;
-        o[0] = s_dy; o[1] = s_dya; o[2] = s_dt; o[3] = s_dtn;
+        // [B][4][C], component order {dy*a, dy, dt, dt*noise}: rows 0-1 of an image ARE its style gradient [d s0 | d s1]
+        float* o = sums + (size_t)b * 4 * C + c;
+        o[0] = s_dya; o[C] = s_dy; o[2 * (size_t)C] = s_dt; o[3 * (size_t)C] = s_dtn;
     }
 }
 
@@ -311,7 +312,7 @@ __global__ __launch_bounds__(256) void fc_grouped_bwd_input_kernel(const FcBwdGr
             float v = 0.f;
             if (b0 + b < B) {
                 const size_t idx = (size_t)(b0 + b) * O + o;
-                v = g.dout[idx] * (g.out[idx] > 0.f ? 1.f : g.slope);
+                v = g.dout[(size_t)(b0 + b) * g.dout_stride + o] * (g.out[idx] > 0.f ? 1.f : g.slope);
             }
             dz_s[e] = v;
         }
@@ -356,7 +357,7 @@ __global__ __launch_bounds__(256) void fc_grouped_bwd_weight_kernel(const FcBwdG
         float acc = 0.f;
         for (int b = 0; b < B; ++b) {
             const float ov = g.out[(size_t)b * O + o];
-            acc += g.dout[(size_t)b * O + o] * (ov > 0.f ? 1.f : g.slope) * g.x[(size_t)b * g.x_stride + i];
+            acc += g.dout[(size_t)b * g.dout_stride + o] * (ov > 0.f ? 1.f : g.slope) * g.x[(size_t)b * g.x_stride + i];
         }
         g.dw[(size_t)o * I + i] = acc * g.wmul;
     }
@@ -364,7 +365,7 @@ __global__ __launch_bounds__(256) void fc_grouped_bwd_weight_kernel(const FcBwdG
         float dzs = 0.f;
         for (int b = 0; b < B; ++b) {
             const float ov = g.out[(size_t)b * O + o];
-            dzs += g.dout[(size_t)b * O + o] * (ov > 0.f ? 1.f : g.slope);
+            dzs += g.dout[(size_t)b * g.dout_stride + o] * (ov > 0.f ? 1.f : g.slope);
         }
         g.db[o] = dzs * g.bmul;
     }
@@ -449,7 +450,7 @@ int spk_fc_grouped_bwd(const spk_fc_bwd_group* groups, int n_groups, int B, void
     bool any_dx = false, any_dw = false;
     for (int i = 0; i < n_groups; ++i) {
         const spk_fc_bwd_group& g = groups[i];
-        SPK_REQUIRE(g.dout && g.out && g.I > 0 && g.O > 0, "fc_grouped_bwd: group %d: bad shape", i);
+        SPK_REQUIRE(g.dout && g.out && g.I > 0 && g.O > 0 && g.dout_stride >= g.O, "fc_grouped_bwd: group %d: bad shape", i);
         SPK_REQUIRE(!g.dx || (g.w && g.dx_stride >= g.I), "fc_grouped_bwd: group %d: dx needs w and dx_stride >= I", i);
         SPK_REQUIRE(!g.dw || (g.x && g.x_stride >= g.I), "fc_grouped_bwd: group %d: dw needs x and x_stride >= I", i);
         SPK_REQUIRE(!g.db || g.dw, "fc_grouped_bwd: group %d: db comes with dw", i);

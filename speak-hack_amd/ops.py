@@ -392,14 +392,15 @@ def fc_grouped_bwd(items, B):
     groups, res, keep = (L.FcBwdGroup * len(items))(), [], []
     for g, (dout, out, x, weight, dx, need_dw, has_bias, wmul, bmul, slope) in zip(groups, items):
         O, I = weight.shape
-        dout = dout.contiguous()
+        if dout.dim() != 2 or dout.stride(1) != 1 or dout.stride(0) < O:      # a row-strided view is read in place
+            dout = dout.contiguous()
         keep.append(dout)
         if x.stride(1) != 1 or (dx is not None and dx.stride(1) != 1):
             raise L.SpkError("fc_grouped_bwd: x / dx must have unit inner stride")
         dw = torch.empty((O, I), device=weight.device, dtype=torch.float32) if need_dw else None
         db = torch.empty(O, device=weight.device, dtype=torch.float32) if (need_dw and has_bias) else None
         res.append((dw, db))
-        g.dout, g.out, g.x, g.x_stride = L.dptr(dout, "dout"), L.dptr(out, "out"), x.data_ptr(), x.stride(0)
+        g.dout, g.dout_stride, g.out, g.x, g.x_stride = dout.data_ptr(), dout.stride(0), L.dptr(out, "out"), x.data_ptr(), x.stride(0)
         g.w, g.dx, g.dx_stride = L.dptr(weight, "weight"), (dx.data_ptr() if dx is not None else None), (dx.stride(0) if dx is not None else 0)
         g.dw, g.db, g.I, g.O = L.dptr(dw), L.dptr(db), I, O
         g.wmul, g.bmul, g.slope = float(wmul), float(bmul), float(slope)
@@ -486,11 +487,12 @@ def conv2d_wgrad(g, x, Cout, Cin, k=3, stride=1, *, upsample=False, in_affine=No
 
 
 def epilogue_bwd(dy, a=None, noise=None, style=None, slope=1.0, inplace=False):
-    """Adjoint of the fused conv epilogue: returns (dt, sums[B,C,4]) with
-    sums = {sum dy, sum dy*a, sum dt, sum dt*noise} per (b,c) plane."""
+    """Adjoint of the fused conv epilogue: returns (dt, sums[B,4,C]) with
+    sums[:, k] = {sum dy*a, sum dy, sum dt, sum dt*noise}[k] per (b,c) plane -- ``sums[:, :2].reshape(B, 2C)`` is the style
+    gradient [d s0 | d s1] (a view), ``sums[:, 2:].sum(0)`` the bias and noise-weight gradients."""
     B, Cc, H, W = dy.shape
     dt = dy if inplace else torch.empty_like(dy)
-    sums = torch.empty((B, Cc, 4), device=dy.device, dtype=torch.float32)
+    sums = torch.empty((B, 4, Cc), device=dy.device, dtype=torch.float32)
     L.check(L.lib().spk_epilogue_bwd(L.dptr(dy, "dy"), L.dptr(a, "a"), L.dptr(noise, "noise"), _style_ptr(style),
                                      style.stride(0) if style is not None else 0, float(slope), L.dptr(dt), L.dptr(sums),
                                      B, Cc, H * W, L.stream_ptr()), "spk_epilogue_bwd")
