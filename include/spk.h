@@ -340,8 +340,9 @@ int spk_maxpool3x3s2_fwd(const float* x, const float* in_scale, const float* in_
  * output of the raw conv output r; g is the gradient w.r.t. relu(z) (mask_mode 1: mask recomputed from r), w.r.t.
  * relu(z + identity) (mask_mode 2: mask = mask_src > 0, mask_src = the block output) or w.r.t. z (mask_mode 0).
  * g_per_plane != 0: g holds one value per (b,c) plane (the global-average-pool gradient), scaled by g_scale.
- *   spk_bn_bwd_reduce: sums[b,c,:] = { sum dz, sum dz*rhat }   (d beta = sum_b sums[..,0], d gamma = sum_b sums[..,1])
- *   spk_bn_bwd_apply : dr = gamma*invstd*(dz - csum[c,0]/count - rhat*csum[c,1]/count); dz_out (may be NULL) = dz
+ *   spk_bn_bwd_reduce: sums[b,:,c] = { sum dz, sum dz*rhat }, layout [B][2][C]: csum = sum_b sums is [2][C], its rows
+ *                      d beta and d gamma as they are (no strided copies)
+ *   spk_bn_bwd_apply : dr = gamma*invstd*(dz - csum[0,c]/count - rhat*csum[1,c]/count); dz_out (may be NULL) = dz
  * replaces: autograd's native_batch_norm_backward + threshold_backward for every BatchNorm2d/ReLU of the trunk. */
 int spk_bn_bwd_reduce(const float* g, const float* r, const float* mask_src, int mask_mode, const float* scale,
                       const float* shift, const float* mean, const float* invstd, float g_scale, int g_per_plane,

@@ -153,7 +153,7 @@ __global__ __launch_bounds__(256) void global_avgpool_kernel(const float* __rest
 //   MASK_RECOMPUTE: relu(z)            -> dz = g * (z > 0)          (conv -> bn -> relu chains)
 //   MASK_TENSOR   : relu(z + identity) -> dz = g * (mask_src > 0)   (block end; mask_src = the block output)
 //   MASK_NONE     : z                  -> dz = g                    (downsample branch; g already masked)
-// pass 1 (one workgroup per (b,c) plane): sums[b,c,:] = { sum dz, sum dz * rhat },  rhat = (r - mean)*invstd
+// pass 1 (one workgroup per (b,c) plane): sums[b,:,c] = { sum dz, sum dz * rhat } (layout [B][2][C]),  rhat = (r - mean)*invstd
 // pass 2: dr = gamma*invstd * (dz - c1[c] - rhat*c2[c]),  c1 = sum_bhw dz / N, c2 = sum_bhw dz*rhat / N;
 //         optionally also writes dz (the identity branch's gradient at a block end).
 enum { MASK_NONE = 0, MASK_RECOMPUTE = 1, MASK_TENSOR = 2 };
@@ -192,7 +192,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* __restr
     }
     s0 = bn_block_sum(s0, red);
     s1 = bn_block_sum(s1, red);
-    if (threadIdx.x == 0) { sums[plane * 2] = s0; sums[plane * 2 + 1] = s1; }
+    if (threadIdx.x == 0) { const long long b = plane / C; sums[(2 * b) * C + c] = s0; sums[(2 * b + 1) * C + c] = s1; }
 }
 
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ g, const float* __restrict__ r,
@@ -205,7 +205,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
     const long long plane = blockIdx.x;
     const int c = (int)(plane % C);
     const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
-    const float c1 = csum[2 * c] * inv_count, c2 = csum[2 * c + 1] * inv_count;   // csum: sums reduced over the batch
+    const float c1 = csum[c] * inv_count, c2 = csum[C + c] * inv_count;   // csum [2][C]: sums reduced over the batch
     const float* gp = g + (g_plane_stride ? plane * g_plane_stride : plane);
     const float* rp = r + plane * HW;
     const float* mp = mask_src ? mask_src + plane * HW : nullptr;
@@ -269,7 +269,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_vec_kernel(const float* __r
 #pragma unroll
         for (int off = 32; off >= 1; off >>= 1) { s0 += __shfl_xor(s0, off); s1 += __shfl_xor(s1, off); }
     }
-    if (live && t == 0) { sums[plane * 2] = s0; sums[plane * 2 + 1] = s1; }
+    if (live && t == 0) { const long long b = plane / C; const int c = (int)(plane % C); sums[(2 * b) * C + c] = s0; sums[(2 * b + 1) * C + c] = s1; }
 }
 
 template <int TPP>
@@ -285,7 +285,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const float* __re
     if (plane >= planes) return;
     const int c = (int)(plane % C);
     const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
-    const float c1 = csum[2 * c] * inv_count, c2 = csum[2 * c + 1] * inv_count;   // csum: sums reduced over the batch
+    const float c1 = csum[c] * inv_count, c2 = csum[C + c] * inv_count;   // csum [2][C]: sums reduced over the batch
     const float* rp = r + plane * HW;
     const float* mp = mask_src ? mask_src + plane * HW : nullptr;
     const float g1 = g_plane_stride ? 0.f : g[plane] * g_scale;

@@ -768,19 +768,19 @@ def bn_backward(g, r, affine, mean, invstd, mask_mode, mask_src=None, g_scale=1.
     [B,C] (one value per plane, e.g. the global-average-pool gradient)."""
     B, Cc, H, W = r.shape
     HW = H * W
-    sums = torch.empty((B, Cc, 2), device=r.device, dtype=torch.float32)
+    sums = torch.empty((B, 2, Cc), device=r.device, dtype=torch.float32)
     args = (L.dptr(g, "g"), L.dptr(r, "r"), L.dptr(mask_src, "mask_src"), int(mask_mode), L.dptr(affine[0], "scale"),
             L.dptr(affine[1], "shift"), L.dptr(mean, "mean"), L.dptr(invstd, "invstd"))
     L.check(L.lib().spk_bn_bwd_reduce(*args, float(g_scale), 1 if g_per_plane else 0, L.dptr(sums), B, Cc, HW,
                                       L.stream_ptr()), "spk_bn_bwd_reduce")
-    csum = sums.sum(0).contiguous()                 # [C,2]: the kernel reduced over pixels, this over the batch
+    csum = sums.sum(0)                              # [2,C]: the kernel reduced over pixels, this over the batch
     dr = torch.empty_like(r)
     dz = torch.empty_like(r) if want_dz else None
     # eval-mode BatchNorm is a fixed affine: no mean / variance terms in the input gradient
     capply = csum if batch_stats else torch.zeros_like(csum)
     L.check(L.lib().spk_bn_bwd_apply(*args, L.dptr(capply), B * HW, float(g_scale), 1 if g_per_plane else 0, L.dptr(dr),
                                      L.dptr(dz), B, Cc, HW, L.stream_ptr()), "spk_bn_bwd_apply")
-    out = (dr, csum[:, 1].contiguous(), csum[:, 0].contiguous())
+    out = (dr, csum[1], csum[0])                    # rows of csum: d gamma, d beta (contiguous views)
     return out + (dz,) if want_dz else out
 
 
