@@ -38,7 +38,8 @@ extern "C" {
 #define SPK_EPI_STYLE  8u
 #define SPK_CONV_UPSAMPLE2X 16u      /* input is bilinearly upsampled x2 while staging (3x3 stride 1 only) */
 #define SPK_EPI_ACCUM  32u           /* y += result */
-#define SPK_EPI_STATS  64u           /* stats[0:Cout] += sum_bhw y, stats[Cout:2Cout] += sum_bhw y^2 (fp64) */
+#define SPK_EPI_STATS  64u           /* stats[0:Cout] += sum_bhw y, stats[Cout:2Cout] += sum_bhw y^2 (fp64); on a 3x3 stride-1
+                                      * conv with a plain or SPK_CONV_IN_AFFINE_RELU input only (not UPSAMPLE2X / IN_BATCH_SCALE) */
 #define SPK_CONV_IN_AFFINE_RELU 128u /* x' = max(x*in_scale[ci] + in_shift[ci], 0) applied while staging */
 #define SPK_CONV_IN_BATCH_SCALE 256u /* x' = x * in_scale[b*Cin + ci] applied while staging (weight modulation); may be
                                       * combined with SPK_CONV_UPSAMPLE2X (configs 4-7) */
