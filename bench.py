@@ -7,9 +7,12 @@ configs[1]: StyleGAN synthesis forward only, batch 8, 1x MI355X).
 A step = one ``StyleGenerator.forward`` (mapping + 13 style affines + prologue + 12 fused 3x3 conv
 launches + toRGB) over one batch of 8 synthetic [6144] latents, inputs and weights resident in HBM,
 noise drawn on the device inside the step as the reference does (styleganv1.py:455).  fp32
-end to end (exact-f32 MFMA).  N > 1: launched by torch.distributed.run, one rank per GPU, each rank
-an independent replica on its own batch (the forward path has no exchange step -- SURVEY.md 8e);
-barrier + synchronize on both sides of the timed region, MAX over ranks, rank 0 prints ONE JSON line.
+end to end (exact-f32 MFMA).  N > 1: one rank per GPU, each rank an independent replica on its own batch for
+the headline (the forward path has no exchange step -- SURVEY.md 8e); barrier + synchronize on both sides of the
+timed region, MAX over ranks, rank 0 prints ONE JSON line.  Either the driver starts the ranks
+(``python -m torch.distributed.run --nproc-per-node N bench.py --gpus N``: WORLD_SIZE is set) or ``python bench.py
+--gpus N`` does it itself: the parent -- before any GPU call -- starts N fresh child ranks through
+torch.distributed.run, relays rank 0's line and exits with the children's return code (it never re-executes itself).
 
 Extra objects in the line (headline fields unchanged):
   roofline       -- the dominant kernel (spkconv::conv_kernel, MFMA-bound): algorithmic conv FLOPs per
@@ -26,14 +29,25 @@ Extra objects in the line (headline fields unchanged):
   train_step     -- BASELINE config 3: the IRFD generator step (3 encoders x 2 images + 2 decoder passes,
                     fwd + bwd + clip + Adam) at batch 16.
   d_step         -- the discriminator step of train.py:155-183 at batch 8.
-(the last four on rank 0 at N=1 only; ``--headline-only`` skips them.)
+  single_frame   -- BASELINE config 1: one 256^2 frame (B=1) on the GPU and on the CPU port.
+(the above on rank 0 at N=1 only; ``--headline-only`` skips them.)
+N > 1 adds, on every rank (figures are MAX over ranks), the ONE path with a real exchange step -- BASELINE config 4:
+  train_step_dp  -- the IRFD generator step at batch 8 per rank through dp.GradBucketReducer on ``--backend`` (nccl = RCCL
+                    over xGMI): ms/step, pairs/s over all ranks, gradient bytes exchanged per step, buckets launched from
+                    backward hooks vs by finish(), the backend and world size torch.distributed reports, and the exposed
+                    communication = step(N ranks) - the same step inside no_sync() (no exchange).
+  d_step_dp      -- the same for the discriminator step (76 MB of gradients, R1 double backward).
+  decoder_512_b4 -- BASELINE config 5 per rank (replicas).
 """
 from __future__ import annotations
 
 import argparse
+import contextlib
 import importlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -200,6 +214,135 @@ def irfd_steps(pkg, dev, which, B, steps, warmup, precision="f32"):
     return ms
 
 
+def irfd_dp_steps(pkg, dev, which, B, steps, warmup, dist, rank):
+    """BASELINE config 4: the generator (or discriminator) step at ``B`` samples per rank with the gradient exchange of
+    train.py:333-338,399-401 (accelerate's DDP) done by dp.GradBucketReducer on the initialised backend.  Times the step
+    WITH the exchange, then the same step inside ``no_sync()`` (every rank steps on its own gradients: no collective) --
+    the difference is the communication backward could not hide.  All figures are MAX over ranks."""
+    import model as M
+    import torch.nn.functional as F
+    dp = importlib.import_module("speak-hack_amd.dp")
+    T = importlib.import_module("speak-hack_amd.training")
+    world = dist.get_world_size()
+    torch.manual_seed(1234 + rank)             # replicas seeded differently: the reducer's broadcast makes them equal
+    net = M.IRFD().to(dev).train()
+    for n, p in net.named_parameters():
+        p.requires_grad_(n.startswith("D.") == (which == "d"))
+    params = [p for p in net.parameters() if p.requires_grad]
+    red = dp.GradBucketReducer(params)
+    with torch.no_grad():
+        for b in net.buffers():                # BatchNorm / spectral-norm buffers, as DDP's broadcast_buffers
+            dist.broadcast(b, src=0)
+    opt = torch.optim.Adam(net.D.parameters() if which == "d" else net.Gd.parameters(), lr=1e-4, betas=(0.5, 0.999))
+    g = torch.Generator().manual_seed(10 + rank)            # SURVEY.md 8(d) cfg4: rank r's shard is seed 10 + r
+    x_s, x_t, f_s, f_t = ((torch.rand(B, 3, 256, 256, generator=g) * 2 - 1).to(dev) for _ in range(4))
+    bce = lambda pred, label: F.binary_cross_entropy_with_logits(pred, torch.full_like(pred, label))
+
+    def step(sync=True):
+        red.zero_grad()
+        with (contextlib.nullcontext() if sync else red.no_sync()):
+            if which == "d":
+                nz = T.add_instance_noise
+                loss = (bce(net.D(nz(x_s)), 0.9) + bce(net.D(nz(x_t)), 0.9)) / 2 + (bce(net.D(nz(f_s)), 0.1) + bce(net.D(nz(f_t)), 0.1)) / 2 \
+                    + 10.0 * (T.compute_r1_reg(net.D, x_s) + T.compute_r1_reg(net.D, x_t)) / 2
+            else:
+                out = net(x_s, x_t)
+                loss = ((out[0] - x_s) ** 2).mean() + ((out[1] - x_t) ** 2).mean()
+            loss.backward()
+        if sync:
+            red.finish()
+        if which == "g":
+            red.clip_(1.0)
+        opt.step()
+
+    def timed(sync):
+        torch.cuda.synchronize()
+        dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            step(sync)
+        torch.cuda.synchronize()
+        dist.barrier()
+        t = torch.tensor([time.perf_counter() - t0], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        return float(t.item()) / steps * 1e3
+
+    for _ in range(max(2, warmup)):            # the first finish() re-buckets in autograd-completion order
+        step()
+    ms = timed(True)
+    by_hook, by_finish = list(red.stats["launched_by_hook"]), list(red.stats["launched_by_finish"])
+    # (stats are reset by zero_grad(): these are the last timed step's)
+    n_buckets, cold = len(red.buckets), [i for i, b in enumerate(red.buckets) if b["cold"]]
+    step(False)
+    ms_local = timed(False)                    # last: the replicas drift apart from here on
+    res = {"ms_per_step": round(ms, 2), "samples_per_rank": B, "pairs_per_s": round(world * B / ms * 1e3, 1),
+           "backend": dist.get_backend(), "world_size": world, "grad_bytes_per_step": red.bytes_per_step(),
+           "buckets": n_buckets, "bucket_bytes": red.bucket_bytes, "buckets_launched_by_hook": len(by_hook),
+           "buckets_launched_by_finish": len(by_finish), "cold_buckets": len(cold),
+           "ms_per_step_no_exchange": round(ms_local, 2), "exposed_comm_ms": round(ms - ms_local, 2)}
+    red.remove()
+    del net, opt, red
+    torch.cuda.empty_cache()
+    return res
+
+
+def single_frame(pkg, dev, threads):
+    """BASELINE config 1: one 256^2 frame from one [1,6144] latent -- hipGraph replay on the GPU, and the CPU port."""
+    gen = pkg.StyleGenerator(6144).eval().to(dev)
+    f1 = torch.randn(1, 6144, device=dev)
+    with torch.no_grad():
+        g1, _ = capture(lambda: gen(f1))
+        ms = event_ms(g1.replay, 50)
+        for _ in range(3):
+            gen(f1)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(20):
+            gen(f1)
+        torch.cuda.synchronize()
+        eager = (time.perf_counter() - t0) / 20 * 1e3
+    res = {"what": "BASELINE config 1: StyleGenerator forward, ONE frame (B=1), 256^2, fp32", "ms_per_frame": round(ms, 4),
+           "frames_per_s": round(1e3 / ms, 1), "eager_ms_per_frame": round(eager, 4)}
+    if threads:
+        from oracle import decoder_ref as R
+        torch.set_num_threads(threads)
+        cpu = pkg.StyleGenerator(6144)
+        sd = {k: v.detach().clone() for k, v in cpu.state_dict().items()}
+        x = torch.randn(1, 6144)
+        noises = [torch.randn(1, 1, r, r) for r in (4, 8, 8, 16, 16, 32, 32, 64, 64, 128, 128, 256, 256)]
+        ts = []
+        with torch.no_grad():
+            for _ in range(6):
+                t0 = time.perf_counter()
+                R.style_generator(x, sd, noises)
+                ts.append(time.perf_counter() - t0)
+        med = sorted(ts[1:])[2]
+        res["cpu_port"] = {"ms_per_frame": round(med * 1e3, 1), "frames_per_s": round(1 / med, 2), "cores": threads,
+                           "sample": "oracle.decoder_ref.style_generator, B=1, median of 5 after 1 warm-up"}
+    del gen, g1
+    return res
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def launch_ranks(n):
+    """``python bench.py --gpus N`` without a launcher: start N fresh child ranks (one per GPU) through
+    torch.distributed.run and relay their output.  Runs BEFORE this process has made any GPU call (importing torch does
+    not initialise HIP); the children are new processes, this one is never replaced."""
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -211,8 +354,11 @@ def main():
                     "rehearse the multi-rank path on a box with fewer GPUs than ranks, together with SPK_BENCH_ONE_DEVICE=1)")
     ap.add_argument("--no-graph", action="store_true", help="launch the step's kernels eagerly instead of replaying "
                     "the hipGraph captured from them")
+    ap.add_argument("--dp-steps", type=int, default=5, help="timed steps of the data-parallel training steps (N > 1)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))          # nothing above touched the GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -424,6 +570,36 @@ def main():
                             "pairs_per_s": round(8 / d_ms * 1e3, 1)}
         d_bf = irfd_steps(pkg, dev, "d", 8, steps=5, warmup=2, precision="bf16x3")
         extras["d_step"]["bf16x3_opt_in"] = {"ms_per_step": round(d_bf, 2), "pairs_per_s": round(8 / d_bf * 1e3, 1)}
+
+        extras["single_frame"] = single_frame(pkg, dev, 0 if args.no_cpu_baseline else host_cores())
+
+    if world > 1 and not args.headline_only:
+        # ---- config 5 per rank: the 512^2 decoder at batch 4 (replicas) ----
+        with torch.no_grad():
+            s512 = pkg.SynthesisNetwork(resolution=512).eval().to(dev)
+            for n, p in s512.named_parameters():
+                if "noise" in n:
+                    p.normal_(0, 0.1)
+            w512 = torch.randn(4, 16, 512, device=dev)
+            g5, _ = capture(lambda: s512(w512))
+            t5 = torch.tensor([event_ms(g5.replay, 20)], device=dev, dtype=torch.float64)
+            dist.all_reduce(t5, op=dist.ReduceOp.MAX)
+            ms5 = float(t5.item())
+            del s512, g5
+        torch.cuda.empty_cache()
+        dp_g = irfd_dp_steps(pkg, dev, "g", BATCH, args.dp_steps, 2, dist, rank)
+        dp_d = irfd_dp_steps(pkg, dev, "d", BATCH, args.dp_steps, 2, dist, rank)
+        if rank == 0:
+            extras["decoder_512_b4"] = {"what": "BASELINE config 5: SynthesisNetwork(resolution=512) forward, batch 4 per rank, fp32 "
+                                                "(hipGraph replay, replicas; slowest rank)", "ms_per_step": round(ms5, 4),
+                                        "frames_per_s": round(world * 4 / ms5 * 1e3, 2), "frames_per_s_per_gpu": round(4 / ms5 * 1e3, 2)}
+            dp_g["what"] = ("BASELINE config 4: IRFD generator step (3 encoders x 2 images, 2 decoder passes, fwd + bwd + global-norm "
+                            "clip + Adam on Gd), batch 8 per rank, fp32, gradients of every trained parameter exchanged by "
+                            "dp.GradBucketReducer (bucketed all-reduce launched from backward hooks) -- slowest rank")
+            dp_g["algorithmic_tflops"] = round(dp_g["pairs_per_s"] * GFLOP_PER_PAIR / 1e3, 1)
+            dp_d["what"] = ("discriminator step of train.py:155-183 at batch 8 per rank with the same exchange (76 MB of gradients, R1 "
+                            "double backward) -- slowest rank")
+            extras["train_step_dp"], extras["d_step_dp"] = dp_g, dp_d
 
     if rank == 0:
         traffic = None

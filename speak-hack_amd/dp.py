@@ -26,6 +26,12 @@ training iteration -- summing parameter gradients over ranks -- is done here:
 * ``no_sync()`` / ``GradAccumulator``: the gradient-accumulation schedule of ``accelerator.accumulate``
   (train.py:152,335; config.yaml gradient_accumulation_steps): micro-steps inside ``no_sync`` only accumulate
   locally, the last micro-step exchanges the sums.
+* A backward that is NOT this reducer's step but reaches its parameters -- the generator step backpropagates through
+  ``model.D`` (train.py:196-203), so a reducer over D's parameters sees its hooks fire during ``loss_G.backward()`` --
+  must run inside ``no_sync()`` (spelled ``foreign_backward()`` for that use): the gradients pile up locally exactly as
+  they do in the reference, and no collective goes out.  Collectives that WERE launched and never finished (a
+  synchronising backward without ``finish()``) are waited for by ``zero_grad()`` / the next re-arm before their flat
+  buffers are written again, never dropped.
 
 Bucket size: xGMI is point-to-point (7 links x ~153 GB/s per GPU), so a ring all-reduce of S bytes costs
 about 2*(7/8)*S/153 GB/s; 32 MiB buckets keep each collective ~0.4 ms (far above the ~20 us launch
@@ -67,6 +73,7 @@ class GradBucketReducer:
         self.rebuilt = not rebuild_after_first_step or self.world == 1
         self._fired: List[int] = []                        # registration indices in hook order (first synced backward)
         self._sync = True
+        self._in_flat = False                              # gradients live in the flat buffers (after a finish(), world > 1)
         self._handles = []
         self._next = 0                                     # lowest bucket index not launched yet
         self.stats = {"launched_by_hook": [], "launched_by_finish": []}     # bucket indices, last step
@@ -157,18 +164,26 @@ class GradBucketReducer:
         self._handles.append(dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
 
     # ---- step protocol -------------------------------------------------------------------------
+    def _wait(self):
+        """Outstanding all-reduces complete (stream-side on RCCL) before anything else touches their flat buffers."""
+        for h in self._handles:
+            h.wait()
+        self._handles = []
+
     def _rearm(self):
+        self._wait()
         for b in self.buckets:
             b["pending"], b["ready"], b["launched"] = b["n"], False, False
         self._next = 0
-        self._handles = []
 
     def zero_grad(self):
         """Drop the gradients (``set_to_none``) and re-arm the buckets."""
+        self._wait()                           # a backward that launched collectives but was never finish()ed
         for b in self.buckets:
             for p in b["params"]:
                 p.grad = None
         self._rearm()
+        self._in_flat = False
         self.stats = {"launched_by_hook": [], "launched_by_finish": []}
 
     @contextlib.contextmanager
@@ -181,6 +196,8 @@ class GradBucketReducer:
         finally:
             self._sync = prev
 
+    foreign_backward = no_sync                 # a backward of ANOTHER network's loss that reaches these parameters
+
     def finish(self):
         """Call after a synchronising ``loss.backward()``: launches, in index order, the buckets the hooks could not
         (a parameter without a gradient this step contributes zeros), waits for every collective, and -- once, after
@@ -188,9 +205,8 @@ class GradBucketReducer:
         for b in self.buckets:
             b["ready"] = True
         self._drain(by_hook=False)
-        for h in self._handles:
-            h.wait()
-        self._handles = []
+        self._wait()
+        self._in_flat = self.world > 1         # every gradient now lives in its bucket's flat buffer
         if not self.rebuilt:
             self._rebuild()
         self._rearm()                          # a caller that never zeroes (the reference's encoder gradients) may go on
@@ -236,7 +252,7 @@ class GradBucketReducer:
         """Global L2 norm of the (already synchronised, hence rank-identical) gradients -- what
         ``clip_grad_norm_`` (train.py:207-208) needs; no further collective and no fp64 copy of the buckets:
         one multi-tensor norm launch, the handful of partial norms combined in fp64."""
-        tensors = [b["flat"] for b in self.buckets] if self.world > 1 else self._grads()
+        tensors = [b["flat"] for b in self.buckets] if self._in_flat else self._grads()
         if not tensors:
             return torch.zeros((), device=self.params[0].device)
         return torch.linalg.vector_norm(torch.stack(torch._foreach_norm(tensors)).double()).float()
@@ -244,7 +260,7 @@ class GradBucketReducer:
     def clip_(self, max_norm: float) -> torch.Tensor:
         total = self.grad_norm()
         coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
-        tensors = [b["flat"] for b in self.buckets] if self.world > 1 else self._grads()
+        tensors = [b["flat"] for b in self.buckets] if self._in_flat else self._grads()
         if tensors:
             torch._foreach_mul_(tensors, coef)
         return total

@@ -102,6 +102,101 @@ def test_bucketed_allreduce_matches_full_batch_gradients(tmp_path):
         assert torch.allclose(a, c * coef, atol=1e-7, rtol=1e-4)
 
 
+def _gan_worker(rank, world, port, tmp):
+    """The D-step / G-step interleaving of train.py:155-210 with one reducer per network: the generator loss
+    backpropagates THROUGH the discriminator, whose reducer must stay silent during that backward."""
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dp = importlib.import_module("speak-hack_amd.dp")
+    torch.manual_seed(3)
+    G = nn.Sequential(nn.Linear(6, 24), nn.Tanh(), nn.Linear(24, 12))
+    D = nn.Sequential(nn.Linear(12, 24), nn.Tanh(), nn.Linear(24, 1))
+    red_G = dp.GradBucketReducer(G.parameters(), bucket_bytes=512)
+    red_D = dp.GradBucketReducer(D.parameters(), bucket_bytes=512)
+    calls = {"n": 0}
+    real_all_reduce = dist.all_reduce
+
+    def counting(*a, **k):
+        calls["n"] += 1
+        return real_all_reduce(*a, **k)
+    dist.all_reduce = counting
+    g = torch.Generator().manual_seed(7)
+    z_all, x_all = torch.randn(8, 6, generator=g), torch.randn(8, 12, generator=g)
+    lo, hi = dp.shard_batch(8, rank, world)
+    z, x = z_all[lo:hi], x_all[lo:hi]
+    out = {}
+    for it in range(2):
+        # ---- D step: its own reducer exchanges ----
+        red_D.zero_grad()
+        loss_D = D(x).mean() - D(G(z).detach()).mean()
+        loss_D.backward()
+        red_D.finish()
+        out[("D", it)] = [p.grad.clone() for p in D.parameters()]
+        # ---- G step: backward runs through D; D's reducer is muted, G's exchanges ----
+        red_G.zero_grad()
+        before = calls["n"]
+        with red_D.foreign_backward():
+            (-D(G(z)).mean()).backward()
+        launched_in_backward = calls["n"] - before
+        n_G = len(red_G.buckets)
+        red_G.finish()
+        assert calls["n"] - before == n_G, (calls["n"] - before, n_G)      # exactly G's buckets, none of D's
+        if it == 1:
+            assert launched_in_backward == n_G                             # (rebuilt order: all from hooks)
+        out[("G", it)] = [p.grad.clone() for p in G.parameters()]
+        # D's gradients: the reduced D-step values plus THIS rank's local G-step contribution (the reference accumulates
+        # them too and optimizer_D.zero_grad() drops them, train.py:157)
+        out[("D_after_G", it)] = [p.grad.clone() for p in D.parameters()]
+    # a synchronising backward that is never finish()ed: zero_grad() must wait for its collectives, and the next step
+    # must come out right (ADVICE r2: handles were dropped un-waited)
+    red_D.zero_grad()
+    (D(x).mean() - D(G(z).detach()).mean()).backward()
+    assert red_D._handles                                                   # launched from hooks, not waited for
+    red_D.zero_grad()
+    assert not red_D._handles and all(p.grad is None for p in D.parameters())
+    (D(x).mean() - D(G(z).detach()).mean()).backward()
+    red_D.finish()
+    out["D_again"] = [p.grad.clone() for p in D.parameters()]
+    dist.all_reduce = real_all_reduce
+    torch.save(out, os.path.join(tmp, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_generator_backward_through_the_discriminator_keeps_its_reducer_silent(tmp_path):
+    world = 2
+    mp.spawn(_gan_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    r0 = torch.load(os.path.join(tmp_path, "rank0.pt"))
+    r1 = torch.load(os.path.join(tmp_path, "rank1.pt"))
+    torch.manual_seed(3)
+    G = nn.Sequential(nn.Linear(6, 24), nn.Tanh(), nn.Linear(24, 12))
+    D = nn.Sequential(nn.Linear(12, 24), nn.Tanh(), nn.Linear(24, 1))
+    g = torch.Generator().manual_seed(7)
+    z_all, x_all = torch.randn(8, 6, generator=g), torch.randn(8, 12, generator=g)
+    # full-batch gradients == mean over ranks of the shard gradients (means over equal shards)
+    D.zero_grad()
+    (D(x_all).mean() - D(G(z_all).detach()).mean()).backward()
+    ref_D = [p.grad.clone() for p in D.parameters()]
+    G.zero_grad(); D.zero_grad()
+    (-D(G(z_all)).mean()).backward()
+    ref_G = [p.grad.clone() for p in G.parameters()]
+    local_D = []
+    for lo, hi in ((0, 4), (4, 8)):
+        D.zero_grad()
+        (-D(G(z_all[lo:hi])).mean()).backward()
+        local_D.append([p.grad.clone() for p in D.parameters()])
+    for it in (0, 1):
+        for a, b, c in zip(r0[("D", it)], r1[("D", it)], ref_D):
+            assert torch.equal(a, b) and torch.allclose(a, c, atol=1e-6, rtol=1e-5)
+        for a, b, c in zip(r0[("G", it)], r1[("G", it)], ref_G):
+            assert torch.equal(a, b) and torch.allclose(a, c, atol=1e-6, rtol=1e-5)
+        for r, loc in ((r0, local_D[0]), (r1, local_D[1])):
+            for a, d, l in zip(r[("D_after_G", it)], ref_D, loc):
+                assert torch.allclose(a, d + l, atol=1e-6, rtol=1e-5)
+    for a, b, c in zip(r0["D_again"], r1["D_again"], ref_D):
+        assert torch.equal(a, b) and torch.allclose(a, c, atol=1e-6, rtol=1e-5)
+
+
 def test_single_process_reducer_is_a_noop_exchange():
     dp = importlib.import_module("speak-hack_amd.dp")
     model = _toy()

@@ -27,39 +27,46 @@ def _free_port():
     return port
 
 
-def test_irfd_generator_step_two_ranks_through_the_reducer(tmp_path):
+def _run_ranks(tmp_path, *extra):
     assert torch.cuda.is_available()
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "workers", "dp_irfd_worker.py"), "--out", str(tmp_path),
-           "--backend", "gloo", "--one-device", "--batch", "2", "--steps", "2"]
+           "--backend", "gloo", "--one-device", "--steps", "2", *extra]
     env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
-    r0 = torch.load(tmp_path / "rank0.pt", weights_only=False)
-    r1 = torch.load(tmp_path / "rank1.pt", weights_only=False)
-    assert r0["names"] == r1["names"] and len(r0["names"]) == 3 * 159 + 83 + 2
-    assert r0["bytes_per_step"] == sum(t.numel() * 4 for t in r0["steps"][0]["reduced"] if t is not None)
-    assert abs(r0["bytes_per_step"] - (115.7e6 - 19.1e6) * 4) < 4e6          # everything but D: ~386 MB of gradients
+    return (torch.load(tmp_path / "rank0.pt", weights_only=False), torch.load(tmp_path / "rank1.pt", weights_only=False))
+
+
+def _check_exchange(r0, r1, never_reached=()):
+    """Reduced gradients are bit-identical on both ranks and equal the mean of the two shards' own gradients; collectives
+    went out in bucket order, each bucket once."""
     for step in (0, 1):
         a, b = r0["steps"][step], r1["steps"][step]
         assert a["loss"] != b["loss"]                                  # different shards ...
         assert abs(a["loss"] - a["loss_local"]) <= 1e-6 * abs(a["loss"])   # ... the exchange does not touch the forward
         assert a["norm"] == b["norm"]
-        worst = 0.0
         for name, ga, gb, la, lb in zip(r0["names"], a["reduced"], b["reduced"], a["local"], b["local"]):
-            if name.startswith("Cm."):                                 # never reached by the reconstruction loss
+            if name.startswith(never_reached):                         # no gradient on any rank: zeros after the exchange
                 assert la is None and lb is None and float(ga.abs().max()) == 0.0 and float(gb.abs().max()) == 0.0
                 continue
             assert la is not None and lb is not None, name
             assert torch.equal(ga, gb), name                           # ranks hold bit-identical gradients
             mean = (la.double() + lb.double()) / 2                     # what DDP's averaging leaves: mean of the shard gradients
             err = float((ga.double() - mean).norm() / mean.norm().clamp_min(1e-30))
-            worst = max(worst, err)
             assert err < 1e-6, (name, err)                             # one fp32 add + one fp32 multiply per element
-        # every collective was issued in bucket order, each bucket once
         assert a["by_hook"] + [i for i in a["by_finish"]] == list(range(a["n_buckets"])), (a["by_hook"], a["by_finish"])
         assert a["by_hook"] == b["by_hook"] and a["by_finish"] == b["by_finish"]
         assert a["rebuilt_after"]
+
+
+def test_irfd_generator_step_two_ranks_through_the_reducer(tmp_path):
+    """BASELINE config 4's per-rank batch: 8 samples per rank."""
+    r0, r1 = _run_ranks(tmp_path, "--batch", "8")
+    assert r0["names"] == r1["names"] and len(r0["names"]) == 3 * 159 + 83 + 2
+    assert r0["bytes_per_step"] == sum(t.numel() * 4 for t in r0["steps"][0]["reduced"] if t is not None)
+    assert abs(r0["bytes_per_step"] - (115.7e6 - 19.1e6) * 4) < 4e6          # everything but D: ~386 MB of gradients
+    _check_exchange(r0, r1, never_reached=("Cm.",))                     # Cm: never reached by the reconstruction loss
     s1 = r0["steps"][1]
     # step 1 runs on buckets rebuilt in autograd-completion order: the only bucket left for finish() is the cold one
     # (Cm: no gradient in a reconstruction-only step) -- every other bucket's all-reduce went out from a hook, i.e. while
@@ -67,3 +74,24 @@ def test_irfd_generator_step_two_ranks_through_the_reducer(tmp_path):
     assert s1["cold"] == [s1["n_buckets"] - 1] and set(s1["cold_names"]) == {"Cm.weight", "Cm.bias"}
     assert s1["by_hook"] == list(range(s1["n_buckets"] - 1)) and s1["by_finish"] == [s1["n_buckets"] - 1]
     assert s1["n_buckets"] >= 12                                       # 386 MB in 32 MiB buckets
+
+
+def test_discriminator_step_two_ranks_through_the_reducer(tmp_path):
+    """The D step's exchange (train.py:155-183): 4 D forwards with instance noise, BCE, the R1 double backward; 76 MB of
+    spectral-norm ``weight_orig`` / bias gradients at 8 samples per rank."""
+    r0, r1 = _run_ranks(tmp_path, "--batch", "8", "--which", "d")
+    assert r0["names"] == r1["names"] and all(n.startswith("D.") for n in r0["names"])
+    assert abs(r0["bytes_per_step"] - 19.11e6 * 4) < 1e6
+    _check_exchange(r0, r1)
+    s1 = r0["steps"][1]
+    assert s1["cold"] == [] and s1["by_hook"] == list(range(s1["n_buckets"])) and s1["by_finish"] == []
+    assert s1["n_buckets"] >= 3
+
+
+def test_generator_step_with_gradient_accumulation_two_ranks(tmp_path):
+    """``gradient_accumulation_steps = 2`` (train.py:152,335) on the HIP path: two micro-batches of 2 samples per rank, the
+    first accumulates locally (hooks disarmed), the second exchanges the sums."""
+    r0, r1 = _run_ranks(tmp_path, "--batch", "4", "--accum", "2")
+    _check_exchange(r0, r1, never_reached=("Cm.",))
+    s1 = r0["steps"][1]
+    assert s1["by_hook"] == list(range(s1["n_buckets"] - 1)) and s1["by_finish"] == [s1["n_buckets"] - 1]

@@ -27,6 +27,10 @@ def main():
     ap.add_argument("--one-device", action="store_true")
     ap.add_argument("--batch", type=int, default=2, help="samples per rank")
     ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--which", default="g", choices=("g", "d"), help="generator step (train.py:186-210) or discriminator "
+                    "step with the R1 double backward (train.py:155-183)")
+    ap.add_argument("--accum", type=int, default=1, help="gradient_accumulation_steps (train.py:152,335): the rank's shard "
+                    "is split into this many micro-batches, exchanged once through dp.GradAccumulator")
     args = ap.parse_args()
     rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
     local = 0 if args.one_device else int(os.environ.get("LOCAL_RANK", "0"))
@@ -38,7 +42,9 @@ def main():
     else:
         dist.init_process_group(args.backend)
     import model as M
+    import torch.nn.functional as F
     dp = importlib.import_module("speak-hack_amd.dp")
+    T = importlib.import_module("speak-hack_amd.training")
 
     torch.manual_seed(1234 + rank)             # replicas are seeded DIFFERENTLY: the reducer's broadcast makes them equal
     net = M.IRFD().to(dev).train()
@@ -46,8 +52,8 @@ def main():
         for n, p in net.named_parameters():
             if ".noise" in n:
                 p.normal_(0, 0.1)
-    for p in net.D.parameters():               # D has its own step (train.py:156-183)
-        p.requires_grad_(False)
+    for n, p in net.named_parameters():        # D has its own step (train.py:156-183), with its own exchange
+        p.requires_grad_(n.startswith("D.") == (args.which == "d"))
     params = [p for p in net.parameters() if p.requires_grad]
     names = {id(p): n for n, p in net.named_parameters()}
     red = dp.GradBucketReducer(params, bucket_bytes=32 << 20)
@@ -63,12 +69,35 @@ def main():
     x_s = (torch.rand(B, 3, 256, 256, generator=g) * 2 - 1).to(dev)
     x_t = (torch.rand(B, 3, 256, 256, generator=g) * 2 - 1).to(dev)
 
-    def forward_backward(step):
+    f_s = (torch.rand(B, 3, 256, 256, generator=g) * 2 - 1).to(dev)       # the D step's "reconstructions"
+    f_t = (torch.rand(B, 3, 256, 256, generator=g) * 2 - 1).to(dev)
+    bce = lambda pred, label: F.binary_cross_entropy_with_logits(pred, torch.full_like(pred, label))
+    K = args.accum
+    assert B % K == 0
+
+    def micro_loss(lo, hi):
+        a, b = x_s[lo:hi], x_t[lo:hi]
+        if args.which == "d":
+            nz = T.add_instance_noise
+            return (bce(net.D(nz(a)), 0.9) + bce(net.D(nz(b)), 0.9)) / 2 \
+                + (bce(net.D(nz(f_s[lo:hi])), 0.1) + bce(net.D(nz(f_t[lo:hi])), 0.1)) / 2 \
+                + 10.0 * (T.compute_r1_reg(net.D, a) + T.compute_r1_reg(net.D, b)) / 2
+        out = net(a, b)
+        return ((out[0] - a) ** 2).mean() + ((out[1] - b) ** 2).mean()
+
+    def forward_backward(step, acc=None):
+        """One optimizer step's worth of backward passes: K micro-batches of B/K samples, each scaled by 1/K; through
+        ``acc`` (dp.GradAccumulator) only the last one exchanges."""
         torch.manual_seed(500 + 10 * step + rank)           # host RNG (swap, style-mix draws) and device RNG (noise)
-        out = net(x_s, x_t)
-        loss = ((out[0] - x_s) ** 2).mean() + ((out[1] - x_t) ** 2).mean()
-        loss.backward()
-        return loss.detach()
+        total = 0.0
+        for m in range(K):
+            loss = micro_loss(m * B // K, (m + 1) * B // K)
+            if acc is not None:
+                acc.backward(loss)
+            else:
+                (loss / K if K > 1 else loss).backward()
+            total = total + loss.detach() / K
+        return total
 
     def restore_buffers():
         with torch.no_grad():
@@ -85,11 +114,17 @@ def main():
         restore_buffers()
         # ---- phase 2: the same step through the reducer ----
         red.zero_grad()
-        loss = forward_backward(step)
-        by_hook_before_finish = list(red.stats["launched_by_hook"])
         n_buckets = len(red.buckets)
         cold = [i for i, b in enumerate(red.buckets) if b["cold"]]
-        red.finish()
+        if K > 1:
+            acc = dp.GradAccumulator(red, steps=K)
+            loss = forward_backward(step, acc)               # the K-th micro-step's backward ends in red.finish()
+            assert acc.sync_gradients
+            by_hook_before_finish = list(red.stats["launched_by_hook"])
+        else:
+            loss = forward_backward(step)
+            by_hook_before_finish = list(red.stats["launched_by_hook"])
+            red.finish()
         total = red.grad_norm()                              # what the global-norm clip uses: rank-identical by construction
         torch.cuda.synchronize()
         restore_buffers()
