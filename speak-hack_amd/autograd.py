@@ -2,6 +2,11 @@
 kernels (include/spk.h); autograd only sequences them.  No torch math on activations -- the only
 torch arithmetic in a backward is on per-(batch,channel) scalars the kernels already reduced
 (e.g. summing ``[B,C]`` partials over ``B``).
+
+Double backward: the discriminator's Functions (``ConvBiasLReLUFn``, ``ConvDgradFn``, ``_LReluMaskFn``, ``FCFn``,
+``GlobalAvgPoolFn``) are built to be differentiated twice -- the R1 penalty of train.py:246-255 needs that.  Every other
+backward here runs raw kernels and is marked ``once_differentiable``: a ``create_graph=True`` pass through it raises
+instead of silently dropping the second-order term.
 """
 from __future__ import annotations
 
@@ -81,6 +86,7 @@ class FusedConvFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, dy):
         x, weight, a, noise, style = ctx.saved_tensors
         upsample, slope, packed, has_bias, has_noise, w_scale = ctx.conf
@@ -147,6 +153,7 @@ class StyleFCGroupFn(torch.autograd.Function):
         return tuple(outs)
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, *douts):
         confs = ctx.confs
         n = len(confs)
@@ -185,6 +192,7 @@ class ToRGBFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, dy):
         x, weight = ctx.saved_tensors
         dx, dw, db = ops.conv1x1_small_bwd(x, weight, dy.contiguous(), need_dx=ctx.needs_input_grad[0])
@@ -209,6 +217,7 @@ class BiasNoiseStyleFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, dy):
         pre, noise, style = ctx.saved_tensors
         broadcast, has_bias, has_noise = ctx.conf
@@ -390,6 +399,7 @@ class ModConvFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, dy):
         x, weight, s, d, y, noise, bias, noise_w = ctx.saved_tensors
         scale, upsample, slope, gain, fir, packed = ctx.conf
@@ -439,6 +449,7 @@ class ModToRGBFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, dy):
         x, weight, s = ctx.saved_tensors
         scale, has_bias, has_skip, fir = ctx.conf
@@ -463,6 +474,7 @@ class UpFirDnFn(torch.autograd.Function):
         return ops.upfirdn2d(x, fir, up=up, down=down, pad=pad)
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, g):
         fir, up, down, pad, (h, w) = ctx.conf
         k = fir.shape[0]
@@ -485,6 +497,7 @@ class InstanceNormAffineFn(torch.autograd.Function):
         return y
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, dy):
         x, scale = ctx.saved_tensors
         dx, dscale, dbias = ops.instance_norm_affine_bwd(x, dy.contiguous(), scale, ctx.eps, need_dx=ctx.needs_input_grad[0])
@@ -499,6 +512,7 @@ class Upsample2xFn(torch.autograd.Function):
         return ops.upsample2x_bilinear(x)
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, dy):
         return ops.upsample2x_bilinear_bwd(dy.contiguous())
 
@@ -548,6 +562,7 @@ class PixelNormFn(torch.autograd.Function):
         return ops.pixelnorm(x, eps, sqrt_form)
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, dy):
         (x,) = ctx.saved_tensors
         return ops.pixelnorm_bwd(x, dy.contiguous(), ctx.eps), None, None
@@ -562,6 +577,7 @@ class Blur2dFn(torch.autograd.Function):
         return ops.blur2d(x, filt, stride)
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, dy):
         filt, stride, hw = ctx.conf
         return ops.blur2d_bwd(dy.contiguous(), filt, stride, hw), None, None
@@ -576,6 +592,7 @@ class Upscale2dFn(torch.autograd.Function):
         return ops.upscale2d_nearest(x, factor, gain)
 
     @staticmethod
+    @torch.autograd.function.once_differentiable
     def backward(ctx, dy):
         factor, gain = ctx.conf
         return ops.upscale2d_nearest_bwd(dy.contiguous(), factor, gain), None, None

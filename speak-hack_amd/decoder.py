@@ -217,7 +217,9 @@ class StyleGenerator(nn.Module):
             if noises is not None and len(noises) != 2 * len(syn.layers) + 1:
                 raise ValueError(f"expected {2 * len(syn.layers) + 1} noise tensors, got {len(noises)}")
             B = features.size(0)
-            key = (B, features.device, torch.cuda.current_stream(features.device).cuda_stream, "features", syn.precision)
+            # (the truncation scale is folded into the style FCs' multipliers when the plan is built: part of the key)
+            key = (B, features.device, torch.cuda.current_stream(features.device).cuda_stream, "features", syn.precision,
+                   self.truncation_psi, self.truncation_cutoff)
             p = PL.plan_for(self, key, lambda: PL.DecoderPlan(syn, B, features.device, generator=self, precision=syn.precision))
             return p.run(features if features.stride(1) == 1 else features.contiguous(),
                          None if noises is None else [n.contiguous() for n in noises])

@@ -40,7 +40,9 @@ class LaunchPlan:
         self._array = None
         self._refreshers = []    # callables re-deriving plan-owned copies of parameters (packed weights, expanded constants)
         self._params = []
+        self._where = []         # per tracked parameter: (module, attribute name) it was found under at build time
         self._stamp = None
+        self.captured = False    # a hipGraph recorded this plan's launches: its buffers must outlive the plan cache
         self.ws = None
         self._ws_bytes = 0
 
@@ -135,7 +137,17 @@ class LaunchPlan:
         self.add(L.OP_FC_GROUPED, L.FcGroupedArgs(groups=C.addressof(arr), n_groups=len(items), B=B))
         return arr
 
-    def finish(self):
+    def finish(self, *owners):
+        """``owners``: the modules whose parameters the plan reads -- every tracked parameter is looked up in them so that
+        ``valid_for`` can tell a re-assigned parameter (``m.weight = nn.Parameter(...)``, ``load_state_dict(assign=True)``, a
+        parametrization swap) from the one whose storage the descriptors point at."""
+        loc = {}
+        for owner in owners:
+            for m in owner.modules():
+                for n, q in m._parameters.items():
+                    if q is not None:
+                        loc.setdefault(id(q), (m, n))
+        self._where = [loc.get(id(q)) for q in self._params]
         if self._ws_bytes:
             self.ws = self.buf((self._ws_bytes + 3) // 4)
             for kind, d in self.ops:
@@ -158,8 +170,14 @@ class LaunchPlan:
             self._stamp = stamp
 
     def valid_for(self):
-        """Pointers baked into the descriptors must still be the parameters' storage."""
-        return self._stamp is not None and all(a[0] == p.data_ptr() for a, p in zip(self._stamp, self._params))
+        """Pointers baked into the descriptors must still be the storage of the parameters the modules hold NOW: the
+        tracked Parameter object is still the one registered under its module attribute, and it has not moved."""
+        if self._stamp is None:
+            return False
+        for a, q, w in zip(self._stamp, self._params, self._where):
+            if a[0] != q.data_ptr() or (w is not None and w[0]._parameters.get(w[1]) is not q):
+                return False
+        return True
 
     def launch(self, kind_mask=L.ALL_OPS):
         L.check(L.lib().spk_launch_list(C.addressof(self._array), len(self.ops), int(kind_mask) & 0xFFFFFFFF, L.stream_ptr()),
@@ -246,7 +264,7 @@ class DecoderPlan(LaunchPlan):
         self.torgb = self.add(L.OP_TORGB, L.ToRGBArgs(x=x.data_ptr(), w=L.dptr(s.to_rgb.weight, "weight"), mod=None,
                                                       bias=L.dptr(s.to_rgb.bias, "bias"), skip=None, y=None, B=B, C=Cc, O=O,
                                                       H=x.shape[2], W=x.shape[3], in_scale=1.0))
-        self.finish()
+        self.finish(*([synthesis] + ([generator] if generator is not None else [])))
 
     @staticmethod
     def _act_floats(s):
@@ -261,6 +279,7 @@ class DecoderPlan(LaunchPlan):
     def run(self, x, noises=None, kind_mask=L.ALL_OPS):
         """``x``: features [B,input_dim] (plan built with the generator) or dlatents w [B,L,512]."""
         self.refresh()
+        self.captured = self.captured or torch.cuda.is_current_stream_capturing()
         if self.with_mapping:
             if x.dim() != 2 or x.stride(1) != 1:
                 raise L.SpkError("DecoderPlan: features must be [B,input_dim] with unit inner stride")
@@ -290,12 +309,24 @@ class DecoderPlan(LaunchPlan):
         return y
 
 
+_retired = []        # plans a hipGraph has recorded, dropped from their cache: kept alive (the graph holds raw addresses)
+
+
+def _drop(plan):
+    if plan is not None and plan.captured:
+        _retired.append(plan)
+
+
 def plan_for(owner, key, build):
     """Per-module plan cache (``owner.__dict__['_plans']``): at most MAX_PLANS entries, least recently used dropped; an
-    entry whose baked parameter pointers went stale (``.to()``, re-assigned parameters) is rebuilt."""
+    entry whose baked parameter pointers went stale (``.to()``, re-assigned parameters) is rebuilt.  A plan whose launches
+    were recorded into a hipGraph is never freed when it leaves the cache -- its packed weights, activation and noise
+    buffers stay where the graph's kernels will read and write them (as ``ops._workspace`` retires outgrown scratch).  Such
+    a graph replays the weights as they were packed at ITS capture: re-capture after an optimizer step."""
     cache = owner.__dict__.setdefault("_plans", {})
     plan = cache.pop(key, None)
     if plan is None or not plan.valid_for():
+        _drop(plan)
         plan = build()
         if torch.cuda.is_current_stream_capturing():
             # built inside a stream capture: its buffers belong to that graph's memory pool and its packing launches were
@@ -304,7 +335,7 @@ def plan_for(owner, key, build):
             return plan
     cache[key] = plan                      # re-insert: most recently used last
     while len(cache) > MAX_PLANS:
-        cache.pop(next(iter(cache)))
+        _drop(cache.pop(next(iter(cache))))
     return plan
 
 
@@ -408,10 +439,11 @@ class StyleGAN2Plan(LaunchPlan):
             skip = nxt
         self.out_shape = (B, 3, x.shape[2], x.shape[3])
         assert x.shape[2] == res_max
-        self.finish()
+        self.finish(gen)
 
     def run(self, features, noises=None, kind_mask=L.ALL_OPS):
         self.refresh()
+        self.captured = self.captured or torch.cuda.is_current_stream_capturing()
         self.pn.x = L.dptr(features, "features")
         if noises is None:
             self.noise_flat.normal_()

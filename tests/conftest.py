@@ -10,9 +10,11 @@ if ROOT not in sys.path:
 
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
-# The upsample-folded weight gradient (csrc/wgrad_mfma_f32.hip, wgrad3x3_up_kernel) is by default used for planes at least 256
-# wide, where it pays; the test process sends EVERY shape it can take through it (the library reads this once, at first use),
-# so the decoder's block / end-to-end gradient tests cover it at 32^2..128^2 as well.
+# The upsample-folded weight gradient (csrc/wgrad_mfma_f32.hip, wgrad3x3_up_kernel) is by default used for planes at least 128
+# wide, where it pays (spk_conv2d_wgrad_up_supported; narrower upsample layers materialise the x2 image and run the plain
+# kernel); the test process sends EVERY shape it can take through it (the library reads this once, at first use), so the
+# decoder's block / end-to-end gradient tests cover it at 16^2..64^2 as well.  The SHIPPED dispatch for those widths is run by
+# tests/test_backward_gpu.py::test_decoder_gradients_with_the_default_upsample_threshold in a child process.
 os.environ.setdefault("SPK_WGRAD_UP_MIN_W", "16")
 
 

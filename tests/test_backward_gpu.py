@@ -4,6 +4,7 @@ PyTorch autograd on the CPU oracle, the SynthesisBlock gradients against the ref
 gradient quirk).  Tolerances: 2e-5 rel-L2 per kernel, 1e-4 per block, 5e-4 end to end (gradients
 flow back through 13 layers; exact fp32 arithmetic, summation order differs)."""
 import importlib
+import os
 
 import numpy as np
 import pytest
@@ -315,3 +316,18 @@ def test_wgrad_of_upsampled_input_without_materialising_it(pkg, dev, B, Cin, Cou
     base = recipe_tensor(tag + ".base", w.shape).to(dev)
     acc = pkg.ops.conv2d_wgrad(g.to(dev), x.to(dev), Cout, Cin, 3, 1, upsample=True, scale=0.5, out=base.clone(), accumulate=True)
     assert rel_l2(acc, base.cpu() + 0.5 * w.grad) < TOL
+
+
+def test_decoder_gradients_with_the_default_upsample_threshold():
+    """conftest.py forces SPK_WGRAD_UP_MIN_W=16 for this process, so the shipped dispatch of the 16 <= W < 128 upsample
+    layers (materialise the x2 image, plain weight-gradient kernel) would never meet the decoder's block / end-to-end
+    gradient goldens.  The library reads the variable once, so those tests run again in a child process without it."""
+    import subprocess
+    import sys
+    env = {k: v for k, v in os.environ.items() if k != "SPK_WGRAD_UP_MIN_W"}
+    env["SPK_WGRAD_UP_MIN_W"] = "128"                       # the product default (csrc/wgrad_mfma_f32.hip), stated
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-m", "gpu", os.path.abspath(__file__), "-k",
+                        "synthesis_block_gradients or style_generator_train_step or batch8_training_step or "
+                        "wgrad_of_upsampled_input"], cwd=root, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-2000:])

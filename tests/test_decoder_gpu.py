@@ -313,6 +313,47 @@ def test_launch_plan_equals_launch_by_launch(pkg, dev):
         # device-drawn noise path: finite, and different draws per call
         a, b = g(feats), g(feats)
         assert torch.isfinite(a).all() and not torch.equal(a, b)
+
+
+def test_launch_plan_follows_reassigned_parameters_and_truncation(pkg, dev):
+    """a plan compared only the Parameter objects it had captured, so ``m.weight = nn.Parameter(...)`` /
+    ``load_state_dict(assign=True)`` left eval forwards on the OLD weights; and the truncation scale, baked into the style
+    FC multipliers at build time, was not part of the plan key."""
+    g, sd = _generator(pkg, dev)
+    B = 2
+    feats = recipe_input("plan2.features", (B, 6144)).to(dev)
+    noises = [n.to(dev) for n in recipe_noises("plan2", B, 256)]
+    syn = g.synthesis
+
+    def by_launch():
+        type(syn).use_plan = False
+        try:
+            return g(feats, noises)
+        finally:
+            type(syn).use_plan = True
+
+    with torch.no_grad():
+        y0 = g(feats, noises)
+        # ---- a re-assigned Parameter: a NEW object, the old one stays alive inside the plan ----
+        conv = syn.layers[1].conv2
+        conv.weight = torch.nn.Parameter(conv.weight.detach() * 1.25 + 0.01)
+        y1 = g(feats, noises)
+        assert rel_l2(y1, y0) > 1e-3                           # the eval output follows the new weight ...
+        assert rel_l2(y1, by_launch()) < 1e-5                   # ... and equals the launch-by-launch path
+        # ---- load_state_dict(assign=True): every Parameter object replaced ----
+        new_sd = {k: (v * 0.9).clone() for k, v in g.state_dict().items()}
+        g.load_state_dict(new_sd, assign=True)
+        y2 = g(feats, noises)
+        assert rel_l2(y2, y1) > 1e-3 and rel_l2(y2, by_launch()) < 1e-5
+        # ---- truncation: psi and the cutoff are baked into the plan, so they key it ----
+        g.truncation_psi = 0.4
+        y3 = g(feats, noises)
+        assert rel_l2(y3, y2) > 1e-3 and rel_l2(y3, by_launch()) < 1e-5
+        g.truncation_cutoff = 3
+        y4 = g(feats, noises)
+        assert rel_l2(y4, y3) > 1e-4 and rel_l2(y4, by_launch()) < 1e-5
+        g.truncation_psi, g.truncation_cutoff = 0.7, 8
+        assert rel_l2(g(feats, noises), y2) < 1e-6
         with pytest.raises(ValueError):
             g(feats, noises[:-1])
     g.load_state_dict(sd)
