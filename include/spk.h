@@ -202,7 +202,8 @@ typedef struct spk_wgrad_desc {
     const float* in_shift;
     float*       dw;         /* [Cout,Cin,kh,kw] */
     int32_t B, Cin, Cout, H, W, Hin, Win, kh, kw, stride;
-    uint32_t flags;          /* 0 or SPK_CONV_IN_AFFINE_RELU */
+    uint32_t flags;          /* 0, SPK_CONV_IN_AFFINE_RELU, SPK_CONV_UPSAMPLE2X, or SPK_CONV_IN_BATCH_SCALE
+                              * [| SPK_CONV_UPSAMPLE2X | SPK_CONV_UP_FIR1331] (the modulated convolution, see g_scale) */
     float scale;
     int32_t accumulate;      /* dw += instead of dw = */
     int32_t splits;          /* pixel-range splits; 0 = auto */
@@ -217,12 +218,20 @@ typedef struct spk_wgrad_desc {
      * images (IRFD runs each encoder on x_s and on x_t, model.py:84-90), so their weight gradients add: dw is
      * [groups/fold * Cout, Cin, kh, kw], summed in the slab reduce instead of by a separate pass. */
     int32_t fold;
+    /* SPK_CONV_IN_BATCH_SCALE (the StyleGAN2 variant's modulated conv, reference/styleganv2.txt:1835): the forward input was
+     * x * in_scale[b,ci] (in_scale = the modulation s, [B][Cin]) and the gradient that reaches the conv output is
+     * g * g_scale[b,co] (g_scale = demodulation x activation gain, [B][Cout]): both factors are applied while the tiles are
+     * staged into LDS, neither rescaled tensor exists.  With SPK_CONV_UPSAMPLE2X | SPK_CONV_UP_FIR1331 x is the low-resolution
+     * tensor and the x2 image (upfirdn2d up = 2, [1,3,3,1]: zero border) is interpolated LDS -> LDS.  3x3 stride 1, ungrouped;
+     * shapes: spk_conv2d_wgrad_mod_supported. */
+    const float* g_scale;
 } spk_wgrad_desc;
 int64_t spk_conv2d_wgrad_workspace_bytes(int kh, int kw, int stride, int splits, int B, int Cin, int Cout, int H, int W);
 int spk_conv2d_wgrad(const spk_wgrad_desc* desc, void* stream);
 /* whether spk_conv2d_wgrad takes SPK_CONV_UPSAMPLE2X for a 3x3 stride-1 problem with OUTPUT size H x W (x is then the
  * low-resolution [B,Cin,H/2,W/2] tensor and the x2 image is never materialised); 0: upsample first. */
 int spk_conv2d_wgrad_up_supported(int B, int Cin, int Cout, int H, int W);
+int spk_conv2d_wgrad_mod_supported(int B, int Cin, int Cout, int H, int W, int upsample);
 
 /* Adjoint of the fused epilogue of spk_conv2d_fwd, one pass.  With y = a*(s0+1)+s1, a = lrelu(t),
  * t = conv + bias + noise_w*noise and dy = dL/dy:
@@ -370,6 +379,25 @@ int spk_global_avgpool_fwd(const float* x, float* y, int64_t planes, int64_t HW,
  *   demodulation), O <= 4. */
 int spk_modconv_demod(const float* w, const float* s, float* d, int B, int Cin, int Cout, int taps, float scale, float eps,
                       void* stream);
+/* ---- backward of the modulated convolution (the parts that are not spk_conv2d_fwd / spk_conv2d_wgrad themselves) ----
+ * With y = gain * lrelu(d[b,co] * scale * conv3x3(up?(x) * s[b,ci], w) + ...), dz the gradient at the conv output
+ * (spk_epilogue_bwd) and dx~ = spk_conv2d_fwd(dz, w transpose-flipped, SPK_CONV_IN_BATCH_SCALE with in_scale = d * gain):
+ *   spk_modconv_dx_finish:  dx = s[b,ci] * up^T(dx~)   (up^T = the adjoint of upfirdn2d(up = 2, [1,3,3,1]) when `upsample`,
+ *                           identity otherwise; dx may be NULL, or == dxt when !upsample) and
+ *                           ds[b,ci] = <up^T(dx~), x>_plane -- the modulation gradient through the conv, evaluated at the
+ *                           LOW resolution, so up(x) is never formed.  dxt [B,C,(2)Hs,(2)Ws], x / dx [B,C,Hs,Ws], s / ds [B,C].
+ *   spk_modconv_demod_bwd:  the adjoint of spk_modconv_demod: with e = -dd * d^3 * scale^2,
+ *                           ds[b,ci] += s[b,ci] * sum_co e[b,co] * sum_k w[co,ci,k]^2,
+ *                           dw[co,ci,k] += w[co,ci,k] * sum_b e[b,co] * s[b,ci]^2      (either output may be NULL).
+ *   spk_torgb_mod_bwd_data: dx[b,c,p] = in_scale * mod[b,c] * sum_o w[o,c] * dy[b,o,p]  (modulated toRGB, O <= 4); its weight /
+ *                           modulation gradients come from spk_conv1x1_small_bwd's per-image partial sums on the UNmodulated x.
+ * replaces: what autograd would run for the published formulas (reference/styleganv2.txt:1835,1912). */
+int spk_modconv_dx_finish(const float* dxt, const float* x, const float* s, float* dx, float* ds, int B, int C, int Hs, int Ws,
+                          int upsample, void* stream);
+int spk_modconv_demod_bwd(const float* w, const float* s, const float* d, const float* dd, float* ds, float* dw, int B, int Cin,
+                          int Cout, int taps, float scale, void* stream);
+int spk_torgb_mod_bwd_data(const float* w, const float* mod, const float* dy, float* dx, int B, int C, int O, int64_t HW,
+                           float in_scale, void* stream);
 /* the same for several layers in one launch (a decoder step's 13 demodulation vectors depend only on its modulations);
  * `groups` is a HOST array of n_groups <= SPK_DEMOD_MAX_GROUPS descriptors. */
 #define SPK_DEMOD_MAX_GROUPS 16

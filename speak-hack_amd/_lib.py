@@ -124,7 +124,7 @@ class WgradDesc(C.Structure):
                 ("Hin", C.c_int32), ("Win", C.c_int32), ("kh", C.c_int32), ("kw", C.c_int32), ("stride", C.c_int32),
                 ("flags", C.c_uint32), ("scale", C.c_float), ("accumulate", C.c_int32), ("splits", C.c_int32),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64), ("groups", C.c_int32), ("group_in_stride", C.c_int32),
-                ("fold", C.c_int32)]
+                ("fold", C.c_int32), ("g_scale", C.c_void_p)]
 
 
 _PROTOTYPES = {
@@ -157,6 +157,10 @@ _PROTOTYPES = {
     "spk_conv2d_wgrad_workspace_bytes": (C.c_int64, [C.c_int] * 9),
     "spk_conv2d_wgrad": (C.c_int, [C.POINTER(WgradDesc), C.c_void_p]),
     "spk_conv2d_wgrad_up_supported": (C.c_int, [C.c_int] * 5),
+    "spk_conv2d_wgrad_mod_supported": (C.c_int, [C.c_int] * 6),
+    "spk_modconv_dx_finish": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 5 + [C.c_void_p]),
+    "spk_modconv_demod_bwd": (C.c_int, [C.c_void_p] * 6 + [C.c_int] * 4 + [C.c_float, C.c_void_p]),
+    "spk_torgb_mod_bwd_data": (C.c_int, [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_float, C.c_void_p]),
     "spk_epilogue_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_float, C.c_void_p,
                                    C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p]),
     "spk_upsample2x_bilinear_bwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),

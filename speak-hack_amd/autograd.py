@@ -376,19 +376,25 @@ def _scale_rows(t):
 
 
 class ModConvFn(torch.autograd.Function):
-    """StyleGAN2 styled conv (build-defined variant):
-    y = gain * lrelu(d[b,co] * scale * conv3x3(up?(x) * s[b,ci], w) + noise_w*noise + bias), with the modulation ``s`` and
-    the demodulation ``d`` as independent inputs (``d``'s own dependence on (w, s) is a [B,Cout] torch expression in
-    the caller, so autograd adds that path).  Backward, all on the HIP kernels: epilogue adjoint (+ the plane sums that
-    give d bias, d noise_w and d d), data gradient = the same modulated MFMA conv with the roles of s and d swapped
-    (batch_scale = d*gain on the way in, then x s on the way out), d s = per-plane <up(x), dx~>, upfirdn adjoint, and
-    the weight gradient on the wgrad kernel over the two rescaled operands."""
+    """StyleGAN2 styled conv (build-defined variant; formulas reference/styleganv2.txt:1835,1912):
+    y = gain * lrelu(d[b,co] * scale * conv3x3(up?(x) * s[b,ci], w) + noise_w*noise + bias), d = rsqrt(scale^2 sum_{ci,k}
+    (w s)^2 + eps) computed HERE from (w, s) (``spk_modconv_demod``; ``demodulate`` False: d = 1).
+
+    Backward, all on the HIP kernels and without a single rescaled activation in HBM:
+      1. epilogue adjoint: dz = dy * lrelu' (gain folded later) + the plane sums that give d bias, d noise_w and d d;
+      2. data gradient: the same modulated MFMA conv with the roles of s and d swapped (dz * d*gain on the way in);
+      3. ``spk_modconv_dx_finish``: the upfirdn2d adjoint, x s on the way out and d s = <up^T(dx~), x> at the LOW resolution;
+      4. weight gradient: ``spk_conv2d_wgrad`` with SPK_CONV_IN_BATCH_SCALE -- x * s and dz * d*gain are formed while the
+         tiles are staged, the x2 image interpolated LDS -> LDS (zero border);
+      5. ``spk_modconv_demod_bwd``: d d into d s and d w.
+    Round 2 materialised up(x) (268 MB at [8,128,256,256]), dz * d and up(x) * s per layer and ran d's adjoint as ATen GEMMs."""
 
     @staticmethod
-    def forward(ctx, x, weight, s, d, bias, noise_w, noise, scale, upsample, slope, gain, fir, packed, grad_mode):
+    def forward(ctx, x, weight, s, bias, noise_w, noise, scale, upsample, slope, gain, fir, packed, demodulate, grad_mode):
         B, Cin, Hs, Ws = x.shape
         Cout = weight.shape[0]
         H, W = (2 * Hs, 2 * Ws) if upsample else (Hs, Ws)
+        d = ops.modconv_demod(weight, s, scale) if demodulate else None
         cfg = ops.conv2d_pick_config(3, 1, B, Cin, Cout, H, W)
         cfg = cfg + 4 if cfg < 4 else cfg
         y = ops.conv2d_fused(x, packed.get(weight, cfg), Cout, 3, 1, bias=bias, noise_w=noise_w, noise=noise, lrelu_slope=slope,
@@ -410,35 +416,48 @@ class ModConvFn(torch.autograd.Function):
         dbias = gain * s_dt.sum(0) if bias is not None else None
         dnw = gain * s_dtn.sum(0) if noise_w is not None else None
         dd = None
-        if d is not None:
+        if d is not None:        # y/gain = lrelu(d*c + n + b): sum dy*y = sum dz*(d*c + n + b) -> d d = (that - noise, bias parts) / d
             r = s_dyy
             if noise_w is not None:
                 r = r - gain * noise_w.view(1, -1) * s_dtn
             if bias is not None:
                 r = r - gain * bias.view(1, -1) * s_dt
-            dd = r / d
+            dd = (r / d).contiguous()
         dprime = (d * gain if d is not None else torch.full((B, Cout), float(gain), device=x.device)).contiguous()
-        x_up = ops.upfirdn2d(x, fir, up=2, down=1, pad=(2, 1)) if upsample else x
+        s = s.contiguous()
+        need_dx, need_dw, need_ds = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         dx = dw = ds = None
-        if ctx.needs_input_grad[0] or ctx.needs_input_grad[2]:
+        if need_dx or need_ds:
             cfg = ops.conv2d_pick_config(3, 1, B, Cout, Cin, H, W)
             cfg = cfg + 4 if cfg < 4 else cfg
             dxt = ops.conv2d_fused(dt, packed.get(weight, cfg, transpose_flip=True), Cin, 3, 1, out_scale=scale,
-                                   batch_scale=dprime, config=cfg)                     # d (up(x) * s)
-            dxu, sums2 = ops.epilogue_bwd(dxt, x_up, None, _scale_rows(s), 1.0)       # x s on the way out; <dx~, up(x)> per plane
-            ds = sums2[:, 0]
-            if ctx.needs_input_grad[0]:
-                dx = ops.upfirdn2d(dxu, torch.flip(fir, [0, 1]), up=1, down=2, pad=(1, 1)) if upsample else dxu
-        if ctx.needs_input_grad[1]:
-            g2 = ops.bias_noise_style(dt, B, None, None, None, _scale_rows(dprime))
-            xs = ops.bias_noise_style(x_up, B, None, None, None, _scale_rows(s))
-            dw = ops.conv2d_wgrad(g2, xs, Cout, Cin, 3, 1, scale=scale)
-        return dx, dw, ds, dd, dbias, dnw, None, None, None, None, None, None, None, None
+                                   batch_scale=dprime, config=cfg)                     # d (up(x) * s), at the output resolution
+            if upsample and (x.shape[-1] % 2 or dxt.data_ptr() % 16):                  # odd widths: the stand-alone adjoint
+                dxu = ops.upfirdn2d(dxt, torch.flip(fir, [0, 1]), up=1, down=2, pad=(1, 1))
+                dx, ds = ops.modconv_dx_finish(dxu, x, s, False, need_dx=need_dx)
+            else:
+                dx, ds = ops.modconv_dx_finish(dxt, x, s, upsample, need_dx=need_dx)
+        if need_dw:
+            if ops.wgrad_mod_supported(B, Cin, Cout, H, W, upsample) and not (x.data_ptr() % 16 or dt.data_ptr() % 16):
+                dw = ops.conv2d_wgrad(dt, x, Cout, Cin, 3, 1, upsample=upsample, up_fir=True, scale=scale, batch_scale=s,
+                                      g_scale=dprime)
+            else:                # tiny planes (the 4^2 layer): rescale the two (few-KB) operands and run the plain kernel
+                x_up = ops.upfirdn2d(x, fir, up=2, down=1, pad=(2, 1)) if upsample else x
+                g2 = ops.bias_noise_style(dt, B, None, None, None, _scale_rows(dprime))
+                xs = ops.bias_noise_style(x_up, B, None, None, None, _scale_rows(s))
+                dw = ops.conv2d_wgrad(g2, xs, Cout, Cin, 3, 1, scale=scale)
+        if dd is not None and (need_ds or need_dw):
+            if need_ds and ds is None:
+                ds = torch.zeros_like(s)
+            ops.modconv_demod_bwd(weight, s, d, dd, scale, ds=ds if need_ds else None, dw=dw if need_dw else None)
+        return dx, dw, ds, dbias, dnw, None, None, None, None, None, None, None, None, None
 
 
 class ModToRGBFn(torch.autograd.Function):
     """y = scale * conv1x1(x * s[b,ci], w) + bias [+ upfirdn2d_up2(skip)] to <= 4 channels (StyleGAN2 toRGB, no
-    demodulation; the skip image's x2 upsample + add ride in the same launch)."""
+    demodulation; the skip image's x2 upsample + add ride in the same launch).  Backward: one streaming pass for dx (the
+    modulation folded into the LDS weights), one for the per-image sums P[b,o,c] = scale * <dy[b,o], x[b,c]> -- from which the
+    weight and modulation gradients are [B,3,C]-sized contractions -- and the upfirdn2d adjoint for the skip image."""
 
     @staticmethod
     def forward(ctx, x, weight, s, bias, scale, skip, fir, grad_mode):
@@ -453,16 +472,15 @@ class ModToRGBFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, weight, s = ctx.saved_tensors
         scale, has_bias, has_skip, fir = ctx.conf
-        B = x.shape[0]
         dy = dy.contiguous()
-        rows = _scale_rows(s)
-        xs = ops.bias_noise_style(x, B, None, None, None, rows)
-        dxs, dw, db = ops.conv1x1_small_bwd(xs, weight, dy, need_dx=True, in_scale=scale)
-        dx, sums = ops.epilogue_bwd(dxs, x, None, rows, 1.0)
+        dx, P, db = ops.torgb_mod_bwd(x, weight, s.contiguous(), dy, in_scale=scale, need_dx=ctx.needs_input_grad[0])
+        O, Cc = weight.shape[:2]
+        dw = torch.einsum("boc,bc->oc", P, s).view(O, Cc, 1, 1) if ctx.needs_input_grad[1] else None
+        ds = torch.einsum("boc,oc->bc", P, weight.view(O, Cc)) if ctx.needs_input_grad[2] else None
         dskip = None
         if has_skip and ctx.needs_input_grad[5]:      # adjoint of upfirdn2d(up=2, pad (2,1)): down=2 with the flipped FIR, pad (1,1)
             dskip = ops.upfirdn2d(dy, torch.flip(fir, [0, 1]), up=1, down=2, pad=(1, 1))
-        return dx, dw, sums[:, 0], (db if has_bias else None), None, dskip, None, None
+        return dx, dw, ds, (db if has_bias else None), None, dskip, None, None
 
 
 class UpFirDnFn(torch.autograd.Function):
@@ -598,6 +616,45 @@ class Upscale2dFn(torch.autograd.Function):
         return ops.upscale2d_nearest_bwd(dy.contiguous(), factor, gain), None, None
 
 
+class FusedUpscaleFn(torch.autograd.Function):
+    """y = conv_transpose2d(x, w[Cin,Cout,4,4], bias, stride 2, padding 1) -- ``GBlock.up_sample`` for res >= 7,
+    styleganv1.py:231,258.  Forward: four output-parity 2x2 MFMA kernels in one launch.  Backward: the transposed conv's
+    adjoint is the plain 4x4 stride-2 pad-1 conv with the SAME parameter read as [out = Cin][in = Cout] (dx, on the MFMA conv
+    kernel), the weight gradient is that conv's weight gradient with the roles of input and output gradient exchanged
+    (dw[ci,co,ky,kx] = sum x[ci,m,n] dy[co,2m+ky-1,2n+kx-1], on the MFMA wgrad kernel, one tap row per workgroup), the bias
+    gradient the plane sums of dy."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, packed, grad_mode):
+        y = ops.conv_transpose4x4_s2(x, weight, bias, packed)
+        if _needs(ctx, grad_mode):
+            ctx.save_for_backward(x, weight)
+            ctx.conf = (packed, bias is not None)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        packed, has_bias = ctx.conf
+        B, Cin, H, W = x.shape
+        Cout = weight.shape[1]
+        dy = dy.contiguous()
+        dx = dw = db = None
+        if ctx.needs_input_grad[0]:
+            cfg = ops.conv2d_pick_config(4, 2, B, Cout, Cin, H, W)
+            dx = ops.conv2d_fused(dy, packed.get(weight, cfg), Cin, 4, 2, config=cfg)
+        if ctx.needs_input_grad[1]:
+            dw = ops.conv2d_wgrad(x, dy, Cin, Cout, 4, 2)
+        if has_bias and ctx.needs_input_grad[2]:
+            db = ops.epilogue_bwd(dy, None, None, None, 1.0)[1][:, 2].sum(0)
+        return dx, dw, db, None, None
+
+
+def fused_upscale(x, weight, bias, packed):
+    return FusedUpscaleFn.apply(x, weight, bias, packed, torch.is_grad_enabled())
+
+
 # call-site spellings: sample the grad mode where it is still visible
 def fused_conv(x, weight, bias, noise_w, noise, style, upsample, slope, packed, w_scale=1.0):
     return FusedConvFn.apply(x, weight, bias, noise_w, noise, style, upsample, slope, packed, torch.is_grad_enabled(), w_scale)
@@ -623,8 +680,9 @@ def global_avgpool(x):
     return GlobalAvgPoolFn.apply(x)
 
 
-def mod_conv(x, weight, s, d, bias, noise_w, noise, scale, upsample, slope, gain, fir, packed):
-    return ModConvFn.apply(x, weight, s, d, bias, noise_w, noise, scale, upsample, slope, gain, fir, packed, torch.is_grad_enabled())
+def mod_conv(x, weight, s, bias, noise_w, noise, scale, upsample, slope, gain, fir, packed, demodulate=True):
+    return ModConvFn.apply(x, weight, s, bias, noise_w, noise, scale, upsample, slope, gain, fir, packed, demodulate,
+                           torch.is_grad_enabled())
 
 
 def mod_to_rgb(x, weight, s, bias, scale, skip=None, fir=None):

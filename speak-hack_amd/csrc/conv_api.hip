@@ -210,6 +210,7 @@ static const CfgDims kDims[kNumConfigs] = {
 
 static bool supported_kernel(int kh, int kw, int stride) {
     if (kh == 2 && kw == 2) return stride == 1;   // the parity form of the 3x3 stride-2 data gradient (SPK_CONV_DGRAD_S2)
+    if (kh == 4 && kw == 4) return stride == 2;   // the data gradient of ConvTranspose2d(4, stride 2, pad 1) (styleganv1.py:231)
     return kh == kw && (kh == 1 || kh == 3 || kh == 7) && (stride == 1 || stride == 2) && !(kh == 7 && stride == 1);
 }
 
@@ -220,7 +221,7 @@ static bool config_valid(int cfg, int kh, int kw, int stride) {
     if (kh == 1) return cfg >= 8;
     if (kh == 2) return cfg <= 3;
     if (kh == 3 && stride == 1) return cfg <= 7;
-    return cfg >= 4 && cfg <= 7;  // 3x3 s2, 7x7 s2
+    return cfg >= 4 && cfg <= 7;  // 3x3 s2, 4x4 s2, 7x7 s2
 }
 
 template <int KH, int S>
@@ -265,6 +266,7 @@ static Geometry geometry_any(int kh, int stride, int cfg, int B, int Cin, int Co
     if (kh == 1) return stride == 1 ? geom_k<1, 1>(cfg, B, Cin, Cout, H, W) : geom_k<1, 2>(cfg, B, Cin, Cout, H, W);
     if (kh == 2) return geom_k<2, 1>(cfg, B, Cin, Cout, H, W);
     if (kh == 3) return stride == 1 ? geom_k<3, 1>(cfg, B, Cin, Cout, H, W) : geom_k<3, 2>(cfg, B, Cin, Cout, H, W);
+    if (kh == 4) return geom_k<4, 2>(cfg, B, Cin, Cout, H, W);
     return geom_k<7, 2>(cfg, B, Cin, Cout, H, W);
 }
 

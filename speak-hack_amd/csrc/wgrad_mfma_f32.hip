@@ -34,13 +34,17 @@ __device__ __forceinline__ void wg_static_for(F&& f) {
 
 namespace {
 
-enum { WG_PLAIN = 0, WG_UPSAMPLE = 1, WG_AFFINE_RELU = 2 };
+// WG_BATCH_SCALE: the modulated convolution (StyleGAN2 variant): the forward input was x * s[b,ci] and the gradient reaching
+// the conv output is g * d'[b,co] (demodulation x activation gain) -- both factors are applied while the tiles are staged, so
+// neither rescaled tensor exists in HBM (in_scale = s [B][Cx], g_scale = d' [B][Cy])
+enum { WG_PLAIN = 0, WG_UPSAMPLE = 1, WG_AFFINE_RELU = 2, WG_BATCH_SCALE = 3 };
 
 struct WgradArgs {
     const float* g;        // [B,Cout,H,W]   output-side gradient
     const float* x;        // [B,Cin,Hs,Ws]  forward input
-    const float* in_scale; // WG_AFFINE_RELU
+    const float* in_scale; // WG_AFFINE_RELU: [Cx]; WG_BATCH_SCALE: s [B][Cx]
     const float* in_shift;
+    const float* g_scale;  // WG_BATCH_SCALE: d' [B][Cy]
     float* slabs;          // [n_slabs][Cout][TAPS][Cin]
     int B, Cin, Cout, H, W, Hs, Ws;   // Cin / Cout PER GROUP
     int lgTW, lgTH, lgTB;
@@ -57,8 +61,10 @@ struct WShape {
     // 7*3 = 21 of 32 lanes do work, where one-channel-per-lane would use 3 -- and there is one accumulator tile per tap
     // ROW (ky); needs KW * Cin <= 32.
     static constexpr bool PACK = KH == 7;
-    static constexpr bool ROWPASS = false;                  // (kept for the launch arithmetic: every kernel is single-pass)
-    static constexpr int TP = PACK ? KH : TAPS;             // accumulator tiles per wave
+    // 4x4 (the weight gradient of ConvTranspose2d(4, s2, p1), styleganv1.py:231): 16 accumulator tiles would be 256 registers
+    // on top of the staging state, so a workgroup owns ONE tap row (blockIdx.y carries the row) and holds KW tiles
+    static constexpr bool ROWPASS = KH == 4;
+    static constexpr int TP = PACK ? KH : (ROWPASS ? KW : TAPS);     // accumulator tiles per wave
     static constexpr int CI_T = PACK ? 4 : ((S == 2 || WGRAD_CI32) ? 32 : 64);
     static constexpr int WCI = PACK ? 1 : CI_T / 32, WPX = 2 / WCI;    // 4 waves = 2 (co) x WCI x WPX
     static constexpr int CO_T = 64, PIX_T = 64, PAD = (KH - 1) / 2;
@@ -471,7 +477,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_wide_kernel(const WgradArgs p) {
     constexpr int GPITCH = SH::GPITCH, XPITCH = SH::XPITCH, BUF = SH::BUF;
     constexpr int NG4 = SH::NG4, NXK = SH::NXK, RS = SH::RS, NX4 = SH::NX4, NXH = SH::NXH, NL = SH::NL, NS = SH::NS;
     constexpr int STEPS = SH::STEPS, HS = SH::HS, PL = SH::PL, PS = SH::PS;
-    constexpr bool AFF = MODE == WG_AFFINE_RELU;
+    constexpr bool AFF = MODE == WG_AFFINE_RELU, BSC = MODE == WG_BATCH_SCALE;
     extern __shared__ __attribute__((aligned(16))) float smem[];
 
     const int tid = threadIdx.x, lane = tid & 63;
@@ -489,10 +495,15 @@ __global__ __launch_bounds__(256) void wgrad3x3_wide_kernel(const WgradArgs p) {
     // ---- staging roles (launch constants; only the tile origin moves) ----
     // gradient piece i: float4 gk of tile row grow of channel (tid >> 4) + 16 i
     const int gk = tid & (TW / 4 - 1), grow = (tid / (TW / 4)) & (TH - 1);
-    int g_off[NG4];
+    int g_off[NG4], g_ch[NG4];
 #pragma unroll
-    for (int i = 0; i < NG4; ++i)
-        g_off[i] = (min(co0 + (tid >> 4) + 16 * i, co_end - 1) * p.H + grow) * p.W + 4 * gk;    // rows past the last channel: clamped (never written out)
+    for (int i = 0; i < NG4; ++i) {
+        g_ch[i] = min(co0 + (tid >> 4) + 16 * i, co_end - 1);                                      // rows past the last channel: clamped (never written out)
+        g_off[i] = (g_ch[i] * p.H + grow) * p.W + 4 * gk;
+    }
+    float g_sc[NG4];                                                                              // BSC: d'[b, g_ch[i]] of the tile being staged
+#pragma unroll
+    for (int i = 0; i < NG4; ++i) g_sc[i] = 1.f;
     const int g_dst = (tid >> 4) * GPITCH + grow * TW + 4 * gk;                                   // + 16 i GPITCH + j
     // input piece i: float4 xk of plane row RS i + xr of channel xc
     const int xk = tid & (NXK - 1), xc = (tid / NXK) & (CI_T - 1), xr = tid / (NXK * CI_T);
@@ -534,6 +545,13 @@ __global__ __launch_bounds__(256) void wgrad3x3_wide_kernel(const WgradArgs p) {
         g_ok = live && y0 + grow < p.H && x0 + 4 * gk < p.W;
         xcol_ok = live && x0 + 4 * xk < p.Ws;
         hcol_ok = live && (unsigned)(x0 + (hs ? TW : -1)) < (unsigned)p.Ws;
+        if constexpr (BSC) {                     // the staged tile's image decides the modulation / demodulation factors
+            const int bb = live ? b : 0;
+            x_sc = p.in_scale[(size_t)bb * p.Cx + x_chan];
+            h_sc = p.in_scale[(size_t)bb * p.Cx + h_chan];
+#pragma unroll
+            for (int i = 0; i < NG4; ++i) g_sc[i] = p.g_scale[(size_t)bb * p.Cy + g_ch[i]];
+        }
     };
     // plane row r of the tile being staged lies inside the image (and inside the plane: the last piece of a two-row role)
     auto row_ok = [&](int r) { return r < PH && (unsigned)(ty0 + r - 1) < (unsigned)p.Hs; };
@@ -555,11 +573,12 @@ __global__ __launch_bounds__(256) void wgrad3x3_wide_kernel(const WgradArgs p) {
         constexpr int s = decltype(s_)::value;
         if constexpr (s < 4 * NG4) {
             constexpr int i = s / 4, j = s % 4;
-            buf[g_dst + 16 * i * GPITCH + j] = g_ok ? gq[i][j] : 0.f;        // only the PIXEL axis (the contraction) needs zeros
+            buf[g_dst + 16 * i * GPITCH + j] = g_ok ? (BSC ? gq[i][j] * g_sc[i] : gq[i][j]) : 0.f;   // only the PIXEL axis (the contraction) needs zeros
         } else if constexpr (s < 4 * NG4 + 4 * NX4) {
             constexpr int i = (s - 4 * NG4) / 4, j = (s - 4 * NG4) % 4;
             float v = xq[i][j];
             if (AFF) v = fmaxf(v * x_sc + x_sh, 0.f);
+            if (BSC) v *= x_sc;
             // (a two-row role's last piece: plane row PH does not exist -- those lanes hit the dump slot, no branch)
             const int dst = (RS * i + RS - 1 < PH || RS * i + xr < PH) ? x_dst + RS * i * PW + j : BUF - 1;
             buf[dst] = (xcol_ok && row_ok(RS * i + xr)) ? v : 0.f;
@@ -567,6 +586,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_wide_kernel(const WgradArgs p) {
             constexpr int i = s - 4 * NG4 - 4 * NX4;
             float v = hq[i];
             if (AFF) v = fmaxf(v * h_sc + h_sh, 0.f);
+            if (BSC) v *= h_sc;
             const int dst = (2 * i + 1 < PH || 2 * i + hr < PH) ? h_dst + 2 * i * PW : BUF - 1;
             buf[dst] = (hcol_ok && row_ok(2 * i + hr)) ? v : 0.f;
         }
@@ -891,7 +911,12 @@ __global__ __launch_bounds__(256) void wgrad3x3_s2_kernel(const WgradArgs p) {
 // materialised form: those 4 loads per element could not be prefetched; LDS reads need no prefetch.
 constexpr int US_PW = 10, US_PH = 4, US_PITCH = US_PW * US_PH + 1, US_FLOATS = 64 * US_PITCH;
 
+// MODE = WG_BATCH_SCALE: the StyleGAN2 variant's x2 layers -- the upsampling is upfirdn2d(up = 2, [1,3,3,1]), i.e. the SAME parity
+// taps (.25 / .75) over a ZERO-bordered source (the bilinear form replicates the edge), the source is x * s[b,ci] and the
+// gradient g * d'[b,co]: all three differences live in the staging (zeros instead of clamped loads, two multiplies).
+template <int MODE>
 __global__ __launch_bounds__(256) void wgrad3x3_up_kernel(const WgradArgs p) {
+    constexpr bool BSC = MODE == WG_BATCH_SCALE;
     using SH = WideShape<1, 1>;
     constexpr int TAPS = 9, CO_T = 64, CI_T = 64, PW = SH::PW, PLANE = SH::PLANE, GPITCH = SH::GPITCH, XPITCH = SH::XPITCH, BUF = SH::BUF;
     constexpr int NG4 = 4, STEPS = 32, HS = 16, EPT = CI_T * PLANE / 256;       // 27 plane elements per thread
@@ -912,14 +937,20 @@ __global__ __launch_bounds__(256) void wgrad3x3_up_kernel(const WgradArgs p) {
 
     // ---- staging roles ----
     const int gk = tid & 3, grow = (tid >> 2) & 3;
-    int g_off[NG4];
+    int g_off[NG4], g_ch[NG4];
+    float g_sc[NG4];
 #pragma unroll
-    for (int i = 0; i < NG4; ++i) g_off[i] = (min(co0 + (tid >> 4) + 16 * i, co_end - 1) * p.H + grow) * p.W + 4 * gk;
+    for (int i = 0; i < NG4; ++i) {
+        g_ch[i] = min(co0 + (tid >> 4) + 16 * i, co_end - 1);
+        g_off[i] = (g_ch[i] * p.H + grow) * p.W + 4 * gk;
+        g_sc[i] = 1.f;
+    }
     const int g_dst = (tid >> 4) * GPITCH + grow * 16 + 4 * gk;
     // source patch: piece i in {0, 1} = source row rh + 2 i of channel sc: float4 sk (columns x0/2 + 4 sk ..) and the halo column
     // x0/2 - 1 (sk = 0) / x0/2 + 8 (sk = 1)
     const int sk = tid & 1, sc = (tid >> 1) & 63, rh = tid >> 7;
-    const int s_chan = (cx0 + ci0 + min(sc, nci - 1)) * p.Hs;
+    const int s_ch = cx0 + ci0 + min(sc, nci - 1);
+    const int s_chan = s_ch * p.Hs;
     const int s_dst4 = sc * US_PITCH + rh * US_PW + 1 + 4 * sk;      // + 2 i US_PW + j
     const int s_dsth = sc * US_PITCH + rh * US_PW + (sk ? 9 : 0);    // + 2 i US_PW
 
@@ -946,6 +977,11 @@ __global__ __launch_bounds__(256) void wgrad3x3_up_kernel(const WgradArgs p) {
         origin(tile, b, y0, x0);
         gbase = p.g + ((size_t)b * p.Cy * p.H + y0) * p.W + x0;
         g_ok = tile < p.n_tiles && y0 + grow < p.H && x0 + 4 * gk < p.W;
+        if constexpr (BSC) {
+            const int bb = tile < p.n_tiles ? b : 0;
+#pragma unroll
+            for (int i = 0; i < NG4; ++i) g_sc[i] = p.g_scale[(size_t)bb * p.Cy + g_ch[i]];
+        }
     };
     // The source patch is REPLICATE-padded (rows / columns outside the image take the nearest edge pixel: loads with clamped
     // coordinates): torch's bilinear clamps its second tap at the border, which is the plain parity weights (.75, .25) applied
@@ -953,6 +989,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_up_kernel(const WgradArgs p) {
     // remains of the border is the conv's ZERO padding of the x2 image, a per-tile row / column mask.
     int s_x0 = 0;
     bool s4_out = false;
+    float s_sc = 1.f;                                                 // BSC: s[b, channel] of the patch being staged
     auto aim_s = [&](int tile) {
         int b, y0, x0;
         origin(tile, b, y0, x0);
@@ -960,6 +997,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_up_kernel(const WgradArgs p) {
         s_x0 = x0 >> 1;
         sbase = p.x + ((size_t)b * p.Cx * p.Hs) * p.Ws;
         s4_out = s_x0 + 4 * sk >= p.Ws;                                // this thread's vector lies right of the image: replicate
+        if constexpr (BSC) s_sc = p.in_scale[(size_t)b * p.Cx + s_ch];  // (aim_s is only ever called with a live tile)
     };
     unsigned i_rows = 0, i_cols = 0;                                  // plane rows / columns inside the x2 image (bit r / bit c)
     auto aim_i = [&](int tile) {
@@ -975,7 +1013,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_up_kernel(const WgradArgs p) {
     auto load_g = [&](auto j_) { constexpr int j = decltype(j_)::value; gq[j] = *reinterpret_cast<const f32x4*>(g_ok ? gbase + g_off[j] : p.g); };
     auto store_g = [&](float* buf, auto s_) {
         constexpr int s = decltype(s_)::value, i = s / 4, j = s % 4;
-        buf[g_dst + 16 * i * GPITCH + j] = g_ok ? gq[i][j] : 0.f;
+        buf[g_dst + 16 * i * GPITCH + j] = g_ok ? (BSC ? gq[i][j] * g_sc[i] : gq[i][j]) : 0.f;
     };
     auto load_s = [&](auto j_) {              // j: 0, 1 = float4 of piece j; 2, 3 = halo of piece j - 2
         constexpr int j = decltype(j_)::value, i = j & 1;
@@ -987,10 +1025,20 @@ __global__ __launch_bounds__(256) void wgrad3x3_up_kernel(const WgradArgs p) {
         constexpr int s = decltype(s_)::value;
         if constexpr (s < 8) {
             constexpr int i = s / 4, j = s % 4;
-            sb[s_dst4 + 2 * i * US_PW + j] = s4_out ? sq[i][3] : sq[i][j];     // (the clamped load fetched the image's last vector)
+            if constexpr (BSC) {     // zero border: a source row / vector outside the image contributes nothing
+                const bool in = (unsigned)(s_y0 + rh + 2 * i) < (unsigned)p.Hs && !s4_out;
+                sb[s_dst4 + 2 * i * US_PW + j] = in ? sq[i][j] * s_sc : 0.f;
+            } else {
+                sb[s_dst4 + 2 * i * US_PW + j] = s4_out ? sq[i][3] : sq[i][j];     // (the clamped load fetched the image's last vector)
+            }
         } else {
             constexpr int i = s - 8;
-            sb[s_dsth + 2 * i * US_PW] = sh[i];
+            if constexpr (BSC) {
+                const bool in = (unsigned)(s_y0 + rh + 2 * i) < (unsigned)p.Hs && (unsigned)(s_x0 + (sk ? 8 : -1)) < (unsigned)p.Ws;
+                sb[s_dsth + 2 * i * US_PW] = in ? sh[i] * s_sc : 0.f;
+            } else {
+                sb[s_dsth + 2 * i * US_PW] = sh[i];
+            }
         }
     };
     // plane element e = wave * 27 + i of channel `lane` (a wave owns a quarter of the 108 positions): everything but the
@@ -1211,7 +1259,7 @@ int run_wgrad_wide(const spk_wgrad_desc* d, hipStream_t stream) {
     SPK_REQUIRE(d->workspace && (size_t)d->workspace_bytes >= g.n_slabs * slab_floats * sizeof(float),
                 "wgrad: needs a %zu-byte workspace (see spk_conv2d_wgrad_workspace_bytes)", g.n_slabs * slab_floats * sizeof(float));
     WgradArgs a;
-    a.g = d->g; a.x = d->x; a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.slabs = static_cast<float*>(d->workspace);
+    a.g = d->g; a.x = d->x; a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.g_scale = d->g_scale; a.slabs = static_cast<float*>(d->workspace);
     a.B = d->B; a.Cin = d->Cin; a.Cout = d->Cout; a.H = d->H; a.W = d->W; a.Hs = d->Hin; a.Ws = d->Win;
     a.gin = G > 1 ? d->group_in_stride : d->Cin;
     a.Cx = a.gin * (G - 1) + d->Cin;
@@ -1244,6 +1292,7 @@ inline bool up_takes(const spk_wgrad_desc* d) {
            ((long long)d->group_in_stride * (G - 1) + d->Cin) * d->Hin * d->Win < (1ll << 31);
 }
 
+template <int MODE>
 int run_wgrad_up(const spk_wgrad_desc* d, hipStream_t stream) {
     using SH = WideShape<1, 1>;
     const int G = d->groups > 1 ? d->groups : 1;
@@ -1252,7 +1301,8 @@ int run_wgrad_up(const spk_wgrad_desc* d, hipStream_t stream) {
     SPK_REQUIRE(d->workspace && (size_t)d->workspace_bytes >= g.n_slabs * slab_floats * sizeof(float),
                 "wgrad: needs a %zu-byte workspace (see spk_conv2d_wgrad_workspace_bytes)", g.n_slabs * slab_floats * sizeof(float));
     WgradArgs a;
-    a.g = d->g; a.x = d->x; a.in_scale = nullptr; a.in_shift = nullptr; a.slabs = static_cast<float*>(d->workspace);
+    a.g = d->g; a.x = d->x; a.in_scale = MODE == WG_BATCH_SCALE ? d->in_scale : nullptr; a.in_shift = nullptr;
+    a.g_scale = MODE == WG_BATCH_SCALE ? d->g_scale : nullptr; a.slabs = static_cast<float*>(d->workspace);
     a.B = d->B; a.Cin = d->Cin; a.Cout = d->Cout; a.H = d->H; a.W = d->W; a.Hs = d->Hin; a.Ws = d->Win;
     a.gin = G > 1 ? d->group_in_stride : d->Cin;
     a.Cx = a.gin * (G - 1) + d->Cin;
@@ -1261,12 +1311,12 @@ int run_wgrad_up(const spk_wgrad_desc* d, hipStream_t stream) {
     a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y; a.n_tiles = g.n_tiles;
     static bool raised = false;
     if (!raised) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_up_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad3x3_up_kernel<MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return spk::fail(SPK_ELAUNCH, "hipFuncSetAttribute(LDS): %s", hipGetErrorString(e));
         raised = true;
     }
     dim3 grid((unsigned)spk::ceil_div(G * d->Cout, SH::CO_T), (unsigned)spk::ceil_div(d->Cin, SH::CI_T), (unsigned)g.splits);
-    hipLaunchKernelGGL(wgrad3x3_up_kernel, grid, dim3(256), (2 * SH::BUF + 2 * US_FLOATS) * sizeof(float), stream, a);
+    hipLaunchKernelGGL(wgrad3x3_up_kernel<MODE>, grid, dim3(256), (2 * SH::BUF + 2 * US_FLOATS) * sizeof(float), stream, a);
     int rc = spk::check_launch("wgrad3x3_up_kernel");
     if (rc != SPK_OK) return rc;
     const unsigned blocks = (unsigned)std::min<size_t>((slab_floats + 255) / 256, 2048);
@@ -1307,7 +1357,7 @@ int run_wgrad_s2(const spk_wgrad_desc* d, hipStream_t stream) {
     SPK_REQUIRE(d->workspace && (size_t)d->workspace_bytes >= g.n_slabs * slab_floats * sizeof(float),
                 "wgrad: needs a %zu-byte workspace (see spk_conv2d_wgrad_workspace_bytes)", g.n_slabs * slab_floats * sizeof(float));
     WgradArgs a;
-    a.g = d->g; a.x = d->x; a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.slabs = static_cast<float*>(d->workspace);
+    a.g = d->g; a.x = d->x; a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.g_scale = d->g_scale; a.slabs = static_cast<float*>(d->workspace);
     a.B = d->B; a.Cin = d->Cin; a.Cout = d->Cout; a.H = d->H; a.W = d->W; a.Hs = d->Hin; a.Ws = d->Win;
     a.gin = G > 1 ? d->group_in_stride : d->Cin;
     a.Cx = a.gin * (G - 1) + d->Cin;
@@ -1365,7 +1415,7 @@ int run_wgrad(const spk_wgrad_desc* d, hipStream_t stream) {
     SPK_REQUIRE(d->workspace && (size_t)d->workspace_bytes >= g.n_slabs * slab_floats * sizeof(float),
                 "wgrad: needs a %zu-byte workspace (see spk_conv2d_wgrad_workspace_bytes)", g.n_slabs * slab_floats * sizeof(float));
     WgradArgs a;
-    a.g = d->g; a.x = d->x; a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.slabs = static_cast<float*>(d->workspace);
+    a.g = d->g; a.x = d->x; a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.g_scale = d->g_scale; a.slabs = static_cast<float*>(d->workspace);
     a.B = d->B; a.Cin = d->Cin; a.Cout = d->Cout; a.H = d->H; a.W = d->W; a.Hs = d->Hin; a.Ws = d->Win;
     a.gin = G > 1 ? d->group_in_stride : d->Cin;
     a.Cx = a.gin * (G - 1) + d->Cin;
@@ -1600,7 +1650,7 @@ int run_wgrad1x1_shape(const spk_wgrad_desc* d, hipStream_t stream) {
     SPK_REQUIRE(d->workspace && (size_t)d->workspace_bytes >= g.splits * slab_floats * sizeof(float),
                 "wgrad: needs a %zu-byte workspace (see spk_conv2d_wgrad_workspace_bytes)", g.splits * slab_floats * sizeof(float));
     WgradArgs a;
-    a.g = d->g; a.x = d->x; a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.slabs = static_cast<float*>(d->workspace);
+    a.g = d->g; a.x = d->x; a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.g_scale = d->g_scale; a.slabs = static_cast<float*>(d->workspace);
     a.B = d->B; a.Cin = d->Cin; a.Cout = d->Cout; a.H = d->H; a.W = d->W; a.Hs = d->Hin; a.Ws = d->Win;
     a.gin = G > 1 ? d->group_in_stride : d->Cin;
     a.Cx = a.gin * (G - 1) + d->Cin;
@@ -1647,6 +1697,7 @@ int by_mode(int mode, const spk_wgrad_desc* d, hipStream_t s) {
 }
 
 bool wg_supported(int kh, int kw, int stride) {
+    if (kh == 4 && kw == 4) return stride == 2;
     return kh == kw && (kh == 1 || kh == 3 || kh == 7) && (stride == 1 || stride == 2) && !(kh == 7 && stride == 1);
 }
 
@@ -1674,6 +1725,7 @@ int64_t spk_conv2d_wgrad_workspace_bytes(int kh, int kw, int stride, int splits,
         return std::max(tap, gemm);
     }
     else if (kh == 3) g = stride == 1 ? wgeom<3, 3, 1>(B, Cin, Cout, H, W, splits) : wgeom<3, 3, 2>(B, Cin, Cout, H, W, splits);
+    else if (kh == 4) g = wgeom<4, 4, 2>(B, Cin, Cout, H, W, splits);
     else g = wgeom<7, 7, 2>(B, Cin, Cout, H, W, splits);
     int n_slabs = g.n_slabs;
     if (kh == 3 && stride == 1) {     // the 16-byte-load form may take the problem
@@ -1694,13 +1746,21 @@ int spk_conv2d_wgrad_up_supported(int B, int Cin, int Cout, int H, int W) {
             (long long)Cin * H * W / 4 < (1ll << 31)) ? 1 : 0;
 }
 
+int spk_conv2d_wgrad_mod_supported(int B, int Cin, int Cout, int H, int W, int upsample) {
+    // shapes (OUTPUT size H x W) whose modulated weight gradient runs fused (SPK_CONV_IN_BATCH_SCALE); 16-byte aligned tensors
+    // are a further, per-call condition.  Everything else: rescale the operands first (tiny layers only: 4^2).
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || (long long)Cout * H * W >= (1ll << 31) || (long long)Cin * H * W >= (1ll << 31)) return 0;
+    if (upsample) return (W >= 16 && W % 8 == 0 && H >= 4 && H % 2 == 0) ? 1 : 0;
+    return (W >= 8 && W % 4 == 0 && H >= 4) ? 1 : 0;
+}
+
 int spk_conv2d_wgrad(const spk_wgrad_desc* d, void* stream) {
     SPK_REQUIRE(d && d->g && d->x && d->dw, "wgrad: null pointer");
     SPK_REQUIRE(d->B > 0 && d->Cin > 0 && d->Cout > 0 && d->H > 0 && d->W > 0 && d->Hin > 0 && d->Win > 0, "wgrad: bad shape");
     SPK_REQUIRE(wg_supported(d->kh, d->kw, d->stride), "wgrad: unsupported kernel %dx%d stride %d", d->kh, d->kw, d->stride);
     SPK_REQUIRE(d->fold <= 1 || (d->groups > 1 && d->groups % d->fold == 0), "wgrad: fold %d must divide groups %d", d->fold, d->groups);
-    const bool ups = d->flags & SPK_CONV_UPSAMPLE2X, aff = d->flags & SPK_CONV_IN_AFFINE_RELU;
-    SPK_REQUIRE(!(ups && aff), "wgrad: UPSAMPLE2X and IN_AFFINE_RELU are exclusive");
+    const bool ups = d->flags & SPK_CONV_UPSAMPLE2X, aff = d->flags & SPK_CONV_IN_AFFINE_RELU, bsc = d->flags & SPK_CONV_IN_BATCH_SCALE;
+    SPK_REQUIRE(!(ups && aff) && !(bsc && aff), "wgrad: IN_AFFINE_RELU excludes UPSAMPLE2X and IN_BATCH_SCALE");
     SPK_REQUIRE(!ups || (d->kh == 3 && d->stride == 1), "wgrad: UPSAMPLE2X needs a 3x3 stride-1 kernel");
     SPK_REQUIRE(!aff || (d->in_scale && d->in_shift), "wgrad: IN_AFFINE_RELU without in_scale/in_shift");
     const int pad = (d->kh - 1) / 2;
@@ -1712,8 +1772,21 @@ int spk_conv2d_wgrad(const spk_wgrad_desc* d, void* stream) {
     // SPK_CONV_UPSAMPLE2X: x is the low-resolution tensor; the x2 plane is interpolated LDS -> LDS from a source patch
     // (wgrad3x3_up_kernel).  Shapes it does not take (W % 8 != 0, planes under 16 x 4): callers upsample with
     // spk_upsample2x_bilinear_fwd first -- spk_conv2d_wgrad_up_supported tells which.
+    if (bsc) {
+        // the modulated convolution's weight gradient (StyleGAN2 variant): x * s[b,ci] and g * d'[b,co] formed while staging
+        SPK_REQUIRE(d->in_scale && d->g_scale, "wgrad: IN_BATCH_SCALE needs in_scale = s[B,Cin] and g_scale = d'[B,Cout]");
+        SPK_REQUIRE(d->kh == 3 && d->stride == 1 && d->groups <= 1, "wgrad: IN_BATCH_SCALE is built for ungrouped 3x3 stride-1 convs");
+        SPK_REQUIRE(!ups || (d->flags & SPK_CONV_UP_FIR1331), "wgrad: IN_BATCH_SCALE with UPSAMPLE2X is the upfirdn2d [1,3,3,1] form (SPK_CONV_UP_FIR1331)");
+        if (ups) {
+            if (up_takes(d)) return run_wgrad_up<WG_BATCH_SCALE>(d, s);
+        } else if (wide_takes(d)) {
+            return run_wgrad_wide_any<WG_BATCH_SCALE>(d, s);
+        }
+        return spk::fail(SPK_EUNSUPPORTED, "wgrad: IN_BATCH_SCALE does not take this shape (spk_conv2d_wgrad_mod_supported): pass rescaled tensors");
+    }
+    SPK_REQUIRE(!(d->flags & SPK_CONV_UP_FIR1331), "wgrad: UP_FIR1331 goes with IN_BATCH_SCALE");
     if (ups) {
-        if (up_takes(d)) return run_wgrad_up(d, s);
+        if (up_takes(d)) return run_wgrad_up<WG_PLAIN>(d, s);
         return spk::fail(SPK_EUNSUPPORTED, "wgrad: SPK_CONV_UPSAMPLE2X does not take this shape: pass the upsampled input (spk_upsample2x_bilinear_fwd)");
     }
     if (d->kh == 1 && g1_takes(d->groups, d->Cout, d->H, d->W)) {
@@ -1722,6 +1795,10 @@ int spk_conv2d_wgrad(const spk_wgrad_desc* d, void* stream) {
     }
     if (d->kh == 1) return d->stride == 1 ? by_mode<1, 1, 1>(mode, d, s) : by_mode<1, 1, 2>(mode, d, s);
     if (d->kh == 3) return d->stride == 1 ? by_mode<3, 3, 1>(mode, d, s) : by_mode<3, 3, 2>(mode, d, s);
+    if (d->kh == 4) {
+        SPK_REQUIRE(!aff, "wgrad: the 4x4 stride-2 form takes a plain input");
+        return run_wgrad<4, 4, 2, WG_PLAIN>(d, s);
+    }
     return by_mode<7, 7, 2>(mode, d, s);
 }
 

@@ -2,7 +2,8 @@
 ``Blur2d``, ``Upscale2d``, ``PixelNorm``, ``InstanceNorm`` -- same constructors and forward signatures, on
 the HIP kernels, forward and backward (``autograd.Blur2dFn`` / ``Upscale2dFn`` / ``PixelNormFn`` /
 ``InstanceNormAffineFn``) -- and ``FusedUpscale``, the ``nn.ConvTranspose2d(4, stride=2, padding=1)`` that
-``GBlock`` uses as its upsampler from 128^2 on (styleganv1.py:231,258), forward on the MFMA parity kernels.
+``GBlock`` uses as its upsampler from 128^2 on (styleganv1.py:231,258), forward on the MFMA parity kernels, backward on
+the 4x4 stride-2 conv / weight-gradient kernels (``autograd.FusedUpscaleFn``).
 (The ``G_synthesis`` graph itself is dead code in the reference -- nothing instantiates it
 and its constructor needs a CUDA device -- and is not rebuilt)"""
 from __future__ import annotations
@@ -68,13 +69,12 @@ class InstanceNorm(nn.Module):
 class FusedUpscale(nn.ConvTranspose2d):
     """``GBlock.up_sample`` for res >= 7 (styleganv1.py:231: ``nn.ConvTranspose2d(nf(res-3), nf(res-2), 4, stride=2,
     padding=1)``): same parameters and ``state_dict`` keys (``weight`` [Cin,Cout,4,4], ``bias``); the forward runs as four
-    output-parity 2x2 MFMA kernels in one launch (include/spk.h, SPK_CONV_TRANSPOSE4X4_S2).  Inference only."""
+    output-parity 2x2 MFMA kernels in one launch (include/spk.h, SPK_CONV_TRANSPOSE4X4_S2); the backward
+    (``autograd.FusedUpscaleFn``) on the 4x4 stride-2 conv / weight-gradient kernels."""
 
     def __init__(self, in_channels, out_channels):
         super().__init__(in_channels, out_channels, 4, stride=2, padding=1)
         self._pk = ops.PackedConvWeight()
 
     def forward(self, x):
-        if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
-            raise NotImplementedError("FusedUpscale: forward only (the legacy G_synthesis graph is never trained in the reference)")
-        return ops.conv_transpose4x4_s2(x.contiguous(), self.weight, self.bias, self._pk)
+        return AG.fused_upscale(x.contiguous(), self.weight, self.bias, self._pk)

@@ -451,15 +451,28 @@ def upsample2x_bilinear(x):
 
 
 # ---- backward launchers ------------------------------------------------------------------------------
+def wgrad_mod_supported(B, Cin, Cout, H, W, upsample) -> bool:
+    """Whether ``conv2d_wgrad(..., batch_scale=, g_scale=)`` runs fused for this OUTPUT shape (H, W)."""
+    return bool(L.lib().spk_conv2d_wgrad_mod_supported(B, Cin, Cout, H, W, 1 if upsample else 0))
+
+
 def conv2d_wgrad(g, x, Cout, Cin, k=3, stride=1, *, upsample=False, in_affine=None, scale=1.0, out=None,
-                 accumulate=False, splits=0, groups=1, shared_input=False, fold=1):
+                 accumulate=False, splits=0, groups=1, shared_input=False, fold=1, batch_scale=None, g_scale=None, up_fir=False):
     """dW[Cout,Cin,k,k] = scale * sum_{b,h,w} g[b,co,h,w] * in(x)[b,ci,h*s+ky-p,w*s+kx-p].
+    ``batch_scale`` [B,Cin] + ``g_scale`` [B,Cout]: the modulated convolution (StyleGAN2 variant) -- in(x) = x * batch_scale
+    and g is multiplied by g_scale, both while staging (no rescaled tensor); with ``upsample`` (and ``up_fir``) x is the
+    low-resolution tensor and the x2 image is upfirdn2d(up=2, [1,3,3,1]).  Shapes: ``wgrad_mod_supported``.
     ``groups`` > 1: Cout / Cin per group, g has groups*Cout channels, the result is [groups*Cout, Cin, k, k].
     ``fold`` > 1: groups q and q + groups/fold share their weights (the same conv on another image set): their
     gradients are summed in the slab reduce and the result is [groups/fold*Cout, Cin, k, k]."""
     B, _, H, W = g.shape
-    if upsample and (int(groups) > 1 or not L.lib().spk_conv2d_wgrad_up_supported(B, Cin, int(groups) * Cout, H, W)
-                     or x.data_ptr() % 16 or g.data_ptr() % 16):
+    if batch_scale is not None:
+        if g_scale is None or in_affine is not None or int(groups) > 1 or (upsample and not up_fir):
+            raise L.SpkError("conv2d_wgrad: batch_scale goes with g_scale, ungrouped, no in_affine, and up_fir when upsampling")
+        if tuple(batch_scale.shape) != (B, Cin) or tuple(g_scale.shape) != (B, Cout):
+            raise L.SpkError("conv2d_wgrad: batch_scale must be [B,Cin] and g_scale [B,Cout]")
+    elif upsample and (int(groups) > 1 or not L.lib().spk_conv2d_wgrad_up_supported(B, Cin, int(groups) * Cout, H, W)
+                       or x.data_ptr() % 16 or g.data_ptr() % 16):
         # small or odd planes: materialise the x2 image once and run the plain kernel.  Everything else (W % 8 == 0, at least
         # 16 x 4) interpolates the plane LDS -> LDS from a low-resolution source patch inside the kernel: no x2 tensor in HBM.
         x, upsample = upsample2x_bilinear(x), False
@@ -474,14 +487,15 @@ def conv2d_wgrad(g, x, Cout, Cin, k=3, stride=1, *, upsample=False, in_affine=No
     if ws_bytes < 0:
         raise L.SpkError("conv2d_wgrad: unsupported problem")
     ws = _workspace(g.device, ws_bytes)
-    flags = (L.CONV_UPSAMPLE2X if upsample else 0) | (L.CONV_IN_AFFINE_RELU if in_affine is not None else 0)
+    flags = (L.CONV_UPSAMPLE2X if upsample else 0) | (L.CONV_IN_AFFINE_RELU if in_affine is not None else 0) | \
+        (L.CONV_IN_BATCH_SCALE if batch_scale is not None else 0) | (L.CONV_UP_FIR1331 if (upsample and up_fir) else 0)
     d = L.WgradDesc(g=L.dptr(g, "g"), x=L.dptr(x, "x"),
-                    in_scale=L.dptr(in_affine[0], "in_scale") if in_affine is not None else None,
+                    in_scale=(L.dptr(in_affine[0], "in_scale") if in_affine is not None else L.dptr(batch_scale, "batch_scale")),
                     in_shift=L.dptr(in_affine[1], "in_shift") if in_affine is not None else None,
                     dw=L.dptr(out, "dw"), B=B, Cin=Cin, Cout=Cout, H=H, W=W, Hin=Hs, Win=Ws, kh=k, kw=k, stride=stride,
                     flags=flags, scale=float(scale), accumulate=1 if accumulate else 0, splits=int(splits),
                     workspace=ws.data_ptr(), workspace_bytes=ws.numel() * 4, groups=G,
-                    group_in_stride=0 if (shared_input or G == 1) else Cin, fold=fold)
+                    group_in_stride=0 if (shared_input or G == 1) else Cin, fold=fold, g_scale=L.dptr(g_scale, "g_scale"))
     L.check(L.lib().spk_conv2d_wgrad(C.byref(d), L.stream_ptr()), "spk_conv2d_wgrad")
     return out
 
@@ -606,6 +620,46 @@ def modconv_demod_grouped(items, eps=1e-8):
     L.check(L.lib().spk_modconv_demod_grouped(C.cast(groups, C.c_void_p), len(items), B, float(eps), L.stream_ptr()),
             "spk_modconv_demod_grouped")
     return outs
+
+
+def modconv_dx_finish(dxt, x, s, upsample, need_dx=True):
+    """The tail of the modulated conv's data path: (dx = s * up^T(dxt) | None, ds[b,ci] = <up^T(dxt), x>) -- the adjoint of
+    upfirdn2d(up=2, [1,3,3,1]) when ``upsample`` (dxt is then at twice x's resolution), identity otherwise."""
+    B, Cc, Hs, Ws = x.shape
+    if tuple(dxt.shape) != ((B, Cc, 2 * Hs, 2 * Ws) if upsample else (B, Cc, Hs, Ws)):
+        raise L.SpkError(f"modconv_dx_finish: gradient {tuple(dxt.shape)} does not match input {tuple(x.shape)} (upsample={upsample})")
+    ds = torch.empty((B, Cc), device=x.device, dtype=torch.float32)
+    dx = (torch.empty_like(x) if upsample else dxt) if need_dx else None      # same resolution: scaled in place
+    L.check(L.lib().spk_modconv_dx_finish(L.dptr(dxt, "dxt"), L.dptr(x, "x"), L.dptr(s, "s"), L.dptr(dx), L.dptr(ds), B, Cc, Hs, Ws,
+                                          1 if upsample else 0, L.stream_ptr()), "spk_modconv_dx_finish")
+    return dx, ds
+
+
+def modconv_demod_bwd(weight, s, d, dd, scale, ds=None, dw=None):
+    """Adjoint of ``modconv_demod``: accumulates into ``ds`` [B,Cin] and / or ``dw`` [Cout,Cin,k,k] (in place)."""
+    Cout, Cin, kh, kw = weight.shape
+    B = s.shape[0]
+    L.check(L.lib().spk_modconv_demod_bwd(L.dptr(weight, "weight"), L.dptr(s, "s"), L.dptr(d, "d"), L.dptr(dd, "dd"), L.dptr(ds),
+                                          L.dptr(dw), B, Cin, Cout, kh * kw, float(scale), L.stream_ptr()), "spk_modconv_demod_bwd")
+
+
+def torgb_mod_bwd(x, weight, mod, dy, in_scale=1.0, need_dx=True):
+    """Backward of the modulated toRGB (``conv1x1_small_mod``) -> (dx | None, P [B,O,C] = in_scale * sum_p dy[b,o,p] x[b,c,p],
+    db [O]): the weight gradient is sum_b mod[b,c] P[b,o,c], the modulation gradient sum_o w[o,c] P[b,o,c]."""
+    B, Cc, H, W = x.shape
+    O = weight.shape[0]
+    w2 = weight.reshape(O, Cc)
+    dx = None
+    if need_dx:
+        dx = torch.empty_like(x)
+        L.check(L.lib().spk_torgb_mod_bwd_data(L.dptr(w2, "weight"), L.dptr(mod, "mod"), L.dptr(dy, "dy"), L.dptr(dx), B, Cc, O, H * W,
+                                               float(in_scale), L.stream_ptr()), "spk_torgb_mod_bwd_data")
+    nblk = L.lib().spk_conv1x1_small_bwd_blocks(B, H * W)
+    partial = torch.empty((nblk, O * Cc + O), device=x.device, dtype=torch.float32)
+    L.check(L.lib().spk_conv1x1_small_bwd(L.dptr(x, "x"), L.dptr(w2, "weight"), L.dptr(dy, "dy"), None, L.dptr(partial), B, Cc, O,
+                                          H * W, float(in_scale), L.stream_ptr()), "spk_conv1x1_small_bwd")
+    per = partial.view(B, nblk // B, O * Cc + O).sum(1)            # blocks are laid out image by image
+    return dx, per[:, :O * Cc].reshape(B, O, Cc), per[:, O * Cc:].sum(0)
 
 
 def upfirdn2d(x, filt2d, up=1, down=1, pad=(0, 0), gain=1.0):

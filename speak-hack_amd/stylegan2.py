@@ -4,7 +4,8 @@ The reference has no StyleGAN2 code; module layout and formulas 
 StyleGAN2 / the common stylegan2-pytorch naming, with the reference decoder's channel schedule and I/O
 signature ([B,6144] latent -> [B,3,256,256]) so it can stand in for ``IRFD.Gd``.  Forward and backward
 (``autograd.ModConvFn`` / ``ModToRGBFn`` / ``UpFirDnFn``): the data gradient of a modulated conv is the same modulated MFMA
-conv with the roles of s and d swapped; d's dependence on (w, s) is a [B,Cout] torch expression in training mode.
+conv with the roles of s and d swapped, the weight gradient the MFMA wgrad kernel with both factors applied while staging, the
+demodulation and its adjoint small kernels of their own -- no rescaled activation and no ATen GEMM in a training step.
 
 How the modulated conv maps to the MI355X kernel: StyleGAN2's per-sample weight
 ``w'' = w * s[b,ci] * d[b,co]`` is never formed.  ``s`` multiplies the *input* while it is staged into LDS
@@ -80,16 +81,18 @@ class ModulatedConv2d(nn.Module):
                                  None if skip is None else skip.contiguous(), _UP_FIR)
         if self.kernel_size != 3:
             raise NotImplementedError("ModulatedConv2d: 3x3 (styled convs) and 1x1 toRGB are on the HIP path")
-        if self.demodulate and d is None:
-            if torch.is_grad_enabled() and (s.requires_grad or self.weight.requires_grad):
-                # training: d as a differentiable [B,Cout] expression of (w, s) -- a [B,Cin] x [Cin,Cout] product
-                w2 = self.weight.pow(2).sum((2, 3))
-                d = torch.rsqrt((self.scale ** 2) * (s.pow(2) @ w2.t()) + 1e-8)
-            else:
-                d = ops.modconv_demod(self.weight, s, self.scale)
-        # upfirdn2d(up=2, [1,3,3,1]) is folded into the conv's input staging: no 4x tensor in HBM
-        return AG.mod_conv(x.contiguous(), self.weight, s.contiguous(), d, bias, noise_w, noise, self.scale, upsample, lrelu,
-                           act_gain, _UP_FIR, self._pk)
+        if d is not None:        # a demodulation vector computed elsewhere (the grouped launch of the inference path)
+            B, Cin, Hs, Ws = x.shape
+            H, W = (2 * Hs, 2 * Ws) if upsample else (Hs, Ws)
+            cfg = ops.conv2d_pick_config(3, 1, B, Cin, self.out_channel, H, W)
+            cfg = cfg + 4 if cfg < 4 else cfg
+            return ops.conv2d_fused(x.contiguous(), self._pk.get(self.weight, cfg), self.out_channel, 3, 1, bias=bias, noise_w=noise_w,
+                                    noise=noise, lrelu_slope=lrelu, out_scale=self.scale, batch_scale=s.contiguous(), demod=d,
+                                    act_gain=act_gain, config=cfg, upsample=upsample, up_fir=True)
+        # upfirdn2d(up=2, [1,3,3,1]) is folded into the conv's input staging: no 4x tensor in HBM; the demodulation vector and
+        # its adjoint are kernels inside the Function (spk_modconv_demod / spk_modconv_demod_bwd)
+        return AG.mod_conv(x.contiguous(), self.weight, s.contiguous(), bias, noise_w, noise, self.scale, upsample, lrelu,
+                           act_gain, _UP_FIR, self._pk, demodulate=self.demodulate)
 
 
 _UP_FIR = make_kernel((1, 3, 3, 1)) * 4.0        # host copy of the x2 FIR (gain up^2), for the backward's materialised passes

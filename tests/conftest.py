@@ -42,7 +42,7 @@ def rel_l2(a, b):
     return float((a - b).norm() / b.norm().clamp_min(1e-30))
 
 
-def grad_close(got, ref32, ref64, pixels=None):
+def grad_close(got, ref32, ref64, pixels=None, noise_floor=0.0):
     """Mask-flip-aware gradient criterion for deep ReLU / LeakyReLU nets; both parts are against the fp64 evaluation of
     the reference.
 
@@ -61,12 +61,20 @@ def grad_close(got, ref32, ref64, pixels=None):
           flip allowance, the round-1 form).  The fixed 1e-4 of round 1 sat AT that footprint for the 32^2..64^2 test nets
           (1 / (2 * 64 * 64) = 1.2e-4) and tripped on any change of summation order.
 
+    ``noise_floor`` (optional): a p90 / rms level established over a whole sub-network (see ``grad_stats`` and
+    tests/test_irfd_gpu.py) that is allowed 4x like the parameter's own fp32 error.
+
     Returns (ok, (err, err_ref32, p90/rms))."""
+    e_got, e_ref, r_got, r_ref = grad_stats(got, ref32, ref64)
+    bound = max(1e-4, 4 * r_ref, 4 * noise_floor, (8.0 / pixels) if pixels else 0.0)
+    return e_got <= max(5e-3, 3 * e_ref) and r_got <= bound, (e_got, e_ref, r_got)
+
+
+def grad_stats(got, ref32, ref64):
+    """(rel-L2 of got, rel-L2 of ref32, p90|got - ref64| / rms, p90|ref32 - ref64| / rms), all against ``ref64``."""
     import torch
     got, ref32, ref64 = (t.detach().cpu().double() for t in (got, ref32, ref64))
-    e_got, e_ref = rel_l2(got, ref64), rel_l2(ref32, ref64)
-    rms = float(ref64.pow(2).mean().sqrt())
+    rms = max(float(ref64.pow(2).mean().sqrt()), 1e-300)
     p90 = float(torch.quantile((got - ref64).abs().flatten()[:4_000_000], 0.9))
     p90_ref = float(torch.quantile((ref32 - ref64).abs().flatten()[:4_000_000], 0.9))
-    bound = max(1e-4 * rms, 4 * p90_ref, (8.0 / pixels) * rms if pixels else 0.0)
-    return e_got <= max(5e-3, 3 * e_ref) and p90 <= bound, (e_got, e_ref, p90 / max(rms, 1e-300))
+    return rel_l2(got, ref64), rel_l2(ref32, ref64), p90 / rms, p90_ref / rms

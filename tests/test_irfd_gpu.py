@@ -6,7 +6,7 @@ import pytest
 import torch
 import torch.nn.functional as F
 
-from conftest import rel_l2
+from conftest import grad_close, grad_stats, rel_l2
 from oracle import irfd_ref as IR
 from oracle.weights_recipe import fill_state_dict, recipe_input, recipe_noises
 
@@ -95,40 +95,111 @@ def test_irfd_forward_train_mode_host_rng_and_running_stats(irfd_and_sd, dev):
     m.load_state_dict({k: v for k, v in sd.items()}, strict=False)      # restore for other tests
 
 
-def test_irfd_generator_step_gradients_vs_oracle(irfd_and_sd, dev):
-    """A10: IRFD.forward with grad + backward of the reconstruction loss, through the decoder AND the three
-    checkpointed encoders (eval-mode BatchNorm here so that the comparison is not dominated by batch-statistics
-    noise at B=1; train-mode BatchNorm backward is covered by test_encoder_backward_gpu.py)."""
-    m, sd = irfd_and_sd
-    m.load_state_dict({k: v for k, v in sd.items()}, strict=False)
-    m.eval()
+def _oracle_step(sd, x_s, x_t, ns, nt, dtype, training, sc=None):
+    """The reconstruction-loss G step on the CPU oracle in ``dtype`` -> (loss, {name: gradient}, scale)."""
+    sd_ref = {k: (v.to(dtype).clone().requires_grad_(True) if v.is_floating_point() and "running" not in k
+                  else (v.to(dtype) if v.is_floating_point() else v.clone())) for k, v in sd.items()}
+    ref = IR.irfd_forward(x_s.to(dtype), x_t.to(dtype), sd_ref, 1, [n.to(dtype) for n in ns], [n.to(dtype) for n in nt],
+                          training=training)
+    if sc is None:      # recipe weights make the frames huge; a constant rescale keeps the squared error inside fp32 range
+        sc = 1.0 / max(float(ref[0].detach().abs().max()), float(ref[1].detach().abs().max()))
+    loss = ((ref[0] * sc - x_s.to(dtype)) ** 2).mean() + ((ref[1] * sc - x_t.to(dtype)) ** 2).mean()
+    loss.backward()
+    return float(loss.detach()), {k: v.grad for k, v in sd_ref.items() if getattr(v, "grad", None) is not None}, sc
+
+
+def _hip_step(m, dev, x_s, x_t, ns, nt, sc):
     for p in m.D.parameters():
         p.requires_grad_(False)
     m.zero_grad(set_to_none=True)
+    try:
+        out = m(x_s.to(dev), x_t.to(dev), swap_type=1, noises_s=[n.to(dev) for n in ns], noises_t=[n.to(dev) for n in nt])
+        loss = ((out[0] * sc - x_s.to(dev)) ** 2).mean() + ((out[1] * sc - x_t.to(dev)) ** 2).mean()
+        loss.backward()
+    finally:
+        for p in m.D.parameters():
+            p.requires_grad_(True)
+    got = {k: p.grad for k, p in m.named_parameters() if not k.startswith("D.")}
+    missing = [k for k, g in got.items() if g is None and not k.startswith("Cm.")]
+    assert not missing, missing[:5]            # every encoder and decoder parameter received a gradient
+    return float(loss.detach()), {k: g for k, g in got.items() if g is not None}
+
+
+GROUPS = ("Ei.", "Ee.", "Ep.", "Gd.mapping.", "Gd.synthesis.")
+
+
+def _check_all_gradients(got, ref32, ref64, pixels, what):
+    """EVERY parameter through conftest.grad_close against the fp64 oracle (this test held nine hand-picked
+    parameters to a flat 2e-2).
+
+    One refinement of the criterion for a WHOLE network: every encoder / mapping parameter sits upstream of the decoder's
+    LeakyReLUs and of its own trunk's ReLUs, so a mask that flips anywhere downstream shifts ALL of its elements, not a
+    receptive field -- and which parameter's own fp32 reference evaluation caught a flip is luck (measured, B = 1: the
+    oracle's fp32 error on ``Ee.6.2.bn3.bias`` is 3.2e-4, on ``Ee.6.3.bn2.bias`` 1.8e-5; the HIP path's 3.7e-4 and 3.6e-4).
+    The yardstick for "the reference's own fp32 noise" is therefore taken per sub-network (the 90th percentile over its
+    parameters of p90|ref32 - ref64| / rms) in addition to the parameter's own; the HIP path may be 4x that, as everywhere."""
+    assert set(got) == set(ref64), sorted(set(got) ^ set(ref64))[:5]
+    stats = {k: grad_stats(got[k], ref32[k], ref64[k]) for k in got if float(ref64[k].abs().max()) > 0.0}
+    floor = {}
+    for gname in GROUPS:
+        r = sorted(v[3] for k, v in stats.items() if k.startswith(gname))
+        floor[gname] = r[int(0.9 * (len(r) - 1))] if r else 0.0
+    bad, worst = [], 0.0
+    for k in sorted(got):
+        if k not in stats:
+            assert float(got[k].abs().max()) == 0.0, k
+            continue
+        nf = next((floor[gname] for gname in GROUPS if k.startswith(gname)), 0.0)
+        ok, (e, e32, p90) = grad_close(got[k], ref32[k], ref64[k], pixels=pixels, noise_floor=nf)
+        worst = max(worst, e)
+        if not ok:
+            bad.append((k, e, e32, p90, nf))
+    print(f"{what}: {len(stats)} parameters, worst rel-L2 {worst:.2e}, sub-network fp32 noise floors "
+          + ", ".join(f"{g}{v:.1e}" for g, v in floor.items()))
+    assert not bad, (what, len(bad), len(got), bad[:8])
+    return worst
+
+
+def test_irfd_generator_step_gradients_vs_oracle(irfd_and_sd, dev):
+    """A10: IRFD.forward with grad + backward of the reconstruction loss, through the decoder AND the three checkpointed
+    encoders, eval-mode BatchNorm, B=1.  All 562 parameters against the oracle evaluated in fp64, by the criterion the
+    other gradient tests use (the oracle's own fp32 evaluation is the yardstick for mask-flip noise)."""
+    m, sd = irfd_and_sd
+    m.load_state_dict({k: v for k, v in sd.items()}, strict=False)
+    m.eval()
     B = 1
     x_s = recipe_input("irfd.g.x_s", (B, 3, 256, 256), "uniform")
     x_t = recipe_input("irfd.g.x_t", (B, 3, 256, 256), "uniform")
     ns, nt = recipe_noises("irfd.g.s", B, 256), recipe_noises("irfd.g.t", B, 256)
-    sd_ref = {k: (v.clone().requires_grad_(True) if v.is_floating_point() and "running" not in k else v.clone())
-              for k, v in sd.items()}
-    ref = IR.irfd_forward(x_s, x_t, sd_ref, 1, ns, nt)
-    # recipe weights make the frames huge; a constant rescale keeps the squared error inside fp32 range
-    sc = 1.0 / max(float(ref[0].detach().abs().max()), float(ref[1].detach().abs().max()))
-    loss_ref = ((ref[0] * sc - x_s) ** 2).mean() + ((ref[1] * sc - x_t) ** 2).mean()
-    loss_ref.backward()
-    out = m(x_s.to(dev), x_t.to(dev), swap_type=1, noises_s=[n.to(dev) for n in ns], noises_t=[n.to(dev) for n in nt])
-    loss = ((out[0] * sc - x_s.to(dev)) ** 2).mean() + ((out[1] * sc - x_t.to(dev)) ** 2).mean()
-    loss.backward()
-    assert abs(loss.item() / loss_ref.item() - 1) < 1e-3
-    got = dict(m.named_parameters())
-    missing = [k for k, p in got.items() if p.requires_grad and p.grad is None and not k.startswith("Cm.")]
-    assert not missing, missing[:5]            # every encoder and decoder parameter received a gradient
-    for k in ("Gd.synthesis.to_rgb.weight", "Gd.synthesis.layers.5.conv2.weight", "Gd.synthesis.layers.0.conv1.weight",
-              "Gd.mapping.0.weight", "Ei.7.2.conv3.weight", "Ee.7.2.bn3.weight", "Ep.7.0.downsample.0.weight",
-              "Ei.4.0.conv1.weight", "Ee.0.weight"):
-        assert rel_l2(got[k].grad, sd_ref[k].grad) < 2e-2, k      # deep ReLU nets: mask-flip noise (see backward tests)
-    for p in m.D.parameters():
-        p.requires_grad_(True)
+    loss64, ref64, sc = _oracle_step(sd, x_s, x_t, ns, nt, torch.float64, training=False)
+    loss32, ref32, _ = _oracle_step(sd, x_s, x_t, ns, nt, torch.float32, training=False, sc=sc)
+    loss, got = _hip_step(m, dev, x_s, x_t, ns, nt, sc)
+    assert abs(loss / loss64 - 1) < 1e-4 and abs(loss32 / loss64 - 1) < 1e-4
+    _check_all_gradients(got, ref32, ref64, B * 256 * 256, "eval B=1")
+
+
+def test_irfd_train_mode_gradients_vs_oracle(irfd_and_sd, dev):
+    """The same step in TRAIN mode at B=2: BatchNorm batch statistics in forward and backward through all three trunks at
+    once (the grouped 6-way launches), train-mode decoder (style mixing off: its device draw is covered by the decoder
+    goldens).  All parameters against the fp64 oracle; running statistics restored afterwards."""
+    m, sd = irfd_and_sd
+    m.load_state_dict({k: v for k, v in sd.items()}, strict=False)
+    m.train()
+    prob, m.Gd.style_mixing_prob = m.Gd.style_mixing_prob, 0.0
+    B = 2
+    x_s = recipe_input("irfd.gt.x_s", (B, 3, 256, 256), "uniform")
+    x_t = recipe_input("irfd.gt.x_t", (B, 3, 256, 256), "uniform")
+    ns, nt = recipe_noises("irfd.gt.s", B, 256), recipe_noises("irfd.gt.t", B, 256)
+    try:
+        loss64, ref64, sc = _oracle_step(sd, x_s, x_t, ns, nt, torch.float64, training=True)
+        loss32, ref32, _ = _oracle_step(sd, x_s, x_t, ns, nt, torch.float32, training=True, sc=sc)
+        loss, got = _hip_step(m, dev, x_s, x_t, ns, nt, sc)
+    finally:
+        m.Gd.style_mixing_prob = prob
+        m.load_state_dict({k: v for k, v in sd.items()}, strict=False)
+        m.eval()
+    assert abs(loss / loss64 - 1) < 1e-4 and abs(loss32 / loss64 - 1) < 1e-4
+    _check_all_gradients(got, ref32, ref64, B * 256 * 256, "train B=2")
 
 
 def test_discriminator_forward_vs_torch_reference(dev):

@@ -193,6 +193,13 @@ def test_fused_upscale(golden):
     w = recipe_tensor("legacy.fused_upscale.weight", (512, 256, 4, 4), 1.0) * (512 * 4) ** -0.5
     b = recipe_tensor("legacy.fused_upscale.bias", (256,), 0.5)
     assert rel_l2(LG.fused_upscale(T(g["x"]), w, b), g["y"]) < TOL
+    # round 3: the reference module's own backward (gx, gb in full, gw sampled + its norm)
+    from oracle.weights_recipe import recipe_input
+    x = T(g["x"]).clone().requires_grad_(True)
+    w, b = w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    LG.fused_upscale(x, w, b).backward(recipe_input("legacy.fused_upscale.gy", tuple(g["y"].shape)))
+    assert rel_l2(x.grad, g["gx"]) < TOL and rel_l2(b.grad, g["gb"]) < TOL
+    assert rel_l2(w.grad[::8, ::4], g["gw_sample"]) < TOL and abs(float(w.grad.double().norm()) / float(g["gw_norm"]) - 1) < 1e-5
 
 
 def test_flop_accounting_matches_survey():

@@ -122,6 +122,46 @@ def test_fused_upscale_vs_reference_golden(dev, golden):
     assert rel_l2(y, g["y"]) < 2e-5
 
 
+def test_fused_upscale_backward_vs_reference_golden(dev, golden):
+    """F3 backward (VERDICT r2 missing 4): gradients of the reference's own ``GBlock.up_sample`` (styleganv1.py:231) -- gx and
+    gb in full, gw on the sampled channels + its norm -- through ``autograd.FusedUpscaleFn``."""
+    from oracle.weights_recipe import recipe_tensor
+    g = golden("legacy_fused_upscale.npz")
+    lg = importlib.import_module("speak-hack_amd.legacy")
+    m = lg.FusedUpscale(512, 256)
+    with torch.no_grad():
+        m.weight.copy_(recipe_tensor("legacy.fused_upscale.weight", (512, 256, 4, 4), 1.0) * (512 * 4) ** -0.5)
+        m.bias.copy_(recipe_tensor("legacy.fused_upscale.bias", (256,), 0.5))
+    m.to(dev)
+    x = T(g["x"]).to(dev).requires_grad_(True)
+    y = m(x)
+    assert rel_l2(y, g["y"]) < 2e-5
+    y.backward(recipe_input("legacy.fused_upscale.gy", tuple(g["y"].shape)).to(dev))
+    assert rel_l2(x.grad, g["gx"]) < 2e-5 and rel_l2(m.bias.grad, g["gb"]) < 2e-5
+    assert rel_l2(m.weight.grad[::8, ::4], g["gw_sample"]) < 2e-5
+    assert abs(float(m.weight.grad.double().norm()) / float(g["gw_norm"]) - 1) < 1e-5
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,bias", [(1, 3, 5, 4, 4, True), (2, 20, 33, 7, 9, False), (3, 64, 32, 16, 16, True),
+                                                  (1, 130, 70, 33, 5, True), (8, 128, 64, 32, 32, False)])
+def test_fused_upscale_backward_ragged_shapes_vs_oracle(dev, B, Cin, Cout, H, W, bias):
+    """The same backward on odd sizes and channel counts off the tile grids, against fp64 autograd of the oracle."""
+    from oracle import legacy_ops_ref as LG
+    from oracle.weights_recipe import recipe_tensor
+    AG = importlib.import_module("speak-hack_amd.autograd")
+    ops = importlib.import_module("speak-hack_amd.ops")
+    x = recipe_input(f"fub.x.{B}.{Cin}.{H}.{W}", (B, Cin, H, W))
+    w = recipe_tensor(f"fub.w.{Cin}.{Cout}", (Cin, Cout, 4, 4), (4 * Cin) ** -0.5)
+    b = recipe_tensor(f"fub.b.{Cout}", (Cout,), 0.3) if bias else None
+    gy = recipe_input(f"fub.gy.{B}.{Cout}.{H}.{W}", (B, Cout, 2 * H, 2 * W))
+    ref_in = [t.double().requires_grad_(True) for t in ((x, w, b) if bias else (x, w))]
+    LG.fused_upscale(ref_in[0], ref_in[1], ref_in[2] if bias else None).backward(gy.double())
+    hip_in = [t.to(dev).requires_grad_(True) for t in ((x, w, b) if bias else (x, w))]
+    AG.fused_upscale(hip_in[0], hip_in[1], hip_in[2] if bias else None, ops.PackedConvWeight()).backward(gy.to(dev))
+    for name, a, r in zip(("gx", "gw", "gb"), hip_in, ref_in):
+        assert rel_l2(a.grad, r.grad) < 2e-5, name
+
+
 @pytest.mark.parametrize("B,Cin,Cout,H,W,bias", [(1, 3, 5, 4, 4, True), (2, 20, 33, 7, 9, False), (3, 64, 32, 16, 16, True),
                                                   (1, 130, 70, 33, 5, True), (8, 128, 64, 32, 32, False)])
 def test_fused_upscale_ragged_shapes_vs_oracle(dev, B, Cin, Cout, H, W, bias):

@@ -152,17 +152,19 @@ def test_variant_generator_vs_oracle(sg2, dev, B, res):
 
 
 @pytest.mark.parametrize("upsample", [False, True])
-def test_styled_conv_backward(sg2, dev, upsample):
+@pytest.mark.parametrize("B,Cin,Cout,H", [(2, 20, 24, 8), (3, 70, 130, 12), (8, 128, 64, 16), (1, 64, 64, 32), (2, 16, 16, 4), (2, 8, 8, 5)])
+def test_styled_conv_backward(sg2, dev, upsample, B, Cin, Cout, H):
     """Backward of the modulated conv (data, weight, modulation incl. the demodulation path, noise weight, bias) vs
-    autograd of the published formulas evaluated in fp64."""
-    B, Cin, Cout, H = 2, 20, 24, 8
+    autograd of the published formulas evaluated in fp64.  Round 3: the fused form (SPK_CONV_IN_BATCH_SCALE weight gradient,
+    spk_modconv_dx_finish, spk_modconv_demod_bwd) on ragged channel blocks, several pixel tiles per workgroup, the batch
+    changing between a workgroup's tiles, and the small / odd planes that take the rescale-first fallback (4^2, 5^2)."""
     m = sg2.StyledConv(Cin, Cout, 3, 32, upsample=upsample)
     with torch.no_grad():
         m.noise.weight.fill_(0.37)
-        m.activate.bias.copy_(recipe_tensor("scb.act.bias", (Cout,), 0.3))
+        m.activate.bias.copy_(recipe_tensor(f"scb.act.bias.{Cout}", (Cout,), 0.3))
     Ho = 2 * H if upsample else H
-    x, st, nz = recipe_input("scb.x", (B, Cin, H, H)), recipe_input("scb.st", (B, 32)), recipe_input(f"scb.nz.{Ho}", (B, 1, Ho, Ho))
-    gy = recipe_input(f"scb.gy.{Ho}", (B, Cout, Ho, Ho))
+    x, st, nz = recipe_input(f"scb.x.{B}.{Cin}.{H}", (B, Cin, H, H)), recipe_input(f"scb.st.{B}", (B, 32)), recipe_input(f"scb.nz.{B}.{Ho}", (B, 1, Ho, Ho))
+    gy = recipe_input(f"scb.gy.{B}.{Cout}.{Ho}", (B, Cout, Ho, Ho))
     res = {}
     for name, dt_, device in (("ref32", torch.float32, "cpu"), ("ref64", torch.float64, "cpu"), ("hip", torch.float32, dev)):
         xi = x.detach().clone().to(device, dt_).requires_grad_(True)

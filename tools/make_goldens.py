@@ -256,7 +256,17 @@ def gen_fused_upscale(ref_sg):
         up.bias.copy_(recipe_tensor("legacy.fused_upscale.bias", up.bias.shape, 0.5))
         x = recipe_input("legacy.fused_upscale.x", (2, 512, 8, 6))
         y = up(x)
-    save("legacy_fused_upscale.npz", x=npf(x), y=npf(y))
+    # round 3: the backward of the same module (autograd of the reference's own ConvTranspose2d): gradient w.r.t. the
+    # input in full, w.r.t. the bias in full, w.r.t. the [512,256,4,4] weight as every 8th input x every 4th output channel
+    # (all 16 taps) plus its norm -- 131 KB instead of 8 MB
+    gy = recipe_input("legacy.fused_upscale.gy", tuple(y.shape))
+    xg = x.clone().requires_grad_(True)
+    up.zero_grad()
+    up(xg).backward(gy)
+    gw = up.weight.grad
+    # (gy is not stored: the tests regenerate it from the same recipe key)
+    save("legacy_fused_upscale.npz", x=npf(x), y=npf(y), gx=npf(xg.grad), gb=npf(up.bias.grad),
+         gw_sample=npf(gw[::8, ::4]), gw_norm=np.float64(gw.double().norm().item()))
 
 
 def progan_noise_shapes(B, steps):
