@@ -166,7 +166,7 @@ def conv_time_ms(module, feats, L):
     return ms, n
 
 
-def irfd_steps(pkg, dev, which, B, steps, warmup, precision="f32"):
+def irfd_steps(pkg, dev, which, B, steps, warmup, precision="f32", sg2=False):
     """The generator step (config 3) / discriminator step of train.py:150-210 on synthetic pairs -- tools/train_step_bench.py
     in brief.  Returns ms per step."""
     import model as M
@@ -174,7 +174,10 @@ def irfd_steps(pkg, dev, which, B, steps, warmup, precision="f32"):
     dp = importlib.import_module("speak-hack_amd.dp")
     T = importlib.import_module("speak-hack_amd.training")
     torch.manual_seed(0)
-    net = M.IRFD().to(dev).train()
+    net = M.IRFD()
+    if sg2:                                    # BASELINE config 3 read literally: the StyleGAN2 decoder behind the encoders
+        net.Gd = importlib.import_module("speak-hack_amd.stylegan2").StyleGAN2Generator(6144)
+    net = net.to(dev).train()
     for n, p in net.named_parameters():
         p.requires_grad_(n.startswith("D.") == (which == "d"))
     params = [p for p in net.parameters() if p.requires_grad]
@@ -564,6 +567,12 @@ def main():
             "what": "OPT-IN ops.train_conv_precision('bf16x3'): the decoder's 3x3 convs forward and their data gradients on the bf16 pipe "
                     "(operands split hi + lo, fp32 accumulation), weight gradients and the encoders exact; gradient parity in "
                     "tests/test_bf16x3_gpu.py", "ms_per_step": round(g_bf, 2), "pairs_per_s": round(16 / g_bf * 1e3, 1)}
+        g2_ms = irfd_steps(pkg, dev, "g", 16, steps=5, warmup=2, sg2=True)
+        extras["stylegan2_variant"]["train_step"] = {
+            "what": "BASELINE config 3 with the StyleGAN2 decoder variant as IRFD.Gd: the same generator step (encoders + 2 decoder "
+                    "passes, fwd + bwd + clip + Adam), batch 16, fp32; the variant's backward runs fused (weight gradient with the "
+                    "modulation / demodulation applied while staging, no materialised up(x), no ATen GEMM)",
+            "ms_per_step": round(g2_ms, 2), "pairs_per_s": round(16 / g2_ms * 1e3, 1), "vs_stylegan1_decoder_step": round(g2_ms / g_ms, 3)}
         d_ms = irfd_steps(pkg, dev, "d", 8, steps=5, warmup=2)
         extras["d_step"] = {"what": "discriminator step of train.py:155-183 (4 D fwd+bwd with instance noise + BCE, 2 R1 double backward, "
                                     "Adam on D), batch 8, fp32, eager launches", "ms_per_step": round(d_ms, 2),

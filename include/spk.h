@@ -392,10 +392,16 @@ int spk_modconv_demod(const float* w, const float* s, float* d, int B, int Cin, 
  *   spk_torgb_mod_bwd_data: dx[b,c,p] = in_scale * mod[b,c] * sum_o w[o,c] * dy[b,o,p]  (modulated toRGB, O <= 4); its weight /
  *                           modulation gradients come from spk_conv1x1_small_bwd's per-image partial sums on the UNmodulated x.
  * replaces: what autograd would run for the published formulas (reference/styleganv2.txt:1835,1912). */
+/* spk_modconv_epi_finish: from spk_epilogue_bwd's plane sums [B][4][C] (a = y, no style) of a modulated conv, in one launch:
+ *   dprime = d * gain (d NULL: 1), dd = (sum dy*y - gain*noise_w*sum dt*noise - gain*bias*sum dt) / d  (NULL: skipped),
+ *   dbias = gain * sum_b sum dt, dnw = gain * sum_b sum dt*noise  (NULL: skipped). */
+int spk_modconv_epi_finish(const float* sums, const float* d, const float* bias, const float* noise_w, float gain, float* dd,
+                           float* dprime, float* dbias, float* dnw, int B, int C, void* stream);
 int spk_modconv_dx_finish(const float* dxt, const float* x, const float* s, float* dx, float* ds, int B, int C, int Hs, int Ws,
                           int upsample, void* stream);
-int spk_modconv_demod_bwd(const float* w, const float* s, const float* d, const float* dd, float* ds, float* dw, int B, int Cin,
-                          int Cout, int taps, float scale, void* stream);
+int64_t spk_modconv_demod_bwd_workspace_bytes(int B, int Cin, int Cout);      /* scratch for the ds half */
+int spk_modconv_demod_bwd(const float* w, const float* s, const float* d, const float* dd, float* ds, float* dw, void* workspace,
+                          int64_t workspace_bytes, int B, int Cin, int Cout, int taps, float scale, void* stream);
 int spk_torgb_mod_bwd_data(const float* w, const float* mod, const float* dy, float* dx, int B, int C, int O, int64_t HW,
                            float in_scale, void* stream);
 /* the same for several layers in one launch (a decoder step's 13 demodulation vectors depend only on its modulations);

@@ -412,18 +412,8 @@ class ModConvFn(torch.autograd.Function):
         B, Cin = x.shape[:2]
         Cout, H, W = y.shape[1:]
         dt, sums = ops.epilogue_bwd(dy.contiguous(), y, noise, None, slope if slope is not None else 1.0)   # dz = gain * dt
-        s_dyy, s_dt, s_dtn = sums[:, 0], sums[:, 2], sums[:, 3]
-        dbias = gain * s_dt.sum(0) if bias is not None else None
-        dnw = gain * s_dtn.sum(0) if noise_w is not None else None
-        dd = None
-        if d is not None:        # y/gain = lrelu(d*c + n + b): sum dy*y = sum dz*(d*c + n + b) -> d d = (that - noise, bias parts) / d
-            r = s_dyy
-            if noise_w is not None:
-                r = r - gain * noise_w.view(1, -1) * s_dtn
-            if bias is not None:
-                r = r - gain * bias.view(1, -1) * s_dt
-            dd = (r / d).contiguous()
-        dprime = (d * gain if d is not None else torch.full((B, Cout), float(gain), device=x.device)).contiguous()
+        # y/gain = lrelu(d*c + n + b): sum dy*y = sum dz*(d*c + n + b) -> d d = (that - the noise and bias parts) / d; d' = d * gain
+        dd, dprime, dbias, dnw = ops.modconv_epi_finish(sums, d, bias, noise_w, gain)
         s = s.contiguous()
         need_dx, need_dw, need_ds = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         dx = dw = ds = None
@@ -475,8 +465,9 @@ class ModToRGBFn(torch.autograd.Function):
         dy = dy.contiguous()
         dx, P, db = ops.torgb_mod_bwd(x, weight, s.contiguous(), dy, in_scale=scale, need_dx=ctx.needs_input_grad[0])
         O, Cc = weight.shape[:2]
-        dw = torch.einsum("boc,bc->oc", P, s).view(O, Cc, 1, 1) if ctx.needs_input_grad[1] else None
-        ds = torch.einsum("boc,oc->bc", P, weight.view(O, Cc)) if ctx.needs_input_grad[2] else None
+        # ([B,3,C]-sized: elementwise products + sums, not a library GEMM)
+        dw = (P * s.unsqueeze(1)).sum(0).view(O, Cc, 1, 1) if ctx.needs_input_grad[1] else None
+        ds = (P * weight.view(1, O, Cc)).sum(1) if ctx.needs_input_grad[2] else None
         dskip = None
         if has_skip and ctx.needs_input_grad[5]:      # adjoint of upfirdn2d(up=2, pad (2,1)): down=2 with the flipped FIR, pad (1,1)
             dskip = ops.upfirdn2d(dy, torch.flip(fir, [0, 1]), up=1, down=2, pad=(1, 1))

@@ -161,9 +161,11 @@ __global__ __launch_bounds__(256) void conv1x1_small_bwd_data_kernel(const float
     }
 }
 
-// toRGB backward, weight half.  A workgroup walks a pixel range of one image in 128-pixel tiles; per 64-channel
-// group the x tile is staged through LDS (coalesced HBM reads, odd row pitch) and thread (c, q) accumulates
-// sum_p dy[o,p]*x[c,p] over its quarter of the tile.  partial[blk][o*C + c], partial[blk][O*C + o] (d bias).
+// toRGB backward, weight half.  A workgroup walks a pixel range of one image in 128-pixel tiles for ONE 64-channel group
+// (blockIdx.z; round 2 looped the groups inside the workgroup, which left the 512-channel 4^2..32^2 toRGB layers of the
+// StyleGAN2 variant on 8 workgroups: 300 us each); the x tile is staged through LDS (coalesced HBM reads, odd row pitch) and
+// thread (c, q) accumulates sum_p dy[o,p]*x[c,p] over its quarter of the tile.  partial[blk][o*C + c], partial[blk][O*C + o]
+// (d bias, written by the first channel group).
 __global__ __launch_bounds__(256) void conv1x1_small_bwd_weight_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                                       float* __restrict__ partial, int C, int O, long long HW,
                                                                       long long px_per_block, float in_scale) {
@@ -176,7 +178,8 @@ __global__ __launch_bounds__(256) void conv1x1_small_bwd_weight_kernel(const flo
     const float* dyb = dy + (size_t)b * O * HW;
     float* part = partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * (O * C + O);
     float dbacc[4] = {0.f, 0.f, 0.f, 0.f};
-    for (int cg = 0; cg < C; cg += 64) {
+    {
+        const int cg = blockIdx.z * 64;
         float acc[4] = {0.f, 0.f, 0.f, 0.f};
         for (long long p0 = p_begin; p0 < p_end; p0 += 128) {
             __syncthreads();
@@ -208,6 +211,7 @@ __global__ __launch_bounds__(256) void conv1x1_small_bwd_weight_kernel(const flo
                 part[o * C + cg + c_l] = (x_s[(o * 4 + 0) * 64 + c_l] + x_s[(o * 4 + 1) * 64 + c_l] + x_s[(o * 4 + 2) * 64 + c_l] +
                                           x_s[(o * 4 + 3) * 64 + c_l]) * in_scale;
     }
+    if (blockIdx.z != 0) return;
     for (int o = 0; o < O; ++o) {
         const float t = block_sum(dbacc[o], red);
         if (tid == 0) part[O * C + o] = t;
@@ -393,7 +397,7 @@ int spk_upsample2x_bilinear_bwd(const float* dy, float* dx, int64_t planes, int 
 }
 
 int spk_conv1x1_small_bwd_blocks(int B, int64_t HW) {
-    const long long per_img = std::max(1ll, std::min((long long)(HW + 1023) / 1024, 128ll));
+    const long long per_img = std::max(1ll, std::min((long long)(HW + 511) / 512, 128ll));
     return (int)(per_img * B);
 }
 
@@ -415,7 +419,7 @@ int spk_conv1x1_small_bwd(const float* x, const float* w, const float* dy, float
     }
     const int per_img = spk_conv1x1_small_bwd_blocks(B, HW) / B;
     const long long px_per_block = ((HW + per_img - 1) / per_img + 127) / 128 * 128;
-    hipLaunchKernelGGL(conv1x1_small_bwd_weight_kernel, dim3((unsigned)per_img, (unsigned)B), dim3(256), 0, s, x, dy, partial, C,
+    hipLaunchKernelGGL(conv1x1_small_bwd_weight_kernel, dim3((unsigned)per_img, (unsigned)B, (unsigned)spk::ceil_div(C, 64)), dim3(256), 0, s, x, dy, partial, C,
                        O, (long long)HW, px_per_block, in_scale);
     return spk::check_launch("conv1x1_small_bwd_weight_kernel");
 }

@@ -100,53 +100,118 @@ __global__ __launch_bounds__(256) void modconv_dx_finish_kernel(const float* __r
 //      e[b,co] = -dd[b,co] * d[b,co]^3 * scale^2:
 //        ds[b,ci]      += s[b,ci] * sum_co e[b,co] * w2[co,ci]
 //        dw[co,ci,k]   += w[co,ci,k] * sum_b e[b,co] * s[b,ci]^2
-//      (a) thread per ci, batch tile of 8 in registers, co looped (w2 formed on the fly: the 9 taps of a weight element are
-//      contiguous); (b) thread per (co,ci).  B, Cin, Cout <= a few hundred: both are tiny next to the convs.
-constexpr int DB_BT = 8;
-__global__ __launch_bounds__(256) void demod_bwd_s_kernel(const float* __restrict__ w, const float* __restrict__ s,
-                                                         const float* __restrict__ d, const float* __restrict__ dd,
-                                                         float* __restrict__ ds, int B, int Cin, int Cout, int taps, float scale2) {
-    extern __shared__ float e_s[];                 // [DB_BT][Cout]
-    const int ci = blockIdx.x * 256 + threadIdx.x;
-    for (int b0 = 0; b0 < B; b0 += DB_BT) {
+//      One pass over the weights: a workgroup owns 64 input channels (the lanes) x DBW_CO output channels (wave v takes
+//      co0 + v, co0 + v + 4, ...); a weight element's taps are read once, w2 feeds the ds sums, m = sum_b e s^2 the dw update.
+//      The ds sums of a workgroup's output-channel chunk go to partial[chunk][b][ci]; demod_bwd_finish_kernel adds the chunks
+//      in order (no atomics: bitwise reproducible).  (The first version ran a thread per ci over ALL co: 2 workgroups for a
+//      512-channel layer, 518 us; this one is ~10.)
+constexpr int DBW_CO = 32, DBW_BT = 16;
+__global__ __launch_bounds__(256) void demod_bwd_kernel(const float* __restrict__ w, const float* __restrict__ s,
+                                                       const float* __restrict__ d, const float* __restrict__ dd,
+                                                       float* __restrict__ partial, float* __restrict__ dw, int B, int Cin, int Cout,
+                                                       int taps, float scale2) {
+    __shared__ float e_s[DBW_BT][DBW_CO];
+    __shared__ float red[4][DBW_BT][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int ci = blockIdx.x * 64 + lane, co0 = blockIdx.y * DBW_CO;
+    const bool ci_ok = ci < Cin;
+    float m[DBW_CO / 4];
+#pragma unroll
+    for (int i = 0; i < DBW_CO / 4; ++i) m[i] = 0.f;
+    for (int b0 = 0; b0 < B; b0 += DBW_BT) {
         __syncthreads();
-        for (int i = threadIdx.x; i < DB_BT * Cout; i += 256) {
-            const int b = i / Cout, co = i - b * Cout;
+        for (int i = threadIdx.x; i < DBW_BT * DBW_CO; i += 256) {
+            const int b = i / DBW_CO, c = i - b * DBW_CO;
             float v = 0.f;
-            if (b0 + b < B) { const float dv = d[(size_t)(b0 + b) * Cout + co]; v = -dd[(size_t)(b0 + b) * Cout + co] * dv * dv * dv * scale2; }
-            e_s[i] = v;
+            if (b0 + b < B && co0 + c < Cout) {
+                const size_t idx = (size_t)(b0 + b) * Cout + co0 + c;
+                const float dv = d[idx];
+                v = -dd[idx] * dv * dv * dv * scale2;
+            }
+            e_s[b][c] = v;
         }
         __syncthreads();
-        if (ci >= Cin) continue;
-        float acc[DB_BT];
+        float s2[DBW_BT], acc[DBW_BT];
 #pragma unroll
-        for (int b = 0; b < DB_BT; ++b) acc[b] = 0.f;
-        for (int co = 0; co < Cout; ++co) {
-            const float* wr = w + ((size_t)co * Cin + ci) * taps;
-            float w2 = 0.f;
-            for (int k = 0; k < taps; ++k) w2 += wr[k] * wr[k];
-#pragma unroll
-            for (int b = 0; b < DB_BT; ++b) acc[b] += e_s[b * Cout + co] * w2;
+        for (int b = 0; b < DBW_BT; ++b) {
+            const float sv = (ci_ok && b0 + b < B) ? s[(size_t)(b0 + b) * Cin + ci] : 0.f;
+            s2[b] = sv * sv;
+            acc[b] = 0.f;
         }
 #pragma unroll
-        for (int b = 0; b < DB_BT; ++b)
-            if (b0 + b < B) { const size_t i = (size_t)(b0 + b) * Cin + ci; ds[i] += s[i] * acc[b]; }
+        for (int i = 0; i < DBW_CO / 4; ++i) {
+            const int c = wave + 4 * i, co = co0 + c;
+            float w2 = 0.f;
+            if (ci_ok && co < Cout) {
+                const float* wr = w + ((size_t)co * Cin + ci) * taps;
+                for (int k = 0; k < taps; ++k) w2 += wr[k] * wr[k];
+            }
+            float mm = 0.f;
+#pragma unroll
+            for (int b = 0; b < DBW_BT; ++b) {
+                const float ev = e_s[b][c];
+                acc[b] += ev * w2;
+                mm += ev * s2[b];
+            }
+            m[i] += mm;
+        }
+        if (partial) {
+#pragma unroll
+            for (int b = 0; b < DBW_BT; ++b) red[wave][b][lane] = acc[b];
+            __syncthreads();
+            for (int i = threadIdx.x; i < DBW_BT * 64; i += 256) {
+                const int b = i >> 6, l = i & 63;
+                if (b0 + b < B && blockIdx.x * 64 + l < Cin)
+                    partial[((size_t)blockIdx.y * B + b0 + b) * Cin + blockIdx.x * 64 + l] =
+                        (red[0][b][l] + red[1][b][l]) + (red[2][b][l] + red[3][b][l]);
+            }
+        }
+    }
+    if (dw && ci_ok) {
+#pragma unroll
+        for (int i = 0; i < DBW_CO / 4; ++i) {
+            const int co = co0 + wave + 4 * i;
+            if (co < Cout) {
+                const size_t base = ((size_t)co * Cin + ci) * taps;
+                for (int k = 0; k < taps; ++k) dw[base + k] += w[base + k] * m[i];
+            }
+        }
     }
 }
 
-__global__ __launch_bounds__(256) void demod_bwd_w_kernel(const float* __restrict__ w, const float* __restrict__ s,
-                                                         const float* __restrict__ d, const float* __restrict__ dd,
-                                                         float* __restrict__ dw, int B, int Cin, int Cout, int taps, float scale2) {
-    const long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
-    if (idx >= (long long)Cout * Cin) return;
-    const int co = (int)(idx / Cin), ci = (int)(idx - (long long)co * Cin);
-    float m = 0.f;
+__global__ __launch_bounds__(256) void demod_bwd_finish_kernel(const float* __restrict__ partial, const float* __restrict__ s,
+                                                              float* __restrict__ ds, int chunks, long long n) {
+    const long long i = (long long)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    float v = 0.f;
+    for (int c = 0; c < chunks; ++c) v += partial[(size_t)c * n + i];
+    ds[i] += s[i] * v;
+}
+
+// ---- everything a modulated conv's backward needs from the epilogue adjoint's plane sums, one launch (round 3's first form
+//      did it in ~10 ATen launches per layer on [B,C] tensors).  sums[b][k][c], k: {sum dy*y, sum dy, sum dt, sum dt*noise}.
+//        dprime[b,c] = d[b,c] * gain            (the factor on dz for the data / weight gradient; d = 1 without demodulation)
+//        dd[b,c]     = (sum dy*y - gain*nw[c]*sum dt*noise - gain*bias[c]*sum dt) / d[b,c]
+//        dbias[c]    = gain * sum_b sum dt,  dnw[c] = gain * sum_b sum dt*noise
+__global__ __launch_bounds__(256) void modconv_epi_finish_kernel(const float* __restrict__ sums, const float* __restrict__ d,
+                                                                const float* __restrict__ bias, const float* __restrict__ nw,
+                                                                float gain, float* __restrict__ dd, float* __restrict__ dprime,
+                                                                float* __restrict__ dbias, float* __restrict__ dnw, int B, int C) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    const float bv = bias ? bias[c] : 0.f, nv = nw ? nw[c] : 0.f;
+    float sb = 0.f, sn = 0.f;
     for (int b = 0; b < B; ++b) {
-        const float dv = d[(size_t)b * Cout + co], sv = s[(size_t)b * Cin + ci];
-        m += -dd[(size_t)b * Cout + co] * dv * dv * dv * scale2 * sv * sv;
+        const float* row = sums + (size_t)b * 4 * C;
+        const float s_dyy = row[c], s_dt = row[2 * C + c], s_dtn = row[3 * C + c];
+        const float dv = d ? d[(size_t)b * C + c] : 1.f;
+        dprime[(size_t)b * C + c] = dv * gain;
+        if (dd) dd[(size_t)b * C + c] = (s_dyy - gain * nv * s_dtn - gain * bv * s_dt) / dv;
+        sb += s_dt;
+        sn += s_dtn;
     }
-    const size_t base = (size_t)idx * taps;
-    for (int k = 0; k < taps; ++k) dw[base + k] += w[base + k] * m;
+    if (dbias) dbias[c] = gain * sb;
+    if (dnw) dnw[c] = gain * sn;
 }
 
 // ---- modulated toRGB, data gradient: dx[b,c,p] = in_scale * s[b,c] * sum_o w[o,c] dy[b,o,p]: the per-image weights
@@ -213,25 +278,39 @@ int spk_modconv_dx_finish(const float* g, const float* x, const float* s, float*
     return spk::check_launch("modconv_dx_finish_kernel");
 }
 
-int spk_modconv_demod_bwd(const float* w, const float* s, const float* d, const float* dd, float* ds, float* dw, int B, int Cin,
-                          int Cout, int taps, float scale, void* stream) {
+int spk_modconv_epi_finish(const float* sums, const float* d, const float* bias, const float* noise_w, float gain, float* dd,
+                           float* dprime, float* dbias, float* dnw, int B, int C, void* stream) {
+    SPK_REQUIRE(sums && dprime && B > 0 && C > 0, "modconv_epi_finish: null pointer or bad shape");
+    SPK_REQUIRE(!dd || d, "modconv_epi_finish: dd (the demodulation gradient) needs d");
+    SPK_REQUIRE((!dbias || bias) && (!dnw || noise_w), "modconv_epi_finish: dbias / dnw go with bias / noise_w");
+    hipLaunchKernelGGL(modconv_epi_finish_kernel, dim3((unsigned)spk::ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, sums, d, bias,
+                       noise_w, gain, dd, dprime, dbias, dnw, B, C);
+    return spk::check_launch("modconv_epi_finish_kernel");
+}
+
+int64_t spk_modconv_demod_bwd_workspace_bytes(int B, int Cin, int Cout) {
+    if (B <= 0 || Cin <= 0 || Cout <= 0) return -1;
+    return (int64_t)spk::ceil_div(Cout, DBW_CO) * B * Cin * (int64_t)sizeof(float);
+}
+
+int spk_modconv_demod_bwd(const float* w, const float* s, const float* d, const float* dd, float* ds, float* dw, void* workspace,
+                          int64_t workspace_bytes, int B, int Cin, int Cout, int taps, float scale, void* stream) {
     SPK_REQUIRE(w && s && d && dd, "modconv_demod_bwd: null pointer");
     SPK_REQUIRE(B > 0 && Cin > 0 && Cout > 0 && taps > 0, "modconv_demod_bwd: bad shape");
-    SPK_REQUIRE((size_t)DB_BT * Cout * sizeof(float) <= 60 * 1024, "modconv_demod_bwd: Cout too large for the LDS tile");
+    if (!ds && !dw) return SPK_OK;
+    const int chunks = spk::ceil_div(Cout, DBW_CO);
+    SPK_REQUIRE(!ds || (workspace && workspace_bytes >= spk_modconv_demod_bwd_workspace_bytes(B, Cin, Cout)),
+                "modconv_demod_bwd: ds needs a %lld-byte workspace (spk_modconv_demod_bwd_workspace_bytes)",
+                (long long)spk_modconv_demod_bwd_workspace_bytes(B, Cin, Cout));
     hipStream_t st = (hipStream_t)stream;
-    const float scale2 = scale * scale;
-    if (ds) {
-        hipLaunchKernelGGL(demod_bwd_s_kernel, dim3((unsigned)spk::ceil_div(Cin, 256)), dim3(256), (size_t)DB_BT * Cout * sizeof(float), st,
-                           w, s, d, dd, ds, B, Cin, Cout, taps, scale2);
-        int rc = spk::check_launch("demod_bwd_s_kernel");
-        if (rc != SPK_OK) return rc;
-    }
-    if (dw) {
-        const long long n = (long long)Cout * Cin;
-        hipLaunchKernelGGL(demod_bwd_w_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, w, s, d, dd, dw, B, Cin, Cout, taps, scale2);
-        return spk::check_launch("demod_bwd_w_kernel");
-    }
-    return SPK_OK;
+    float* partial = ds ? static_cast<float*>(workspace) : nullptr;
+    hipLaunchKernelGGL(demod_bwd_kernel, dim3((unsigned)spk::ceil_div(Cin, 64), (unsigned)chunks), dim3(256), 0, st, w, s, d, dd, partial, dw,
+                       B, Cin, Cout, taps, scale * scale);
+    int rc = spk::check_launch("demod_bwd_kernel");
+    if (rc != SPK_OK || !ds) return rc;
+    const long long n = (long long)B * Cin;
+    hipLaunchKernelGGL(demod_bwd_finish_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, partial, s, ds, chunks, n);
+    return spk::check_launch("demod_bwd_finish_kernel");
 }
 
 int spk_torgb_mod_bwd_data(const float* w, const float* mod, const float* dy, float* dx, int B, int C, int O, int64_t HW,

@@ -622,6 +622,20 @@ def modconv_demod_grouped(items, eps=1e-8):
     return outs
 
 
+def modconv_epi_finish(sums, d, bias, noise_w, gain):
+    """-> (dd [B,C] | None, dprime [B,C], dbias [C] | None, dnw [C] | None) from the epilogue adjoint's plane sums."""
+    B, _, Cc = sums.shape
+    dev = sums.device
+    dd = torch.empty((B, Cc), device=dev, dtype=torch.float32) if d is not None else None
+    dprime = torch.empty((B, Cc), device=dev, dtype=torch.float32)
+    dbias = torch.empty(Cc, device=dev, dtype=torch.float32) if bias is not None else None
+    dnw = torch.empty(Cc, device=dev, dtype=torch.float32) if noise_w is not None else None
+    L.check(L.lib().spk_modconv_epi_finish(L.dptr(sums, "sums"), L.dptr(d, "d"), L.dptr(bias, "bias"), L.dptr(noise_w, "noise_w"),
+                                           float(gain), L.dptr(dd), L.dptr(dprime), L.dptr(dbias), L.dptr(dnw), B, Cc, L.stream_ptr()),
+            "spk_modconv_epi_finish")
+    return dd, dprime, dbias, dnw
+
+
 def modconv_dx_finish(dxt, x, s, upsample, need_dx=True):
     """The tail of the modulated conv's data path: (dx = s * up^T(dxt) | None, ds[b,ci] = <up^T(dxt), x>) -- the adjoint of
     upfirdn2d(up=2, [1,3,3,1]) when ``upsample`` (dxt is then at twice x's resolution), identity otherwise."""
@@ -639,8 +653,10 @@ def modconv_demod_bwd(weight, s, d, dd, scale, ds=None, dw=None):
     """Adjoint of ``modconv_demod``: accumulates into ``ds`` [B,Cin] and / or ``dw`` [Cout,Cin,k,k] (in place)."""
     Cout, Cin, kh, kw = weight.shape
     B = s.shape[0]
+    ws = _workspace(s.device, L.lib().spk_modconv_demod_bwd_workspace_bytes(B, Cin, Cout)) if ds is not None else None
     L.check(L.lib().spk_modconv_demod_bwd(L.dptr(weight, "weight"), L.dptr(s, "s"), L.dptr(d, "d"), L.dptr(dd, "dd"), L.dptr(ds),
-                                          L.dptr(dw), B, Cin, Cout, kh * kw, float(scale), L.stream_ptr()), "spk_modconv_demod_bwd")
+                                          L.dptr(dw), ws.data_ptr() if ws is not None else None, ws.numel() * 4 if ws is not None else 0,
+                                          B, Cin, Cout, kh * kw, float(scale), L.stream_ptr()), "spk_modconv_demod_bwd")
 
 
 def torgb_mod_bwd(x, weight, mod, dy, in_scale=1.0, need_dx=True):

@@ -193,7 +193,14 @@ class StyleGAN2Generator(nn.Module):
                                                for m in (self.convs[2 * i], self.convs[2 * i + 1], self.to_rgbs[i])]
         mods = [m.conv.modulation for m in layers]
         if train:
-            ss = [None] * len(mods)          # each layer computes its own modulation through autograd
+            # one autograd node per <= 16 affines: grouped forward launch, two grouped backward launches (20 FCFn nodes cost
+            # 20 + 40 launches and 20 accumulations into d w)
+            ss = []
+            for k in range(0, len(mods), ops.L.FC_MAX_GROUPS):
+                part = mods[k:k + ops.L.FC_MAX_GROUPS]
+                confs = tuple((float(m.scale), float(m.lr_mul), 1.0, True) for m in part)
+                w3 = w.unsqueeze(1).expand(B, len(part), w.shape[1])
+                ss += list(AG.StyleFCGroupFn.apply(w3, confs, torch.is_grad_enabled(), *[t for m in part for t in (m.weight, m.bias)]))
         else:
             ss = []
             for k in range(0, len(mods), ops.L.FC_MAX_GROUPS):
