@@ -62,6 +62,10 @@ extern "C" {
                                   * exact-f32 matrix rate at ~3e-5 rel-L2 through the whole decoder (csrc/conv3x3_bf16x3.hip).
                                   * w_packed from spk_conv2d_pack_weights_bf16x3; flags: BIAS / NOISE / LRELU / STYLE /
                                   * UPSAMPLE2X (+ UP_FIR1331) / IN_BATCH_SCALE (+ out_scale_bc), y_pre; config / ksplit ignored. */
+#define SPK_EPI_ACCUM_HALF 8192u     /* y += accum_half at the EVEN pixels: accum_half is [B, groups*Cout, ceil(H/2), ceil(W/2)], element
+                                      * (h, w) is added to y(2h, 2w) -- the data gradient of a stride-2 1x1 conv (the
+                                      * trunk's downsample.0, model.py:60-62 via torchvision Bottleneck) joins the block input's
+                                      * gradient without ever being dilated in memory.  1x1 stride-1 GEMM form (configs 14, 15). */
 #define SPK_CONV_UP_FIR1331 512u     /* with UPSAMPLE2X: the x2 interpolation is upfirdn2d(up=2, FIR [1,3,3,1], pad (2,1)) --
                                       * the same (.75,.25) taps as bilinear, but neighbours outside the image are zero */
 
@@ -130,6 +134,7 @@ typedef struct spk_conv2d_desc {
      * spk_conv2d_stats_slots(...) every pixel tile owns its copy and the sums are plain stores (no atomics at all):
      * the setting for high-resolution layers.  The caller zeroes all copies either way. */
     int32_t stats_slots;
+    const float* accum_half; /* SPK_EPI_ACCUM_HALF: [B, groups*Cout, ceil(H/2), ceil(W/2)], added at the even pixels; else NULL */
 } spk_conv2d_desc;
 
 int spk_conv2d_num_configs(void);

@@ -32,7 +32,8 @@ class Conv2dDesc(C.Structure):
                 ("out_scale", C.c_float), ("config", C.c_int32), ("ksplit", C.c_int32),
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
                 ("out_scale_bc", C.c_void_p), ("act_gain", C.c_float),
-                ("groups", C.c_int32), ("group_in_stride", C.c_int32), ("stats_slots", C.c_int32)]
+                ("groups", C.c_int32), ("group_in_stride", C.c_int32), ("stats_slots", C.c_int32),
+                ("accum_half", C.c_void_p)]
 
 
 CONV_IN_BATCH_SCALE = 256
@@ -40,6 +41,7 @@ CONV_UP_FIR1331 = 512
 CONV_DGRAD_S2 = 1024
 CONV_TRANSPOSE4X4_S2 = 2048
 CONV_BF16X3 = 4096
+EPI_ACCUM_HALF = 8192
 
 
 FC_MAX_GROUPS = 16

@@ -26,6 +26,16 @@ def _hipcc() -> str:
     return exe
 
 
+def _file_flags(src):
+    """Extra compiler flags a source asks for on a `// hipcc-flags: ...` line (first 40 lines)."""
+    out = []
+    with open(src) as f:
+        for _, line in zip(range(40), f):
+            if line.startswith("// hipcc-flags:"):
+                out += line.split(":", 1)[1].split()
+    return out
+
+
 def sources():
     return sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".hip"))
 
@@ -52,7 +62,7 @@ def build_lib(force: bool = False, verbose: bool = False) -> str:
         obj = os.path.join(OBJ, os.path.basename(src)[:-4] + ".o")
         if not force and os.path.exists(obj) and os.path.getmtime(obj) >= max(os.path.getmtime(src), hdr_time):
             return obj
-        cmd = [hipcc, *FLAGS, "-c", src, "-o", obj]
+        cmd = [hipcc, *FLAGS, *_file_flags(src), "-c", src, "-o", obj]
         if verbose:
             print(" ".join(cmd))
         r = subprocess.run(cmd, capture_output=True, text=True)

@@ -148,10 +148,6 @@ int launch_splitk_epilogue(const ConvArgs& a_in, const float* ws, int ksplit, hi
     return spk::check_launch("splitk_epilogue_kernel");
 }
 
-// several weight tensors of one shape on one launch (blockIdx.y = which): their packed images one after another, as a
-// grouped conv launch reads them
-struct PackList { const float* w[SPK_PACK_LIST_MAX]; };
-
 __global__ void pack_weights_kernel(const PackList list, float* __restrict__ wp, int taps, int Cin_orig,
                                     int opCin, int opCout, int CO_T, int CI_T, int n_chunks, int tf, long long total) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -206,7 +202,7 @@ static const CfgDims kDims[kNumConfigs] = {
     {Cfg3::CO_T, Cfg3::CI_T, Cfg3::PIX_T},   {Cfg4::CO_T, Cfg4::CI_T, Cfg4::PIX_T},   {Cfg5::CO_T, Cfg5::CI_T, Cfg5::PIX_T},
     {Cfg6::CO_T, Cfg6::CI_T, Cfg6::PIX_T},   {Cfg7::CO_T, Cfg7::CI_T, Cfg7::PIX_T},   {Cfg8::CO_T, Cfg8::CI_T, Cfg8::PIX_T},
     {Cfg9::CO_T, Cfg9::CI_T, Cfg9::PIX_T},   {Cfg10::CO_T, Cfg10::CI_T, Cfg10::PIX_T}, {Cfg11::CO_T, Cfg11::CI_T, Cfg11::PIX_T},
-    {128, 32, 128}, {64, 8, 128}};
+    {128, 32, 128}, {64, 8, 128}, {128, 16, 128}, {64, 16, 128}};
 
 static bool supported_kernel(int kh, int kw, int stride) {
     if (kh == 2 && kw == 2) return stride == 1;   // the parity form of the 3x3 stride-2 data gradient (SPK_CONV_DGRAD_S2)
@@ -216,9 +212,9 @@ static bool supported_kernel(int kh, int kw, int stride) {
 
 static bool config_valid(int cfg, int kh, int kw, int stride) {
     if (!supported_kernel(kh, kw, stride) || cfg < 0 || cfg >= kNumConfigs) return false;
-    if (cfg == kGemmConfig) return kh == 1 && stride == 1;
+    if (cfg == kGemmConfig || is_gemm2(cfg)) return kh == 1 && stride == 1;
     if (cfg == kDgradS2Config) return kh == 2;
-    if (kh == 1) return cfg >= 8;
+    if (kh == 1) return cfg >= 8 && cfg <= 11;
     if (kh == 2) return cfg <= 3;
     if (kh == 3 && stride == 1) return cfg <= 7;
     return cfg >= 4 && cfg <= 7;  // 3x3 s2, 4x4 s2, 7x7 s2
@@ -251,6 +247,15 @@ static Geometry geometry_any(int kh, int stride, int cfg, int B, int Cin, int Co
         g.tiles_x = (int)gemm1x1_pixel_tiles(B, H, W); g.tiles_y = g.tiles_b = 1;
         g.n_chunks = 1;                  // never splits K
         g.co_tiles = spk::ceil_div(Cout, 128);
+        g.lds_bytes = 0;
+        return g;
+    }
+    if (is_gemm2(cfg)) {                 // pixel tiles of 128 over the flattened (b, pix) axis; a one-dimensional grid
+        g.ok = gemm2_takes(kh, stride, Cin, Cout, H, W);
+        g.TW = g.TH = g.TB = 1; g.PLANE = 1;
+        g.tiles_x = (int)gemm2_pixel_tiles(B, H, W); g.tiles_y = g.tiles_b = 1;
+        g.n_chunks = 1;                  // never splits K
+        g.co_tiles = spk::ceil_div(Cout, gemm2_co_tile(cfg));
         g.lds_bytes = 0;
         return g;
     }
@@ -293,6 +298,22 @@ static int pick_config(int kh, int stride, int B, int Cin, int Cout, int H, int 
     // full 128-row block of output channels, a contraction no deeper than the output is wide (it has no split-K), and
     // enough pixels -- e.g. 64->256 @64^2: 123 us against 168, 128->512 @32^2: 96 against 119; but 2048->512 @8^2: 200
     // against 87.
+    // The three-per-CU GEMM form (conv1x1_gemm2.hip, configs 14 / 15); SPK_CONV1X1_GEMM2 = 1 forces it wherever it
+    // applies, 0 nowhere, 2 = 64-row tiles everywhere, 3 = 128-row tiles everywhere (tools/bench_encoder_layers.py).
+    static const int gemm2_mode = [] { const char* e = getenv("SPK_CONV1X1_GEMM2"); return e ? atoi(e) : -1; }();
+    if (kh == 1 && stride == 1 && gemm2_mode != 0 && gemm2_takes(kh, stride, Cin, Cout, H, W)) {
+        if (gemm2_mode > 0)
+            return gemm2_mode == 2 ? kGemm2NarrowConfig : (gemm2_mode == 3 ? kGemm2Config : (Cout <= 64 ? kGemm2NarrowConfig : kGemm2Config));
+        // Measured on the trunk's shapes, 6 groups x batch 8 (profiles/r03_*: tools/lab_gemm2.py, tools/bench_encoder_layers.py): the lean
+        // form wins wherever the launch fills the chip -- >= 768 workgroups of 128 rows (three per CU), else >= 768 of 64 rows --
+        // and the contraction is not so deep that a few long workgroups are all there is (Cin <= 512; 1024 -> 256 @16^2 ties with
+        // the tap kernel's split-K, 2048 -> 512 @8^2 loses).  The heuristic does not see the group count: it assumes the trunk's six.
+        const long long px_tiles = gemm2_pixel_tiles(B, H, W);
+        if (Cin <= 512) {
+            if (Cout > 64 && px_tiles * spk::ceil_div(Cout, 128) >= 128) return kGemm2Config;
+            if (px_tiles * spk::ceil_div(Cout, 64) >= 128) return kGemm2NarrowConfig;
+        }
+    }
     static const int gemm_mode = [] { const char* e = getenv("SPK_CONV1X1_GEMM"); return e ? atoi(e) : -1; }();
     if (kh == 1 && stride == 1 && gemm_mode != 0 && gemm1x1_takes(kh, stride, Cin, H, W)) {
         const bool wins = Cout >= 128 && ((Cin <= Cout && pixels >= 2048) || (Cin <= 2 * Cout && pixels >= 8192));
@@ -347,6 +368,7 @@ int spk_conv2d_config_info(int config, int* co_tile, int* ci_tile, int* pix_tile
 int64_t spk_conv2d_packed_floats(int config, int kh, int kw, int Cin, int Cout) {
     if (config < 0 || config >= kNumConfigs || Cin <= 0 || Cout <= 0 || kh <= 0 || kw <= 0) return -1;
     if (config == kGemmConfig) return kh == 1 && kw == 1 ? (int64_t)Cout * Cin : -1;      // plain [Cout][Cin]
+    if (is_gemm2(config)) return kh == 1 && kw == 1 ? (int64_t)gemm2_packed_floats(config, Cin, Cout) : -1;
     if (config == kDgradS2Config) return (kh == 2 && kw == 2 && Cout % 4 == 0) ? (int64_t)dgrad_s2_fused_packed_floats(Cin, Cout / 4) : -1;
     const CfgDims& c = kDims[config];
     return (int64_t)spk::ceil_div(Cout, c.co_t) * spk::ceil_div(Cin, c.ci_t) * kh * kw * c.ci_t * c.co_t;
@@ -400,6 +422,10 @@ int spk_conv2d_pack_weights_list(const float* const* ws, int n, float* w_packed,
         hipLaunchKernelGGL(pack_rowmajor_kernel, dim3((unsigned)((nf + 255) / 256), (unsigned)n), dim3(256), 0, (hipStream_t)stream, list,
                            w_packed, Cin, Cout, transpose_flip, nf);
         return spk::check_launch("pack_rowmajor_kernel");
+    }
+    if (is_gemm2(config)) {             // [co tile][k tile][16 k][CO_T] of the weight or of its transpose
+        SPK_REQUIRE(kh == 1 && kw == 1 && transpose_flip < 2, "pack_weights: config %d packs 1x1 kernels", config);
+        return pack_gemm2(list, n, w_packed, Cin, Cout, config, transpose_flip, (hipStream_t)stream);
     }
     if (config == kDgradS2Config) {     // the transposed 3x3 operator itself, in 64-channel x 8-channel tiles (kDims[13])
         SPK_REQUIRE(transpose_flip == 2, "pack_weights: config %d packs the stride-2 data-gradient form (transpose_flip = 2)", kDgradS2Config);
@@ -478,8 +504,8 @@ int spk_conv2d_fwd(const spk_conv2d_desc* d, void* stream) {
     SPK_REQUIRE(!aff || (d->in_scale && d->in_shift), "conv2d: IN_AFFINE_RELU without in_scale/in_shift");
     SPK_REQUIRE((long long)d->B * d->Cout * d->H * d->W < (1ll << 40), "conv2d: tensor too large");
     if (d->groups > 1) {
-        SPK_REQUIRE(!(d->flags & ~(SPK_EPI_BIAS | SPK_EPI_LRELU | SPK_EPI_ACCUM | SPK_EPI_STATS | SPK_CONV_IN_AFFINE_RELU)) && !d->out_scale_bc,
-                    "conv2d: a grouped launch takes bias / lrelu / accum / stats / in-affine only");
+        SPK_REQUIRE(!(d->flags & ~(SPK_EPI_BIAS | SPK_EPI_LRELU | SPK_EPI_ACCUM | SPK_EPI_STATS | SPK_CONV_IN_AFFINE_RELU | SPK_EPI_ACCUM_HALF)) && !d->out_scale_bc,
+                    "conv2d: a grouped launch takes bias / lrelu / accum / accum-half / stats / in-affine only");
         SPK_REQUIRE(d->group_in_stride == 0 || d->group_in_stride >= d->Cin, "conv2d: group_in_stride must be 0 (shared input) or >= Cin");
     }
     int cfg = d->config;
@@ -492,6 +518,8 @@ int spk_conv2d_fwd(const spk_conv2d_desc* d, void* stream) {
     const int mode = ups ? (bsc ? MODE_UPSAMPLE_BATCH_SCALE : MODE_UPSAMPLE) : (aff ? MODE_AFFINE_RELU : (bsc ? MODE_BATCH_SCALE : MODE_PLAIN));
     hipStream_t s = (hipStream_t)stream;
     if (cfg == kGemmConfig) return run_1x1_gemm(&dd, s);
+    if (is_gemm2(cfg)) return run_1x1_gemm2(&dd, s);
+    SPK_REQUIRE(!(d->flags & SPK_EPI_ACCUM_HALF), "conv2d: SPK_EPI_ACCUM_HALF is built into the GEMM form of a 1x1 (configs 14, 15)");
     if (d->kh == 1) return run_1x1(d->stride, cfg, mode, &dd, s);
     if (d->kh == 3 && d->stride == 1) {
         if ((d->flags & SPK_EPI_STATS) && mode != MODE_AFFINE_RELU) {

@@ -865,9 +865,16 @@ typedef Cfg<2, 2, 2, 2, 16> Cfg8;  //  128   128   1x1 s1/s2   (16-channel chunk
 typedef Cfg<1, 4, 2, 2, 16> Cfg9;  //   64   256   1x1 s1/s2
 typedef Cfg<2, 2, 1, 1, 16> Cfg10; //   64    64   1x1 s1/s2
 typedef Cfg<1, 4, 1, 1, 16> Cfg11; //   32   128   1x1 s1/s2
-constexpr int kNumConfigs = 14;   // 12 = the GEMM form of a stride-1 1x1 (conv1x1_gemm.hip): 128co x 128px block, 32-channel k-tiles
+constexpr int kNumConfigs = 16;   // 12 = the GEMM form of a stride-1 1x1 (conv1x1_gemm.hip): 128co x 128px block, 32-channel k-tiles
 constexpr int kGemmConfig = 12;
 constexpr int kDgradS2Config = 13;   // the exact-tap data gradient of a 3x3 stride-2 conv (dgrad3x3s2.hip): 64co x 128px block, 8-channel chunks
+constexpr int kGemm2Config = 14;     // the three-per-CU GEMM form of a stride-1 1x1 (conv1x1_gemm2.hip): 128co x 128px block, 16-channel k-tiles
+constexpr int kGemm2NarrowConfig = 15;   // the same with a 64co x 128px block (four per CU)
+inline bool is_gemm2(int cfg) { return cfg == kGemm2Config || cfg == kGemm2NarrowConfig; }
+
+// several weight tensors of one shape on one launch (blockIdx.y = which): their packed images one after another, as a
+// grouped conv launch reads them
+struct PackList { const float* w[SPK_PACK_LIST_MAX]; };
 
 // per-family dispatchers, one translation unit each (parallel compilation)
 int run_3x3s1_a(int cfg, int mode, const spk_conv2d_desc* d, hipStream_t s);  // ids 0-3
@@ -882,5 +889,11 @@ bool dgrad_s2_fused_takes(int B, int K, int Cc, int Hg, int Wg);
 long long dgrad_s2_fused_packed_floats(int K, int Cc);
 bool gemm1x1_takes(int kh, int stride, int Cin, int H, int W);
 long long gemm1x1_pixel_tiles(int B, int H, int W);
+int run_1x1_gemm2(const spk_conv2d_desc* d, hipStream_t s);                               // ids 14, 15
+bool gemm2_takes(int kh, int stride, int Cin, int Cout, int H, int W);
+int gemm2_co_tile(int config);
+long long gemm2_pixel_tiles(int B, int H, int W);
+long long gemm2_packed_floats(int config, int Cin, int Cout);
+int pack_gemm2(const PackList& list, int n_list, float* w_packed, int Cin, int Cout, int config, int tf, hipStream_t stream);
 
 }  // namespace spkconv

@@ -107,8 +107,9 @@ class _ConvBN:
                               want_dz=want_dz, batch_stats=rec["training"], **kw)
         return out
 
-    def conv_bwd(self, rec, dr, grads, need_dx, dx_out=None, accumulate=False):
-        """Weight gradient (into ``grads``) and, if asked, the gradient w.r.t. the conv's (staged) input."""
+    def conv_bwd(self, rec, dr, grads, need_dx, dx_out=None, accumulate=False, dilate=True, half=None):
+        """Weight gradient (into ``grads``) and, if asked, the gradient w.r.t. the conv's (staged) input.  ``dilate=False``
+        (a strided 1x1): that gradient stays at the conv's output size; ``half``: such a tensor, added at the even pixels."""
         conv = self.conv
         Cout, Cin = conv.out_channels, conv.in_channels
         x = rec["x"]
@@ -117,8 +118,11 @@ class _ConvBN:
         if not need_dx:
             return None
         cfg, tf = ops.dgrad_plan(self.k, self.stride, B, Cout, Cin, (H, W), dr.shape[-2:], dx_out, accumulate)
+        if half is not None and (cfg not in ops.GEMM2_CONFIGS or W % 4):
+            dx_out, accumulate, half = ops.dilate2x(half, H, W), True, None     # the form that cannot add it in its epilogue
+            cfg, tf = ops.dgrad_plan(self.k, self.stride, B, Cout, Cin, (H, W), dr.shape[-2:], dx_out, accumulate)
         return ops.conv2d_dgrad(dr, self.packed.get(conv.weight, cfg, transpose_flip=tf), Cin, self.k, self.stride,
-                                (H, W), cfg, out=dx_out, accumulate=accumulate)
+                                (H, W), cfg, out=dx_out, accumulate=accumulate, dilate=dilate, accum_half=half)
 
 
 class _StatsPool:
@@ -250,7 +254,7 @@ class _GroupedConvBN:
         return ops.bn_backward(g, rec["y"], rec["affine"], rec["mean"], rec["invstd"], mask_mode, mask_src,
                                want_dz=want_dz, batch_stats=rec["training"], **kw)
 
-    def conv_bwd(self, rec, dr, grads, need_dx, dx_out=None, accumulate=False):
+    def conv_bwd(self, rec, dr, grads, need_dx, dx_out=None, accumulate=False, dilate=True, half=None):
         conv, G = self.convs[0], self.G
         Cout, Cin = conv.out_channels, conv.in_channels
         x = rec["x"]
@@ -263,8 +267,11 @@ class _GroupedConvBN:
         if not need_dx:
             return None
         cfg, tf = ops.dgrad_plan(self.k, self.stride, B, Cout, Cin, (H, W), dr.shape[-2:], dx_out, accumulate)
+        if half is not None and (cfg not in ops.GEMM2_CONFIGS or W % 4):
+            dx_out, accumulate, half = ops.dilate2x(half, H, W), True, None     # the form that cannot add it in its epilogue
+            cfg, tf = ops.dgrad_plan(self.k, self.stride, B, Cout, Cin, (H, W), dr.shape[-2:], dx_out, accumulate)
         return ops.conv2d_dgrad(dr, self.packed.get(self._weights(), cfg, transpose_flip=tf), Cin, self.k, self.stride,
-                                (H, W), cfg, out=dx_out, accumulate=accumulate, groups=G)
+                                (H, W), cfg, out=dx_out, accumulate=accumulate, groups=G, dilate=dilate, accum_half=half)
 
 
 class GroupedTrunks:
@@ -513,8 +520,14 @@ class ResNet50Trunk(nn.Sequential):
             else:
                 drd, dg, db = down.bn_bwd(rd, dz, ops.MASK_NONE)
                 down.put_bn_grads(grads, dg, db)
-                g = down.conv_bwd(rd, drd, grads, need_dx=True)
-                g = c1.conv_bwd(r1, dr1, grads, need_dx=True, dx_out=g, accumulate=True)
+                if down.stride == 2:
+                    # the downsample conv reads the even pixels only: its data gradient stays at ITS output size and conv1's
+                    # data gradient adds it at the even pixels in its own epilogue -- no dilated copy, no read of one
+                    t = down.conv_bwd(rd, drd, grads, need_dx=True, dilate=False)
+                    g = c1.conv_bwd(r1, dr1, grads, need_dx=True, half=t)
+                else:
+                    g = down.conv_bwd(rd, drd, grads, need_dx=True)
+                    g = c1.conv_bwd(r1, dr1, grads, need_dx=True, dx_out=g, accumulate=True)
             per_plane = False
         # stem: max-pool adjoint (bn1+relu re-formed on the fly), BatchNorm backward, 7x7 weight gradient
         s = recs["stem"]

@@ -164,8 +164,11 @@ def conv_out_size(n, k, stride):
 def conv2d_fused(x, w_packed, Cout: int, k: int = 3, stride: int = 1, *, bias=None, noise_w=None, noise=None,
                  style=None, style_stride=None, upsample=False, lrelu_slope=None, out_scale=1.0, in_affine=None,
                  stats=None, config=-1, ksplit=0, out=None, accumulate=False, out_pre=None, batch_scale=None, demod=None,
-                 act_gain=1.0, up_fir=False, groups=1, shared_input=False):
+                 act_gain=1.0, up_fir=False, groups=1, shared_input=False, accum_half=None):
     """y = style(lrelu(conv_kxk(in(x)) * out_scale + bias + noise_w*noise)) -- one launch.
+
+    ``accum_half`` [B, groups*Cout, ceil(H/2), ceil(W/2)]: added to y at the even pixels (``SPK_EPI_ACCUM_HALF``; the
+    GEMM form of a stride-1 1x1, configs 14 / 15).
 
     ``groups`` > 1: that many independent convs of the same shape in one launch (``Cout`` per group; ``w_packed`` = the
     groups' packed images concatenated; x carries the groups' input channels side by side, or -- ``shared_input`` -- one
@@ -207,6 +210,10 @@ def conv2d_fused(x, w_packed, Cout: int, k: int = 3, stride: int = 1, *, bias=No
         flags |= L.EPI_ACCUM
     if in_affine is not None:
         flags |= L.CONV_IN_AFFINE_RELU
+    if accum_half is not None:
+        if tuple(accum_half.shape) != (B, G * Cout, (H + 1) // 2, (W + 1) // 2) or not accum_half.is_contiguous():
+            raise L.SpkError(f"conv2d_fused: accum_half must be a contiguous {(B, G * Cout, (H + 1) // 2, (W + 1) // 2)} tensor")
+        flags |= L.EPI_ACCUM_HALF
     if batch_scale is not None:          # modulated convolution: s[B,Cin] applied to the input while staging
         if tuple(batch_scale.shape) != (B, Cin) or in_affine is not None:
             raise L.SpkError("conv2d_fused: batch_scale must be [B,Cin] and excludes in_affine")
@@ -242,7 +249,8 @@ def conv2d_fused(x, w_packed, Cout: int, k: int = 3, stride: int = 1, *, bias=No
                      lrelu_slope=float(lrelu_slope if lrelu_slope is not None else 1.0), out_scale=float(out_scale),
                      config=int(config), ksplit=int(ksplit), workspace=ws.data_ptr() if ws is not None else None,
                      workspace_bytes=ws.numel() * 4 if ws is not None else 0, groups=G,
-                     group_in_stride=0 if (shared_input or G == 1) else Cin, stats_slots=slots)
+                     group_in_stride=0 if (shared_input or G == 1) else Cin, stats_slots=slots,
+                     accum_half=L.dptr(accum_half, "accum_half"))
     _launch_conv2d(d)
     return out
 
@@ -903,23 +911,30 @@ def _dgrad_s2_parity(g, weight_packed, Cin, in_hw, config, out, accumulate, grou
     return out
 
 
-def conv2d_dgrad(g, weight_packed_tf, Cin, k, stride, in_hw, config, out=None, accumulate=False, groups=1):
+GEMM2_CONFIGS = (14, 15)        # the lean GEMM form of a stride-1 1x1 (csrc/conv1x1_gemm2.hip): the configs that take accum_half
+
+
+def conv2d_dgrad(g, weight_packed_tf, Cin, k, stride, in_hw, config, out=None, accumulate=False, groups=1, dilate=True,
+                 accum_half=None):
     """Data gradient of a k x k conv.  Stride 1: the forward MFMA kernel on ``g`` with transpose-flipped weights.
     3x3 stride 2: by output parity (``SPK_CONV_DGRAD_S2``: dx[2m+py, 2n+px] needs 1/2/2/4 of the 9 taps; four 2x2
     kernels in one launch over the gradient's own pixels, stored interleaved).  1x1 stride 2 without a destination: at
     the output size, dilated afterwards; into a destination: on the zero-dilated ``g``.  ``in_hw`` = (H, W) of the
-    conv's input; ``config`` / the packing of ``weight_packed_tf`` from ``dgrad_plan``."""
+    conv's input; ``config`` / the packing of ``weight_packed_tf`` from ``dgrad_plan``.  ``dilate=False`` (strided 1x1 without a
+    destination): the gradient stays at the output size; ``accum_half``: such a tensor, added at the even pixels by a stride-1
+    1x1 data gradient running in the lean GEMM form (``GEMM2_CONFIGS``)."""
     if k == 3 and stride == 2:
         return _dgrad_s2_parity(g, weight_packed_tf, Cin, in_hw, config, out, accumulate, groups)
     if dgrad_at_output_size(k, stride, out, accumulate):
         # a strided 1x1 reads only the even input pixels: dx = dilate(W^T g), the contraction at the OUTPUT size
         t = conv2d_fused(g, weight_packed_tf, Cin, 1, 1, config=config, groups=groups)
-        return dilate2x(t, in_hw[0], in_hw[1])
+        return dilate2x(t, in_hw[0], in_hw[1]) if dilate else t      # not dilated: the caller adds it through ``accum_half``
     if stride == 2:
         # dx[i] = sum_k gd[i + k' - p] * w[k-1-k'] with gd[2o] = g[o], zeros elsewhere, extended to the input size
         # (an even-sized input has a last row/column no window's stride lattice reaches: it stays zero)
         g = dilate2x(g, in_hw[0], in_hw[1])
-    return conv2d_fused(g, weight_packed_tf, Cin, k, 1, config=config, out=out, accumulate=accumulate, groups=groups)
+    return conv2d_fused(g, weight_packed_tf, Cin, k, 1, config=config, out=out, accumulate=accumulate, groups=groups,
+                        accum_half=accum_half)
 
 
 # ---- BatchNorm / pooling pieces of the ResNet-50 trunk ----------------------------------------------

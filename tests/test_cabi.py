@@ -43,8 +43,10 @@ def test_host_side_queries_and_argument_errors(pkg):
         co, ci, px = pkg.ops.conv3x3_config_info(cfg)
         assert co % 32 == 0 and px % 32 == 0 and ci % 2 == 0
         if lib.spk_conv2d_config_valid(cfg, 1, 1, 1) and not lib.spk_conv2d_config_valid(cfg, 1, 1, 2):
-            # the GEMM form of a stride-1 1x1: its packed image is the plain [Cout][Cin] matrix
-            assert lib.spk_conv2d_packed_floats(cfg, 1, 1, 8, 5) == 40 and lib.spk_conv2d_packed_floats(cfg, 3, 3, 3, 5) == -1
+            # the GEMM forms of a stride-1 1x1: the packed image is the plain [Cout][Cin] matrix (32-channel k-tiles) or
+            # [co tile][k tile][16][CO_T], zero padded (16-channel k-tiles)
+            want = 40 if ci == 32 else -(-5 // co) * -(-8 // 16) * 16 * co
+            assert lib.spk_conv2d_packed_floats(cfg, 1, 1, 8, 5) == want and lib.spk_conv2d_packed_floats(cfg, 3, 3, 3, 5) == -1
             continue
         if lib.spk_conv2d_config_valid(cfg, 2, 2, 1) and not lib.spk_conv2d_config_valid(cfg, 3, 3, 1):
             # the exact-tap data gradient of a 3x3 stride-2 conv: the transposed 3x3 operator in 64 x 8 channel tiles

@@ -207,18 +207,25 @@ def test_trunk_train_mode_batch_statistics_and_running_update(pkg, dev):
     assert int(got["6.3.bn1.num_batches_tracked"]) == 1
 
 
+@pytest.mark.parametrize("cfg", [12, 14, 15])
 @pytest.mark.parametrize("B,Cin,Cout,H,W,groups", [
     (2, 64, 256, 8, 8, 1),       # 64-pixel planes: a 128-pixel tile spans two images
     (3, 20, 72, 8, 12, 1),       # ragged channels (Cin % 32 != 0, Cout % 128 != 0), 288 pixels: a partial last tile
     (1, 256, 64, 16, 16, 1),     # one co tile half empty
     (2, 36, 136, 4, 8, 3),       # grouped, two co tiles per group (the second ragged)
     (8, 128, 512, 32, 32, 1),    # a trunk shape
+    (3, 24, 40, 4, 4, 2),        # a ragged second k-tile (moved back to end at Cin), 16-pixel planes
+    (2, 16, 8, 2, 2, 1),         # one k-tile, one group of 8 rows, 4-pixel planes
 ])
-def test_conv1x1_gemm_form(pkg, dev, B, Cin, Cout, H, W, groups):
-    """Tile config 12: the stride-1 1x1 conv as a plain GEMM (128co x 128px blocks over the flattened pixel axis, packed
-    weight = the [Cout][Cin] matrix), with every epilogue / staging option it carries, against F.conv2d."""
+def test_conv1x1_gemm_form(pkg, dev, B, Cin, Cout, H, W, groups, cfg):
+    """Tile configs 12 / 14 / 15: the stride-1 1x1 conv as a plain GEMM (128co- or 64co- x 128px blocks over the flattened
+    pixel axis; packed weight = the [Cout][Cin] matrix for 12, [co tile][k tile][16][CO_T] for 14 / 15), with every
+    epilogue / staging option it carries, against F.conv2d."""
     ops, L = pkg.ops, pkg._lib
-    cfg = 12
+    if cfg == 12 and (H * W) % 32:
+        pytest.skip("config 12 needs H*W % 32 == 0")
+    if cfg != 12:      # what the lean form asks for: >= 16 contraction channels in fours, output channels in eights
+        assert not ops.conv2d_config_fits(cfg, 1, 1, B, 8, Cout, H, W) and not ops.conv2d_config_fits(cfg, 1, 1, B, Cin, Cout + 4, H, W)
     assert ops.conv2d_config_fits(cfg, 1, 1, B, Cin, Cout, H, W) and not ops.conv2d_config_fits(cfg, 3, 1, B, Cin, Cout, H, W)
     tag = f"g1x1.{B}.{Cin}.{Cout}.{H}.{W}.{groups}"
     G = groups
@@ -236,7 +243,12 @@ def test_conv1x1_gemm_form(pkg, dev, B, Cin, Cout, H, W, groups):
         return F.leaky_relu(y, slope) if slope is not None else y
 
     wp = torch.cat([ops.pack_conv_weight(w.to(dev), cfg) for w in ws])
-    assert wp.numel() == G * Cout * Cin
+    if cfg == 12:
+        assert wp.numel() == G * Cout * Cin
+    else:
+        co_t = 128 if cfg == 14 else 64
+        assert wp.numel() == G * (-(-Cout // co_t)) * (-(-Cin // 16)) * 16 * co_t
+        assert torch.equal(wp, ops.pack_conv_weights_list([w.to(dev) for w in ws], cfg))
     xd = x.to(dev)
     # plain
     assert rel_l2(ops.conv2d_fused(xd, wp, Cout, 1, 1, config=cfg, groups=G), ref(x, False, None)) < TOL_OP
@@ -265,6 +277,16 @@ def test_conv1x1_gemm_form(pkg, dev, B, Cin, Cout, H, W, groups):
         if ops.conv2d_config_fits(cfg, 1, 1, B, Cout, Cin, H, W):
             wt = ops.pack_conv_weight(ws[0].to(dev), cfg, transpose_flip=True)
             assert rel_l2(ops.conv2d_fused(g.to(dev), wt, Cin, 1, 1, config=cfg), xg.grad) < TOL_OP
+    # the half-resolution accumulate: y(2h, 2w) += t(h, w) -- a stride-2 1x1 conv's data gradient joining without dilation
+    if cfg != 12 and W % 4 == 0:
+        t = recipe_input(tag + ".half", (B, G * Cout, (H + 1) // 2, (W + 1) // 2))
+        dil = torch.zeros(B, G * Cout, H, W)
+        dil[:, :, ::2, ::2] = t
+        y = ops.conv2d_fused(xd, wp, Cout, 1, 1, config=cfg, groups=G, bias=bias.to(dev), accum_half=t.to(dev))
+        assert rel_l2(y, ref(x, True, None) + dil) < TOL_OP
+    elif cfg == 12:
+        with pytest.raises(L.SpkError):
+            ops.conv2d_fused(xd, wp, Cout, 1, 1, config=cfg, groups=G, accum_half=torch.zeros(B, G * Cout, (H + 1) // 2, (W + 1) // 2, device=dev))
     # what it does not carry is refused, not mis-computed
     with pytest.raises(L.SpkError):
         ops.conv2d_fused(xd, wp, Cout, 1, 1, config=cfg, groups=G, noise_w=bias.to(dev), noise=torch.zeros(B, 1, H, W, device=dev))
