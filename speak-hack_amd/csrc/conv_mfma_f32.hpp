@@ -34,6 +34,7 @@ namespace spkconv {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) float lds_f32_t;        // LDS-typed accesses: volatile ones stay ds_read / ds_write
 
 // MODE_PLAIN_STATS: MODE_PLAIN of a 3x3 stride-1 conv with the BatchNorm-statistics epilogue compiled in (see HAS_STATS in
 // the kernel); every other kernel shape carries that epilogue in all its modes.
@@ -126,7 +127,12 @@ constexpr int pick_pd(int want, int steps) {
 __device__ __forceinline__ float w1_of(unsigned code) { return code == 1 ? 0.25f : (code == 2 ? 0.75f : 0.f); }
 __device__ __forceinline__ float w0_of(unsigned code) { return code == 0 ? 1.f : (code == 2 ? 0.25f : 0.75f); }
 
-template <class C, int KH, int KW, int S, int MODE>
+// FG (fixed geometry): the pixel tile is the 32-wide one of every layer at least 32 pixels wide -- TW = 32, TH = PIX_T / 32,
+// TB = 1 -- as compile-time constants, so that every LDS offset of the main loop (tap rows, channel planes, k-steps) is an
+// instruction immediate off one base register per operand and chunk.  On gfx950 the f32 MFMA shares the SIMD's vector ALU
+// (tools/mfma_valu_coexec.hip): each v_add_u32 that forms an LDS address costs ~5 of an MFMA's 64 cycles, and the runtime-
+// geometry loop carries 32-50 of them per 72 MFMAs.  The host picks the FG instantiation when the layer's geometry is this one.
+template <class C, int KH, int KW, int S, int MODE, bool FG = false>
 __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
     using SH = Shape<C, KH, KW, S>;
     constexpr bool UPS = MODE == MODE_UPSAMPLE || MODE == MODE_UPSAMPLE_BATCH_SCALE, AFF = MODE == MODE_AFFINE_RELU;
@@ -145,10 +151,18 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
     const int half = lane >> 5, l32 = lane & 31;
     const int wm = wave / C::WN, wn = wave % C::WN;
 
-    const int TW = 1 << p.lgTW, TH = 1 << p.lgTH, TB = 1 << p.lgTB;
+    const int lgTW = FG ? 5 : p.lgTW, lgTH = FG ? (C::PIX_T == 256 ? 3 : (C::PIX_T == 128 ? 2 : (C::PIX_T == 64 ? 1 : 0))) : p.lgTH;
+    const int lgTB = FG ? 0 : p.lgTB;
+    static_assert(!FG || (C::PIX_T >= 32 && C::PIX_T <= 256), "fixed geometry: 32 x (PIX_T / 32) pixel tiles");
+    const int TW = 1 << lgTW, TH = 1 << lgTH, TB = 1 << lgTB;
     constexpr int SL = SH::SL;
     const int PW = (TW - 1) * SL + KW, PLANE = ((TH - 1) * SL + KH) * PW;
-    const int IN_FLOATS = C::CI_T * TB * PLANE;
+    // FG: every wave stages ONE input plane (CI_T = waves, TB = 1) and the planes sit NSLOT * 64 floats apart, so that lane l's
+    // element of gather slot s lives at plane + s * 64 + l for every lane (lanes past the plane write into the pitch's padding):
+    // an LDS store is one base register + an immediate, and needs no dump slot
+    static_assert(!FG || (C::CI_T == C::NW && S == 1 && KH == 3 && (MODE == MODE_PLAIN || MODE == MODE_UPSAMPLE)), "fixed geometry: 3x3 stride 1, one plane per wave");
+    const int PP = FG ? NSLOT * 64 : PLANE;
+    const int IN_FLOATS = C::CI_T * TB * PP;
     const int BUF_FLOATS = W_FLOATS + ((IN_FLOATS + 3) & ~3) + 4;  // +4: dump slot for lanes without an element
     // XCD-aware tile order: the hardware deals workgroup i to XCD i % 8 (profiles/r01_e_workgroup_placement.txt), so in
     // launch order neighbouring pixel tiles land on different L2s and each re-fetches the halo rows they share.  Remap
@@ -164,7 +178,7 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
     bx /= p.tiles_x;
     const int ty = bx % p.tiles_y;
     const int tbi = bx / p.tiles_y;
-    const int b0 = tbi << p.lgTB, y0 = ty << p.lgTH, x0 = tx << p.lgTW;
+    const int b0 = tbi << lgTB, y0 = ty << lgTH, x0 = tx << lgTW;
     const int grp = (int)blockIdx.y / p.co_tiles_g;
     const int co_tile0 = ((int)blockIdx.y - grp * p.co_tiles_g) * C::CO_T;   // within the group
     const int c_begin = blockIdx.z * p.chunks_per_split;
@@ -184,31 +198,38 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
     const int wave_elems = ppw * PLANE;
     const size_t src_plane = (size_t)p.Hs * p.Ws;
     const int ci_left_last = p.Cin - (p.n_chunks - 1) * C::CI_T;
-    unsigned s_xoff[NSLOT], s_xoffl[NSLOT], s_dst[NSLOT], s_vc[NSLOT];
+    unsigned s_xoff[NSLOT], s_xoffl[FG ? 1 : NSLOT], s_dst[FG ? 1 : NSLOT], s_vc[FG ? 1 : NSLOT];
+    float s_mask[(FG && !UPS) ? NSLOT : 1];               // FG: 1 / 0 (zero padding) -- multiplied in, or folded into the bilinear weights
+    const unsigned dst_lane = (unsigned)(W_FLOATS + wave * PP + lane) * 4u;
     unsigned s_dxb[UPS ? NSLOT : 1], s_dyb[UPS ? NSLOT : 1];
     float s_lx0[UPS ? NSLOT : 1], s_lx1[UPS ? NSLOT : 1], s_ly0[UPS ? NSLOT : 1], s_ly1[UPS ? NSLOT : 1];
     unsigned s_sc[(AFF || BSC) ? NSLOT : 1], s_scl[(AFF || BSC) ? NSLOT : 1];
 #pragma unroll
     for (int s = 0; s < NSLOT; ++s) {
-        s_xoff[s] = s_xoffl[s] = 0;
-        s_vc[s] = 0;
-        s_dst[s] = (unsigned)(BUF_FLOATS - 1) * 4u;
+        s_xoff[s] = 0;
+        bool live = false;                                    // the element exists (inside the image)
+        if constexpr (!FG) {
+            s_xoffl[s] = 0;
+            s_vc[s] = 0;
+            s_dst[s] = (unsigned)(BUF_FLOATS - 1) * 4u;
+        }
         if (UPS) { s_dxb[s] = s_dyb[s] = 0; s_lx0[s] = s_ly0[s] = 1.f; s_lx1[s] = s_ly1[s] = 0.f; }
         if (AFF || BSC) s_sc[s] = s_scl[s] = 0;
         const int e = s * 64 + lane;
         if (e < wave_elems) {
             // e < 2^16 and PLANE, PW < 2^16: __umulhi with ceil(2^32/d) is the exact quotient (no integer-divide sequences)
-            const int pl = p.magic_plane ? (int)__umulhi((unsigned)e, p.magic_plane) : e, pidx = e - pl * PLANE;
+            const int pl = FG ? e / PLANE : (p.magic_plane ? (int)__umulhi((unsigned)e, p.magic_plane) : e), pidx = e - pl * PLANE;
             const int q = wave * ppw + pl;
-            const int ci = q >> p.lgTB, tb = q & (TB - 1);
-            const int r = p.magic_pw ? (int)__umulhi((unsigned)pidx, p.magic_pw) : pidx, c = pidx - r * PW;
+            const int ci = q >> lgTB, tb = q & (TB - 1);
+            const int r = FG ? pidx / PW : (p.magic_pw ? (int)__umulhi((unsigned)pidx, p.magic_pw) : pidx), c = pidx - r * PW;
             const int psh = KH == 2 ? p.pshift : 0;
             const int uy = (y0 * SL + r) * (S / SL) - PAD - psh, ux = (x0 * SL + c) * (S / SL) - PAD - psh;
             const bool past = ci >= ci_left_last;
-            s_dst[s] = (unsigned)(W_FLOATS + wave * wave_elems + e) * 4u;
+            if constexpr (!FG) s_dst[s] = (unsigned)(W_FLOATS + wave * wave_elems + e) * 4u;
             unsigned off = (unsigned)(grp * p.gin + ci) * (unsigned)src_plane;  // padding elements read any address inside the tensor
             if (uy >= 0 && uy < Hv && ux >= 0 && ux < Wv && b0 + tb < p.B) {
-                s_vc[s] = past ? 1u : 2u;
+                live = true;
+                if constexpr (!FG) s_vc[s] = past ? 1u : 2u;
                 int goff;
                 if (!UPS) {
                     goff = uy * p.Ws + ux;
@@ -230,13 +251,23 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
                 off = (unsigned)((size_t)(tb * p.Cx + grp * p.gin + ci) * src_plane) + (unsigned)goff;
             }
             s_xoff[s] = off * 4u;
-            s_xoffl[s] = (off - (past ? (unsigned)ci * (unsigned)src_plane : 0u)) * 4u;   // stays >= the group's first plane
+            if constexpr (!FG) s_xoffl[s] = (off - (past ? (unsigned)ci * (unsigned)src_plane : 0u)) * 4u;   // stays >= the group's first plane
             if (BSC) {   // modulation s[b,ci]: the per-sample input scale of a modulated convolution
                 const unsigned b_ = (unsigned)min(b0 + tb, p.B - 1);
                 s_sc[s] = (b_ * (unsigned)p.Cx + (unsigned)(grp * p.gin + ci)) * 4u;
                 s_scl[s] = (b_ * (unsigned)p.Cx + (unsigned)(grp * p.gin) + (past ? 0u : (unsigned)ci)) * 4u;
             }
             if (AFF) { s_sc[s] = (unsigned)(grp * p.gin + ci) * 4u; s_scl[s] = (unsigned)(grp * p.gin + (past ? 0 : ci)) * 4u; }
+        }
+        if constexpr (FG) {
+            if (UPS) {
+                // the four tap weights as products (1 mul + 3 fma per element instead of 3 mul + 3 fma), zero for padding:
+                // s_lx0 = w00, s_lx1 = w01 (row iy0), s_ly0 = w10, s_ly1 = w11 (row iy0 + 1)
+                const float m = live ? 1.f : 0.f, x0 = s_lx0[s], x1 = s_lx1[s], y0w = s_ly0[s] * m, y1w = s_ly1[s] * m;
+                s_lx0[s] = y0w * x0; s_lx1[s] = y0w * x1; s_ly0[s] = y1w * x0; s_ly1[s] = y1w * x1;
+            } else {
+                s_mask[s] = live ? 1.f : 0.f;
+            }
         }
     }
     // weight vectors: lane offsets inside a chunk's packed block; the ragged last vector is clamped
@@ -249,12 +280,12 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
 #pragma unroll
     for (int n = 0; n < C::NT; ++n) {
         const int pt = (wn * C::NT + n) * 32 + l32;
-        const int px = pt & (TW - 1), py = (pt >> p.lgTW) & (TH - 1);
-        const int tb = min(pt >> (p.lgTW + p.lgTH), TB - 1);  // pixel groups beyond the tile idle (results dropped)
-        b_off[n] = W_FLOATS + half * TB * PLANE + tb * PLANE + py * SL * PW + px * SL;
+        const int px = pt & (TW - 1), py = (pt >> lgTW) & (TH - 1);
+        const int tb = min(pt >> (lgTW + lgTH), TB - 1);  // pixel groups beyond the tile idle (results dropped)
+        b_off[n] = W_FLOATS + half * TB * PP + tb * PP + py * SL * PW + px * SL;
     }
     const int a_off = half * C::CO_T + wm * C::MT * 32 + l32;
-    const int ci_stride2 = 2 * TB * PLANE;
+    const int ci_stride2 = 2 * TB * PP;
 
     f32x16 acc[C::MT][C::NT];
 #pragma unroll
@@ -286,7 +317,10 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
         /* loads from always-valid addresses; masking happens at LDS-store time */                            \
         const float* xc = xblk + (size_t)(chunk_) * C::CI_T * src_plane; /* uniform */                        \
         const bool lastc_ = (chunk_) == p.n_chunks - 1;                                                       \
-        const unsigned vo_ = lastc_ ? s_xoffl[s_] : s_xoff[s_];                                               \
+        /* FG: the offset register is made opaque per chunk (in place), so that (base + offset) is not hoisted as a 64-bit \
+           per-lane pointer that then costs a 64-bit vector add per load: the loads keep the scalar-base + 32-bit-offset form */ \
+        if constexpr (FG) asm volatile("" : "+v"(s_xoff[s_]));                                                \
+        const unsigned vo_ = FG ? s_xoff[s_] : (lastc_ ? s_xoffl[FG ? 0 : (s_)] : s_xoff[s_]);                  \
         if (!UPS) {                                                                                           \
             xin[s_] = *reinterpret_cast<const float*>(SPK_BYTES(xc, vo_));                                    \
         } else {                                                                                              \
@@ -311,13 +345,21 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
         float v;                                                                                              \
         if (!UPS) {                                                                                           \
             v = xin[s_];                                                                                      \
+        } else if constexpr (FG) {                                                                            \
+            v = fmaf(s_ly1[s_], xin[4 * (s_) + 3], fmaf(s_ly0[s_], xin[4 * (s_) + 2],                         \
+                     fmaf(s_lx1[s_], xin[4 * (s_) + 1], s_lx0[s_] * xin[4 * (s_)])));                         \
         } else {                                                                                              \
             v = s_ly0[s_] * (s_lx0[s_] * xin[4 * (s_)] + s_lx1[s_] * xin[4 * (s_) + 1]) +                     \
                 s_ly1[s_] * (s_lx0[s_] * xin[4 * (s_) + 2] + s_lx1[s_] * xin[4 * (s_) + 3]);                  \
         }                                                                                                     \
         if (AFF) v = fmaxf(v * xsc[s_] + xsh[s_], 0.f);                                                       \
         if (BSC) v *= xsc[s_];                                                                                \
-        *reinterpret_cast<float*>(reinterpret_cast<char*>(buf_) + s_dst[s_]) = s_vc[s_] > ((lastc_) ? 1u : 0u) ? v : 0.f; \
+        if constexpr (FG) {                                                                                   \
+            if (!UPS) v *= s_mask[UPS ? 0 : (s_)];          /* UPS: the mask sits in the row weights */             \
+            *((volatile lds_f32_t*)(buf_) + ((dst_lane >> 2) + (s_) * 64)) = v;                                   \
+        } else {                                                                                              \
+            *reinterpret_cast<float*>(reinterpret_cast<char*>(buf_) + s_dst[s_]) = s_vc[s_] > ((lastc_) ? 1u : 0u) ? v : 0.f; \
+        }                                                                                                     \
     }
     // Weights by LDS-DMA (global_load_lds_dwordx4: global -> LDS without touching VGPRs; each wave copies 64-vector
     // = 1 KB blocks of the chunk's packed image to the same offset of a ring slot) when the image is a whole number
@@ -389,14 +431,20 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
     static_assert(ROWLOOP || (NST_S + NST_L <= STEPS && SB <= STEPS - PD - 1), "staging pieces do not fit the k-steps");
     float fa[PD + 1][C::MT], fb[PD + 1][C::NT];
 
+    // (FG: LDS-typed volatile reads -- one ds_read_b32 with a 16-bit immediate per value; merged ds_read2_b32 forms reach 1 KB
+    // and cost a vector add per pair of k-steps)
 #define SPK_LOAD_FRAG(abuf_, bbuf_, step_, slot_)                                                             \
     {                                                                                                         \
         constexpr int tap_ = (step_) / (C::CI_T / 2), kk_ = (step_) % (C::CI_T / 2);                          \
         const int tapoff_ = (tap_ / KW) * PW + (tap_ % KW);                                                   \
-        _Pragma("unroll") for (int m = 0; m < C::MT; ++m)                                                     \
-            fa[slot_][m] = (abuf_)[a_off + (tap_ * C::CI_T + 2 * kk_) * C::CO_T + m * 32];                    \
-        _Pragma("unroll") for (int n = 0; n < C::NT; ++n)                                                     \
-            fb[slot_][n] = (bbuf_)[b_off[n] + kk_ * ci_stride2 + tapoff_];                                    \
+        _Pragma("unroll") for (int m = 0; m < C::MT; ++m) {                                                   \
+            if constexpr (FG) fa[slot_][m] = *((const volatile lds_f32_t*)(abuf_) + (a_off + (tap_ * C::CI_T + 2 * kk_) * C::CO_T + m * 32)); \
+            else fa[slot_][m] = (abuf_)[a_off + (tap_ * C::CI_T + 2 * kk_) * C::CO_T + m * 32];               \
+        }                                                                                                     \
+        _Pragma("unroll") for (int n = 0; n < C::NT; ++n) {                                                   \
+            if constexpr (FG) fb[slot_][n] = *((const volatile lds_f32_t*)(bbuf_) + (b_off[n] + kk_ * ci_stride2 + tapoff_)); \
+            else fb[slot_][n] = (bbuf_)[b_off[n] + kk_ * ci_stride2 + tapoff_];                               \
+        }                                                                                                     \
     }
 #define SPK_MFMA_STEP(slot_)                                                                                  \
     _Pragma("unroll") for (int m = 0; m < C::MT; ++m)                                                         \
@@ -528,7 +576,7 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
         float* const red_s = ot + (C::CO_T / rounds) * OP;    // [2][CO_T] row sums / sums of squares (SPK_EPI_STATS)
         const int f4 = tid % F4, row0 = tid / F4;
         const int pt = 4 * f4;
-        const int px = pt & (TW - 1), py = (pt >> p.lgTW) & (TH - 1), tb = pt >> (p.lgTW + p.lgTH);
+        const int px = pt & (TW - 1), py = (pt >> lgTW) & (TH - 1), tb = pt >> (lgTW + lgTH);
         const int b = b0 + tb, yy = y0 + py, xx = x0 + px;
         const bool pvv = tb < TB && b < p.B && yy < p.H && xx < p.W;      // W % 4 == 0: the vector is in or out as a whole
         const size_t pix = (size_t)yy * p.W + xx;
@@ -627,7 +675,7 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
 #pragma unroll
     for (int n = 0; n < C::NT; ++n) {
         const int pt = (wn * C::NT + n) * 32 + l32;
-        const int px = pt & (TW - 1), py = (pt >> p.lgTW) & (TH - 1), tb = pt >> (p.lgTW + p.lgTH);
+        const int px = pt & (TW - 1), py = (pt >> lgTW) & (TH - 1), tb = pt >> (lgTW + lgTH);
         const int b = b0 + tb, yy = y0 + py, xx = x0 + px;
         pv[n] = tb < TB && b < p.B && yy < p.H && xx < p.W;
         const size_t pix = (size_t)yy * p.W + xx;
@@ -779,7 +827,7 @@ inline int resolve_ksplit(const Geometry& g, int requested, int* chunks_per_spli
 int launch_splitk_epilogue(const ConvArgs& a, const float* ws, int ksplit, hipStream_t stream);
 
 // Fill ConvArgs from the public descriptor, pick geometry / split-K, launch (and the split-K epilogue).
-template <class C, int KH, int KW, int S, int MODE>
+template <class C, int KH, int KW, int S, int MODE, bool TRY_FG = false>
 int run(const spk_conv2d_desc* d, hipStream_t stream, int Hd = 0, int Wd = 0, int pshift = 0) {
     ConvArgs a;
     a.Hd = Hd; a.Wd = Wd; a.pshift = pshift;
@@ -807,6 +855,14 @@ int run(const spk_conv2d_desc* d, hipStream_t stream, int Hd = 0, int Wd = 0, in
     a.n_chunks = g.n_chunks;
     a.style_stride = d->style_stride; a.flags = d->flags; a.slope = d->lrelu_slope; a.out_scale = d->out_scale; a.act_gain = d->act_gain != 0.f ? d->act_gain : 1.f;
     const int ksplit = resolve_ksplit(g, d->ksplit, &a.chunks_per_split);
+    // the fixed-geometry build of the same kernel, where the layer's tile is that one (and no chunk is ragged)
+    bool use_fg = false;
+    if constexpr (TRY_FG) {
+        static const bool fg_on = [] { const char* e = getenv("SPK_CONV_FG"); return !e || atoi(e) != 0; }();
+        use_fg = fg_on && g.TW == 32 && g.TH == C::PIX_T / 32 && g.TB == 1 && d->Cin % C::CI_T == 0;
+        if (use_fg)                       // planes NSLOT * 64 floats apart (see the kernel)
+            g.lds_bytes = 3 * ((size_t)Shape<C, KH, KW, S>::W_FLOATS + (size_t)C::CI_T * Shape<C, KH, KW, S>::NSLOT * 64 + 4) * sizeof(float);
+    }
     // staged epilogue: whenever its LDS tile costs no workgroup slot and the vectors are whole and aligned
     a.staged = 0;
     {
@@ -832,13 +888,16 @@ int run(const spk_conv2d_desc* d, hipStream_t stream, int Hd = 0, int Wd = 0, in
         a.y = static_cast<float*>(d->workspace);
     }
     auto kern = &conv_kernel<C, KH, KW, S, MODE>;
-    if (g.lds_bytes > 64 * 1024) {  // dynamic LDS above 64 KiB needs the attribute raised (once)
-        static bool raised = false;
-        if (!raised) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    if constexpr (TRY_FG) {
+        if (use_fg) kern = &conv_kernel<C, KH, KW, S, MODE, true>;
+    }
+    if (g.lds_bytes > 64 * 1024) {  // dynamic LDS above 64 KiB needs the attribute raised (once per kernel)
+        static const void* raised[2] = {nullptr, nullptr};
+        const void* kp = reinterpret_cast<const void*>(kern);
+        if (raised[0] != kp && raised[1] != kp) {
+            hipError_t e = hipFuncSetAttribute(kp, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return spk::fail(SPK_ELAUNCH, "hipFuncSetAttribute(LDS): %s", hipGetErrorString(e));
-            raised = true;
+            raised[raised[0] ? 1 : 0] = kp;
         }
     }
     const long long gx = (long long)g.tiles_x * g.tiles_y * g.tiles_b;
