@@ -3,17 +3,17 @@
 
 namespace spkconv {
 
-// (the decoders' hot modes also exist with the fixed 32-wide tile geometry -- conv_kernel<..., FG = true> -- for the 128- and
-// 256-pixel tiles: the layers from 32^2 up)
+// (every mode also exists with the fixed 32-wide tile geometry -- conv_kernel<..., FG = true> -- for the 128- and 256-pixel
+// tiles: the layers from 32^2 up)
 template <class C>
 static int by_mode(int mode, const spk_conv2d_desc* d, hipStream_t s) {
     constexpr bool FG = C::PIX_T >= 128;
     switch (mode) {
         case MODE_PLAIN: return run<C, 3, 3, 1, MODE_PLAIN, FG>(d, s);
         case MODE_UPSAMPLE: return run<C, 3, 3, 1, MODE_UPSAMPLE, FG>(d, s);
-        case MODE_BATCH_SCALE: return run<C, 3, 3, 1, MODE_BATCH_SCALE>(d, s);
-        case MODE_UPSAMPLE_BATCH_SCALE: return run<C, 3, 3, 1, MODE_UPSAMPLE_BATCH_SCALE>(d, s);
-        default: return run<C, 3, 3, 1, MODE_AFFINE_RELU>(d, s);
+        case MODE_BATCH_SCALE: return run<C, 3, 3, 1, MODE_BATCH_SCALE, FG>(d, s);
+        case MODE_UPSAMPLE_BATCH_SCALE: return run<C, 3, 3, 1, MODE_UPSAMPLE_BATCH_SCALE, FG>(d, s);
+        default: return run<C, 3, 3, 1, MODE_AFFINE_RELU, FG>(d, s);
     }
 }
 

@@ -160,7 +160,7 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
     // FG: every wave stages ONE input plane (CI_T = waves, TB = 1) and the planes sit NSLOT * 64 floats apart, so that lane l's
     // element of gather slot s lives at plane + s * 64 + l for every lane (lanes past the plane write into the pitch's padding):
     // an LDS store is one base register + an immediate, and needs no dump slot
-    static_assert(!FG || (C::CI_T == C::NW && S == 1 && KH == 3 && (MODE == MODE_PLAIN || MODE == MODE_UPSAMPLE)), "fixed geometry: 3x3 stride 1, one plane per wave");
+    static_assert(!FG || (C::CI_T == C::NW && S == 1 && KH == 3), "fixed geometry: 3x3 stride 1, one plane per wave");
     const int PP = FG ? NSLOT * 64 : PLANE;
     const int IN_FLOATS = C::CI_T * TB * PP;
     const int BUF_FLOATS = W_FLOATS + ((IN_FLOATS + 3) & ~3) + 4;  // +4: dump slot for lanes without an element
@@ -201,7 +201,7 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
     unsigned s_xoff[NSLOT], s_xoffl[FG ? 1 : NSLOT], s_dst[FG ? 1 : NSLOT], s_vc[FG ? 1 : NSLOT];
     float s_mask[(FG && !UPS) ? NSLOT : 1];               // FG: 1 / 0 (zero padding) -- multiplied in, or folded into the bilinear weights
     const unsigned dst_lane = (unsigned)(W_FLOATS + wave * PP + lane) * 4u;
-    unsigned s_dxb[UPS ? NSLOT : 1], s_dyb[UPS ? NSLOT : 1];
+    unsigned s_dxb[(UPS && !FG) ? NSLOT : 1], s_dyb[(UPS && !FG) ? NSLOT : 1];
     float s_lx0[UPS ? NSLOT : 1], s_lx1[UPS ? NSLOT : 1], s_ly0[UPS ? NSLOT : 1], s_ly1[UPS ? NSLOT : 1];
     unsigned s_sc[(AFF || BSC) ? NSLOT : 1], s_scl[(AFF || BSC) ? NSLOT : 1];
 #pragma unroll
@@ -213,7 +213,7 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
             s_vc[s] = 0;
             s_dst[s] = (unsigned)(BUF_FLOATS - 1) * 4u;
         }
-        if (UPS) { s_dxb[s] = s_dyb[s] = 0; s_lx0[s] = s_ly0[s] = 1.f; s_lx1[s] = s_ly1[s] = 0.f; }
+        if (UPS) { if constexpr (!FG) s_dxb[s] = s_dyb[s] = 0; s_lx0[s] = s_ly0[s] = 1.f; s_lx1[s] = s_ly1[s] = 0.f; }
         if (AFF || BSC) s_sc[s] = s_scl[s] = 0;
         const int e = s * 64 + lane;
         if (e < wave_elems) {
@@ -242,11 +242,25 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
                     const int iy0 = uy == 0 ? 0 : (uy - 1) >> 1, ix0 = ux == 0 ? 0 : (ux - 1) >> 1;
                     unsigned ly = uy == 0 ? (zb ? 3u : 0u) : ((uy & 1) ? 1u : 2u);
                     unsigned lx = ux == 0 ? (zb ? 3u : 0u) : ((ux & 1) ? 1u : 2u);
-                    if (iy0 + 1 < p.Hs) s_dyb[s] = (unsigned)p.Ws * 4u; else if (zb) ly = 3u;
-                    if (ix0 + 1 < p.Ws) s_dxb[s] = 4u; else if (zb) lx = 3u;
-                    s_lx0[s] = w0_of(lx); s_lx1[s] = w1_of(lx);
-                    s_ly0[s] = w0_of(ly); s_ly1[s] = w1_of(ly);
-                    goff = iy0 * p.Ws + ix0;
+                    int gy = iy0, gx = ix0;
+                    float wx0, wx1, wy0, wy1;
+                    if constexpr (FG) {
+                        // FG: the second column / row tap is ALWAYS one element / one row further (an instruction immediate and
+                        // a second scalar base: no per-lane address arithmetic).  Where bilinear clamps that tap onto the first
+                        // (last column / row), the pair moves one back and the whole weight goes to ITS second tap -- the same
+                        // value, every read inside the plane (host: Hs, Ws >= 2 for this build).
+                        // (zero border: the clamped-away neighbour counts as zero, the tap keeps its own weight)
+                        wx0 = w0_of(lx); wx1 = w1_of(lx); wy0 = w0_of(ly); wy1 = w1_of(ly);
+                        if (ix0 + 1 >= p.Ws) { gx = ix0 - 1; wx1 = zb ? wx0 : wx0 + wx1; wx0 = 0.f; }
+                        if (iy0 + 1 >= p.Hs) { gy = iy0 - 1; wy1 = zb ? wy0 : wy0 + wy1; wy0 = 0.f; }
+                    } else {
+                        if (iy0 + 1 < p.Hs) s_dyb[FG ? 0 : s] = (unsigned)p.Ws * 4u; else if (zb) ly = 3u;
+                        if (ix0 + 1 < p.Ws) s_dxb[FG ? 0 : s] = 4u; else if (zb) lx = 3u;
+                        wx0 = w0_of(lx); wx1 = w1_of(lx); wy0 = w0_of(ly); wy1 = w1_of(ly);
+                    }
+                    s_lx0[s] = wx0; s_lx1[s] = wx1;
+                    s_ly0[s] = wy0; s_ly1[s] = wy1;
+                    goff = gy * p.Ws + gx;
                 }
                 off = (unsigned)((size_t)(tb * p.Cx + grp * p.gin + ci) * src_plane) + (unsigned)goff;
             }
@@ -323,6 +337,12 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
         const unsigned vo_ = FG ? s_xoff[s_] : (lastc_ ? s_xoffl[FG ? 0 : (s_)] : s_xoff[s_]);                  \
         if (!UPS) {                                                                                           \
             xin[s_] = *reinterpret_cast<const float*>(SPK_BYTES(xc, vo_));                                    \
+        } else if constexpr (FG) {   /* second taps: +1 element (an immediate), +1 row (a second scalar base) */ \
+            const float* xr = xc + p.Ws;                                                                      \
+            xin[4 * (s_) + 0] = *reinterpret_cast<const float*>(SPK_BYTES(xc, vo_));                          \
+            xin[4 * (s_) + 1] = *reinterpret_cast<const float*>(SPK_BYTES(xc, vo_) + 4);                      \
+            xin[4 * (s_) + 2] = *reinterpret_cast<const float*>(SPK_BYTES(xr, vo_));                          \
+            xin[4 * (s_) + 3] = *reinterpret_cast<const float*>(SPK_BYTES(xr, vo_) + 4);                      \
         } else {                                                                                              \
             xin[4 * (s_) + 0] = *reinterpret_cast<const float*>(SPK_BYTES(xc, vo_));                          \
             xin[4 * (s_) + 1] = *reinterpret_cast<const float*>(SPK_BYTES(xc, vo_ + s_dxb[s_]));              \
@@ -330,7 +350,7 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
             xin[4 * (s_) + 3] = *reinterpret_cast<const float*>(SPK_BYTES(xc, vo_ + s_dyb[s_] + s_dxb[s_]));  \
         }                                                                                                     \
         if (BSC || AFF) {                                                                                     \
-            const unsigned so_ = lastc_ ? s_scl[s_] : s_sc[s_];                                               \
+            const unsigned so_ = FG ? s_sc[s_] : (lastc_ ? s_scl[s_] : s_sc[s_]);   /* FG: no ragged chunk */   \
             xsc[s_] = *reinterpret_cast<const float*>(SPK_BYTES(p.in_scale + (size_t)(chunk_) * C::CI_T, so_)); \
             if (AFF) xsh[s_] = *reinterpret_cast<const float*>(SPK_BYTES(p.in_shift + (size_t)(chunk_) * C::CI_T, so_)); \
         }                                                                                                     \
@@ -859,7 +879,7 @@ int run(const spk_conv2d_desc* d, hipStream_t stream, int Hd = 0, int Wd = 0, in
     bool use_fg = false;
     if constexpr (TRY_FG) {
         static const bool fg_on = [] { const char* e = getenv("SPK_CONV_FG"); return !e || atoi(e) != 0; }();
-        use_fg = fg_on && g.TW == 32 && g.TH == C::PIX_T / 32 && g.TB == 1 && d->Cin % C::CI_T == 0;
+        use_fg = fg_on && g.TW == 32 && g.TH == C::PIX_T / 32 && g.TB == 1 && d->Cin % C::CI_T == 0 && d->Hin >= 2 && d->Win >= 2;
         if (use_fg)                       // planes NSLOT * 64 floats apart (see the kernel)
             g.lds_bytes = 3 * ((size_t)Shape<C, KH, KW, S>::W_FLOATS + (size_t)C::CI_T * Shape<C, KH, KW, S>::NSLOT * 64 + 4) * sizeof(float);
     }
