@@ -1515,23 +1515,33 @@ __global__ __launch_bounds__(256) void wgrad1x1_kernel(const WgradArgs p, int ti
         if (AFF && x_ok[i]) { a_sc[i] = p.in_scale[cx0 + r]; a_sh[i] = p.in_shift[cx0 + r]; }
     }
 
-#define SPK_G1_LOAD(t_)                                                                                      \
+    // Vector-instruction diet (the f32 MFMA shares the SIMD's vector ALU, tools/mfma_valu_coexec.hip: the first version of this
+    // loop spent 150 vector instructions per 64 MFMAs -- a uniform integer division, 64-bit address products per load, a zero
+    // select per staged value):
+    //   * a load is a SCALAR base (image / k-tile: advanced with scalar adds) + the lane's constant 32-bit offset (row, pixels);
+    //   * rows past the group / past Cin are loaded from a valid row and NOT zeroed: they only reach accumulator rows / columns
+    //     that the final store skips;
+    //   * stride 2 gathers keep their per-lane pixel arithmetic (they are three launches of the trunk).
+    unsigned g_lane[RG], x_lane[RX];                       // element offsets of (row, scol) from the k-tile's first pixel
+#pragma unroll
+    for (int i = 0; i < RG; ++i) g_lane[i] = (unsigned)((g_ok[i] ? co0 + srow + 32 * i : co0) * HW) + (unsigned)scol;
+#pragma unroll
+    for (int i = 0; i < RX; ++i) x_lane[i] = (unsigned)((x_ok[i] ? cx0 + srow + 32 * i : cx0) * src_plane) + (S == 1 ? (unsigned)scol : 0u);
+    // (uniform) position of k-tile t: image b, first pixel q of the tile inside the image
+    int tb = t_begin / tpi, tq = (t_begin - tb * tpi) * G1_KT;
+#define SPK_G1_LOAD(tb_, tq_)                                                                                \
     {                                                                                                        \
-        const int b_ = (t_) / tpi;                                                                           \
-        const size_t q0_ = (size_t)((t_) - b_ * tpi) * G1_KT + scol;          /* output pixel in the image */  \
-        _Pragma("unroll") for (int i = 0; i < RG; ++i) {                                                     \
-            const int r = srow + 32 * i;                                                                     \
-            const size_t go = ((size_t)b_ * p.Cy + (g_ok[i] ? co0 + r : co0)) * HW + q0_;                     \
-            gq[i] = *reinterpret_cast<const float4*>(p.g + go);                                              \
-        }                                                                                                    \
-        _Pragma("unroll") for (int i = 0; i < RX; ++i) {                                                     \
-            const int r = srow + 32 * i;                                                                     \
-            const float* xr = p.x + ((size_t)b_ * p.Cx + (x_ok[i] ? cx0 + r : cx0)) * src_plane;             \
-            if (S == 1) {                                                                                    \
-                xq[i] = *reinterpret_cast<const float4*>(xr + q0_);                                          \
-            } else {                                                                                         \
-                const int y_ = (int)(q0_ / p.W), x_ = (int)(q0_ - (size_t)y_ * p.W);   /* 4 pixels of one row (W % 4 == 0) */ \
-                const float* xp = xr + (size_t)(y_ * S) * p.Ws + x_ * S;                                     \
+        const float* gb_ = p.g + ((size_t)(tb_) * p.Cy * HW + (size_t)(tq_));                  /* uniform */  \
+        _Pragma("unroll") for (int i = 0; i < RG; ++i) gq[i] = *reinterpret_cast<const float4*>(gb_ + g_lane[i]); \
+        if (S == 1) {                                                                                        \
+            const float* xb_ = p.x + ((size_t)(tb_) * p.Cx * src_plane + (size_t)(tq_));       /* uniform */  \
+            _Pragma("unroll") for (int i = 0; i < RX; ++i) xq[i] = *reinterpret_cast<const float4*>(xb_ + x_lane[i]); \
+        } else {                                                                                             \
+            const float* xb_ = p.x + (size_t)(tb_) * p.Cx * src_plane;                                       \
+            const int q0_ = (tq_) + scol;                                                                    \
+            const int y_ = q0_ / p.W, x_ = q0_ - y_ * p.W;   /* 4 pixels of one row (W % 4 == 0) */           \
+            _Pragma("unroll") for (int i = 0; i < RX; ++i) {                                                 \
+                const float* xp = xb_ + x_lane[i] + (size_t)(y_ * S) * p.Ws + x_ * S;                        \
                 xq[i] = make_float4(xp[0], xp[S], xp[2 * S], xp[3 * S]);                                     \
             }                                                                                                \
         }                                                                                                    \
@@ -1542,8 +1552,7 @@ __global__ __launch_bounds__(256) void wgrad1x1_kernel(const WgradArgs p, int ti
         float* xd = xs + (buf_) * BN * G1_PITCH;                                                             \
         _Pragma("unroll") for (int i = 0; i < RG; ++i) {                                                     \
             const int o = (srow + 32 * i) * G1_PITCH + scol;                                                 \
-            const float4 gv = g_ok[i] ? gq[i] : make_float4(0.f, 0.f, 0.f, 0.f);                             \
-            gd[o] = gv.x; gd[o + 1] = gv.y; gd[o + 2] = gv.z; gd[o + 3] = gv.w;                              \
+            gd[o] = gq[i].x; gd[o + 1] = gq[i].y; gd[o + 2] = gq[i].z; gd[o + 3] = gq[i].w;                  \
         }                                                                                                    \
         _Pragma("unroll") for (int i = 0; i < RX; ++i) {                                                     \
             const int o = (srow + 32 * i) * G1_PITCH + scol;                                                 \
@@ -1552,7 +1561,6 @@ __global__ __launch_bounds__(256) void wgrad1x1_kernel(const WgradArgs p, int ti
                 xv.x = fmaxf(xv.x * a_sc[i] + a_sh[i], 0.f); xv.y = fmaxf(xv.y * a_sc[i] + a_sh[i], 0.f);    \
                 xv.z = fmaxf(xv.z * a_sc[i] + a_sh[i], 0.f); xv.w = fmaxf(xv.w * a_sc[i] + a_sh[i], 0.f);    \
             }                                                                                                \
-            if (!x_ok[i]) xv = make_float4(0.f, 0.f, 0.f, 0.f);                                              \
             xd[o] = xv.x; xd[o + 1] = xv.y; xd[o + 2] = xv.z; xd[o + 3] = xv.w;                              \
         }                                                                                                    \
     }
@@ -1566,14 +1574,16 @@ __global__ __launch_bounds__(256) void wgrad1x1_kernel(const WgradArgs p, int ti
             for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
 
     if (t_begin < t_end) {
-        SPK_G1_LOAD(t_begin);
+        SPK_G1_LOAD(tb, tq);
         SPK_G1_STORE(0);
     }
     __syncthreads();
     for (int t = t_begin; t < t_end; ++t) {
         const int buf = (t - t_begin) & 1;
         const bool more = t + 1 < t_end;
-        if (more) SPK_G1_LOAD(t + 1);
+        tq += G1_KT;                                        // (uniform) the next k-tile: same image, or the next one's first
+        if (tq >= (int)HW) { tq = 0; ++tb; }
+        if (more) SPK_G1_LOAD(tb, tq);
         const float* ga = gs + buf * BM * G1_PITCH + (wm * 32 * MT + l32) * G1_PITCH + half;
         const float* xb = xs + buf * BN * G1_PITCH + (wn * 32 * NT + l32) * G1_PITCH + half;
         float fa[2][MT], fb[2][NT];
@@ -1664,6 +1674,8 @@ int run_wgrad1x1_shape(const spk_wgrad_desc* d, hipStream_t stream) {
         if (e != hipSuccess) return spk::fail(SPK_ELAUNCH, "hipFuncSetAttribute(LDS): %s", hipGetErrorString(e));
         raised = true;
     }
+    SPK_REQUIRE((long long)a.Cy * d->H * d->W < (1ll << 31) && (long long)a.Cx * d->Hin * d->Win < (1ll << 31),
+                "wgrad 1x1 GEMM form: an image's planes are addressed with 32-bit offsets");
     // a co block must not straddle two groups
     SPK_REQUIRE(G == 1 || d->Cout % BM == 0, "wgrad 1x1 GEMM form: grouped launches need Cout %% %d == 0 (use the tap kernel)", BM);
     dim3 grid((unsigned)spk::ceil_div(G * d->Cout, BM), (unsigned)spk::ceil_div(d->Cin, BN), (unsigned)g.splits);
