@@ -166,7 +166,7 @@ def conv_time_ms(module, feats, L):
     return ms, n
 
 
-def irfd_steps(pkg, dev, which, B, steps, warmup, precision="f32", sg2=False):
+def irfd_steps(pkg, dev, which, B, steps, warmup, precision="f32", sg2=False, observe=None):
     """The generator step (config 3) / discriminator step of train.py:150-210 on synthetic pairs -- tools/train_step_bench.py
     in brief.  Returns ms per step."""
     import model as M
@@ -207,8 +207,13 @@ def irfd_steps(pkg, dev, which, B, steps, warmup, precision="f32", sg2=False):
             step()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
-        for _ in range(steps):
-            step()
+        if observe is not None:                # tools/op_callsites.py: the timed steps under a TorchDispatchMode
+            with observe:
+                for _ in range(steps):
+                    step()
+        else:
+            for _ in range(steps):
+                step()
         torch.cuda.synchronize()
         ms = (time.perf_counter() - t0) / steps * 1e3
     red.remove()

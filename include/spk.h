@@ -365,6 +365,13 @@ int spk_bn_bwd_reduce(const float* g, const float* r, const float* mask_src, int
 int spk_bn_bwd_apply(const float* g, const float* r, const float* mask_src, int mask_mode, const float* scale,
                      const float* shift, const float* mean, const float* invstd, const float* csum, int64_t count,
                      float g_scale, int g_per_plane, float* dr, float* dz_out, int B, int C, int64_t HW, void* stream);
+/* spk_bn_bwd_apply taking the reduce pass's per-image sums [B][2][C] as they are: every workgroup adds up its channel's B pairs
+ * itself (no batch-reduction launch in between) and the totals -- rows d beta, d gamma -- are written to csum_out [2][C].
+ * batch_stats = 0: an eval-mode BatchNorm (a fixed affine: no mean / variance terms in dr; csum_out is still the totals). */
+int spk_bn_bwd_apply_sums(const float* g, const float* r, const float* mask_src, int mask_mode, const float* scale,
+                          const float* shift, const float* mean, const float* invstd, const float* sums, float* csum_out,
+                          int batch_stats, int64_t count, float g_scale, int g_per_plane, float* dr, float* dz_out, int B, int C,
+                          int64_t HW, void* stream);
 /* zero-insertion x2 ([planes,H,W] -> [planes,Ho,Wo], Ho in {2H-1,2H}): the data gradient of a stride-2 conv is the
  * stride-1 transpose_flip conv of the dilated output gradient. */
 int spk_dilate2x(const float* x, float* y, int64_t planes, int H, int W, int Ho, int Wo, void* stream);

@@ -154,6 +154,8 @@ _PROTOTYPES = {
                           [C.c_float, C.c_int, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p]),
     "spk_bn_bwd_apply": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 5 +
                          [C.c_int64, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p]),
+    "spk_bn_bwd_apply_sums": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int] + [C.c_void_p] * 6 +
+                              [C.c_int, C.c_int64, C.c_float, C.c_int, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int64, C.c_void_p]),
     "spk_dilate2x": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "spk_maxpool3x3s2_bwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 4 + [C.c_void_p]),
     "spk_conv2d_wgrad_workspace_bytes": (C.c_int64, [C.c_int] * 9),

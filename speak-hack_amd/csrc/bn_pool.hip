@@ -201,11 +201,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restri
                                                           const float* __restrict__ mean, const float* __restrict__ invstd,
                                                           const float* __restrict__ csum, float inv_count, float g_scale,
                                                           long long g_plane_stride, float* __restrict__ dr, float* __restrict__ dz_out,
-                                                          int C, long long HW) {
+                                                          int C, long long HW, int n_sums, float* __restrict__ csum_out, float stat_w) {
     const long long plane = blockIdx.x;
     const int c = (int)(plane % C);
     const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
-    const float c1 = csum[c] * inv_count, c2 = csum[C + c] * inv_count;   // csum [2][C]: sums reduced over the batch
+    // csum [n_sums][2][C]: the per-image sums of the reduce pass (n_sums = B: added up here, every workgroup for itself --
+    // 2 B floats out of L2 instead of a reduction launch) or the batch totals (n_sums = 1)
+    float t1 = 0.f, t2 = 0.f;
+    for (int b = 0; b < n_sums; ++b) { t1 += csum[(size_t)(2 * b) * C + c]; t2 += csum[(size_t)(2 * b + 1) * C + c]; }
+    if (csum_out && plane < C && blockIdx.y == 0 && threadIdx.x == 0) { csum_out[c] = t1; csum_out[C + c] = t2; }
+    const float c1 = t1 * inv_count * stat_w, c2 = t2 * inv_count * stat_w;
     const float* gp = g + (g_plane_stride ? plane * g_plane_stride : plane);
     const float* rp = r + plane * HW;
     const float* mp = mask_src ? mask_src + plane * HW : nullptr;
@@ -279,13 +284,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_vec_kernel(const float* __re
                                                               const float* __restrict__ mean, const float* __restrict__ invstd,
                                                               const float* __restrict__ csum, float inv_count, float g_scale,
                                                               long long g_plane_stride, float* __restrict__ dr,
-                                                              float* __restrict__ dz_out, int C, long long HW, long long planes) {
+                                                              float* __restrict__ dz_out, int C, long long HW, long long planes,
+                                                              int n_sums, float* __restrict__ csum_out, float stat_w) {
     const int t = threadIdx.x % TPP;
     const long long plane = (long long)blockIdx.x * (256 / TPP) + threadIdx.x / TPP;
     if (plane >= planes) return;
     const int c = (int)(plane % C);
     const float sc = scale[c], sh = shift[c], mu = mean[c], is = invstd[c];
-    const float c1 = csum[c] * inv_count, c2 = csum[C + c] * inv_count;   // csum [2][C]: sums reduced over the batch
+    float t1 = 0.f, t2 = 0.f;                               // (see bn_bwd_apply_kernel)
+    for (int b = 0; b < n_sums; ++b) { t1 += csum[(size_t)(2 * b) * C + c]; t2 += csum[(size_t)(2 * b + 1) * C + c]; }
+    if (csum_out && plane < C && blockIdx.y == 0 && t == 0) { csum_out[c] = t1; csum_out[C + c] = t2; }
+    const float c1 = t1 * inv_count * stat_w, c2 = t2 * inv_count * stat_w;
     const float* rp = r + plane * HW;
     const float* mp = mask_src ? mask_src + plane * HW : nullptr;
     const float g1 = g_plane_stride ? 0.f : g[plane] * g_scale;
@@ -454,10 +463,11 @@ int spk_bn_bwd_reduce(const float* g, const float* r, const float* mask_src, int
     return spk::check_launch("bn_bwd_reduce_kernel");
 }
 
-int spk_bn_bwd_apply(const float* g, const float* r, const float* mask_src, int mask_mode, const float* scale,
-                     const float* shift, const float* mean, const float* invstd, const float* csum, int64_t count,
-                     float g_scale, int g_per_plane, float* dr, float* dz_out, int B, int C, int64_t HW, void* stream) {
-    SPK_REQUIRE(g && r && scale && shift && mean && invstd && csum && dr && B > 0 && C > 0 && HW > 0 && count > 0,
+static int bn_bwd_apply_impl(const float* g, const float* r, const float* mask_src, int mask_mode, const float* scale,
+                             const float* shift, const float* mean, const float* invstd, const float* csum, int n_sums,
+                             float* csum_out, float stat_w, int64_t count, float g_scale, int g_per_plane, float* dr,
+                             float* dz_out, int B, int C, int64_t HW, void* stream) {
+    SPK_REQUIRE(g && r && scale && shift && mean && invstd && csum && dr && B > 0 && C > 0 && HW > 0 && count > 0 && n_sums >= 1,
                 "bn_bwd_apply: bad arguments");
     SPK_REQUIRE(mask_mode != MASK_TENSOR || mask_src, "bn_bwd_apply: MASK_TENSOR without mask tensor");
     const long long planes = (long long)B * C, gps = g_per_plane ? 0 : HW;
@@ -465,19 +475,36 @@ int spk_bn_bwd_apply(const float* g, const float* r, const float* mask_src, int 
         if (HW <= 1024) {
             hipLaunchKernelGGL(bn_bwd_apply_vec_kernel<64>, dim3((unsigned)((planes + 3) / 4)), dim3(256), 0, (hipStream_t)stream, g, r,
                                mask_src, mask_mode, scale, shift, mean, invstd, csum, 1.0f / (float)count, g_scale, gps, dr, dz_out,
-                               C, (long long)HW, planes);
+                               C, (long long)HW, planes, n_sums, csum_out, stat_w);
         } else {
             const unsigned chunks = (unsigned)std::max(1ll, std::min((long long)HW / (256 * 4 * 4), 16ll));   // >= 4 vectors per thread
             hipLaunchKernelGGL(bn_bwd_apply_vec_kernel<256>, dim3((unsigned)planes, chunks), dim3(256), 0, (hipStream_t)stream, g, r,
                                mask_src, mask_mode, scale, shift, mean, invstd, csum, 1.0f / (float)count, g_scale, gps, dr, dz_out,
-                               C, (long long)HW, planes);
+                               C, (long long)HW, planes, n_sums, csum_out, stat_w);
         }
         return spk::check_launch("bn_bwd_apply_vec_kernel");
     }
     dim3 grid((unsigned)(B * C), (unsigned)std::max(1ll, std::min(((long long)HW + 255) / 256, 64ll)));
     hipLaunchKernelGGL(bn_bwd_apply_kernel, grid, dim3(256), 0, (hipStream_t)stream, g, r, mask_src, mask_mode, scale, shift, mean,
-                       invstd, csum, 1.0f / (float)count, g_scale, (long long)(g_per_plane ? 0 : HW), dr, dz_out, C, (long long)HW);
+                       invstd, csum, 1.0f / (float)count, g_scale, (long long)(g_per_plane ? 0 : HW), dr, dz_out, C, (long long)HW,
+                       n_sums, csum_out, stat_w);
     return spk::check_launch("bn_bwd_apply_kernel");
+}
+
+int spk_bn_bwd_apply(const float* g, const float* r, const float* mask_src, int mask_mode, const float* scale,
+                     const float* shift, const float* mean, const float* invstd, const float* csum, int64_t count,
+                     float g_scale, int g_per_plane, float* dr, float* dz_out, int B, int C, int64_t HW, void* stream) {
+    return bn_bwd_apply_impl(g, r, mask_src, mask_mode, scale, shift, mean, invstd, csum, 1, nullptr, 1.f, count, g_scale, g_per_plane,
+                             dr, dz_out, B, C, HW, stream);
+}
+
+int spk_bn_bwd_apply_sums(const float* g, const float* r, const float* mask_src, int mask_mode, const float* scale,
+                          const float* shift, const float* mean, const float* invstd, const float* sums, float* csum_out,
+                          int batch_stats, int64_t count, float g_scale, int g_per_plane, float* dr, float* dz_out, int B, int C,
+                          int64_t HW, void* stream) {
+    SPK_REQUIRE(csum_out, "bn_bwd_apply_sums: null csum_out");
+    return bn_bwd_apply_impl(g, r, mask_src, mask_mode, scale, shift, mean, invstd, sums, B, csum_out, batch_stats ? 1.f : 0.f, count,
+                             g_scale, g_per_plane, dr, dz_out, B, C, HW, stream);
 }
 
 int spk_dilate2x(const float* x, float* y, int64_t planes, int H, int W, int Ho, int Wo, void* stream) {

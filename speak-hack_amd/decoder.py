@@ -239,3 +239,40 @@ class StyleGenerator(nn.Module):
                     # gradient of the mixed rows still flows into the first mapping pass (a reference quirk)
                     w[:, mix_layer:] = w2[:, mix_layer:]
         return self.synthesis(w, noises)
+
+    def forward_pair(self, features_a, features_b, noises_a=None, noises_b=None):
+        """``(self(features_a, noises_a), self(features_b, noises_b))`` as ONE pass over the concatenated batch -- the two
+        decoder calls of ``IRFD.forward`` (model.py:107-108).  The decoder has no cross-sample operation, so the frames are
+        those of the two calls; the HOST RNG is consumed exactly as by two calls in sequence (rand, randint of call a, then of
+        call b: styleganv1.py:548-552) and each half gets its own style-mixing decision and layer.  Device noise is one draw
+        for both halves (device RNG streams are not comparable with the reference's per-layer draws either way; parity tests
+        pass explicit noise).  Half the launches, twice the work per launch (the 4^2 .. 16^2 layers at batch 8 leave most
+        of the chip idle), and the shared parameters' gradients come out of one backward instead of two plus an add."""
+        if (noises_a is None) != (noises_b is None) or features_a.shape != features_b.shape:
+            return self.forward(features_a, noises_a), self.forward(features_b, noises_b)
+        B = features_a.size(0)
+        feats = torch.cat([features_a, features_b], 0)
+        noises = None if noises_a is None else [torch.cat([na, nb], 0) for na, nb in zip(noises_a, noises_b)]
+        if not (self.training and self.style_mixing_prob > 0):
+            y = self.forward(feats, noises, style_mix=False)
+            return y[:B], y[B:]
+        L = self.synthesis.num_layers
+        w = self.mapping(feats).unsqueeze(1).repeat(1, L, 1)
+        if self.truncation_psi and self.truncation_cutoff:
+            coefs = torch.ones_like(w)
+            coefs[:, :self.truncation_cutoff] *= self.truncation_psi
+            w = coefs * w
+        # the draws of call a, then of call b, in the reference's order; the second mapping passes run as one
+        picks = []
+        for half, f in enumerate((features_a, features_b)):
+            if torch.rand(1) < self.style_mixing_prob:
+                z2 = torch.randn_like(f)
+                picks.append((half, z2, torch.randint(1, L, (1,)).item()))
+        if picks:
+            with torch.no_grad():
+                w2 = self.mapping(torch.cat([z for _, z, _ in picks], 0)).unsqueeze(1).repeat(1, L, 1)
+                for j, (half, _, mix_layer) in enumerate(picks):
+                    # in place and under no_grad, as the reference (the gradient quirk of the overwrite is kept)
+                    w[half * B:(half + 1) * B, mix_layer:] = w2[j * B:(j + 1) * B, mix_layer:]
+        y = self.synthesis(w, noises)
+        return y[:B], y[B:]

@@ -32,6 +32,7 @@ class IRFD(nn.Module):
     # Ei, Ee, Ep run the same ResNet-50 on the same image: by default every layer of the three is ONE grouped launch
     # (encoder.GroupedTrunks); False runs them one after another as the reference does.  Same parameters, same results.
     group_encoders = True
+    pair_decoder = True          # the two Gd calls of a forward as one pass over both batches (StyleGenerator.forward_pair)
 
     def __init__(self, max_resolution=256):
         super().__init__()
@@ -94,6 +95,11 @@ class IRFD(nn.Module):
             fe_s, fe_t = fe_t, fe_s
         else:
             fp_s, fp_t = fp_t, fp_s
-        x_s_recon = self.Gd(self._prepare_generator_input(fi_s, fe_s, fp_s), noises_s)
-        x_t_recon = self.Gd(self._prepare_generator_input(fi_t, fe_t, fp_t), noises_t)
+        gin_s, gin_t = self._prepare_generator_input(fi_s, fe_s, fp_s), self._prepare_generator_input(fi_t, fe_t, fp_t)
+        if self.pair_decoder and hasattr(self.Gd, "forward_pair"):
+            # model.py:107-108's two decoder calls as one pass over both batches (decoder.StyleGenerator.forward_pair)
+            x_s_recon, x_t_recon = self.Gd.forward_pair(gin_s, gin_t, noises_s, noises_t)
+        else:
+            x_s_recon = self.Gd(gin_s, noises_s)
+            x_t_recon = self.Gd(gin_t, noises_t)
         return (x_s_recon, x_t_recon, fi_s, fe_s, fp_s, fi_t, fe_t, fp_t, self._emotion(fe_s), self._emotion(fe_t))

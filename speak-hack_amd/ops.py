@@ -851,13 +851,14 @@ def bn_backward(g, r, affine, mean, invstd, mask_mode, mask_src=None, g_scale=1.
             L.dptr(affine[1], "shift"), L.dptr(mean, "mean"), L.dptr(invstd, "invstd"))
     L.check(L.lib().spk_bn_bwd_reduce(*args, float(g_scale), 1 if g_per_plane else 0, L.dptr(sums), B, Cc, HW,
                                       L.stream_ptr()), "spk_bn_bwd_reduce")
-    csum = sums.sum(0)                              # [2,C]: the kernel reduced over pixels, this over the batch
+    # the reduce pass summed over pixels; the apply pass adds up the B per-image pairs of its channel itself and leaves the totals
+    # in csum [2,C] (no reduction launch in between).  Eval-mode BatchNorm is a fixed affine: no mean / variance terms in dr.
+    csum = torch.empty((2, Cc), device=r.device, dtype=torch.float32)
     dr = torch.empty_like(r)
     dz = torch.empty_like(r) if want_dz else None
-    # eval-mode BatchNorm is a fixed affine: no mean / variance terms in the input gradient
-    capply = csum if batch_stats else torch.zeros_like(csum)
-    L.check(L.lib().spk_bn_bwd_apply(*args, L.dptr(capply), B * HW, float(g_scale), 1 if g_per_plane else 0, L.dptr(dr),
-                                     L.dptr(dz), B, Cc, HW, L.stream_ptr()), "spk_bn_bwd_apply")
+    L.check(L.lib().spk_bn_bwd_apply_sums(*args, L.dptr(sums), L.dptr(csum), 1 if batch_stats else 0, B * HW, float(g_scale),
+                                          1 if g_per_plane else 0, L.dptr(dr), L.dptr(dz), B, Cc, HW, L.stream_ptr()),
+            "spk_bn_bwd_apply_sums")
     out = (dr, csum[1], csum[0])                    # rows of csum: d gamma, d beta (contiguous views)
     return out + (dz,) if want_dz else out
 

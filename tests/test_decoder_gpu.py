@@ -357,3 +357,45 @@ def test_launch_plan_follows_reassigned_parameters_and_truncation(pkg, dev):
         with pytest.raises(ValueError):
             g(feats, noises[:-1])
     g.load_state_dict(sd)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("train", [False, True])
+def test_forward_pair_equals_two_calls(pkg, dev, train):
+    """``StyleGenerator.forward_pair`` -- IRFD.forward's two decoder calls (model.py:107-108) as one pass over both batches:
+    the same frames and, in training mode, the same host-RNG draws (per-call style-mixing decision and layer), the same
+    parameter gradients as two calls in sequence."""
+    g = pkg.StyleGenerator(6144)
+    g.load_state_dict(fill_state_dict(g.state_dict(), prefix="Gd."))
+    g.to(dev).train(train)
+    B = 2
+    fa, fb = recipe_input("pair.fa", (B, 6144)).to(dev), recipe_input("pair.fb", (B, 6144)).to(dev)
+    na = [n.to(dev) for n in recipe_noises("pair.a", B, 256)]
+    nb = [n.to(dev) for n in recipe_noises("pair.b", B, 256)]
+
+    def run(pair):
+        torch.manual_seed(1234)                   # host draws (mixing decisions) and the device draws of the second latents
+        g.zero_grad()
+        with torch.set_grad_enabled(train):
+            if pair:
+                ya, yb = g.forward_pair(fa, fb, na, nb)
+            else:
+                ya, yb = g(fa, na), g(fb, nb)
+            if train:
+                ((ya ** 2).mean() + (yb * yb.detach().roll(1, 0)).mean()).backward()
+        grads = {k: p.grad.clone() for k, p in g.named_parameters() if p.grad is not None}
+        return ya.detach(), yb.detach(), grads
+
+    ya0, yb0, g0 = run(False)
+    ya1, yb1, g1 = run(True)
+    assert rel_l2(ya1, ya0) < 1e-5 and rel_l2(yb1, yb0) < 1e-5
+    assert g0.keys() == g1.keys()
+    for k in g0:
+        # same products, another summation order (one weight-gradient launch over both batches instead of two and an add); the
+        # per-channel noise weights' gradients are cancelling sums over 2^16 - 2^19 pixels and carry that order's rounding
+        assert rel_l2(g1[k], g0[k]) < (2e-3 if "noise" in k else 2e-4), k
+    # a lone explicit-noise list cannot be paired: the method falls back to two calls
+    torch.manual_seed(5)
+    with torch.no_grad():
+        ya2, yb2 = g.forward_pair(fa, fb, na, None)
+    assert ya2.shape == yb2.shape == ya0.shape
