@@ -108,6 +108,21 @@ def cpu_baseline(threads):
                       f"({med * 1e3:.0f} ms/step)"}
 
 
+def committed_traffic(which, launches):
+    """HBM bytes per conv launch from the committed PMC passes (profiles/conv_traffic.json: FETCH_SIZE / WRITE_SIZE, separate
+    rocprofv3 passes over tools/pmc_decoder.py); None when the file does not hold that figure."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "conv_traffic.json")) as f:
+            t = json.load(f)
+        if which == "bf16x3":
+            return int((t["bf16x3_fetch_bytes_per_step"] + t["bf16x3_write_bytes_per_step"]) / max(1, launches))
+        if which == "sg2":
+            return int(t["sg2_bytes_per_launch"])
+        return int(t["bytes_per_launch"])
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def event_ms(fn, reps):
     """HIP events on the launch stream around ``reps`` calls of ``fn`` (after one untimed call)."""
     fn()
@@ -483,7 +498,8 @@ def main():
                 "roofline": {"bound": "mfma", "kernel": "spkbf::conv3x3_bf16x3_kernel (v_mfma_f32_32x32x16_bf16 x3 per product) + the f32 kernel on the "
                                                         "8^2 layers", "achieved": round((3 * fl_fast + (fl_all - fl_fast)) / (cb_ms * 1e-3) / 1e12, 1),
                              "peak": BF16_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s (executed: 3 bf16 MFMA FLOPs per algorithmic FLOP on the split layers)",
-                             "frac": round((3 * fl_fast + (fl_all - fl_fast)) / (cb_ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4), "traffic": None}}
+                             "frac": round((3 * fl_fast + (fl_all - fl_fast)) / (cb_ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4),
+                             "traffic": committed_traffic("bf16x3", nb)}}
 
             # ---- the build-defined StyleGAN2 variant (modulated conv + upfirdn2d, A11) on the same workload ----
             sg2 = importlib.import_module("speak-hack_amd.stylegan2")
@@ -514,7 +530,7 @@ def main():
                 "frames_per_s_per_gpu": round(BATCH / sg2_ms * 1e3, 2), "ms_per_step": round(sg2_ms, 4), "eager_ms_per_step": round(sg2_eager, 4),
                 "bf16x3_opt_in": {"ms_per_step": round(sg2_bf_ms, 4), "frames_per_s_per_gpu": round(BATCH / sg2_bf_ms * 1e3, 2)},
                 "roofline": {"bound": "mfma", "kernel": "spkconv::conv_kernel<Cfg,3,3,1,MODE_(UPSAMPLE_)BATCH_SCALE>", "achieved": round(a2, 2),
-                             "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(a2 / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                             "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(a2 / F32_MFMA_PEAK_TFLOPS, 4), "traffic": committed_traffic("sg2", n2),
                              "launches_per_step": n2, "conv_ms_per_step": round(c2_ms, 4), "conv_share_of_step": round(c2_ms / sg2_ms, 3),
                              "algorithmic_gflop_per_step": round(fl / 1e9, 2)}}
             del gen2, g2

@@ -3,11 +3,11 @@
 
 namespace spkconv {
 
-// (every mode also exists with the fixed 32-wide tile geometry -- conv_kernel<..., FG = true> -- for the 128- and 256-pixel
+// (every mode also exists with the fixed 32-wide tile geometry -- conv_kernel<..., FG = true> -- for the 64-, 128- and 256-pixel
 // tiles: the layers from 32^2 up)
 template <class C>
 static int by_mode(int mode, const spk_conv2d_desc* d, hipStream_t s) {
-    constexpr bool FG = C::PIX_T >= 128;
+    constexpr bool FG = C::PIX_T >= 64;
     switch (mode) {
         case MODE_PLAIN: return run<C, 3, 3, 1, MODE_PLAIN, FG>(d, s);
         case MODE_UPSAMPLE: return run<C, 3, 3, 1, MODE_UPSAMPLE, FG>(d, s);

@@ -29,7 +29,28 @@ def calls(d, counter):
     return out
 
 
+def flat_total(d, counter):
+    """All 3x3 stride-1 conv launches of a run: (bytes, dispatches)."""
+    f = glob.glob(f"{d}/**/*_counter_collection.csv", recursive=True)[0]
+    rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter and "conv_kernel<" in r["Kernel_Name"]
+            and ", 3, 3, 1, " in r["Kernel_Name"]]
+    return sum(float(r["Counter_Value"]) * 1024.0 for r in rows), len(rows)
+
+
 def main():
+    if "--sg2" in sys.argv:
+        # the StyleGAN2 variant's step (tools/pmc_decoder.py --sg2: N forwards, the first builds the launch plan): its skip toRGB
+        # launches do not mark a forward's end, so the conv launches are averaged over all forwards of the run
+        fb, nf = flat_total(sys.argv[1], "FETCH_SIZE")
+        wb, nw = flat_total(sys.argv[2], "WRITE_SIZE")
+        print(f"sg2    : {nf} conv dispatches; FETCH {fb / nf / 1e6:8.1f} MB, WRITE {wb / nw / 1e6:8.1f} MB per conv launch "
+              f"= {(fb / nf + wb / nw) / 1e6:6.1f} MB")
+        if "--json" in sys.argv:
+            path = sys.argv[sys.argv.index("--json") + 1]
+            out = json.load(open(path))
+            out["sg2_bytes_per_launch"] = int(fb / nf + wb / nw)
+            json.dump(out, open(path, "w"), indent=1)
+        return
     fetch, write = calls(sys.argv[1], "FETCH_SIZE"), calls(sys.argv[2], "WRITE_SIZE")
     res = {}
     for tag, pred in (("f32", lambda c: not any("bf16x3" in n for n, _ in c)), ("bf16x3", lambda c: any("bf16x3" in n for n, _ in c))):
@@ -53,8 +74,7 @@ def main():
     if "--json" in sys.argv:
         fb, wb, n = res["f32"]
         out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python3 tools/pmc_decoder.py` "
-                         "(the headline decoder step launched eagerly through its launch plan, round 2 final kernels); summary in "
-                         "profiles/r02_r_final_conv_traffic.txt",
+                         "(the headline decoder step launched eagerly through its launch plan); summary in profiles/r03_m_conv_traffic.txt",
                "kernel": "spkconv::conv_kernel<Cfg,3,3,1,MODE 0|1>", "launches_per_step": 12, "steps_counted": n,
                "fetch_bytes_per_step": int(fb), "write_bytes_per_step": int(wb), "bytes_per_launch": int((fb + wb) / 12),
                "bf16x3_fetch_bytes_per_step": int(res["bf16x3"][0]), "bf16x3_write_bytes_per_step": int(res["bf16x3"][1]),
