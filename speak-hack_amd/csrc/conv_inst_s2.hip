@@ -11,8 +11,9 @@ static int by_mode(int mode, const spk_conv2d_desc* d, hipStream_t s) {
     if constexpr (K == 7 || K == 4) {   // the stem reads the raw image, the 4x4 a gradient: no producer BatchNorm to fold in
         if (mode != MODE_PLAIN) return spk::fail(SPK_EUNSUPPORTED, "conv2d: 7x7 / 4x4 are built for plain input only");
         return run<C, K, K, 2, MODE_PLAIN>(d, s);
-    } else {
-        return mode == MODE_AFFINE_RELU ? run<C, K, K, 2, MODE_AFFINE_RELU>(d, s) : run<C, K, K, 2, MODE_PLAIN>(d, s);
+    } else {      // 3x3 stride 2: also in the fixed-geometry build (32-wide output tiles; conv_mfma_f32.hpp, FG)
+        constexpr bool FG = C::PIX_T >= 64;
+        return mode == MODE_AFFINE_RELU ? run<C, K, K, 2, MODE_AFFINE_RELU, FG>(d, s) : run<C, K, K, 2, MODE_PLAIN, FG>(d, s);
     }
 }
 

@@ -160,7 +160,7 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
     // FG: every wave stages ONE input plane (CI_T = waves, TB = 1) and the planes sit NSLOT * 64 floats apart, so that lane l's
     // element of gather slot s lives at plane + s * 64 + l for every lane (lanes past the plane write into the pitch's padding):
     // an LDS store is one base register + an immediate, and needs no dump slot
-    static_assert(!FG || (C::CI_T == C::NW && S == 1 && KH == 3), "fixed geometry: 3x3 stride 1, one plane per wave");
+    static_assert(!FG || (C::CI_T == C::NW && (S == 1 || S == 2) && KH == 3), "fixed geometry: 3x3 stride 1 / 2, one plane per wave");
     const int PP = FG ? NSLOT * 64 : PLANE;
     const int IN_FLOATS = C::CI_T * TB * PP;
     const int BUF_FLOATS = W_FLOATS + ((IN_FLOATS + 3) & ~3) + 4;  // +4: dump slot for lanes without an element
