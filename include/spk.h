@@ -135,6 +135,9 @@ typedef struct spk_conv2d_desc {
      * the setting for high-resolution layers.  The caller zeroes all copies either way. */
     int32_t stats_slots;
     const float* accum_half; /* SPK_EPI_ACCUM_HALF: [B, groups*Cout, ceil(H/2), ceil(W/2)], added at the even pixels; else NULL */
+    const float* out_scale_dev; /* optional DEVICE scalar multiplied into out_scale (NULL = 1): 1 / sigma of a spectrally normalised
+                                 * weight (styleganv1.py:644-672 wraps every discriminator layer), so that weight_orig is packed once
+                                 * per optimizer step instead of W / sigma once per forward.  Tap kernels and SPK_CONV_DGRAD_S2. */
 } spk_conv2d_desc;
 
 int spk_conv2d_num_configs(void);
@@ -342,6 +345,20 @@ int spk_upsample2x_bilinear_fwd(const float* x, float* y, int64_t planes, int Hi
 int spk_bn_finalize(double* stats, int stats_slots, int64_t count, const float* gamma, const float* beta, float* running_mean,
                     float* running_var, float momentum, float eps, float* scale, float* shift, float* save_mean,
                     float* save_invstd, int C, void* stream);
+/* The replayed running-statistics update of a pass (the visible side effect of the reference's re-entrant checkpoint,
+ * model.py:84-90: every BatchNorm's momentum update happens a second time) for MANY BatchNorms on one launch: item i applies
+ * exactly spk_bn_finalize's update -- running = (1 - momentum) running + momentum {mean, unbiased var} -- from the TOTALS
+ * stats[i] = [2*C[i]] (copy 0 of a finalized sums buffer).  Host array of up to SPK_BN_LIST_MAX items per call. */
+#define SPK_BN_LIST_MAX 64
+typedef struct spk_bn_replay_item {
+    const double* stats;     /* [2*C] totals: sum, sum of squares */
+    float* running_mean;     /* [C] */
+    float* running_var;      /* [C] */
+    int64_t count;           /* elements per channel the sums run over */
+    int32_t C;
+    int32_t reserved;
+} spk_bn_replay_item;
+int spk_bn_replay_list(const spk_bn_replay_item* items_host, int n, float momentum, void* stream);
 /* y = [relu]( a*sa[c] + ba[c] + (b ? b*sb[c] + bb[c] : 0) ): BatchNorm apply (+ residual add) (+ ReLU).
  * sb/bb NULL = identity on b.  replaces: bn3 + `out += identity` + relu at the end of every torchvision
  * Bottleneck.forward, bn1+relu of the stem (with b = NULL). */

@@ -33,7 +33,7 @@ class Conv2dDesc(C.Structure):
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
                 ("out_scale_bc", C.c_void_p), ("act_gain", C.c_float),
                 ("groups", C.c_int32), ("group_in_stride", C.c_int32), ("stats_slots", C.c_int32),
-                ("accum_half", C.c_void_p)]
+                ("accum_half", C.c_void_p), ("out_scale_dev", C.c_void_p)]
 
 
 CONV_IN_BATCH_SCALE = 256
@@ -46,6 +46,15 @@ EPI_ACCUM_HALF = 8192
 
 FC_MAX_GROUPS = 16
 DEMOD_MAX_GROUPS = 16
+
+
+BN_LIST_MAX = 64
+
+
+class BnReplayItem(C.Structure):
+    """``spk_bn_replay_item`` (include/spk.h)."""
+    _fields_ = [("stats", C.c_void_p), ("running_mean", C.c_void_p), ("running_var", C.c_void_p), ("count", C.c_int64),
+                ("C", C.c_int32), ("reserved", C.c_int32)]
 
 
 class FcGroup(C.Structure):
@@ -201,6 +210,7 @@ _PROTOTYPES = {
     "spk_conv2d_stats_slots": (C.c_int, [C.c_int] * 9),
     "spk_bn_finalize": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
                                   C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),
+    "spk_bn_replay_list": (C.c_int, [C.c_void_p, C.c_int, C.c_float, C.c_void_p]),
     "spk_bn_add_relu_fwd": (C.c_int, [C.c_void_p] * 7 + [C.c_int, C.c_int, C.c_int64, C.c_int, C.c_void_p]),
     "spk_maxpool3x3s2_fwd": (C.c_int, [C.c_void_p] * 4 + [C.c_int] * 4 + [C.c_void_p]),
     "spk_global_avgpool_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int64, C.c_void_p]),

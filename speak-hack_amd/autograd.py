@@ -247,6 +247,17 @@ class _LReluMaskFn(torch.autograd.Function):
 
 
 def _packed(weight, cfg, tf=False):
+    """-> (packed image, device scalar for ``out_scale_dev`` or None).  A spectrally normalised weight that carries
+    ``_spk_sn = (weight_orig, 1 / sigma)`` (``SpectralNormAllFn``) is served by the image of ``weight_orig`` -- cached on the
+    Parameter, so it is packed once per optimizer step instead of once per forward (the discriminator runs six forwards per step:
+    164 -> 34 pack launches) -- and the scalar goes into the conv epilogue.  The bf16x3 path keeps W / sigma's own image."""
+    sn = getattr(weight, "_spk_sn", None)
+    if sn is not None and cfg not in ("bf16x3", 12) + ops.GEMM2_CONFIGS:     # (out_scale_dev lives in the tap kernels)
+        return _packed_of(sn[0], cfg, tf), sn[1]
+    return _packed_of(weight, cfg, tf), None
+
+
+def _packed_of(weight, cfg, tf=False):
     """Packed image of a per-forward weight tensor (the discriminator's W / sigma: a fresh tensor every forward, so the
     per-parameter cache of ``ops.PackedConvWeight`` cannot hold it).  The images ride on the tensor object itself and die with
     it: the forward pack is reused by the R1 double backward, the data-gradient pack by both backward passes (64 of the 220
@@ -270,18 +281,20 @@ def _conv_plain(x, weight, k, stride):
     Cout = weight.shape[0]
     Ho, Wo = ops.conv_out_size(H, k, stride), ops.conv_out_size(W, k, stride)
     if k == 3 and stride == 1 and ops.train_bf16x3(B, Cin, Cout, Ho, Wo):
-        return ops.conv3x3_bf16x3(x.contiguous(), _packed(weight, "bf16x3"), Cout)
+        return ops.conv3x3_bf16x3(x.contiguous(), _packed(weight, "bf16x3")[0], Cout)
     cfg = ops.conv2d_pick_config(k, stride, B, Cin, Cout, Ho, Wo)
-    return ops.conv2d_fused(x, _packed(weight, cfg), Cout, k, stride, config=cfg)
+    wp, sd = _packed(weight, cfg)
+    return ops.conv2d_fused(x, wp, Cout, k, stride, config=cfg, out_scale_dev=sd)
 
 
 def _conv_dgrad(dt, weight, k, stride, in_hw):
     B, Cout = dt.shape[:2]
     Cin = weight.shape[1]
     if k == 3 and stride == 1 and ops.train_bf16x3(B, Cout, Cin, in_hw[0], in_hw[1]):
-        return ops.conv3x3_bf16x3(dt, _packed(weight, "bf16x3", True), Cin)
+        return ops.conv3x3_bf16x3(dt, _packed(weight, "bf16x3", True)[0], Cin)
     cfg, tf = ops.dgrad_plan(k, stride, B, Cout, Cin, in_hw, dt.shape[-2:])
-    return ops.conv2d_dgrad(dt, _packed(weight, cfg, tf), Cin, k, stride, in_hw, cfg)
+    wp, sd = _packed(weight, cfg, tf)
+    return ops.conv2d_dgrad(dt, wp, Cin, k, stride, in_hw, cfg, out_scale_dev=sd)
 
 
 class ConvDgradFn(torch.autograd.Function):
@@ -318,10 +331,11 @@ class ConvBiasLReLUFn(torch.autograd.Function):
         Cout = weight.shape[0]
         Ho, Wo = ops.conv_out_size(H, k, stride), ops.conv_out_size(W, k, stride)
         if k == 3 and stride == 1 and ops.train_bf16x3(B, Cin, Cout, Ho, Wo):
-            y = ops.conv3x3_bf16x3(x.contiguous(), _packed(weight, "bf16x3"), Cout, bias=bias, lrelu_slope=slope)
+            y = ops.conv3x3_bf16x3(x.contiguous(), _packed(weight, "bf16x3")[0], Cout, bias=bias, lrelu_slope=slope)
         else:
             cfg = ops.conv2d_pick_config(k, stride, B, Cin, Cout, Ho, Wo)
-            y = ops.conv2d_fused(x, _packed(weight, cfg), Cout, k, stride, bias=bias, lrelu_slope=slope, config=cfg)
+            wp, sd = _packed(weight, cfg)
+            y = ops.conv2d_fused(x, wp, Cout, k, stride, bias=bias, lrelu_slope=slope, config=cfg, out_scale_dev=sd)
         if _needs(ctx, grad_mode):
             ctx.save_for_backward(x, weight, y)
             ctx.conf = (k, stride, slope, bias is not None)
@@ -537,6 +551,10 @@ class SpectralNormAllFn(torch.autograd.Function):
     def forward(ctx, bufs, power_iteration, eps, *weights):
         us, vs = [b[0] for b in bufs], [b[1] for b in bufs]
         hats, sigma = ops.spectral_norm_grouped([w.detach() for w in weights], us, vs, power_iteration, eps)
+        inv = sigma.reciprocal()
+        for i, (h, w) in enumerate(zip(hats, weights)):
+            if w.dim() == 4:                  # conv layers: weight_orig's packed image + 1 / sigma in the epilogue (see _packed)
+                h._spk_sn = (w, inv[i:i + 1])
         if any(ctx.needs_input_grad[3:]):
             ru, cv = [u.numel() for u in us], [v.numel() for v in vs]
             ctx.save_for_backward(torch.cat([u.reshape(-1) for u in us]), torch.cat([v.reshape(-1) for v in vs]), sigma, *weights)

@@ -12,6 +12,12 @@
 
 namespace {
 
+// nn.BatchNorm2d's training-mode momentum update, spelled with explicit roundings so that every kernel that performs it
+// (the finalize of a pass, the replayed second update) rounds identically whatever the compiler would contract
+__device__ __forceinline__ float bn_momentum_update(float running, float batch_value, float momentum) {
+    return __fmaf_rn(momentum, batch_value, __fmul_rn(1.f - momentum, running));
+}
+
 __global__ __launch_bounds__(256) void bn_finalize_kernel(double* __restrict__ stats, int slots, long long count,
                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
                                                          float* running_mean, float* running_var, float momentum,
@@ -53,8 +59,8 @@ __global__ __launch_bounds__(256) void bn_finalize_kernel(double* __restrict__ s
         var = (float)v;
         if (momentum > 0.f && running_mean && running_var) {   // nn.BatchNorm2d training-mode update
             const double unbiased = count > 1 ? v * (double)count / (double)(count - 1) : v;
-            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
-            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+            running_mean[c] = bn_momentum_update(running_mean[c], mean, momentum);
+            running_var[c] = bn_momentum_update(running_var[c], (float)unbiased, momentum);
         }
     } else {
         mean = running_mean[c];
@@ -411,6 +417,36 @@ int spk_bn_finalize(double* stats, int stats_slots, int64_t count, const float* 
                        stats_slots > 1 ? stats_slots : 1, (long long)count, gamma, beta, running_mean, running_var, momentum, eps, scale, shift, save_mean,
                        save_invstd, C);
     return spk::check_launch("bn_finalize_kernel");
+}
+
+namespace {
+struct BnReplayList { spk_bn_replay_item it[SPK_BN_LIST_MAX]; };
+// one workgroup per BatchNorm; the arithmetic of bn_finalize_kernel's running-statistics update, term for term
+__global__ __launch_bounds__(256) void bn_replay_list_kernel(const BnReplayList L, float momentum) {
+    const spk_bn_replay_item it = L.it[blockIdx.x];
+    for (int c = threadIdx.x; c < it.C; c += 256) {
+        const double s1 = it.stats[c], s2 = it.stats[it.C + c];
+        const double m = s1 / (double)it.count;
+        double v = s2 / (double)it.count - m * m;
+        v = v > 0.0 ? v : 0.0;
+        const float mean = (float)m;
+        const double unbiased = it.count > 1 ? v * (double)it.count / (double)(it.count - 1) : v;
+        it.running_mean[c] = bn_momentum_update(it.running_mean[c], mean, momentum);
+        it.running_var[c] = bn_momentum_update(it.running_var[c], (float)unbiased, momentum);
+    }
+}
+}  // namespace
+
+int spk_bn_replay_list(const spk_bn_replay_item* items_host, int n, float momentum, void* stream) {
+    SPK_REQUIRE(items_host && n >= 1 && n <= SPK_BN_LIST_MAX, "bn_replay_list: 1..%d items", SPK_BN_LIST_MAX);
+    BnReplayList L;
+    for (int i = 0; i < n; ++i) {
+        L.it[i] = items_host[i];
+        SPK_REQUIRE(L.it[i].stats && L.it[i].running_mean && L.it[i].running_var && L.it[i].C > 0 && L.it[i].count > 0,
+                    "bn_replay_list: bad item %d", i);
+    }
+    hipLaunchKernelGGL(bn_replay_list_kernel, dim3((unsigned)n), dim3(256), 0, (hipStream_t)stream, L, momentum);
+    return spk::check_launch("bn_replay_list_kernel");
 }
 
 int spk_bn_add_relu_fwd(const float* a, const float* sa, const float* ba, const float* b, const float* sb,

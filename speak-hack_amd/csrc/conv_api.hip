@@ -26,7 +26,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const ConvArgs p, 
             const size_t pix = idx % HW;
             co = (int)((idx / HW) % p.Cout);
             const int b = (int)(idx / (HW * p.Cout));
-            v *= p.out_scale;
+            v *= p.out_scale_dev ? p.out_scale * *p.out_scale_dev : p.out_scale;
             if (p.out_scale_bc) v *= p.out_scale_bc[(size_t)b * p.Cout + co];
             if (f_bias) v += p.bias[co];
             if (f_noise) v += p.noise_w[co] * p.noise[(size_t)b * HW + pix];
@@ -89,7 +89,7 @@ __global__ __launch_bounds__(256) void splitk_epilogue_vec_kernel(const ConvArgs
             const size_t pix = idx % HW;
             co = (int)((idx / HW) % p.Cout);
             const int b = (int)(idx / (HW * p.Cout));
-            float scale = p.out_scale;
+            float scale = p.out_scale_dev ? p.out_scale * *p.out_scale_dev : p.out_scale;
             if (p.out_scale_bc) scale *= p.out_scale_bc[(size_t)b * p.Cout + co];
             const float bb = f_bias ? p.bias[co] : 0.f;
             const float nw = f_noise ? p.noise_w[co] : 0.f;
@@ -517,6 +517,7 @@ int spk_conv2d_fwd(const spk_conv2d_desc* d, void* stream) {
     dd.config = cfg;
     const int mode = ups ? (bsc ? MODE_UPSAMPLE_BATCH_SCALE : MODE_UPSAMPLE) : (aff ? MODE_AFFINE_RELU : (bsc ? MODE_BATCH_SCALE : MODE_PLAIN));
     hipStream_t s = (hipStream_t)stream;
+    SPK_REQUIRE(!d->out_scale_dev || !(cfg == kGemmConfig || is_gemm2(cfg)), "conv2d: out_scale_dev is built into the tap kernels (not the GEMM forms of a 1x1)");
     if (cfg == kGemmConfig) return run_1x1_gemm(&dd, s);
     if (is_gemm2(cfg)) return run_1x1_gemm2(&dd, s);
     SPK_REQUIRE(!(d->flags & SPK_EPI_ACCUM_HALF), "conv2d: SPK_EPI_ACCUM_HALF is built into the GEMM form of a 1x1 (configs 14, 15)");

@@ -71,6 +71,7 @@ struct ConvArgs {
     int style_stride;
     unsigned flags;
     float slope, out_scale, act_gain;
+    const float* out_scale_dev;   // optional device scalar multiplied into out_scale (spk_conv2d_desc.out_scale_dev)
     unsigned magic_plane, magic_pw;   // ceil(2^32 / PLANE), ceil(2^32 / PW): exact division of the small tile indices
     // Grouped convolution (G independent convs of the same shape in one launch -- the three IRFD encoders): Cin / Cout
     // above are PER GROUP; x has Cx channels, group g reading [g*gin, g*gin + Cin) (gin = 0: every group reads the same
@@ -580,6 +581,7 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
     constexpr bool HAS_STATS = !(KH == 3 && KW == 3 && S == 1) || MODE == MODE_AFFINE_RELU || MODE == MODE_PLAIN_STATS;
     const bool f_accum = p.flags & SPK_EPI_ACCUM, f_stats = HAS_STATS && (p.flags & SPK_EPI_STATS) && !split;
     const size_t HW = (size_t)p.H * p.W;
+    const float osc = p.out_scale_dev ? p.out_scale * *p.out_scale_dev : p.out_scale;   // (uniform: one scalar load)
     if (p.staged) {
         // ---- staged form (host: no split-K, not the parity kernel, W % 4 == 0, 16-byte aligned tensors, TW >= 4, and an
         // LDS tile that does not cost a workgroup slot): the block goes through LDS and a thread finishes 4 consecutive
@@ -630,7 +632,7 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
             float ssum = 0.f, ssq = 0.f;
             if (cv && pvv) {
                 float4 v = *reinterpret_cast<const float4*>(ot + cl * OP + pt);
-                float sc = p.out_scale;
+                float sc = osc;
                 v.x *= sc; v.y *= sc; v.z *= sc; v.w *= sc;
                 if (BSC && p.out_scale_bc) {
                     const float d = p.out_scale_bc[(size_t)b * p.Cy + cg];
@@ -739,7 +741,7 @@ __global__ __launch_bounds__(C::NTHREADS) void conv_kernel(const ConvArgs p) {
                         *dst = acc[m][n][r];
                         continue;
                     }
-                    float v = acc[m][n][r] * p.out_scale;
+                    float v = acc[m][n][r] * osc;
                     if (BSC && p.out_scale_bc) v *= p.out_scale_bc[(size_t)pb[n] * p.Cy + cg];   // demodulation d[b,co]
                     v += bb;
                     if (f_noise) v += nwc * nz[n];
@@ -874,6 +876,7 @@ int run(const spk_conv2d_desc* d, hipStream_t stream, int Hd = 0, int Wd = 0, in
     a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y;
     a.n_chunks = g.n_chunks;
     a.style_stride = d->style_stride; a.flags = d->flags; a.slope = d->lrelu_slope; a.out_scale = d->out_scale; a.act_gain = d->act_gain != 0.f ? d->act_gain : 1.f;
+    a.out_scale_dev = d->out_scale_dev;
     const int ksplit = resolve_ksplit(g, d->ksplit, &a.chunks_per_split);
     // the fixed-geometry build of the same kernel, where the layer's tile is that one (and no chunk is ragged)
     bool use_fg = false;

@@ -44,6 +44,7 @@ struct Args {
     int tiles_x, tiles_y;
     int accumulate;
     float out_scale;
+    const float* out_scale_dev;
 };
 
 template <int I, int N, class F>
@@ -173,6 +174,7 @@ __global__ __launch_bounds__(256, 2) void dgrad3x3s2_kernel(const Args p) {
     }
 
     // ---- epilogue: the px = 0 / 1 classes of a pixel are adjacent in memory: one 8-byte store per (channel, row parity) ----
+    const float osc = p.out_scale_dev ? p.out_scale * *p.out_scale_dev : p.out_scale;   // (uniform)
     const bool pair_ok = (p.Wd & 1) == 0 && (reinterpret_cast<uintptr_t>(p.y) & 7) == 0;
 #pragma unroll
     for (int n = 0; n < 2; ++n) {
@@ -188,7 +190,7 @@ __global__ __launch_bounds__(256, 2) void dgrad3x3s2_kernel(const Args p) {
                 const int c = co0 + wc * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (c >= p.Cc) continue;
                 float* dst = p.y + (((size_t)b * p.Cy + (size_t)grp * p.Cc + c) * p.Hd + Y) * p.Wd + X;
-                float v0 = acc[2 * qy][n][r] * p.out_scale, v1 = acc[2 * qy + 1][n][r] * p.out_scale;
+                float v0 = acc[2 * qy][n][r] * osc, v1 = acc[2 * qy + 1][n][r] * osc;
                 if (pair_ok) {                             // Wd even: X + 1 exists and the pair is 8-byte aligned
                     if (p.accumulate) {
                         const f32x2 old = *reinterpret_cast<const f32x2*>(dst);
@@ -232,7 +234,7 @@ int run_dgrad_s2_fused(const spk_conv2d_desc* d, hipStream_t stream) {
     a.n_chunks = spk::ceil_div(d->Cin, CI_T);
     a.tiles_x = spk::ceil_div(d->Win, TW); a.tiles_y = spk::ceil_div(d->Hin, TH);
     a.accumulate = (d->flags & SPK_EPI_ACCUM) ? 1 : 0;
-    a.out_scale = d->out_scale;
+    a.out_scale = d->out_scale; a.out_scale_dev = d->out_scale_dev;
     SPK_REQUIRE(dgrad_s2_fused_takes(d->B, d->Cin, d->Cout, d->Hin, d->Win), "conv2d: DGRAD_S2 (config 13): gradient plane too large");
     SPK_REQUIRE((reinterpret_cast<uintptr_t>(d->w_packed) & 15) == 0, "conv2d: DGRAD_S2 (config 13): w_packed must be 16-byte aligned");
     const long long gx = (long long)a.tiles_x * a.tiles_y * d->B;

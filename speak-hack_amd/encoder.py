@@ -88,15 +88,16 @@ class _ConvBN:
                 rec.update(stats=stats[:2 * Cout], count=B * Ho * Wo, momentum=momentum)   # copy 0 = the totals now
         return rec
 
-    def second_update(self, rec, counters):
+    def second_update(self, rec, counters, replay):
         """The running-statistics update the reference's re-entrant checkpoint performs a second time when it re-runs
-        the forward inside backward (model.py:84-90): same batch sums, same arithmetic, without recomputing the conv."""
+        the forward inside backward (model.py:84-90): same batch sums, same arithmetic, without recomputing the conv.
+        Queued on ``replay``: every BatchNorm of the pass is updated by one launch (``ops.bn_replay_running``)."""
         bn = self.bn
         if not rec.get("training") or "stats" not in rec:
             return
         if bn.num_batches_tracked is not None:
             counters.append(bn.num_batches_tracked)
-        ops.bn_finalize(rec["stats"], rec["count"], bn.weight, bn.bias, bn.running_mean, bn.running_var, rec["momentum"], bn.eps)
+        replay.append((rec["momentum"], rec["stats"], rec["count"], bn.running_mean, bn.running_var))
 
     def put_bn_grads(self, grads, dg, db):
         grads[self.bn.weight], grads[self.bn.bias] = dg, db
@@ -216,12 +217,12 @@ class _GroupedConvBN:
                 rec.update(stats=stats[:2 * G * Cout], count=B * Ho * Wo, momentum=bn.momentum)   # copy 0 = the totals now
         return rec
 
-    def second_update(self, rec, counters):
+    def second_update(self, rec, counters, replay):
         if not rec.get("training") or "stats" not in rec:
             return
         counters.extend(b.num_batches_tracked for b in self.bns[:len(self.uniq)] if b.num_batches_tracked is not None)
         gamma, beta, rm, rv = self.flat
-        ops.bn_finalize(rec["stats"], rec["count"], gamma, beta, rm, rv, rec["momentum"], self.bns[0].eps)
+        replay.append((rec["momentum"], rec["stats"], rec["count"], rm, rv))
 
     def put_bn_grads(self, grads, dg, db):
         if self.G == len(self.uniq):
@@ -485,14 +486,16 @@ class ResNet50Trunk(nn.Sequential):
 
     def _second_bn_update(self, recs):
         stem, blocks = self._plan
-        counters = []
-        stem.second_update(recs["stem"], counters)
+        counters, replay = [], []
+        stem.second_update(recs["stem"], counters, replay)
         for (c1, c2, c3, down), (r1, r2, r3, rd, _) in zip(blocks, recs["blocks"]):
-            c1.second_update(r1, counters)
-            c2.second_update(r2, counters)
-            c3.second_update(r3, counters)
+            c1.second_update(r1, counters, replay)
+            c2.second_update(r2, counters, replay)
+            c3.second_update(r3, counters, replay)
             if down is not None:
-                down.second_update(rd, counters)
+                down.second_update(rd, counters, replay)
+        for mom in sorted({m for m, *_ in replay}):          # one launch for all BatchNorms (per momentum value: one)
+            ops.bn_replay_running([it[1:] for it in replay if it[0] == mom], mom)
         if counters:
             torch._foreach_add_(counters, getattr(self, "images", 1))
 

@@ -164,11 +164,12 @@ def conv_out_size(n, k, stride):
 def conv2d_fused(x, w_packed, Cout: int, k: int = 3, stride: int = 1, *, bias=None, noise_w=None, noise=None,
                  style=None, style_stride=None, upsample=False, lrelu_slope=None, out_scale=1.0, in_affine=None,
                  stats=None, config=-1, ksplit=0, out=None, accumulate=False, out_pre=None, batch_scale=None, demod=None,
-                 act_gain=1.0, up_fir=False, groups=1, shared_input=False, accum_half=None):
+                 act_gain=1.0, up_fir=False, groups=1, shared_input=False, accum_half=None, out_scale_dev=None):
     """y = style(lrelu(conv_kxk(in(x)) * out_scale + bias + noise_w*noise)) -- one launch.
 
     ``accum_half`` [B, groups*Cout, ceil(H/2), ceil(W/2)]: added to y at the even pixels (``SPK_EPI_ACCUM_HALF``; the
-    GEMM form of a stride-1 1x1, configs 14 / 15).
+    GEMM form of a stride-1 1x1, configs 14 / 15).  ``out_scale_dev``: a one-element device tensor multiplied into
+    ``out_scale`` (1 / sigma of a spectrally normalised weight whose packed image is that of ``weight_orig``).
 
     ``groups`` > 1: that many independent convs of the same shape in one launch (``Cout`` per group; ``w_packed`` = the
     groups' packed images concatenated; x carries the groups' input channels side by side, or -- ``shared_input`` -- one
@@ -250,7 +251,7 @@ def conv2d_fused(x, w_packed, Cout: int, k: int = 3, stride: int = 1, *, bias=No
                      config=int(config), ksplit=int(ksplit), workspace=ws.data_ptr() if ws is not None else None,
                      workspace_bytes=ws.numel() * 4 if ws is not None else 0, groups=G,
                      group_in_stride=0 if (shared_input or G == 1) else Cin, stats_slots=slots,
-                     accum_half=L.dptr(accum_half, "accum_half"))
+                     accum_half=L.dptr(accum_half, "accum_half"), out_scale_dev=L.dptr(out_scale_dev, "out_scale_dev"))
     _launch_conv2d(d)
     return out
 
@@ -894,7 +895,7 @@ def dgrad_plan(k, stride, B, Cout, Cin, in_hw, g_hw, out=None, accumulate=False)
     return conv2d_pick_config(k, 1, B, Cout, Cin, hw[0], hw[1]), 1
 
 
-def _dgrad_s2_parity(g, weight_packed, Cin, in_hw, config, out, accumulate, groups):
+def _dgrad_s2_parity(g, weight_packed, Cin, in_hw, config, out, accumulate, groups, out_scale_dev=None):
     B, Cg, Hg, Wg = g.shape
     G = int(groups)
     if Cg % G:
@@ -907,7 +908,8 @@ def _dgrad_s2_parity(g, weight_packed, Cin, in_hw, config, out, accumulate, grou
     d = L.Conv2dDesc(x=L.dptr(g, "g"), w_packed=L.dptr(weight_packed, "w_packed"), y=L.dptr(out, "out"), B=B, Cin=Cg // G,
                      Cout=Cin, H=H, W=W, Hin=Hg, Win=Wg, kh=3, kw=3, stride=2,
                      flags=L.CONV_DGRAD_S2 | (L.EPI_ACCUM if accumulate else 0), lrelu_slope=1.0, out_scale=1.0,
-                     config=int(config), ksplit=1, groups=G, group_in_stride=0 if G == 1 else Cg // G)
+                     config=int(config), ksplit=1, groups=G, group_in_stride=0 if G == 1 else Cg // G,
+                     out_scale_dev=L.dptr(out_scale_dev, "out_scale_dev"))
     _launch_conv2d(d)
     return out
 
@@ -916,7 +918,7 @@ GEMM2_CONFIGS = (14, 15)        # the lean GEMM form of a stride-1 1x1 (csrc/con
 
 
 def conv2d_dgrad(g, weight_packed_tf, Cin, k, stride, in_hw, config, out=None, accumulate=False, groups=1, dilate=True,
-                 accum_half=None):
+                 accum_half=None, out_scale_dev=None):
     """Data gradient of a k x k conv.  Stride 1: the forward MFMA kernel on ``g`` with transpose-flipped weights.
     3x3 stride 2: by output parity (``SPK_CONV_DGRAD_S2``: dx[2m+py, 2n+px] needs 1/2/2/4 of the 9 taps; four 2x2
     kernels in one launch over the gradient's own pixels, stored interleaved).  1x1 stride 2 without a destination: at
@@ -925,17 +927,17 @@ def conv2d_dgrad(g, weight_packed_tf, Cin, k, stride, in_hw, config, out=None, a
     destination): the gradient stays at the output size; ``accum_half``: such a tensor, added at the even pixels by a stride-1
     1x1 data gradient running in the lean GEMM form (``GEMM2_CONFIGS``)."""
     if k == 3 and stride == 2:
-        return _dgrad_s2_parity(g, weight_packed_tf, Cin, in_hw, config, out, accumulate, groups)
+        return _dgrad_s2_parity(g, weight_packed_tf, Cin, in_hw, config, out, accumulate, groups, out_scale_dev)
     if dgrad_at_output_size(k, stride, out, accumulate):
         # a strided 1x1 reads only the even input pixels: dx = dilate(W^T g), the contraction at the OUTPUT size
-        t = conv2d_fused(g, weight_packed_tf, Cin, 1, 1, config=config, groups=groups)
+        t = conv2d_fused(g, weight_packed_tf, Cin, 1, 1, config=config, groups=groups, out_scale_dev=out_scale_dev)
         return dilate2x(t, in_hw[0], in_hw[1]) if dilate else t      # not dilated: the caller adds it through ``accum_half``
     if stride == 2:
         # dx[i] = sum_k gd[i + k' - p] * w[k-1-k'] with gd[2o] = g[o], zeros elsewhere, extended to the input size
         # (an even-sized input has a last row/column no window's stride lattice reaches: it stays zero)
         g = dilate2x(g, in_hw[0], in_hw[1])
     return conv2d_fused(g, weight_packed_tf, Cin, k, 1, config=config, out=out, accumulate=accumulate, groups=groups,
-                        accum_half=accum_half)
+                        accum_half=accum_half, out_scale_dev=out_scale_dev)
 
 
 # ---- BatchNorm / pooling pieces of the ResNet-50 trunk ----------------------------------------------
@@ -969,6 +971,22 @@ def bn_finalize(stats, count, gamma, beta, running_mean, running_var, momentum=0
                                     L.dptr(running_var, "running_var"), float(momentum), float(eps), L.dptr(scale),
                                     L.dptr(shift), L.dptr(mean), L.dptr(invstd), Cc, L.stream_ptr()), "spk_bn_finalize")
     return (scale, shift, mean, invstd) if save else (scale, shift)
+
+
+def bn_replay_running(items, momentum):
+    """The second running-statistics update of a pass for many BatchNorms on one launch per 64 (``spk_bn_replay_list``):
+    ``items`` = [(stats totals fp64 [2C], count, running_mean [C], running_var [C])]."""
+    items = list(items)
+    for i in range(0, len(items), L.BN_LIST_MAX):
+        part = items[i:i + L.BN_LIST_MAX]
+        arr = (L.BnReplayItem * len(part))()
+        for j, (stats, count, rm, rv) in enumerate(part):
+            Cc = rm.numel()
+            if stats.dtype != torch.float64 or stats.numel() < 2 * Cc or rv.numel() != Cc or not stats.is_contiguous():
+                raise L.SpkError("bn_replay_running: stats must be a contiguous float64 [2C] next to running buffers of C")
+            arr[j] = L.BnReplayItem(stats=stats.data_ptr(), running_mean=L.dptr(rm, "running_mean"),
+                                    running_var=L.dptr(rv, "running_var"), count=int(count), C=Cc)
+        L.check(L.lib().spk_bn_replay_list(arr, len(part), float(momentum), L.stream_ptr()), "spk_bn_replay_list")
 
 
 def bn_add_relu(a, sa, ba, b=None, sb=None, bb=None, relu=True):
