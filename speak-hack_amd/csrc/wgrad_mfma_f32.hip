@@ -22,6 +22,10 @@
 #include <type_traits>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+// LDS-typed fragment pointers: a volatile read stays ONE ds_read_b32 with a 16-bit immediate offset.  Left to itself the compiler
+// merges neighbouring reads into ds_read2_b32 (1 KB reach) and pays a v_add_u32 per pair -- and on gfx950 every vector-ALU
+// instruction of an f32-MFMA kernel is paid for in matrix time: 67 of the 183 per 288 MFMAs of the wide kernel.
+typedef __attribute__((address_space(3))) float wg_lds_f32;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 template <int I, int N, class F>
@@ -377,8 +381,8 @@ __global__ __launch_bounds__(256) void wgrad3x3_pipe_kernel(const WgradArgs p) {
         constexpr bool PIPE = decltype(pipe_)::value;
         const float* cbuf = smem + cur * BUF;
         float* nbuf = smem + (cur ^ 1) * BUF;
-        const float* ga = cbuf + (wco * 32 + l32) * GPITCH + half;              // pixel 2 st + half of this lane's channel row
-        const float* xb = cbuf + CO_T * GPITCH + (wci * 32 + l32) * XPITCH + half;
+        const volatile wg_lds_f32* ga = (const volatile wg_lds_f32*)(cbuf + (wco * 32 + l32) * GPITCH + half);              // pixel 2 st + half of this lane's channel row
+        const volatile wg_lds_f32* xb = (const volatile wg_lds_f32*)(cbuf + CO_T * GPITCH + (wci * 32 + l32) * XPITCH + half);
         float fa[2], fb[2][TAPS];
 #define SPK_WP_FRAG(st_, slot_)                                                                               \
     {                                                                                                         \
@@ -606,8 +610,8 @@ __global__ __launch_bounds__(256) void wgrad3x3_wide_kernel(const WgradArgs p) {
     auto run_tile = [&]() {
         const float* cbuf = smem + cur * BUF;
         float* nbuf = smem + (cur ^ 1) * BUF;
-        const float* ga = cbuf + (wco * 32 + l32) * GPITCH + half;
-        const float* xb = cbuf + CO_T * GPITCH + (wci * 32 + l32) * XPITCH + half;
+        const volatile wg_lds_f32* ga = (const volatile wg_lds_f32*)(cbuf + (wco * 32 + l32) * GPITCH + half);
+        const volatile wg_lds_f32* xb = (const volatile wg_lds_f32*)(cbuf + CO_T * GPITCH + (wci * 32 + l32) * XPITCH + half);
         float fa[2], fb[2][TAPS];
 #define SPK_WW_FRAG(st_, slot_)                                                                               \
     {                                                                                                         \
@@ -830,8 +834,8 @@ __global__ __launch_bounds__(256) void wgrad3x3_s2_kernel(const WgradArgs p) {
         constexpr bool PIPE = decltype(pipe_)::value;
         const float* cbuf = smem + cur * BUF;
         float* nbuf = smem + (cur ^ 1) * BUF;
-        const float* ga = cbuf + (wave * 32 + l32) * GPITCH + half;
-        const float* xb = cbuf + CO_T * GPITCH + l32 * XPITCH + 2 * half;
+        const volatile wg_lds_f32* ga = (const volatile wg_lds_f32*)(cbuf + (wave * 32 + l32) * GPITCH + half);
+        const volatile wg_lds_f32* xb = (const volatile wg_lds_f32*)(cbuf + CO_T * GPITCH + l32 * XPITCH + 2 * half);
         float fa[2], fb[2][TAPS];
 #define SPK_W2_FRAG(st_, slot_)                                                                               \
     {                                                                                                         \
@@ -1094,8 +1098,8 @@ __global__ __launch_bounds__(256) void wgrad3x3_up_kernel(const WgradArgs p) {
         float* nbuf = smem + (cur ^ 1) * BUF;
         const int s_next = (par ^ 1) * US_FLOATS;                      // patch of tile k+1 (float offset behind sbuf)
         float* s_fill = sbuf + par * US_FLOATS;                       // patch of tile k+2 goes here
-        const float* ga = cbuf + (wco * 32 + l32) * GPITCH + half;
-        const float* xb = cbuf + CO_T * GPITCH + (wci * 32 + l32) * XPITCH + half;
+        const volatile wg_lds_f32* ga = (const volatile wg_lds_f32*)(cbuf + (wco * 32 + l32) * GPITCH + half);
+        const volatile wg_lds_f32* xb = (const volatile wg_lds_f32*)(cbuf + CO_T * GPITCH + (wci * 32 + l32) * XPITCH + half);
         float fa[2], fb[2][TAPS];
 #define SPK_WU_FRAG(st_, slot_)                                                                               \
     {                                                                                                         \
@@ -1184,6 +1188,71 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
         const size_t idx = ((size_t)co * Cin + ci) * taps + tap;
         dw[idx] = accumulate ? dw[idx] + v : v;
     }
+}
+
+// The same sum, four input channels per thread (Cin % 4 == 0): 16-byte loads and EIGHT slabs in flight per thread.  The
+// dword form above waits for every round of four loads before it issues the next -- with 16-42 slabs that is 4-10 memory
+// latencies in a row, 2.3 TB/s on slabs that mostly still sit in the memory-side cache; this one runs at 13 -> ~7 us per
+// trunk / decoder layer, ~65 (G step) to ~100 (D step) times per training step.  Same summation order as the dword form.
+__global__ __launch_bounds__(256) void wgrad_reduce_vec_kernel(const float* __restrict__ slabs, float* __restrict__ dw,
+                                                              int n_slabs, int Cout_all, int Cin, int taps, float scale,
+                                                              int accumulate, int fold) {
+    const int Cout = Cout_all / fold;
+    const size_t total = (size_t)Cout * Cin * taps, slab_stride = (size_t)Cout_all * Cin * taps;
+    const int cin4 = Cin >> 2;
+    for (size_t q = (size_t)blockIdx.x * blockDim.x + threadIdx.x; q < total / 4; q += (size_t)gridDim.x * blockDim.x) {
+        const int ci = (int)(q % cin4) * 4;
+        const int tap = (int)((q / cin4) % taps);
+        const int co = (int)(q / ((size_t)cin4 * taps));
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        for (int f = 0; f < fold; ++f) {
+            const float* sl = slabs + (size_t)f * total + 4 * q;
+            f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0, v2 = v0, v3 = v0;
+            int s = 0;
+            for (; s + 8 <= n_slabs; s += 8) {
+                f32x4 a[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) a[j] = *reinterpret_cast<const f32x4*>(sl + (size_t)(s + j) * slab_stride);
+                v0 += a[0]; v1 += a[1]; v2 += a[2]; v3 += a[3];
+                v0 += a[4]; v1 += a[5]; v2 += a[6]; v3 += a[7];
+            }
+            if (s + 4 <= n_slabs) {
+                f32x4 a[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) a[j] = *reinterpret_cast<const f32x4*>(sl + (size_t)(s + j) * slab_stride);
+                v0 += a[0]; v1 += a[1]; v2 += a[2]; v3 += a[3];
+                s += 4;
+            }
+            for (; s < n_slabs; ++s) v0 += *reinterpret_cast<const f32x4*>(sl + (size_t)s * slab_stride);
+            v += (v0 + v1) + (v2 + v3);
+        }
+        v *= scale;
+        const size_t idx = ((size_t)co * Cin + ci) * taps + tap;
+        if (taps == 1) {
+            f32x4* o = reinterpret_cast<f32x4*>(dw + idx);
+            *o = accumulate ? *o + v : v;
+        } else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) dw[idx + (size_t)j * taps] = accumulate ? dw[idx + (size_t)j * taps] + v[j] : v[j];
+        }
+    }
+}
+
+// slabs -> dW on `stream`, after the kernel that wrote them
+inline int launch_wgrad_reduce(hipStream_t stream, const float* slabs, float* dw, int n_slabs, int Cout_all, int Cin, int taps,
+                               float scale, int accumulate, int fold) {
+    const size_t slab_floats = (size_t)Cout_all * Cin * taps;
+    const bool vec = Cin % 4 == 0 && (reinterpret_cast<uintptr_t>(slabs) & 15) == 0 && (reinterpret_cast<uintptr_t>(dw) & 15) == 0;
+    if (vec) {
+        const unsigned blocks = (unsigned)std::min<size_t>((slab_floats / fold / 4 + 255) / 256, 4096);
+        hipLaunchKernelGGL(wgrad_reduce_vec_kernel, dim3(std::max(blocks, 1u)), dim3(256), 0, stream, slabs, dw, n_slabs, Cout_all, Cin,
+                           taps, scale, accumulate, fold);
+    } else {
+        const unsigned blocks = (unsigned)std::min<size_t>((slab_floats + 255) / 256, 2048);
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, slabs, dw, n_slabs, Cout_all, Cin, taps, scale,
+                           accumulate, fold);
+    }
+    return spk::check_launch("wgrad_reduce_kernel");
 }
 
 struct WGeom {
@@ -1277,10 +1346,8 @@ int run_wgrad_wide(const spk_wgrad_desc* d, hipStream_t stream) {
     hipLaunchKernelGGL(kern, grid, dim3(256), 2 * SH::BUF * sizeof(float), stream, a);
     int rc = spk::check_launch("wgrad3x3_wide_kernel");
     if (rc != SPK_OK) return rc;
-    const unsigned blocks = (unsigned)std::min<size_t>((slab_floats + 255) / 256, 2048);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, a.slabs, d->dw, g.n_slabs, G * d->Cout, d->Cin, 9,
-                       d->scale, d->accumulate ? 1 : 0, d->fold > 1 ? d->fold : 1);
-    return spk::check_launch("wgrad_reduce_kernel");
+    return launch_wgrad_reduce(stream, a.slabs, d->dw, g.n_slabs, G * d->Cout, d->Cin, 9, d->scale, d->accumulate ? 1 : 0,
+                               d->fold > 1 ? d->fold : 1);
 }
 
 // the upsample-folded form: x is the LOW-resolution tensor [B, Cin, H/2, W/2]
@@ -1319,10 +1386,8 @@ int run_wgrad_up(const spk_wgrad_desc* d, hipStream_t stream) {
     hipLaunchKernelGGL(wgrad3x3_up_kernel<MODE>, grid, dim3(256), (2 * SH::BUF + 2 * US_FLOATS) * sizeof(float), stream, a);
     int rc = spk::check_launch("wgrad3x3_up_kernel");
     if (rc != SPK_OK) return rc;
-    const unsigned blocks = (unsigned)std::min<size_t>((slab_floats + 255) / 256, 2048);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, a.slabs, d->dw, g.n_slabs, G * d->Cout, d->Cin, 9,
-                       d->scale, d->accumulate ? 1 : 0, d->fold > 1 ? d->fold : 1);
-    return spk::check_launch("wgrad_reduce_kernel");
+    return launch_wgrad_reduce(stream, a.slabs, d->dw, g.n_slabs, G * d->Cout, d->Cin, 9, d->scale, d->accumulate ? 1 : 0,
+                               d->fold > 1 ? d->fold : 1);
 }
 
 // the stride-2 form: 128co x 32ci blocks, 16x4 or 8x8 output-pixel tiles
@@ -1386,10 +1451,8 @@ int run_wgrad_s2(const spk_wgrad_desc* d, hipStream_t stream) {
     hipLaunchKernelGGL(kern, grid, dim3(256), 2 * SH::BUF * sizeof(float), stream, a);
     int rc = spk::check_launch("wgrad3x3_s2_kernel");
     if (rc != SPK_OK) return rc;
-    const unsigned blocks = (unsigned)std::min<size_t>((slab_floats + 255) / 256, 2048);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, a.slabs, d->dw, g.n_slabs, G * d->Cout, d->Cin, 9,
-                       d->scale, d->accumulate ? 1 : 0, d->fold > 1 ? d->fold : 1);
-    return spk::check_launch("wgrad_reduce_kernel");
+    return launch_wgrad_reduce(stream, a.slabs, d->dw, g.n_slabs, G * d->Cout, d->Cin, 9, d->scale, d->accumulate ? 1 : 0,
+                               d->fold > 1 ? d->fold : 1);
 }
 
 template <int MODE>
@@ -1441,10 +1504,8 @@ int run_wgrad(const spk_wgrad_desc* d, hipStream_t stream) {
         hipLaunchKernelGGL(wgrad3x3_pipe_kernel, pgrid, dim3(256), 2 * WP_BUF * sizeof(float), stream, a);
         int prc = spk::check_launch("wgrad3x3_pipe_kernel");
         if (prc != SPK_OK) return prc;
-        const unsigned pblocks = (unsigned)std::min<size_t>((slab_floats + 255) / 256, 2048);
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(pblocks), dim3(256), 0, stream, a.slabs, d->dw, g.n_slabs, G * d->Cout,
-                           d->Cin, SH::TAPS, d->scale, d->accumulate ? 1 : 0, d->fold > 1 ? d->fold : 1);
-        return spk::check_launch("wgrad_reduce_kernel");
+        return launch_wgrad_reduce(stream, a.slabs, d->dw, g.n_slabs, G * d->Cout, d->Cin, SH::TAPS, d->scale, d->accumulate ? 1 : 0,
+                                   d->fold > 1 ? d->fold : 1);
     }
     auto kern = fixed ? &wgrad_kernel<KH, KW, S, MODE, HAS_FIXED ? 1 : 0> : &wgrad_kernel<KH, KW, S, MODE, 0>;
     if (g.lds_bytes > 64 * 1024) {
@@ -1460,10 +1521,8 @@ int run_wgrad(const spk_wgrad_desc* d, hipStream_t stream) {
     hipLaunchKernelGGL(kern, grid, dim3(256), g.lds_bytes, stream, a);
     int rc = spk::check_launch("wgrad_kernel");
     if (rc != SPK_OK) return rc;
-    const unsigned blocks = (unsigned)std::min<size_t>((slab_floats + 255) / 256, 2048);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, a.slabs, d->dw, g.n_slabs, G * d->Cout,
-                       d->Cin, SH::TAPS, d->scale, d->accumulate ? 1 : 0, d->fold > 1 ? d->fold : 1);
-    return spk::check_launch("wgrad_reduce_kernel");
+    return launch_wgrad_reduce(stream, a.slabs, d->dw, g.n_slabs, G * d->Cout, d->Cin, SH::TAPS, d->scale, d->accumulate ? 1 : 0,
+                               d->fold > 1 ? d->fold : 1);
 }
 
 // ---- 1x1 weight gradient as a GEMM: dW[co][ci] = sum_{b,pix} g[b,co,pix] * in(x)[b,ci,pix*S] --------------------------------
@@ -1584,8 +1643,8 @@ __global__ __launch_bounds__(256) void wgrad1x1_kernel(const WgradArgs p, int ti
         tq += G1_KT;                                        // (uniform) the next k-tile: same image, or the next one's first
         if (tq >= (int)HW) { tq = 0; ++tb; }
         if (more) SPK_G1_LOAD(tb, tq);
-        const float* ga = gs + buf * BM * G1_PITCH + (wm * 32 * MT + l32) * G1_PITCH + half;
-        const float* xb = xs + buf * BN * G1_PITCH + (wn * 32 * NT + l32) * G1_PITCH + half;
+        const volatile wg_lds_f32* ga = (const volatile wg_lds_f32*)(gs + buf * BM * G1_PITCH + (wm * 32 * MT + l32) * G1_PITCH + half);
+        const volatile wg_lds_f32* xb = (const volatile wg_lds_f32*)(xs + buf * BN * G1_PITCH + (wn * 32 * NT + l32) * G1_PITCH + half);
         float fa[2][MT], fb[2][NT];
 #define SPK_G1_FRAG(ks_, slot_)                                                                              \
     {                                                                                                        \
@@ -1682,10 +1741,8 @@ int run_wgrad1x1_shape(const spk_wgrad_desc* d, hipStream_t stream) {
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, stream, a, g.tiles_per_split);
     int rc = spk::check_launch("wgrad1x1_kernel");
     if (rc != SPK_OK) return rc;
-    const unsigned blocks = (unsigned)std::min<size_t>((slab_floats + 255) / 256, 2048);
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, stream, a.slabs, d->dw, g.splits, G * d->Cout, d->Cin, 1,
-                       d->scale, d->accumulate ? 1 : 0, d->fold > 1 ? d->fold : 1);
-    return spk::check_launch("wgrad_reduce_kernel");
+    return launch_wgrad_reduce(stream, a.slabs, d->dw, g.splits, G * d->Cout, d->Cin, 1, d->scale, d->accumulate ? 1 : 0,
+                               d->fold > 1 ? d->fold : 1);
 }
 
 template <int S, int MODE>

@@ -35,6 +35,8 @@ def main():
                     "(4 D passes with BCE + 2 R1 penalties, backward, Adam on D); fakes are synthetic images")
     ap.add_argument("--precision", default="f32", choices=("f32", "bf16x3"), help="bf16x3: the opt-in reduced-precision training "
                     "switch (ops.train_conv_precision): 3x3 stride-1 convs forward + data gradients on the bf16 pipe")
+    ap.add_argument("--graph", action="store_true", help="EXPERIMENT: capture one step (fixed host-RNG decisions) as a hipGraph "
+                    "and time its replays -- what the launch gaps of the eager step are worth")
     args = ap.parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -61,7 +63,8 @@ def main():
             p.requires_grad_(False)
     params = [p for p in net.parameters() if p.requires_grad]
     red = dp.GradBucketReducer(params)
-    opt = torch.optim.Adam(net.D.parameters() if args.d_step else net.Gd.parameters(), lr=1e-4, betas=(0.5, 0.999))
+    opt = torch.optim.Adam(net.D.parameters() if args.d_step else net.Gd.parameters(), lr=1e-4, betas=(0.5, 0.999),
+                           capturable=args.graph)
     torch.manual_seed(10 + rank)               # per-rank data and per-rank host RNG
     B = args.batch
     x_s = torch.rand(B, 3, 256, 256, device=dev) * 2 - 1
@@ -107,15 +110,36 @@ def main():
 
     ops = importlib.import_module("speak-hack_amd").ops
     ops.TRAIN_CONV_PRECISION = args.precision          # (the context manager's global, set for the whole run)
-    for _ in range(args.warmup):
-        step()
+    graph = None
+    if args.graph:
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(max(args.warmup, 3)):
+                step()
+            with torch.no_grad():                       # every packed-weight cache keys on the version: the captured step repacks
+                for p in net.parameters():
+                    p.add_(0)
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            loss = step()
+        torch.cuda.synchronize()
+        graph.replay()
+    else:
+        for _ in range(args.warmup):
+            step()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
         torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        loss = step()
+        if graph is not None:
+            graph.replay()
+        else:
+            loss = step()
     torch.cuda.synchronize()
     if dist is not None:
         dist.barrier()
