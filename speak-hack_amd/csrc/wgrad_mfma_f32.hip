@@ -1687,6 +1687,165 @@ __global__ __launch_bounds__(256) void wgrad1x1_kernel(const WgradArgs p, int ti
         }
 }
 
+// ---- the same GEMM, stride 1, with EVERY operand by LDS-DMA ---------------------------------------------------------------------
+// The register-staged kernel above pays, per 32-pixel k-tile and thread, 8 float4 loads, 32 ds_write_b32 and (folded BatchNorm) 32
+// fma / max -- about 45 vector instructions per 64 MFMAs after its diet, and on gfx950 every one of them is matrix time (the f32
+// MFMA and the vector ALU do not overlap); its LDS pitch of 33 also rules out wide fragment reads.  Here:
+//   * a k-tile row (one channel, 32 pixels = 128 B = eight 16-byte chunks) goes global -> LDS by `global_load_lds_dwordx4`, 8 rows
+//     per instruction (scalar base + one constant lane offset), rows at a pitch of exactly 128 B.  Lane i of the instruction fetches
+//     chunk (i & 7) ^ f(row) of its row, f(row) = (row >> 1) & 7: the XOR swizzle costs nothing (a lane may fetch any address);
+//   * a fragment read is ONE ds_read_b128 per MFMA tile and FOUR k-steps: lane (channel l32, half) takes pixels
+//     8 jq + 4 half .. + 3 -- the pixel sum may run in any order as long as G and X use the same one -- and with the swizzle the
+//     16 lanes of every ds_read_b128 lane group ({0-3,12-15,20-27} ...) fall on 16 distinct 16-byte slots: conflict-free;
+//   * two ring slots, one bare barrier per k-tile, two workgroups per CU (64 KB each): one's DMA wait, barrier and slab
+//     store hide behind the other's MFMAs; the loop's only vector instructions are the folded BatchNorm + ReLU of the X
+//     fragments (2 per value and NT tiles; none for plain layers).
+// Needs whole blocks (Cout % BM == 0, Cin % BN == 0), HW % 32 == 0 and 16-byte aligned tensors: dma_takes().
+typedef __attribute__((address_space(3))) f32x4 wg_lds_f32x4;
+typedef __attribute__((address_space(3))) unsigned char wg_lds_u8;
+
+template <int MODE, int MT, int NT>
+__global__ __launch_bounds__(256, 2) void wgrad1x1_dma_kernel(const WgradArgs p, int tiles_per_split) {
+    constexpr bool AFF = MODE == WG_AFFINE_RELU;
+    constexpr int BM = 64 * MT, BN = 64 * NT, KT = G1_KT;
+    constexpr int SLOT_B = (BM + BN) * KT * 4;            // bytes per ring slot: rows [0, BM) of G, then [BM, BM + BN) of X
+    constexpr int NJ = (BM + BN) / 32;                    // DMA instructions per wave and k-tile (8 rows each)
+    static_assert(KT == 32 && 2 * SLOT_B <= 65536, "immediate LDS offsets reach 64 KB");
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l32 = lane & 31;
+    const int wm = wave & 1, wn = wave >> 1;
+
+    const int co0 = blockIdx.x * BM;                      // in the gradient tensor (all groups)
+    const int grp = co0 / p.Cout;
+    const int ci0 = blockIdx.y * BN;                      // within the group
+    const int cx0 = grp * p.gin + ci0;                    // first x channel of this block
+    const size_t HW = (size_t)p.H * p.W;
+    const int tpi = (int)(HW / KT);
+    const int t_begin = blockIdx.z * tiles_per_split, t_end = min(p.n_tiles, t_begin + tiles_per_split);
+
+    // DMA role of a lane: row lane / 8 of the instruction's 8 rows; LDS chunk lane % 8 of that row receives global chunk
+    // (lane % 8) ^ f(row).  Instruction j = 4 jj + wave covers rows 8 j .. 8 j + 7, so f(row) = (4 (j & 1) + lane / 16) & 7 and
+    // j & 1 = wave & 1: ONE constant lane offset per wave.
+    // (a BYTE offset added to a byte pointer: base + zext(u32) is the scalar-base form of the load; scaled by 4 it is not)
+    unsigned dma_lane = ((unsigned)((lane >> 3) * HW) + (unsigned)((((lane & 7) ^ (4 * (wave & 1) + (lane >> 4))) & 7) * 4)) * 4u;
+    const float* const g_w = p.g + (size_t)(co0 + 8 * wave) * HW;
+    const float* const x_w = p.x + (size_t)(cx0 + 8 * wave) * HW;
+    auto dma_tile = [&](int tb_, int tq_, int slot_) {
+        const float* gb = g_w + ((size_t)tb_ * p.Cy * HW + (size_t)tq_);            // uniform
+        const float* xb = x_w + ((size_t)tb_ * p.Cx * HW + (size_t)tq_);
+        char* dst = reinterpret_cast<char*>(smem) + slot_ * SLOT_B + wave * 1024;
+        asm volatile("" : "+v"(dma_lane));                // keep (scalar base, 32-bit lane offset): no per-lane 64-bit pointers
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) {
+            const float* src = jj * 32 < BM ? gb + (size_t)(jj * 32) * HW : xb + (size_t)(jj * 32 - BM) * HW;
+            __builtin_amdgcn_global_load_lds(reinterpret_cast<const char*>(src) + dma_lane, dst + jj * 4096, 16, 0, 0);
+        }
+    };
+
+    // fragment byte addresses inside a slot, one per 8-pixel group jq (the XOR with the lane's f is not an immediate)
+    const unsigned fl = (unsigned)(l32 >> 1) & 7u;
+    unsigned a_addr[4], b_addr[4];
+#pragma unroll
+    for (int jq = 0; jq < 4; ++jq) {
+        const unsigned posb = (((unsigned)(2 * jq + half)) ^ fl) * 16u;
+        a_addr[jq] = (unsigned)(wm * 32 * MT + l32) * 128u + posb;
+        b_addr[jq] = (unsigned)(BM + wn * 32 * NT + l32) * 128u + posb;
+        asm volatile("" : "+v"(a_addr[jq]), "+v"(b_addr[jq]));      // eight registers, not a row + chunk add per read
+    }
+    float sc[NT], sh[NT];
+#pragma unroll
+    for (int n = 0; n < NT; ++n) {
+        sc[n] = 1.f; sh[n] = 0.f;
+        if (AFF) { sc[n] = p.in_scale[cx0 + (wn * NT + n) * 32 + l32]; sh[n] = p.in_shift[cx0 + (wn * NT + n) * 32 + l32]; }
+    }
+
+    f32x16 acc[MT][NT];
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][n][r] = 0.f;
+
+    int tb = t_begin / tpi, tq = (t_begin - tb * tpi) * KT;    // (uniform) image and first pixel of the k-tile being fetched
+    if (t_begin < t_end) dma_tile(tb, tq, 0);
+
+    // one k-tile out of ring slot SLOT (compile-time: every LDS offset is an immediate)
+    auto run_tile = [&](auto slot_c, bool more) {
+        constexpr int SLOT = decltype(slot_c)::value;
+        __builtin_amdgcn_sched_barrier(0);
+        __builtin_amdgcn_s_waitcnt(0x0070);               // vmcnt(0) lgkmcnt(0): this wave's rows of the k-tile have landed
+        __builtin_amdgcn_s_barrier();                     // ... and everyone's; everyone is done reading the other slot
+        __builtin_amdgcn_sched_barrier(0);
+        tq += KT;
+        if (tq >= (int)HW) { tq = 0; ++tb; }
+        if (more) dma_tile(tb, tq, SLOT ^ 1);
+        f32x4 fa[2][MT], fb[2][NT];
+#define SPK_GD_FRAG(jq_, f_)                                                                                                   \
+    {                                                                                                                          \
+        _Pragma("unroll") for (int m = 0; m < MT; ++m)                                                                         \
+            fa[f_][m] = *(const wg_lds_f32x4*)((wg_lds_u8*)smem + (a_addr[jq_] + (unsigned)(SLOT * SLOT_B + m * 4096)));      \
+        _Pragma("unroll") for (int n = 0; n < NT; ++n)                                                                         \
+            fb[f_][n] = *(const wg_lds_f32x4*)((wg_lds_u8*)smem + (b_addr[jq_] + (unsigned)(SLOT * SLOT_B + n * 4096)));      \
+    }
+        SPK_GD_FRAG(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        wg_static_for<0, 4>([&](auto q_) {
+            constexpr int jq = decltype(q_)::value;
+            if constexpr (jq + 1 < 4) {
+                SPK_GD_FRAG(jq + 1, (jq + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);          // the next group's reads first: 16 MFMAs of flight
+                __builtin_amdgcn_s_waitcnt(0xC07F | ((MT + NT) << 8));      // lgkmcnt(MT + NT): this group's have landed, no more
+                __builtin_amdgcn_sched_barrier(0);
+            }
+            if constexpr (AFF) {
+#pragma unroll
+                for (int n = 0; n < NT; ++n)
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) fb[jq & 1][n][i] = fmaxf(__builtin_fmaf(fb[jq & 1][n][i], sc[n], sh[n]), 0.f);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int m = 0; m < MT; ++m)
+#pragma unroll
+                    for (int n = 0; n < NT; ++n)
+                        acc[m][n] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[jq & 1][m][i], fb[jq & 1][n][i], acc[m][n], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+#undef SPK_GD_FRAG
+    };
+    for (int t = t_begin; t < t_end; t += 2) {
+        run_tile(std::integral_constant<int, 0>{}, t + 1 < t_end);
+        if (t + 1 < t_end) run_tile(std::integral_constant<int, 1>{}, t + 2 < t_end);
+    }
+
+    // partial block -> slab [slab][co][ci] (ci contiguous)
+    float* out = p.slabs + (size_t)blockIdx.z * p.Cy * p.Cin;
+#pragma unroll
+    for (int m = 0; m < MT; ++m)
+#pragma unroll
+        for (int n = 0; n < NT; ++n) {
+            const int ci = ci0 + (wn * NT + n) * 32 + l32;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int co = co0 + (wm * MT + m) * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+                out[(size_t)co * p.Cin + ci] = acc[m][n][r];
+            }
+        }
+}
+
+// whether the LDS-DMA form takes a stride-1 problem of block shape (bm, bn)
+inline bool dma_takes(const spk_wgrad_desc* d, int bm, int bn) {
+    static const bool allow = [] { const char* e = getenv("SPK_WGRAD1X1_DMA"); return !e || atoi(e) != 0; }();
+    const auto aligned = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    const long long HW = (long long)d->H * d->W;
+    return allow && d->stride == 1 && d->Cout % bm == 0 && d->Cin % bn == 0 && HW % G1_KT == 0 && HW * 8 * 4 < (1ll << 31) &&
+           aligned(d->g) && aligned(d->x) && d->Hin == d->H && d->Win == d->W;
+}
+
 // block shape of the GEMM form for a problem: tiles per wave along co / ci
 inline void g1_shape(int groups, int Cout, int Cin, int* mt, int* nt) {
     const int G = groups > 1 ? groups : 1;
@@ -1726,12 +1885,20 @@ int run_wgrad1x1_shape(const spk_wgrad_desc* d, hipStream_t stream) {
     a.Cy = G * d->Cout;
     a.lgTW = a.lgTH = a.lgTB = 0; a.tiles_x = a.tiles_y = 0; a.n_tiles = g.n_tiles;
     auto kern = &wgrad1x1_kernel<S, MODE, MT, NT>;
-    const size_t lds = 2 * (size_t)(BM + BN) * G1_PITCH * sizeof(float);
-    static bool raised = false;
-    if (!raised) {
+    size_t lds = 2 * (size_t)(BM + BN) * G1_PITCH * sizeof(float);
+    bool dma = false;
+    if constexpr (S == 1) {
+        if (dma_takes(d, BM, BN)) {
+            kern = &wgrad1x1_dma_kernel<MODE, MT, NT>;
+            lds = 2 * (size_t)(BM + BN) * G1_KT * sizeof(float);
+            dma = true;
+        }
+    }
+    static bool raised[2] = {false, false};
+    if (!raised[dma]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return spk::fail(SPK_ELAUNCH, "hipFuncSetAttribute(LDS): %s", hipGetErrorString(e));
-        raised = true;
+        raised[dma] = true;
     }
     SPK_REQUIRE((long long)a.Cy * d->H * d->W < (1ll << 31) && (long long)a.Cx * d->Hin * d->Win < (1ll << 31),
                 "wgrad 1x1 GEMM form: an image's planes are addressed with 32-bit offsets");
