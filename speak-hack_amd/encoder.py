@@ -33,6 +33,20 @@ WIDTHS = (64, 128, 256, 512)
 EXPANSION = 4
 
 
+
+def _wgrad_aside(side, dr, launch):
+    """``launch()`` (a weight-gradient launch reading ``dr``) on the stream ``side``, behind everything queued on the current
+    stream so far; None: in order on the current stream.  ``dr`` is a temporary of the backward: the allocator must not hand
+    its memory out again before the side stream is done with it.  The caller joins ``side`` before it returns gradients."""
+    if side is None:
+        return launch()
+    side.wait_stream(torch.cuda.current_stream(dr.device))
+    with torch.cuda.stream(side):
+        dw = launch()
+    dr.record_stream(side)
+    return dw
+
+
 class Bottleneck(nn.Module):
     """Parameter holder with torchvision's Bottleneck attribute names (v1.5: stride on conv2)."""
 
@@ -108,14 +122,15 @@ class _ConvBN:
                               want_dz=want_dz, batch_stats=rec["training"], **kw)
         return out
 
-    def conv_bwd(self, rec, dr, grads, need_dx, dx_out=None, accumulate=False, dilate=True, half=None):
+    def conv_bwd(self, rec, dr, grads, need_dx, dx_out=None, accumulate=False, dilate=True, half=None, side=None):
         """Weight gradient (into ``grads``) and, if asked, the gradient w.r.t. the conv's (staged) input.  ``dilate=False``
         (a strided 1x1): that gradient stays at the conv's output size; ``half``: such a tensor, added at the even pixels."""
         conv = self.conv
         Cout, Cin = conv.out_channels, conv.in_channels
         x = rec["x"]
         B, _, H, W = x.shape
-        grads[conv.weight] = ops.conv2d_wgrad(dr, x, Cout, Cin, self.k, self.stride, in_affine=rec["in_affine"])
+        grads[conv.weight] = _wgrad_aside(side, dr, lambda: ops.conv2d_wgrad(dr, x, Cout, Cin, self.k, self.stride,
+                                                                            in_affine=rec["in_affine"]))
         if not need_dx:
             return None
         cfg, tf = ops.dgrad_plan(self.k, self.stride, B, Cout, Cin, (H, W), dr.shape[-2:], dx_out, accumulate)
@@ -255,14 +270,15 @@ class _GroupedConvBN:
         return ops.bn_backward(g, rec["y"], rec["affine"], rec["mean"], rec["invstd"], mask_mode, mask_src,
                                want_dz=want_dz, batch_stats=rec["training"], **kw)
 
-    def conv_bwd(self, rec, dr, grads, need_dx, dx_out=None, accumulate=False, dilate=True, half=None):
+    def conv_bwd(self, rec, dr, grads, need_dx, dx_out=None, accumulate=False, dilate=True, half=None, side=None):
         conv, G = self.convs[0], self.G
         Cout, Cin = conv.out_channels, conv.in_channels
         x = rec["x"]
         B, _, H, W = x.shape
         T = len(self.uniq)
-        dw = ops.conv2d_wgrad(dr, x, Cout, Cin, self.k, self.stride, in_affine=rec["in_affine"], groups=G,
-                              shared_input=self.shared_input, fold=G // T).view(T, Cout, Cin, self.k, self.k)
+        dw = _wgrad_aside(side, dr, lambda: ops.conv2d_wgrad(dr, x, Cout, Cin, self.k, self.stride, in_affine=rec["in_affine"],
+                                                             groups=G, shared_input=self.shared_input, fold=G // T))
+        dw = dw.view(T, Cout, Cin, self.k, self.k)
         for q in range(T):
             grads[self.convs[q].weight] = dw[q]
         if not need_dx:
@@ -501,6 +517,7 @@ class ResNet50Trunk(nn.Sequential):
 
     def _backward(self, recs, dfeat):
         """dfeat [B,2048,1,1] -> {parameter: gradient}."""
+        side = ops.side_stream(dfeat.device)           # the weight gradients' stream (joined before the gradients are returned)
         stem, blocks = self._plan
         grads = {}
         g, per_plane, g_scale = dfeat.view(dfeat.size(0), -1).contiguous(), True, None
@@ -511,32 +528,34 @@ class ResNet50Trunk(nn.Sequential):
             dr3, dg, db, dz = c3.bn_bwd(r3, g, ops.MASK_TENSOR, mask_src=out, want_dz=True,
                                         g_scale=g_scale if per_plane else 1.0, g_per_plane=per_plane)
             c3.put_bn_grads(grads, dg, db)
-            dv2 = c3.conv_bwd(r3, dr3, grads, need_dx=True)
+            dv2 = c3.conv_bwd(r3, dr3, grads, need_dx=True, side=side)
             dr2, dg, db = c2.bn_bwd(r2, dv2, ops.MASK_RECOMPUTE)
             c2.put_bn_grads(grads, dg, db)
-            dv1 = c2.conv_bwd(r2, dr2, grads, need_dx=True)
+            dv1 = c2.conv_bwd(r2, dr2, grads, need_dx=True, side=side)
             dr1, dg, db = c1.bn_bwd(r1, dv1, ops.MASK_RECOMPUTE)
             c1.put_bn_grads(grads, dg, db)
             if down is None:
                 # d(block input) = dz (identity) + conv1's data gradient, summed in the conv epilogue
-                g = c1.conv_bwd(r1, dr1, grads, need_dx=True, dx_out=dz, accumulate=True)
+                g = c1.conv_bwd(r1, dr1, grads, need_dx=True, dx_out=dz, accumulate=True, side=side)
             else:
                 drd, dg, db = down.bn_bwd(rd, dz, ops.MASK_NONE)
                 down.put_bn_grads(grads, dg, db)
                 if down.stride == 2:
                     # the downsample conv reads the even pixels only: its data gradient stays at ITS output size and conv1's
                     # data gradient adds it at the even pixels in its own epilogue -- no dilated copy, no read of one
-                    t = down.conv_bwd(rd, drd, grads, need_dx=True, dilate=False)
-                    g = c1.conv_bwd(r1, dr1, grads, need_dx=True, half=t)
+                    t = down.conv_bwd(rd, drd, grads, need_dx=True, dilate=False, side=side)
+                    g = c1.conv_bwd(r1, dr1, grads, need_dx=True, half=t, side=side)
                 else:
-                    g = down.conv_bwd(rd, drd, grads, need_dx=True)
-                    g = c1.conv_bwd(r1, dr1, grads, need_dx=True, dx_out=g, accumulate=True)
+                    g = down.conv_bwd(rd, drd, grads, need_dx=True, side=side)
+                    g = c1.conv_bwd(r1, dr1, grads, need_dx=True, dx_out=g, accumulate=True, side=side)
             per_plane = False
         # stem: max-pool adjoint (bn1+relu re-formed on the fly), BatchNorm backward, 7x7 weight gradient
         s = recs["stem"]
         dv0 = ops.maxpool3x3s2_bwd(s["y"], g, s["affine"][0], s["affine"][1])
         dr0, dg, db = stem.bn_bwd(s, dv0, ops.MASK_RECOMPUTE)
         stem.put_bn_grads(grads, dg, db)
-        stem.conv_bwd(s, dr0, grads, need_dx=False)       # the image itself takes no gradient
+        stem.conv_bwd(s, dr0, grads, need_dx=False, side=side)       # the image itself takes no gradient
         _GroupedConvBN.flush_bn_grads(grads)
+        if side is not None:
+            torch.cuda.current_stream(dfeat.device).wait_stream(side)     # every weight gradient is complete behind this point
         return grads
