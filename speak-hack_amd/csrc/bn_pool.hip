@@ -353,7 +353,9 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_bwd_kernel(const float* __re
                                                               float* __restrict__ dx, int C, int Hin, int Win, int Ho, int Wo,
                                                               int tiles_x, int tiles_y) {
     constexpr int TO = 16, TW = TO + 1;            // windows per tile side (+1: the odd last row / column reaches the next)
+    constexpr int TI = 2 * TO + 3, TP = TI + 2;    // staged input rows / columns (2 oy0 - 1 .. 2 oy0 + 33: window 16 ends there), LDS pitch
     __shared__ unsigned char code[TW * TW];
+    __shared__ float xs[TI * TP];
     int bx = blockIdx.x;
     const int tx = bx % tiles_x; bx /= tiles_x;
     const int ty = bx % tiles_y;
@@ -363,23 +365,32 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_bwd_kernel(const float* __re
     const float s = sc ? sc[c] : 1.f, o = sc ? sh[c] : 0.f;
     const float* xp = x + plane * Hin * Win;
     const float* gp = dy + plane * Ho * Wo;
+    // the tile's input pixels once, row-contiguous, (folded BatchNorm + ReLU applied) into LDS: the window search below read every
+    // pixel 2.25 times with stride-2 gathers (375 us for the stem's 450 MB: 1.2 TB/s)
+    for (int e = threadIdx.x; e < TI * TI; e += 256) {
+        const int r = e / TI, q = e - r * TI;
+        const int yy = 2 * oy0 - 1 + r, xx = 2 * ox0 - 1 + q;
+        float v = -INFINITY;
+        if ((unsigned)yy < (unsigned)Hin && (unsigned)xx < (unsigned)Win) {
+            v = xp[yy * Win + xx];
+            if (sc) v = fmaxf(v * s + o, 0.f);
+        }
+        xs[r * TP + q] = v;
+    }
+    __syncthreads();
     for (int w = threadIdx.x; w < TW * TW; w += 256) {
-        const int oy = oy0 + w / TW, ox = ox0 + w % TW;
+        const int wy = w / TW, wx = w - wy * TW;
+        const int oy = oy0 + wy, ox = ox0 + wx;
         int best = 255;
         if (oy < Ho && ox < Wo) {
             float m = -INFINITY;
 #pragma unroll
-            for (int ky = 0; ky < 3; ++ky) {
-                const int yy = oy * 2 + ky - 1;
+            for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
                 for (int kx = 0; kx < 3; ++kx) {
-                    const int xx = ox * 2 + kx - 1;
-                    if (yy < 0 || yy >= Hin || xx < 0 || xx >= Win) continue;
-                    float v = xp[yy * Win + xx];
-                    if (sc) v = fmaxf(v * s + o, 0.f);
+                    const float v = xs[(2 * wy + ky) * TP + 2 * wx + kx];      // (-inf outside the image: never the maximum)
                     if (v > m) { m = v; best = ky * 3 + kx; }
                 }
-            }
         }
         code[w] = (unsigned char)best;
     }
