@@ -280,8 +280,13 @@ static Geometry geometry_any(int kh, int stride, int cfg, int B, int Cin, int Co
 // epilogues; the wide-pixel tile for Cout <= 64; the small tile when the whole problem is small.
 static int pick_config(int kh, int stride, int B, int Cin, int Cout, int H, int W) {
     const long long pixels = (long long)B * H * W;
-    // (128 -> 128 at 128^2: the wide-pixel tile measured 335 us against 350 for the square one; with Cin = 256 the square wins)
-    const bool wide = Cout <= 64 ? pixels >= 64 * 1024 : (Cout <= 128 && Cin <= 128 && kh == 3 && stride == 1 && pixels >= 128 * 1024);
+    // Cout = 128, 3x3 stride 1, the fixed-geometry builds (tools/bench_conv.py, profiles/r03_u_conv_config_ab.txt): the
+    // wide-pixel tile (64 co x 256 px, three per CU) wins with Cin = 256 (256 -> 128 @128^2 x2: 552 us against 568 at B=8, 1085 /
+    // 1107 at B=16) and with Cin <= 128 once there are >= 256K pixels (128 -> 128 @128^2, B=16: 584 / 596); at B=8 that layer is
+    // 1024 workgroups = 1.33 rounds of 768 slots and the square tile's two full rounds of 512 win (305 against 323).
+    const bool wide = Cout <= 64 ? pixels >= 64 * 1024
+                                 : (Cout <= 128 && Cin <= 256 && kh == 3 && stride == 1 && pixels >= 128 * 1024 &&
+                                    !(Cin <= 128 && pixels < 256 * 1024));
     // 1x1 on the tap kernel: the 64x64 tile beats the 128x128 one up to 16^2 x 8 pixels, and for Cout = 128 up to 32^2 x 8
     // (sweep of configs 8-12 over the trunk's shapes, 6 groups: e.g. 256->1024 @16^2 data gradient 76 us against 85)
     const bool small1x1 = kh == 1 && (pixels <= 2048 || (Cout <= 128 && pixels <= 8192));

@@ -31,11 +31,13 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--res", type=int, default=256)
     ap.add_argument("--rounds", type=int, default=5)
+    ap.add_argument("--dgrad", action="store_true", help="the data-gradient shapes of the same layers (channels swapped, plain)")
     args = ap.parse_args()
     dev = torch.device("cuda:0")
     B = args.batch
     ncfg = pkg._lib.lib().spk_conv2d_num_configs()
-    for cin, cout, r, ups in layers(args.res):
+    shapes = [(co, ci, r, False) for ci, co, r, _ in layers(args.res) if ci != co] if args.dgrad else layers(args.res)
+    for cin, cout, r, ups in shapes:
         hs = r // 2 if ups else r
         x = torch.randn(B, cin, hs, hs, device=dev)
         w = torch.randn(cout, cin, 3, 3, device=dev) * 0.02
