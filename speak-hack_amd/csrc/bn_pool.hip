@@ -121,20 +121,24 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_kernel(const float* __restri
         const int c = (int)(plane % C);
         const float s = sc ? sc[c] : 1.f, o = sc ? sh[c] : 0.f;
         const float* xp = x + plane * Hin * Win;
+        // nine loads in flight at once (clamped address, -inf where the window leaves the image): with a branch per tap they
+        // ran one memory latency after the other
+        float v[3][3];
+#pragma unroll
+        for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+                v[ky][kx] = xp[min(max(oy * 2 + ky - 1, 0), Hin - 1) * Win + min(max(ox * 2 + kx - 1, 0), Win - 1)];
         float m = -INFINITY;
 #pragma unroll
-        for (int ky = 0; ky < 3; ++ky) {
-            const int iy = oy * 2 + ky - 1;
-            if (iy < 0 || iy >= Hin) continue;
+        for (int ky = 0; ky < 3; ++ky)
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
-                const int ix = ox * 2 + kx - 1;
-                if (ix < 0 || ix >= Win) continue;
-                float v = xp[iy * Win + ix];
-                if (sc) v = fmaxf(v * s + o, 0.f);
-                m = fmaxf(m, v);
+                const bool in = (unsigned)(oy * 2 + ky - 1) < (unsigned)Hin && (unsigned)(ox * 2 + kx - 1) < (unsigned)Win;
+                float t = v[ky][kx];
+                if (sc) t = fmaxf(t * s + o, 0.f);
+                m = fmaxf(m, in ? t : -INFINITY);
             }
-        }
         y[idx] = m;
     }
 }
@@ -356,6 +360,7 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_bwd_kernel(const float* __re
     constexpr int TI = 2 * TO + 3, TP = TI + 2;    // staged input rows / columns (2 oy0 - 1 .. 2 oy0 + 33: window 16 ends there), LDS pitch
     __shared__ unsigned char code[TW * TW];
     __shared__ float xs[TI * TP];
+    __shared__ float gs[TW * TW];
     int bx = blockIdx.x;
     const int tx = bx % tiles_x; bx /= tiles_x;
     const int ty = bx % tiles_y;
@@ -365,17 +370,38 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_bwd_kernel(const float* __re
     const float s = sc ? sc[c] : 1.f, o = sc ? sh[c] : 0.f;
     const float* xp = x + plane * Hin * Win;
     const float* gp = dy + plane * Ho * Wo;
-    // the tile's input pixels once, row-contiguous, (folded BatchNorm + ReLU applied) into LDS: the window search below read every
-    // pixel 2.25 times with stride-2 gathers (375 us for the stem's 450 MB: 1.2 TB/s)
-    for (int e = threadIdx.x; e < TI * TI; e += 256) {
+    // the tile's input pixels once, row-contiguous, (folded BatchNorm + ReLU applied) into LDS, and the 17 x 17 gradients it can
+    // receive: ALL global loads of the workgroup are issued before the first one is used (the first version searched the
+    // windows with 2.25 strided gathers per pixel and looked the gradients up under a branch: 375 us for the stem's 450 MB)
+    constexpr int NXL = (TI * TI + 255) / 256, NGL = (TW * TW + 255) / 256;
+    float xv[NXL], gv[NGL];
+#pragma unroll
+    for (int k = 0; k < NXL; ++k) {
+        const int e = min((int)threadIdx.x + 256 * k, TI * TI - 1);
         const int r = e / TI, q = e - r * TI;
-        const int yy = 2 * oy0 - 1 + r, xx = 2 * ox0 - 1 + q;
-        float v = -INFINITY;
-        if ((unsigned)yy < (unsigned)Hin && (unsigned)xx < (unsigned)Win) {
-            v = xp[yy * Win + xx];
+        xv[k] = xp[min(max(2 * oy0 - 1 + r, 0), Hin - 1) * Win + min(max(2 * ox0 - 1 + q, 0), Win - 1)];
+    }
+#pragma unroll
+    for (int k = 0; k < NGL; ++k) {
+        const int w = min((int)threadIdx.x + 256 * k, TW * TW - 1);
+        const int wy = w / TW, wx = w - wy * TW;
+        gv[k] = gp[min(oy0 + wy, Ho - 1) * Wo + min(ox0 + wx, Wo - 1)];
+    }
+#pragma unroll
+    for (int k = 0; k < NXL; ++k) {
+        const int e = threadIdx.x + 256 * k;
+        if (e < TI * TI) {
+            const int r = e / TI, q = e - r * TI;
+            const int yy = 2 * oy0 - 1 + r, xx = 2 * ox0 - 1 + q;
+            float v = xv[k];
             if (sc) v = fmaxf(v * s + o, 0.f);
+            xs[r * TP + q] = ((unsigned)yy < (unsigned)Hin && (unsigned)xx < (unsigned)Win) ? v : -INFINITY;
         }
-        xs[r * TP + q] = v;
+    }
+#pragma unroll
+    for (int k = 0; k < NGL; ++k) {
+        const int w = threadIdx.x + 256 * k;
+        if (w < TW * TW) gs[w] = gv[k];
     }
     __syncthreads();
     for (int w = threadIdx.x; w < TW * TW; w += 256) {
@@ -406,7 +432,7 @@ __global__ __launch_bounds__(256) void maxpool3x3s2_bwd_kernel(const float* __re
             const int ky = ly - 2 * wy + 1;
             for (int wx = lx >> 1; wx <= (lx + 1) >> 1; ++wx) {
                 const int kx = lx - 2 * wx + 1;
-                if (code[wy * TW + wx] == ky * 3 + kx) acc += gp[(oy0 + wy) * Wo + ox0 + wx];   // 255 = no such window
+                if (code[wy * TW + wx] == ky * 3 + kx) acc += gs[wy * TW + wx];                 // 255 = no such window
             }
         }
         dx[plane * Hin * Win + (long long)iy * Win + ix] = acc;

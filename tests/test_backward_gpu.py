@@ -144,6 +144,13 @@ def test_pointwise_backward_kernels(pkg, dev, golden):
     g = golden("decoder_ops.npz")
     for tag in ("up_a", "up_b", "up_c"):
         assert rel_l2(pkg.ops.upsample2x_bilinear_bwd(T(g[f"{tag}.gy"]).to(dev)), g[f"{tag}.gx"]) < TOL
+    # widths that are multiples of 4 take the four-pixels-per-thread kernel (16-byte loads): borders, one-row planes, many planes
+    for i, shp in enumerate([(2, 3, 4, 4), (1, 2, 8, 12), (2, 2, 16, 4), (1, 1, 1, 4), (3, 5, 32, 32)]):
+        xs = recipe_input(f"upv{i}.x", shp).requires_grad_(True)
+        ys = F.interpolate(xs, scale_factor=2, mode="bilinear", align_corners=False)
+        gy = recipe_input(f"upv{i}.g", ys.shape)
+        ys.backward(gy)
+        assert rel_l2(pkg.ops.upsample2x_bilinear_bwd(gy.to(dev)), xs.grad) < TOL, shp
     # fused-epilogue adjoint vs autograd of the op chain
     B, C, H = 3, 10, 7
     t = recipe_input("eb.t", (B, C, H, H)).requires_grad_(True)
