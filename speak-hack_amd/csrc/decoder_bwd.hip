@@ -307,6 +307,17 @@ __global__ __launch_bounds__(256) void fc_bwd_input_kernel(const float* __restri
         for (int b = 0; b < FCB_BT; ++b) acc[b] = 0.f;
         if (i < I) {
             int o = wave;
+            // 32 independent row loads in flight (8 waves' worth of CUs run this kernel: it is latency, and with 8 loads per
+            // round a 512 x 512 layer took 16 rounds = 33 us)
+            for (; o + 124 < O; o += 128) {
+                float wv[32];
+#pragma unroll
+                for (int u = 0; u < 32; ++u) wv[u] = w[(size_t)(o + 4 * u) * I + i];
+#pragma unroll
+                for (int u = 0; u < 32; ++u)
+#pragma unroll
+                    for (int b = 0; b < FCB_BT; ++b) acc[b] += dz_s[b * O + o + 4 * u] * wv[u];
+            }
             for (; o + 28 < O; o += 32) {            // 8 independent row loads in flight
                 float wv[8];
 #pragma unroll

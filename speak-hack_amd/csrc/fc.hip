@@ -10,6 +10,27 @@ namespace {
 constexpr int FC_BT = 8;       // batch rows accumulated per pass over the weight row
 constexpr int FC_WAVES = 4;    // waves (= output rows) per workgroup
 
+// The mapping network's and the style affines' 512-wide rows: both weight loads and all 2 x FC_BT latent loads of a lane in flight
+// at once (the generic loop runs its two iterations one memory latency after the other; such a layer is latency, not bandwidth:
+// 1 MB of weights).  One body for fc_kernel and fc_grouped_kernel: their results are bitwise equal.
+__device__ __forceinline__ void fc_dot512(const float* __restrict__ wr, const float* __restrict__ x, long long x_stride, int b0, int B,
+                                          int lane, float (&acc)[FC_BT]) {
+    const float4 w0 = *reinterpret_cast<const float4*>(wr + lane * 4);
+    const float4 w1 = *reinterpret_cast<const float4*>(wr + 256 + lane * 4);
+    float4 x0[FC_BT], x1[FC_BT];
+#pragma unroll
+    for (int b = 0; b < FC_BT; ++b) {
+        const float* xr = x + (size_t)min(b0 + b, B - 1) * x_stride + lane * 4;
+        x0[b] = *reinterpret_cast<const float4*>(xr);
+        x1[b] = *reinterpret_cast<const float4*>(xr + 256);
+    }
+#pragma unroll
+    for (int b = 0; b < FC_BT; ++b) {
+        acc[b] += w0.x * x0[b].x + w0.y * x0[b].y + w0.z * x0[b].z + w0.w * x0[b].w;
+        acc[b] += w1.x * x1[b].x + w1.y * x1[b].y + w1.z * x1[b].z + w1.w * x1[b].w;
+    }
+}
+
 template <bool VEC>
 __global__ __launch_bounds__(FC_WAVES * 64) void fc_kernel(const float* __restrict__ x, long long x_stride,
                                                           const float* __restrict__ w, const float* __restrict__ bias,
@@ -24,7 +45,9 @@ __global__ __launch_bounds__(FC_WAVES * 64) void fc_kernel(const float* __restri
         float acc[FC_BT];
 #pragma unroll
         for (int b = 0; b < FC_BT; ++b) acc[b] = 0.f;
-        if (VEC) {
+        if (VEC && I == 512) {
+            fc_dot512(wr, x, x_stride, b0, B, lane, acc);
+        } else if (VEC) {
             for (int i = lane * 4; i < I; i += 256) {
                 const float4 wv = *reinterpret_cast<const float4*>(wr + i);
 #pragma unroll
@@ -139,13 +162,17 @@ __global__ __launch_bounds__(FC_WAVES * 64) void fc_grouped_kernel(const FcGroup
         float acc[FC_BT];
 #pragma unroll
         for (int b = 0; b < FC_BT; ++b) acc[b] = 0.f;
-        for (int i = lane * 4; i < g.I; i += 256) {
-            const float4 wv = *reinterpret_cast<const float4*>(wr + i);
+        if (g.I == 512) {
+            fc_dot512(wr, g.x, g.x_stride, b0, B, lane, acc);
+        } else {
+            for (int i = lane * 4; i < g.I; i += 256) {
+                const float4 wv = *reinterpret_cast<const float4*>(wr + i);
 #pragma unroll
-            for (int b = 0; b < FC_BT; ++b) {
-                if (b0 + b < B) {
-                    const float4 xv = *reinterpret_cast<const float4*>(g.x + (size_t)(b0 + b) * g.x_stride + i);
-                    acc[b] += wv.x * xv.x + wv.y * xv.y + wv.z * xv.z + wv.w * xv.w;
+                for (int b = 0; b < FC_BT; ++b) {
+                    if (b0 + b < B) {
+                        const float4 xv = *reinterpret_cast<const float4*>(g.x + (size_t)(b0 + b) * g.x_stride + i);
+                        acc[b] += wv.x * xv.x + wv.y * xv.y + wv.z * xv.z + wv.w * xv.w;
+                    }
                 }
             }
         }
