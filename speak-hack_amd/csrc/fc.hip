@@ -141,6 +141,70 @@ __global__ __launch_bounds__(256) void fc_wide_kernel(const float* __restrict__ 
     }
 }
 
+// The same long rows, FOUR output rows per workgroup (I = 1024 U, U <= FC_WIDE_U, O % 4 == 0): all 4 U weight loads of a lane are
+// issued first (one HBM latency for the whole 12.6 MB layer), then U rounds of FC_BT latent loads serve four rows each -- the
+// one-row kernel issued its latent loads under a branch per chunk, six L2 latencies in a row, and re-read the latents per row
+// (24 us for the 6144 -> 512 layer; this one: ~8).  Same per-lane summation order as fc_wide_kernel.
+__global__ __launch_bounds__(256) void fc_wide4_kernel(const float* __restrict__ x, long long x_stride, const float* __restrict__ w,
+                                                      const float* __restrict__ bias, float* __restrict__ out, long long out_stride,
+                                                      int B, int I, int O, float wmul, float bmul, float slope) {
+    __shared__ float red[4][4][FC_BT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int o0 = blockIdx.x * 4;
+    const int U = I >> 10;
+    float4 wv[4][FC_WIDE_U];
+#pragma unroll
+    for (int r = 0; r < 4; ++r)
+#pragma unroll
+        for (int u = 0; u < FC_WIDE_U; ++u)
+            wv[r][u] = *reinterpret_cast<const float4*>(w + (size_t)(o0 + r) * I + tid * 4 + min(u, U - 1) * 1024);
+    for (int b0 = 0; b0 < B; b0 += FC_BT) {
+        float acc[4][FC_BT];
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int b = 0; b < FC_BT; ++b) acc[r][b] = 0.f;
+#pragma unroll
+        for (int u = 0; u < FC_WIDE_U; ++u) {
+            if (u < U) {
+                float4 xv[FC_BT];
+#pragma unroll
+                for (int b = 0; b < FC_BT; ++b)
+                    xv[b] = *reinterpret_cast<const float4*>(x + (size_t)min(b0 + b, B - 1) * x_stride + tid * 4 + u * 1024);
+#pragma unroll
+                for (int r = 0; r < 4; ++r)
+#pragma unroll
+                    for (int b = 0; b < FC_BT; ++b)
+                        acc[r][b] += wv[r][u].x * xv[b].x + wv[r][u].y * xv[b].y + wv[r][u].z * xv[b].z + wv[r][u].w * xv[b].w;
+            }
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+#pragma unroll
+            for (int b = 0; b < FC_BT; ++b) {
+#pragma unroll
+                for (int off = 32; off >= 1; off >>= 1) acc[r][b] += __shfl_xor(acc[r][b], off);
+            }
+        __syncthreads();
+        if (lane == 0) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+#pragma unroll
+                for (int b = 0; b < FC_BT; ++b) red[wave][r][b] = acc[r][b];
+        }
+        __syncthreads();
+        if (tid < 4 * FC_BT) {
+            const int r = tid / FC_BT, b = tid % FC_BT;
+            if (b0 + b < B) {
+                float v = (red[0][r][b] + red[1][r][b]) + (red[2][r][b] + red[3][r][b]);
+                v = v * wmul + (bias ? bias[o0 + r] * bmul : 0.f);
+                v = v > 0.f ? v : v * slope;
+                out[(size_t)(b0 + b) * out_stride + o0 + r] = v;
+            }
+        }
+    }
+}
+
 // Several independent FCs on one launch (the 13 style affines of a decoder step all depend only on the dlatents):
 // same wave-per-row body as fc_kernel, the (group, row) pair comes from a prefix table in the kernel arguments.
 struct FcGroups {
@@ -201,6 +265,11 @@ extern "C" int spk_fc_fwd(const float* x, int64_t x_stride, const float* w, cons
     SPK_REQUIRE(B > 0 && I > 0 && O > 0, "fc: bad shape B=%d I=%d O=%d", B, I, O);
     SPK_REQUIRE(x_stride >= I && out_stride >= O, "fc: row stride smaller than row");
     const bool vec = (I % 4 == 0) && (x_stride % 4 == 0) && ((uintptr_t)x % 16 == 0) && ((uintptr_t)w % 16 == 0);
+    if (vec && I >= 2048 && I % 1024 == 0 && I <= 1024 * FC_WIDE_U && O % 4 == 0) {
+        hipLaunchKernelGGL(fc_wide4_kernel, dim3((unsigned)(O / 4)), dim3(256), 0, (hipStream_t)stream, x, (long long)x_stride, w, bias, out,
+                           (long long)out_stride, B, I, O, wmul, bmul, slope);
+        return spk::check_launch("fc_wide4_kernel");
+    }
     if (vec && I >= 2048) {
         hipLaunchKernelGGL(fc_wide_kernel, dim3((unsigned)O), dim3(256), 0, (hipStream_t)stream, x, (long long)x_stride, w, bias, out,
                            (long long)out_stride, B, I, O, wmul, bmul, slope);
