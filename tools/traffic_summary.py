@@ -74,7 +74,7 @@ def main():
     if "--json" in sys.argv:
         fb, wb, n = res["f32"]
         out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python3 tools/pmc_decoder.py` "
-                         "(the headline decoder step launched eagerly through its launch plan); summary in profiles/r03_m_conv_traffic.txt",
+                         "(the headline decoder step launched eagerly through its launch plan); summary in profiles/r03_v_conv_traffic.txt",
                "kernel": "spkconv::conv_kernel<Cfg,3,3,1,MODE 0|1>", "launches_per_step": 12, "steps_counted": n,
                "fetch_bytes_per_step": int(fb), "write_bytes_per_step": int(wb), "bytes_per_launch": int((fb + wb) / 12),
                "bf16x3_fetch_bytes_per_step": int(res["bf16x3"][0]), "bf16x3_write_bytes_per_step": int(res["bf16x3"][1]),
