@@ -106,6 +106,40 @@ def test_wgrad_stride1_wide_form(pkg, dev, B, Cin, Cout, H, W, groups, aff):
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W,groups,aff", [
+    (2, 64, 64, 8, 8, 1, False),         # 64 x 64 block (one MFMA tile per wave), two k-tiles per image
+    (3, 128, 64, 8, 4, 2, True),         # 64 co x 128 ci, grouped, folded BatchNorm, an odd number of k-tiles (3)
+    (2, 64, 128, 16, 16, 1, True),       # 128 co x 64 ci
+    (2, 128, 256, 8, 8, 3, False),       # 128 x 128 blocks, two co blocks per group, grouped
+    (1, 256, 128, 4, 8, 1, True),        # ONE k-tile in all: the ring's prologue alone
+    (5, 128, 128, 8, 12, 2, True),       # k-tiles that cross images (96 pixels per image = 3 tiles), folded pair of groups below
+])
+def test_wgrad_1x1_lds_dma_form(pkg, dev, B, Cin, Cout, H, W, groups, aff):
+    """wgrad1x1_dma_kernel (whole 64 / 128-channel blocks, H W % 32 == 0: operands by LDS-DMA into XOR-swizzled 128-byte rows,
+    ds_read_b128 fragments, two ring slots) against autograd: split counts, fold, scale + accumulate."""
+    tag = f"wgd.{B}.{Cin}.{Cout}.{H}.{W}.{groups}.{int(aff)}"
+    G = groups
+    x = recipe_input(tag + ".x", (B, G * Cin, H, W))
+    a = 1.0 + recipe_tensor(tag + ".a", (G * Cin,), 0.3)
+    b = recipe_tensor(tag + ".b", (G * Cin,), 0.3)
+    xin = F.relu(x * a.view(1, -1, 1, 1) + b.view(1, -1, 1, 1)) if aff else x
+    ws = [recipe_tensor(tag + f".weight{q}", (Cout, Cin, 1, 1)).requires_grad_(True) for q in range(G)]
+    y = torch.cat([F.conv2d(xin[:, q * Cin:(q + 1) * Cin], ws[q]) for q in range(G)], 1)
+    g = recipe_input(tag + ".g", y.shape)
+    y.backward(g)
+    ref = torch.cat([w.grad for w in ws], 0)
+    kw = dict(in_affine=(a.to(dev), b.to(dev))) if aff else {}
+    for splits in (0, 1, 2, 5):
+        dw = pkg.ops.conv2d_wgrad(g.to(dev), x.to(dev), Cout, Cin, 1, 1, splits=splits, groups=G, **kw)
+        assert rel_l2(dw, ref) < TOL, splits
+    if G % 2 == 0:
+        dw = pkg.ops.conv2d_wgrad(g.to(dev), x.to(dev), Cout, Cin, 1, 1, groups=G, fold=2, **kw)
+        assert rel_l2(dw, ref[:G // 2 * Cout] + ref[G // 2 * Cout:]) < TOL
+    base = recipe_tensor(tag + ".base", ref.shape).to(dev)
+    acc = pkg.ops.conv2d_wgrad(g.to(dev), x.to(dev), Cout, Cin, 1, 1, scale=0.5, out=base.clone(), accumulate=True, groups=G, **kw)
+    assert rel_l2(acc, base.cpu() + 0.5 * ref) < TOL
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,groups,aff", [
     (2, 32, 128, 16, 16, 1, False),      # 16 x 4 output tiles, whole blocks
     (3, 40, 160, 10, 20, 1, True),       # ragged channels (8 live rows in the second ci block, 32 in the second co block), partial tiles
     (2, 64, 128, 8, 8, 1, False),        # 8 x 8 tiles (the 16^2 -> 8^2 layers)

@@ -270,6 +270,30 @@ def test_stored_activations_equal_checkpoint_recompute(pkg, dev):
     assert int(a[3]["1.num_batches_tracked"]) == 2
 
 
+def test_weight_gradients_on_the_second_stream_equal_in_order_launches(pkg, dev, monkeypatch):
+    """The trunk backward queues its weight gradients on ``ops.side_stream`` (behind the producer of their operands, joined
+    before the gradients are returned) -- the same kernels on the same operands, so every gradient is bitwise what the
+    in-order schedule (``SPK_WGRAD_STREAM=0`` / no side stream) gives; repeated, so that a missing wait shows."""
+    x = recipe_input("trw.x", (4, 3, 64, 64), "uniform").to(dev)
+    gfeat = recipe_input("trw.g", (4, 2048, 1, 1)).to(dev)
+    m, _ = _trunk(dev, "Ee.")
+    m.train(True)
+
+    def grads():
+        for p in m.parameters():
+            p.grad = None
+        m(x).backward(gfeat)
+        return {k: p.grad.clone() for k, p in m.named_parameters()}
+
+    assert pkg.ops.side_stream(dev) is not None
+    aside = [grads() for _ in range(3)]
+    monkeypatch.setattr(pkg.ops, "side_stream", lambda device: None)
+    inline = grads()
+    for got in aside:
+        bad = [k for k in inline if not torch.equal(got[k], inline[k])]
+        assert not bad, bad[:4]
+
+
 def test_grouped_trunks_equal_three_separate_trunks(pkg, dev):
     """``GroupedTrunks`` (Ei, Ee, Ep as one network of grouped launches) vs the three trunks run one after another on
     the same image: features, every parameter gradient, running statistics and batch counters.  Not bitwise -- a grouped
