@@ -202,7 +202,7 @@ static const CfgDims kDims[kNumConfigs] = {
     {Cfg3::CO_T, Cfg3::CI_T, Cfg3::PIX_T},   {Cfg4::CO_T, Cfg4::CI_T, Cfg4::PIX_T},   {Cfg5::CO_T, Cfg5::CI_T, Cfg5::PIX_T},
     {Cfg6::CO_T, Cfg6::CI_T, Cfg6::PIX_T},   {Cfg7::CO_T, Cfg7::CI_T, Cfg7::PIX_T},   {Cfg8::CO_T, Cfg8::CI_T, Cfg8::PIX_T},
     {Cfg9::CO_T, Cfg9::CI_T, Cfg9::PIX_T},   {Cfg10::CO_T, Cfg10::CI_T, Cfg10::PIX_T}, {Cfg11::CO_T, Cfg11::CI_T, Cfg11::PIX_T},
-    {128, 32, 128}, {64, 8, 128}, {128, 16, 128}, {64, 16, 128}};
+    {128, 32, 128}, {64, 8, 128}, {128, 16, 128}, {64, 16, 128}, {64, 3, 512}};
 
 static bool supported_kernel(int kh, int kw, int stride) {
     if (kh == 2 && kw == 2) return stride == 1;   // the parity form of the 3x3 stride-2 data gradient (SPK_CONV_DGRAD_S2)
@@ -214,6 +214,7 @@ static bool config_valid(int cfg, int kh, int kw, int stride) {
     if (!supported_kernel(kh, kw, stride) || cfg < 0 || cfg >= kNumConfigs) return false;
     if (cfg == kGemmConfig || is_gemm2(cfg)) return kh == 1 && stride == 1;
     if (cfg == kDgradS2Config) return kh == 2;
+    if (cfg == kStemConfig) return kh == 7 && stride == 2;
     if (kh == 1) return cfg >= 8 && cfg <= 11;
     if (kh == 2) return cfg <= 3;
     if (kh == 3 && stride == 1) return cfg <= 7;
@@ -256,6 +257,15 @@ static Geometry geometry_any(int kh, int stride, int cfg, int B, int Cin, int Co
         g.tiles_x = (int)gemm2_pixel_tiles(B, H, W); g.tiles_y = g.tiles_b = 1;
         g.n_chunks = 1;                  // never splits K
         g.co_tiles = spk::ceil_div(Cout, gemm2_co_tile(cfg));
+        g.lds_bytes = 0;
+        return g;
+    }
+    if (cfg == kStemConfig) {            // 16 x 32 pixel tiles of one image; all 64 channels of a group per workgroup
+        g.ok = stem_takes(kh, stride, Cin, Cout, H, W);
+        g.TW = 32; g.TH = 16; g.TB = 1; g.PLANE = 37 * 69;
+        stem_tiles(H, W, &g.tiles_x, &g.tiles_y); g.tiles_b = B;
+        g.n_chunks = 1;                  // never splits K
+        g.co_tiles = 1;
         g.lds_bytes = 0;
         return g;
     }
@@ -324,6 +334,7 @@ static int pick_config(int kh, int stride, int B, int Cin, int Cout, int H, int 
         const bool wins = Cout >= 128 && ((Cin <= Cout && pixels >= 2048) || (Cin <= 2 * Cout && pixels >= 8192));
         if (gemm_mode > 0 ? (Cout >= 64 && pixels >= 128) : wins) return kGemmConfig;
     }
+    if (stem_takes(kh, stride, Cin, Cout, H, W)) return kStemConfig;     // (SPK_CONV_STEM=0: the tap kernel)
     const int want = base + shape;
     if (geometry_any(kh, stride, want, B, Cin, Cout, H, W).ok) return want;
     static const int alt[4][3] = {{2, 3, 1}, {2, 3, 0}, {3, 0, 1}, {2, 0, 1}};
@@ -374,6 +385,7 @@ int64_t spk_conv2d_packed_floats(int config, int kh, int kw, int Cin, int Cout) 
     if (config < 0 || config >= kNumConfigs || Cin <= 0 || Cout <= 0 || kh <= 0 || kw <= 0) return -1;
     if (config == kGemmConfig) return kh == 1 && kw == 1 ? (int64_t)Cout * Cin : -1;      // plain [Cout][Cin]
     if (is_gemm2(config)) return kh == 1 && kw == 1 ? (int64_t)gemm2_packed_floats(config, Cin, Cout) : -1;
+    if (config == kStemConfig) return kh == 7 && kw == 7 && Cin == 3 && Cout == 64 ? (int64_t)stem_packed_floats() : -1;
     if (config == kDgradS2Config) return (kh == 2 && kw == 2 && Cout % 4 == 0) ? (int64_t)dgrad_s2_fused_packed_floats(Cin, Cout / 4) : -1;
     const CfgDims& c = kDims[config];
     return (int64_t)spk::ceil_div(Cout, c.co_t) * spk::ceil_div(Cin, c.ci_t) * kh * kw * c.ci_t * c.co_t;
@@ -431,6 +443,10 @@ int spk_conv2d_pack_weights_list(const float* const* ws, int n, float* w_packed,
     if (is_gemm2(config)) {             // [co tile][k tile][16 k][CO_T] of the weight or of its transpose
         SPK_REQUIRE(kh == 1 && kw == 1 && transpose_flip < 2, "pack_weights: config %d packs 1x1 kernels", config);
         return pack_gemm2(list, n, w_packed, Cin, Cout, config, transpose_flip, (hipStream_t)stream);
+    }
+    if (config == kStemConfig) {        // [148 k][64 co], k = (ci, ky, kx)
+        SPK_REQUIRE(kh == 7 && kw == 7, "pack_weights: config %d packs 7x7 kernels", config);
+        return pack_stem(list, n, w_packed, Cin, Cout, transpose_flip, (hipStream_t)stream);
     }
     if (config == kDgradS2Config) {     // the transposed 3x3 operator itself, in 64-channel x 8-channel tiles (kDims[13])
         SPK_REQUIRE(transpose_flip == 2, "pack_weights: config %d packs the stride-2 data-gradient form (transpose_flip = 2)", kDgradS2Config);
@@ -525,6 +541,10 @@ int spk_conv2d_fwd(const spk_conv2d_desc* d, void* stream) {
     SPK_REQUIRE(!d->out_scale_dev || !(cfg == kGemmConfig || is_gemm2(cfg)), "conv2d: out_scale_dev is built into the tap kernels (not the GEMM forms of a 1x1)");
     if (cfg == kGemmConfig) return run_1x1_gemm(&dd, s);
     if (is_gemm2(cfg)) return run_1x1_gemm2(&dd, s);
+    if (cfg == kStemConfig) {
+        SPK_REQUIRE(mode == MODE_PLAIN && !(d->flags & SPK_EPI_ACCUM_HALF), "conv2d: the stem form reads a plain input");
+        return run_stem(&dd, s);
+    }
     SPK_REQUIRE(!(d->flags & SPK_EPI_ACCUM_HALF), "conv2d: SPK_EPI_ACCUM_HALF is built into the GEMM form of a 1x1 (configs 14, 15)");
     if (d->kh == 1) return run_1x1(d->stride, cfg, mode, &dd, s);
     if (d->kh == 3 && d->stride == 1) {

@@ -947,12 +947,13 @@ typedef Cfg<2, 2, 2, 2, 16> Cfg8;  //  128   128   1x1 s1/s2   (16-channel chunk
 typedef Cfg<1, 4, 2, 2, 16> Cfg9;  //   64   256   1x1 s1/s2
 typedef Cfg<2, 2, 1, 1, 16> Cfg10; //   64    64   1x1 s1/s2
 typedef Cfg<1, 4, 1, 1, 16> Cfg11; //   32   128   1x1 s1/s2
-constexpr int kNumConfigs = 16;   // 12 = the GEMM form of a stride-1 1x1 (conv1x1_gemm.hip): 128co x 128px block, 32-channel k-tiles
+constexpr int kNumConfigs = 17;   // 12 = the GEMM form of a stride-1 1x1 (conv1x1_gemm.hip): 128co x 128px block, 32-channel k-tiles
 constexpr int kGemmConfig = 12;
 constexpr int kDgradS2Config = 13;   // the exact-tap data gradient of a 3x3 stride-2 conv (dgrad3x3s2.hip): 64co x 128px block, 8-channel chunks
 constexpr int kGemm2Config = 14;     // the three-per-CU GEMM form of a stride-1 1x1 (conv1x1_gemm2.hip): 128co x 128px block, 16-channel k-tiles
 constexpr int kGemm2NarrowConfig = 15;   // the same with a 64co x 128px block (four per CU)
 inline bool is_gemm2(int cfg) { return cfg == kGemm2Config || cfg == kGemm2NarrowConfig; }
+constexpr int kStemConfig = 16;          // the 7x7 stride-2 stem, Cin 3 -> Cout 64 per group (conv7x7_stem.hip): K = 147 exactly, 16 x 32 pixel tiles
 
 // several weight tensors of one shape on one launch (blockIdx.y = which): their packed images one after another, as a
 // grouped conv launch reads them
@@ -977,5 +978,10 @@ int gemm2_co_tile(int config);
 long long gemm2_pixel_tiles(int B, int H, int W);
 long long gemm2_packed_floats(int config, int Cin, int Cout);
 int pack_gemm2(const PackList& list, int n_list, float* w_packed, int Cin, int Cout, int config, int tf, hipStream_t stream);
+int run_stem(const spk_conv2d_desc* d, hipStream_t s);                                    // id 16
+bool stem_takes(int kh, int stride, int Cin, int Cout, int H, int W);
+long long stem_packed_floats();
+void stem_tiles(int H, int W, int* tiles_x, int* tiles_y);
+int pack_stem(const PackList& list, int n_list, float* w_packed, int Cin, int Cout, int tf, hipStream_t stream);
 
 }  // namespace spkconv

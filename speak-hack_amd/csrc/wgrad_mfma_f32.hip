@@ -474,8 +474,11 @@ template <int MCO, int MCI>
 struct WideShape : WideShapeT<16> { static_assert(MCO == 1 && MCI == 1, "one accumulator tile set per wave"); };
 
 // TW = 16: 16 x 4 pixel tiles (18 x 6 plane); TW = 8: 8 x 8 tiles (10 x 10 plane) for the 8^2 layers, one tile per image.
-template <int TW_, int MODE>
-__global__ __launch_bounds__(256) void wgrad3x3_wide_kernel(const WgradArgs p) {
+// SB (single buffer): ONE LDS tile (44.5 KB) and <= 256 registers, so that TWO workgroups share a CU -- the next tile's loads
+// still fly behind the first half of the k-steps, but its LDS stores wait for a barrier after the last MFMA (the other
+// workgroup's MFMAs fill that gap, and each other's first-tile latency, slab stores and barriers).
+template <int TW_, int MODE, bool SB = false>
+__global__ __launch_bounds__(256, SB ? 2 : 1) void wgrad3x3_wide_kernel(const WgradArgs p) {
     using SH = WideShapeT<TW_>;
     constexpr int TAPS = 9, CO_T = SH::CO_T, CI_T = SH::CI_T, TW = SH::TW, TH = SH::TH, PW = SH::PW, PH = SH::PH;
     constexpr int GPITCH = SH::GPITCH, XPITCH = SH::XPITCH, BUF = SH::BUF;
@@ -608,8 +611,8 @@ __global__ __launch_bounds__(256) void wgrad3x3_wide_kernel(const WgradArgs p) {
     // one tile's 32 k-steps out of buffer `cur`; the next tile is staged into the other buffer on the way (its loads behind the
     // first half of the k-steps, its LDS stores behind the second half)
     auto run_tile = [&]() {
-        const float* cbuf = smem + cur * BUF;
-        float* nbuf = smem + (cur ^ 1) * BUF;
+        const float* cbuf = smem + (SB ? 0 : cur * BUF);
+        float* nbuf = smem + (SB ? 0 : (cur ^ 1) * BUF);
         const volatile wg_lds_f32* ga = (const volatile wg_lds_f32*)(cbuf + (wco * 32 + l32) * GPITCH + half);
         const volatile wg_lds_f32* xb = (const volatile wg_lds_f32*)(cbuf + CO_T * GPITCH + (wci * 32 + l32) * XPITCH + half);
         float fa[2], fb[2][TAPS];
@@ -630,7 +633,7 @@ __global__ __launch_bounds__(256) void wgrad3x3_wide_kernel(const WgradArgs p) {
             if constexpr (st + 1 < STEPS) SPK_WW_FRAG(st + 1, (st + 1) & 1);
             constexpr int nl = st < HS ? ((PL * st + PL <= NL) ? PL : (PL * st < NL ? NL - PL * st : 0)) : 0;
             constexpr int s0 = PS * (st - HS);
-            constexpr int ns = st >= HS ? ((s0 + PS <= NS) ? PS : (s0 < NS ? NS - s0 : 0)) : 0;
+            constexpr int ns = (!SB && st >= HS) ? ((s0 + PS <= NS) ? PS : (s0 < NS ? NS - s0 : 0)) : 0;
             if constexpr (nl > 0) wg_static_for<PL * st, PL * st + nl>([&](auto j_) { load_piece(j_); });
             if constexpr (ns > 0) wg_static_for<s0, s0 + ns>([&](auto q_) { store_piece(nbuf, q_); });
 #pragma unroll
@@ -651,6 +654,10 @@ __global__ __launch_bounds__(256) void wgrad3x3_wide_kernel(const WgradArgs p) {
             }
         });
 #undef SPK_WW_FRAG
+        if constexpr (SB) {
+            __syncthreads();                  // every wave is done reading the tile
+            wg_static_for<0, NS>([&](auto s_) { store_piece(nbuf, s_); });
+        }
     };
 
     // ONE loop body: after the last tile the staging still runs, with every piece masked off (it reads the tensors' first
@@ -1289,13 +1296,21 @@ WGeom wgeom(int B, int Cin, int Cout, int H, int W, int want_splits) {
 
 // geometry of the wide form: 16 x 4 (or, tw = 8, 8 x 8) pixel tiles, one workgroup per CU
 struct WideGeom { int tiles_x, tiles_y, n_tiles, splits, n_slabs; };
-inline WideGeom wide_geom(int co_t, int ci_t, int B, int Cin, int Cout_all, int H, int W, int want_splits, int tw = 16) {
+// (SPK_WGRAD_WIDE_SB = 1: the single-buffer form of wgrad3x3_wide_kernel, two workgroups per CU, for the plain and the
+// BatchNorm-folded modes; its split rule aims at SPK_WGRAD_WIDE_SB_TARGET workgroups)
+inline bool wide_sb_on() {
+    static const bool on = [] { const char* e = getenv("SPK_WGRAD_WIDE_SB"); return e && atoi(e) != 0; }();
+    return on;
+}
+inline WideGeom wide_geom(int co_t, int ci_t, int B, int Cin, int Cout_all, int H, int W, int want_splits, int tw = 16, bool sb = false) {
     WideGeom g;
     g.tiles_x = spk::ceil_div(W, tw);
     g.tiles_y = spk::ceil_div(H, 64 / tw);
     g.n_tiles = g.tiles_x * g.tiles_y * B;
     const int blocks = spk::ceil_div(Cout_all, co_t) * spk::ceil_div(Cin, ci_t);
-    static const int target = [] { const char* e = getenv("SPK_WGRAD_WIDE_TARGET"); return e ? atoi(e) : 256; }();
+    static const int target1 = [] { const char* e = getenv("SPK_WGRAD_WIDE_TARGET"); return e ? atoi(e) : 256; }();
+    static const int target2 = [] { const char* e = getenv("SPK_WGRAD_WIDE_SB_TARGET"); return e ? atoi(e) : 512; }();
+    const int target = sb ? target2 : target1;
     const int sp = want_splits > 0 ? want_splits : std::max(1, target / blocks);
     g.splits = std::max(1, std::min(sp, g.n_tiles));
     g.n_slabs = g.splits;
@@ -1323,7 +1338,9 @@ template <int TW, int MODE>
 int run_wgrad_wide(const spk_wgrad_desc* d, hipStream_t stream) {
     using SH = WideShapeT<TW>;
     const int G = d->groups > 1 ? d->groups : 1;
-    const WideGeom g = wide_geom(SH::CO_T, SH::CI_T, d->B, d->Cin, G * d->Cout, d->H, d->W, d->splits, TW);
+    constexpr bool HAS_SB = MODE == WG_PLAIN || MODE == WG_AFFINE_RELU;      // (the modulated form needs > 256 registers)
+    const bool sb = HAS_SB && wide_sb_on();
+    const WideGeom g = wide_geom(SH::CO_T, SH::CI_T, d->B, d->Cin, G * d->Cout, d->H, d->W, d->splits, TW, sb);
     const size_t slab_floats = (size_t)G * d->Cout * d->Cin * 9;
     SPK_REQUIRE(d->workspace && (size_t)d->workspace_bytes >= g.n_slabs * slab_floats * sizeof(float),
                 "wgrad: needs a %zu-byte workspace (see spk_conv2d_wgrad_workspace_bytes)", g.n_slabs * slab_floats * sizeof(float));
@@ -1335,15 +1352,18 @@ int run_wgrad_wide(const spk_wgrad_desc* d, hipStream_t stream) {
     a.Cy = G * d->Cout;
     a.lgTW = spk::ilog2(TW); a.lgTH = spk::ilog2(64 / TW); a.lgTB = 0;
     a.tiles_x = g.tiles_x; a.tiles_y = g.tiles_y; a.n_tiles = g.n_tiles;
-    auto kern = &wgrad3x3_wide_kernel<TW, MODE>;
-    static bool raised = false;
-    if (!raised) {
+    auto kern = &wgrad3x3_wide_kernel<TW, MODE, false>;
+    if constexpr (HAS_SB) {
+        if (sb) kern = &wgrad3x3_wide_kernel<TW, MODE, true>;
+    }
+    static bool raised[2] = {false, false};
+    if (!raised[sb]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return spk::fail(SPK_ELAUNCH, "hipFuncSetAttribute(LDS): %s", hipGetErrorString(e));
-        raised = true;
+        raised[sb] = true;
     }
     dim3 grid((unsigned)spk::ceil_div(G * d->Cout, SH::CO_T), (unsigned)spk::ceil_div(d->Cin, SH::CI_T), (unsigned)g.splits);
-    hipLaunchKernelGGL(kern, grid, dim3(256), 2 * SH::BUF * sizeof(float), stream, a);
+    hipLaunchKernelGGL(kern, grid, dim3(256), (sb ? 1 : 2) * SH::BUF * sizeof(float), stream, a);
     int rc = spk::check_launch("wgrad3x3_wide_kernel");
     if (rc != SPK_OK) return rc;
     return launch_wgrad_reduce(stream, a.slabs, d->dw, g.n_slabs, G * d->Cout, d->Cin, 9, d->scale, d->accumulate ? 1 : 0,
@@ -1926,6 +1946,196 @@ inline bool g1_takes(int groups, int Cout, int H, int W) {
     return ((long long)H * W) % G1_KT == 0 && W % 4 == 0 && (G == 1 || Cout % 64 == 0);
 }
 
+// ---- the stem's weight gradient: 7x7 stride 2, Cin = 3, Cout = 64 per group --------------------------------------------------
+// dW[co][k] = sum_{b, oy, ox} g[b, co, oy, ox] * x[b, ci, 2 oy + ky - 3, 2 ox + kx - 3], k = (ci, ky, kx): a GEMM of 64 x 147 outputs over
+// B H W pixels.  The generic tap kernel runs it with 49 taps of a padded 4-channel chunk (46 TFLOP/s, 0.32 ms of a G step).  Here,
+// as in conv7x7_stem.hip: a 4 x 32 output tile's input patch (13 rows x 69 columns x 3 channels) in LDS with its columns split by
+// parity, the tile's gradients [64 co][128 px] beside it; MFMA 32x32x2 with A = gradients (lane = channel, half = one of two adjacent
+// pixels) and B = patch values (lane = k: a per-lane constant offset (ci, ky, kx) + the pixel as an immediate); every wave owns one
+// row of the tile and ALL 2 x 5 accumulator tiles (64 co x 160 k, 160 registers), workgroups are persistent over tiles, the four
+// waves' sums meet in LDS at the end and leave as one slab per workgroup ([co][147], the layout of dW itself).
+constexpr int SW_TH = 4, SW_TW = 32, SW_PR = 2 * SW_TH + 5, SW_PC = 2 * SW_TW + 5, SW_PH = SW_TW + 3, SW_PROW = 2 * SW_PH;
+constexpr int SW_K = 147, SW_NT = 5;
+constexpr int SW_GP = SW_TH * SW_TW + 1;                       // pitch of a channel's gradients (odd: 32 channels, 32 banks)
+constexpr int SW_G_FL = 64 * SW_GP, SW_P_FL = 3 * SW_PR * SW_PROW;
+constexpr int SW_LDS_FL = SW_G_FL + SW_P_FL;                   // 8256 + 2730 floats = 43.9 KB: two workgroups per CU
+constexpr int SW_TASKS = 3 * SW_PR, SW_TPW = (SW_TASKS + 3) / 4;
+static_assert(SW_LDS_FL * 4 >= 4 * 2 * 16 * 64 * 4, "the final cross-wave sum of one n-tile fits the same LDS");
+
+__global__ __launch_bounds__(256, 2) void wgrad_stem_kernel(const WgradArgs p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l32 = lane & 31;
+    const int grp = blockIdx.y;
+    const float* gb = p.g + (size_t)grp * 64 * p.H * p.W;             // + b Cy H W
+    const float* xb = p.x + (size_t)grp * p.gin * p.Hs * p.Ws;       // + b Cx Hs Ws
+
+    // staging roles: gradients -- float4 f = tid + 256 i of the tile's [64 co][4 rows][8 float4]; patch -- as conv7x7_stem.hip
+    float4 gq[8];
+    float pa[SW_TPW], pb[SW_TPW];
+    const int g_co = tid >> 5, g_row = (tid >> 3) & 3, g_c4 = tid & 7;                     // + 8 i channels
+    const unsigned g_dst = (unsigned)(g_co * SW_GP + g_row * SW_TW + 4 * g_c4) * 4u;      // + 8 i SW_GP floats
+    const unsigned p_dst_a = (unsigned)(SW_G_FL + wave * SW_PROW + (lane & 1) * SW_PH + (lane >> 1)) * 4u;
+    const unsigned p_dst_b = p_dst_a + 32 * 4;
+    auto load_tile = [&](int t) {
+        const bool live = t < p.n_tiles;
+        const int tt = live ? t : 0;
+        const int tx = tt % p.tiles_x, q = tt / p.tiles_x;
+        const int ty = q % p.tiles_y, b = q / p.tiles_y;
+        const int oy0 = ty * SW_TH, ox0 = tx * SW_TW;
+        const float* gt = gb + (size_t)b * p.Cy * p.H * p.W;
+        const bool g_ok = live && oy0 + g_row < p.H && ox0 + 4 * g_c4 < p.W;            // (W % 4 == 0: host-checked)
+        const unsigned g_off = (unsigned)((min(oy0 + g_row, p.H - 1)) * p.W + min(ox0 + 4 * g_c4, p.W - 4)) * 4u;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float4 v = *reinterpret_cast<const float4*>(reinterpret_cast<const char*>(gt + (size_t)(g_co + 8 * i) * p.H * p.W) + g_off);
+            gq[i] = g_ok ? v : make_float4(0.f, 0.f, 0.f, 0.f);      // zero gradients outside: the pixel sum ignores them
+        }
+        const float* xt = xb + (size_t)b * p.Cx * p.Hs * p.Ws;
+        const int ix_a = 2 * ox0 - 3 + lane, ix_b = ix_a + 64;
+        const bool ok_a = (unsigned)ix_a < (unsigned)p.Ws, ok_b = lane < SW_PC - 64 && (unsigned)ix_b < (unsigned)p.Ws;
+        const unsigned off_a = (unsigned)min(max(ix_a, 0), p.Ws - 1) * 4u, off_b = (unsigned)min(max(ix_b, 0), p.Ws - 1) * 4u;
+#pragma unroll
+        for (int j = 0; j < SW_TPW; ++j) {
+            const int qq = min(wave + 4 * j, SW_TASKS - 1);                  // (uniform)
+            const int ci = qq / SW_PR, r = qq - ci * SW_PR;
+            const int iy = 2 * oy0 - 3 + r;
+            const bool row_ok = (unsigned)iy < (unsigned)p.Hs;
+            const char* row = reinterpret_cast<const char*>(xt + ((size_t)ci * p.Hs + min(max(iy, 0), p.Hs - 1)) * p.Ws);
+            const float a = *reinterpret_cast<const float*>(row + off_a);
+            const float c = *reinterpret_cast<const float*>(row + off_b);
+            pa[j] = (row_ok && ok_a) ? a : 0.f;
+            pb[j] = (row_ok && ok_b) ? c : 0.f;
+        }
+    };
+    auto store_tile = [&]() {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            volatile wg_lds_f32* d = (volatile wg_lds_f32*)((wg_lds_u8*)smem + (g_dst + (unsigned)(8 * i * SW_GP * 4)));
+            d[0] = gq[i].x; d[1] = gq[i].y; d[2] = gq[i].z; d[3] = gq[i].w;
+        }
+#pragma unroll
+        for (int j = 0; j < SW_TPW; ++j) {
+            if (wave + 4 * j < SW_TASKS) {                                   // (uniform)
+                *(volatile wg_lds_f32*)((wg_lds_u8*)smem + (p_dst_a + (unsigned)(j * 4 * SW_PROW * 4))) = pa[j];
+                if (lane < SW_PC - 64) *(volatile wg_lds_f32*)((wg_lds_u8*)smem + (p_dst_b + (unsigned)(j * 4 * SW_PROW * 4))) = pb[j];
+            }
+        }
+    };
+
+    // fragment addresses (bytes): A -- channel m 32 + l32, pixel row = wave, pixels 2 s + half; B -- k = 32 j + l32 (clamped: columns
+    // >= 147 are never written out), the same pixels
+    unsigned a_addr = (unsigned)(l32 * SW_GP + wave * SW_TW + half) * 4u;
+    unsigned b_addr[SW_NT];
+#pragma unroll
+    for (int j = 0; j < SW_NT; ++j) {
+        const int k = min(32 * j + l32, SW_K - 1);
+        const int ci = k / 49, ky = (k % 49) / 7, kx = k % 7;
+        b_addr[j] = (unsigned)(SW_G_FL + ((ci * SW_PR + 2 * wave + ky) * 2 + (kx & 1)) * SW_PH + (kx >> 1) + half) * 4u;
+        asm volatile("" : "+v"(b_addr[j]));
+    }
+    asm volatile("" : "+v"(a_addr));
+
+    f32x16 acc[2][SW_NT];
+#pragma unroll
+    for (int m = 0; m < 2; ++m)
+#pragma unroll
+        for (int j = 0; j < SW_NT; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[m][j][r] = 0.f;
+
+    int tile = blockIdx.x;
+    load_tile(tile);
+    store_tile();
+    __syncthreads();
+    for (; tile < p.n_tiles; tile += gridDim.x) {
+        load_tile(tile + (int)gridDim.x);                   // the next tile's loads fly behind this tile's MFMAs
+        float fa[2][2], fb[2][SW_NT];
+#define SPK_SW_FRAG(s_, f_)                                                                                                   \
+    {                                                                                                                         \
+        fa[f_][0] = *(const volatile wg_lds_f32*)((wg_lds_u8*)smem + (a_addr + (unsigned)(2 * (s_) * 4)));                    \
+        fa[f_][1] = *(const volatile wg_lds_f32*)((wg_lds_u8*)smem + (a_addr + (unsigned)((32 * SW_GP + 2 * (s_)) * 4)));     \
+        _Pragma("unroll") for (int j = 0; j < SW_NT; ++j)                                                                     \
+            fb[f_][j] = *(const volatile wg_lds_f32*)((wg_lds_u8*)smem + (b_addr[j] + (unsigned)(2 * (s_) * 4)));             \
+    }
+        SPK_SW_FRAG(0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+        wg_static_for<0, SW_TW / 2>([&](auto s_) {
+            constexpr int st = decltype(s_)::value;
+            if constexpr (st + 1 < SW_TW / 2) {
+                SPK_SW_FRAG(st + 1, (st + 1) & 1);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+#pragma unroll
+            for (int j = 0; j < SW_NT; ++j)
+#pragma unroll
+                for (int m = 0; m < 2; ++m)
+                    acc[m][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[st & 1][m], fb[st & 1][j], acc[m][j], 0, 0, 0);
+            __builtin_amdgcn_sched_barrier(0);
+        });
+#undef SPK_SW_FRAG
+        __syncthreads();                                    // every wave is done reading the tile
+        store_tile();
+        __syncthreads();
+    }
+
+    // ---- the four waves' sums, one n-tile at a time through LDS, -> slab [slab][co_all][147] ----
+    float* out = p.slabs + ((size_t)blockIdx.x * p.Cy + (size_t)grp * 64) * SW_K;
+#pragma unroll
+    for (int j = 0; j < SW_NT; ++j) {
+#pragma unroll
+        for (int m = 0; m < 2; ++m)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) smem[((wave * 2 + m) * 16 + r) * 64 + lane] = acc[m][j][r];
+        __syncthreads();
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const int idx = tid + 256 * e;                  // (m, r, lane) of 2 x 16 x 64
+            const int ln = idx & 63, r = (idx >> 6) & 15, m = idx >> 10;
+            const float v = (smem[idx] + smem[2048 + idx]) + (smem[4096 + idx] + smem[6144 + idx]);
+            const int co = m * 32 + (r & 3) + 8 * (r >> 2) + 4 * (ln >> 5), k = 32 * j + (ln & 31);
+            if (k < SW_K) out[co * SW_K + k] = v;
+        }
+        __syncthreads();
+    }
+}
+
+inline bool stem_wgrad_takes(const spk_wgrad_desc* d) {
+    static const bool allow = [] { const char* e = getenv("SPK_WGRAD_STEM"); return !e || atoi(e) != 0; }();
+    const int G = d->groups > 1 ? d->groups : 1;
+    const auto aligned = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    return allow && d->kh == 7 && d->kw == 7 && d->stride == 2 && d->Cin == 3 && d->Cout == 64 && d->W % 4 == 0 && aligned(d->g) &&
+           (d->flags & ~0u) == 0 && (long long)G * 64 * d->H * d->W < (1ll << 29) && (long long)3 * G * d->Hin * d->Win < (1ll << 29) &&
+           (G == 1 || d->group_in_stride == 0 || d->group_in_stride >= 3);
+}
+// slabs (= persistent workgroups per group) of the stem form
+inline int stem_wgrad_slabs(int B, int H, int W, int G) {
+    const long long tiles = (long long)B * spk::ceil_div(H, SW_TH) * spk::ceil_div(W, SW_TW);
+    return (int)std::max(1ll, std::min(tiles, (long long)std::max(1, 512 / std::max(G, 1))));
+}
+
+int run_wgrad_stem(const spk_wgrad_desc* d, hipStream_t stream) {
+    const int G = d->groups > 1 ? d->groups : 1;
+    const int n_slabs = d->splits > 0 ? std::min(d->splits, 512) : stem_wgrad_slabs(d->B, d->H, d->W, G);
+    const size_t slab_floats = (size_t)G * 64 * SW_K;
+    SPK_REQUIRE(d->workspace && (size_t)d->workspace_bytes >= n_slabs * slab_floats * sizeof(float),
+                "wgrad: needs a %zu-byte workspace (see spk_conv2d_wgrad_workspace_bytes)", n_slabs * slab_floats * sizeof(float));
+    WgradArgs a;
+    a.g = d->g; a.x = d->x; a.in_scale = nullptr; a.in_shift = nullptr; a.g_scale = nullptr; a.slabs = static_cast<float*>(d->workspace);
+    a.B = d->B; a.Cin = 3; a.Cout = 64; a.H = d->H; a.W = d->W; a.Hs = d->Hin; a.Ws = d->Win;
+    a.gin = G > 1 ? d->group_in_stride : 3;
+    a.Cx = a.gin * (G - 1) + 3;
+    a.Cy = G * 64;
+    a.lgTW = a.lgTH = a.lgTB = 0;
+    a.tiles_x = spk::ceil_div(d->W, SW_TW); a.tiles_y = spk::ceil_div(d->H, SW_TH); a.n_tiles = a.tiles_x * a.tiles_y * d->B;
+    const int wgs = std::min(n_slabs, a.n_tiles);
+    hipLaunchKernelGGL(wgrad_stem_kernel, dim3((unsigned)wgs, (unsigned)G), dim3(256), SW_LDS_FL * sizeof(float), stream, a);
+    int rc = spk::check_launch("wgrad_stem_kernel");
+    if (rc != SPK_OK) return rc;
+    return launch_wgrad_reduce(stream, a.slabs, d->dw, wgs, G * 64, SW_K, 1, d->scale, d->accumulate ? 1 : 0, d->fold > 1 ? d->fold : 1);
+}
+
 template <int KH, int KW, int S>
 int by_mode(int mode, const spk_wgrad_desc* d, hipStream_t s) {
     if (mode == WG_AFFINE_RELU) return run_wgrad<KH, KW, S, WG_AFFINE_RELU>(d, s);
@@ -1965,9 +2175,11 @@ int64_t spk_conv2d_wgrad_workspace_bytes(int kh, int kw, int stride, int splits,
     else g = wgeom<7, 7, 2>(B, Cin, Cout, H, W, splits);
     int n_slabs = g.n_slabs;
     if (kh == 3 && stride == 1) {     // the 16-byte-load form may take the problem
-        n_slabs = std::max(n_slabs, wide_geom(64, 64, B, Cin, Cout, H, W, splits, W >= 16 ? 16 : 8).n_slabs);
+        n_slabs = std::max(n_slabs, wide_geom(64, 64, B, Cin, Cout, H, W, splits, W >= 16 ? 16 : 8, wide_sb_on()).n_slabs);
     }
     if (kh == 3 && stride == 2 && W >= 8) n_slabs = std::max(n_slabs, s2_geom(W >= 16 ? 16 : 8, B, Cin, Cout, H, W, splits).n_slabs);
+    if (kh == 7 && Cin == 3 && Cout % 64 == 0)       // the stem form (Cout here = groups * 64): one slab per persistent workgroup
+        n_slabs = std::max(n_slabs, splits > 0 ? std::min(splits, 512) : stem_wgrad_slabs(B, H, W, Cout / 64));
     return (int64_t)n_slabs * Cout * Cin * kh * kw * (int64_t)sizeof(float);
 }
 
@@ -2035,6 +2247,7 @@ int spk_conv2d_wgrad(const spk_wgrad_desc* d, void* stream) {
         SPK_REQUIRE(!aff, "wgrad: the 4x4 stride-2 form takes a plain input");
         return run_wgrad<4, 4, 2, WG_PLAIN>(d, s);
     }
+    if (!aff && stem_wgrad_takes(d)) return run_wgrad_stem(d, s);
     return by_mode<7, 7, 2>(mode, d, s);
 }
 

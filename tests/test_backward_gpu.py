@@ -105,6 +105,28 @@ def test_wgrad_stride1_wide_form(pkg, dev, B, Cin, Cout, H, W, groups, aff):
     assert rel_l2(acc, base.cpu() + 0.5 * ref) < TOL
 
 
+@pytest.mark.parametrize("B,Hin,Win,G,shared", [(2, 40, 40, 1, False), (3, 50, 72, 2, False), (2, 34, 136, 4, True), (1, 128, 128, 2, True)])
+def test_wgrad_stem_form(pkg, dev, B, Hin, Win, G, shared):
+    """wgrad_stem_kernel (7x7 stride 2, 3 -> 64 per group: 64 x 147 GEMM over the pixels, persistent workgroups, one slab each)
+    against autograd: partial tiles, grouped with own / shared images, slab counts, fold, scale + accumulate."""
+    tag = f"wgst.{B}.{Hin}.{Win}.{G}.{int(shared)}"
+    x = recipe_input(tag + ".x", (B, 3 if shared else 3 * G, Hin, Win), "uniform")
+    ws = [recipe_tensor(tag + f".weight{q}", (64, 3, 7, 7)).requires_grad_(True) for q in range(G)]
+    y = torch.cat([F.conv2d(x if shared else x[:, 3 * q:3 * q + 3], ws[q], stride=2, padding=3) for q in range(G)], 1)
+    g = recipe_input(tag + ".g", y.shape)
+    y.backward(g)
+    ref = torch.cat([w.grad for w in ws], 0)
+    for splits in (0, 1, 7):
+        dw = pkg.ops.conv2d_wgrad(g.to(dev), x.to(dev), 64, 3, 7, 2, splits=splits, groups=G, shared_input=shared)
+        assert rel_l2(dw, ref) < TOL, splits
+    if G % 2 == 0:
+        dw = pkg.ops.conv2d_wgrad(g.to(dev), x.to(dev), 64, 3, 7, 2, groups=G, shared_input=shared, fold=2)
+        assert rel_l2(dw, ref[:G // 2 * 64] + ref[G // 2 * 64:]) < TOL
+    base = recipe_tensor(tag + ".base", ref.shape).to(dev)
+    acc = pkg.ops.conv2d_wgrad(g.to(dev), x.to(dev), 64, 3, 7, 2, scale=0.5, out=base.clone(), accumulate=True, groups=G, shared_input=shared)
+    assert rel_l2(acc, base.cpu() + 0.5 * ref) < TOL
+
+
 @pytest.mark.parametrize("B,Cin,Cout,H,W,groups,aff", [
     (2, 64, 64, 8, 8, 1, False),         # 64 x 64 block (one MFMA tile per wave), two k-tiles per image
     (3, 128, 64, 8, 4, 2, True),         # 64 co x 128 ci, grouped, folded BatchNorm, an odd number of k-tiles (3)

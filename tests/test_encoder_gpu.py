@@ -57,6 +57,31 @@ def test_conv2d_kernels_strides(pkg, dev, k, stride, B, Cin, Cout, H, W):
     assert ran >= 2
 
 
+@pytest.mark.parametrize("B,Hin,Win,G,shared", [(2, 64, 64, 1, False), (3, 50, 72, 2, False), (2, 34, 136, 3, True), (1, 256, 256, 2, True)])
+def test_stem_form_7x7_stride2(pkg, dev, B, Hin, Win, G, shared):
+    """Config 16 (conv7x7_stem.hip: K = 147 implicit GEMM on v_mfma_f32_32x32x1_2b, parity-split input patch in LDS): partial
+    tiles in both directions, grouped with own / shared images, BatchNorm sums from the epilogue (own slots and shared slot)."""
+    tag = f"stem.{B}.{Hin}.{Win}.{G}.{int(shared)}"
+    x = recipe_input(tag + ".x", (B, 3 if shared else 3 * G, Hin, Win), "uniform")
+    ws = [recipe_tensor(tag + f".weight{q}", (64, 3, 7, 7)) for q in range(G)]
+    ref = torch.cat([F.conv2d(x if shared else x[:, 3 * q:3 * q + 3], ws[q], stride=2, padding=3) for q in range(G)], 1)
+    Ho, Wo = ref.shape[-2:]
+    cfg = pkg.ops.conv2d_pick_config(7, 2, B, 3, 64, Ho, Wo)
+    assert cfg == 16
+    wp = pkg.ops.pack_conv_weights_list([w.to(dev) for w in ws], cfg)
+    slots = pkg.ops.stats_slots(cfg, 7, 2, B, 3, 64, Ho, Wo)
+    r64 = ref.double()
+    sums = torch.cat([r64.sum((0, 2, 3)), (r64 * r64).sum((0, 2, 3))])
+    for ns in (slots, 1):
+        stats = torch.zeros(ns * 2 * G * 64, device=dev, dtype=torch.float64)
+        y = pkg.ops.conv2d_fused(x.to(dev), wp, 64, 7, 2, stats=stats, config=cfg, groups=G, shared_input=shared)
+        assert rel_l2(y, ref) < TOL_OP
+        got = stats.view(ns, -1).sum(0).cpu()
+        assert torch.allclose(got, sums, rtol=2e-5, atol=1e-3), (got - sums).abs().max()
+    y = pkg.ops.conv2d_fused(x.to(dev), wp, 64, 7, 2, config=cfg, groups=G, shared_input=shared)      # no statistics
+    assert rel_l2(y, ref) < TOL_OP
+
+
 @pytest.mark.parametrize("k,stride", [(1, 1), (3, 1), (3, 2), (1, 2)])
 def test_conv2d_folded_bn_relu_input_and_statistics(pkg, dev, k, stride):
     """x' = relu(x*a+b) applied while staging; sum / sum-of-squares of y from the epilogue."""

@@ -70,7 +70,9 @@ def main():
         else:
             cfd, tf = ops.dgrad_plan(k, s, B, Cout, Cin, (H, H), (Ho, Ho))
             wt = torch.cat([ops.pack_conv_weight(w, cfd, tf) for w in ws])
-            t_d = timeit(lambda: ops.conv2d_dgrad(g, wt, Cin, k, s, (H, H), cfd, groups=G))
+            # (a strided 1x1 -- the downsample convs: as encoder._backward runs it since round 3, the gradient stays at the conv's
+            # output size and conv1's data gradient adds it at the even pixels in its epilogue; no dilated copy)
+            t_d = timeit(lambda: ops.conv2d_dgrad(g, wt, Cin, k, s, (H, H), cfd, groups=G, dilate=not (k == 1 and s == 2)))
         tf = lambda t: flops / (t * 1e-3) / 1e12 if t else 0.0
         print(f"{Cin:5d} {Cout:5d} {k} {s} {H:4d} {n:2d} | {t_f * 1e3:8.1f} {tf(t_f):6.1f} | {t_d * 1e3:8.1f} {tf(t_d):6.1f} | "
               f"{t_w * 1e3:8.1f} {tf(t_w):6.1f}", flush=True)

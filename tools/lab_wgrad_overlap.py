@@ -15,7 +15,8 @@ pkg = importlib.import_module("speak-hack_amd")
 ops = pkg.ops
 
 # (Cin, Cout, k, H, B, groups, affine)
-CASES = [(256, 256, 3, 64, 16, 1, 0), (512, 512, 3, 32, 16, 1, 0), (128, 128, 3, 128, 16, 1, 0),
+CASES = [(64, 64, 3, 256, 8, 1, 0), (128, 128, 3, 128, 8, 1, 0), (256, 256, 3, 64, 8, 1, 0), (512, 512, 3, 32, 8, 1, 0), (512, 512, 3, 16, 8, 1, 0),
+         (256, 256, 3, 64, 16, 1, 0), (512, 512, 3, 32, 16, 1, 0), (128, 128, 3, 128, 16, 1, 0),
          (256, 1024, 1, 16, 8, 6, 1), (1024, 256, 1, 16, 8, 6, 1), (256, 256, 3, 16, 8, 6, 1), (64, 64, 3, 64, 8, 6, 1)]
 
 

@@ -70,8 +70,9 @@ def main():
                 res.append(timeit(lambda: ops.conv2d_wgrad(g, x, Cout, Cin, k, s, in_affine=a, groups=G, splits=sp)))
             except Exception:                                    # more splits than tiles, workspace limits
                 res.append(float("nan"))
-        best = min((r, c) for r, c in zip(res, cand) if r == r and c > 0)
-        print(f"{Cin:5d} {Cout:5d} {k} {s} {Hin:4d} {G:2d} | " + " ".join(f"{r:7.1f}" for r in res) + f" | {best[1]:3d} ({res[0] / best[0]:.2f}x)", flush=True)
+        explicit = [(r, c) for r, c in zip(res, cand) if r == r and c > 0]
+        tail = f" | {min(explicit)[1]:3d} ({res[0] / min(explicit)[0]:.2f}x)" if explicit else ""
+        print(f"{Cin:5d} {Cout:5d} {k} {s} {Hin:4d} {G:2d} | " + " ".join(f"{r:7.1f}" for r in res) + tail, flush=True)
 
 
 if __name__ == "__main__":
