@@ -41,6 +41,14 @@ def test_host_side_queries_and_argument_errors(pkg):
     assert n >= 4
     for cfg in range(n):
         co, ci, px = pkg.ops.conv3x3_config_info(cfg)
+        if lib.spk_conv2d_config_valid(cfg, 7, 7, 2) and not lib.spk_conv2d_config_valid(cfg, 3, 3, 2):
+            # the 7x7 stride-2 stem form (Cin 3 -> 64 per group): packed [148 k][64 co], k = (ci, ky, kx), one zero row
+            assert (co, ci, px) == (64, 3, 512)
+            assert lib.spk_conv2d_packed_floats(cfg, 7, 7, 3, 64) == 148 * 64 and lib.spk_conv2d_packed_floats(cfg, 7, 7, 4, 64) == -1
+            assert lib.spk_conv2d_packed_floats(cfg, 3, 3, 3, 64) == -1
+            assert lib.spk_conv2d_pick_config(7, 7, 2, 2, 3, 64, 32, 32) == cfg and lib.spk_conv2d_pick_config(7, 7, 2, 2, 3, 64, 32, 30) != cfg
+            assert lib.spk_conv2d_stats_slots(cfg, 7, 7, 2, 2, 3, 64, 40, 36) == 2 * 3 * 2      # 16 x 32 pixel tiles per image
+            continue
         assert co % 32 == 0 and px % 32 == 0 and ci % 2 == 0
         if lib.spk_conv2d_config_valid(cfg, 1, 1, 1) and not lib.spk_conv2d_config_valid(cfg, 1, 1, 2):
             # the GEMM forms of a stride-1 1x1: the packed image is the plain [Cout][Cin] matrix (32-channel k-tiles) or
