@@ -345,6 +345,69 @@ __global__ __launch_bounds__(256) void fc_bwd_input_kernel(const float* __restri
     }
 }
 
+// The same gradient with SIXTEEN columns per workgroup (O % 512 == 0, I % 16 == 0, 16-byte aligned rows): lane (r = lane / 4,
+// c = lane % 4) of wave w reads the 16-byte pieces w[128 w' + r + 16 j][i0 + 4 c .. + 3] -- all of them in flight before the first
+// use -- so a 512 x 512 layer is 32 workgroups and ONE memory latency instead of 8 workgroups and 16 (42 us per mapping layer
+// at the pair decoder's 16 rows: 0.34 ms of a G step).  Fixed summation order: o ascending within a lane, then the 16 lanes of
+// a column group by xor-shuffles, then the four waves.
+constexpr int FCI_BT = 16;
+__global__ __launch_bounds__(256) void fc_bwd_input_cols_kernel(const float* __restrict__ dout, const float* __restrict__ out,
+                                                               const float* __restrict__ w, float* __restrict__ dx,
+                                                               long long dx_stride, int B, int I, int O, float wmul, float slope) {
+    extern __shared__ float dz_s[];            // [FCI_BT][O]
+    __shared__ float red[4][FCI_BT][16];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int r = lane >> 2, c4 = lane & 3;
+    const int i0 = blockIdx.x * 16;
+    const int o_per_wave = O >> 2;             // rows of this wave: [wave * O/4, + O/4), r + 16 j within
+    for (int b0 = 0; b0 < B; b0 += FCI_BT) {
+        __syncthreads();
+        for (int e = tid; e < FCI_BT * O; e += 256) {
+            const int b = e / O, o = e - b * O;
+            float v = 0.f;
+            if (b0 + b < B) {
+                const size_t idx = (size_t)(b0 + b) * O + o;
+                v = dout[idx] * (out[idx] > 0.f ? 1.f : slope);
+            }
+            dz_s[e] = v;
+        }
+        __syncthreads();
+        float4 acc[FCI_BT];
+#pragma unroll
+        for (int b = 0; b < FCI_BT; ++b) acc[b] = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int o0 = wave * o_per_wave; o0 < (wave + 1) * o_per_wave; o0 += 128) {
+            float4 wv[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) wv[j] = *reinterpret_cast<const float4*>(w + (size_t)(o0 + r + 16 * j) * I + i0 + 4 * c4);
+#pragma unroll
+            for (int j = 0; j < 8; ++j)
+#pragma unroll
+                for (int b = 0; b < FCI_BT; ++b) {
+                    const float z = dz_s[b * O + o0 + r + 16 * j];
+                    acc[b].x += z * wv[j].x; acc[b].y += z * wv[j].y; acc[b].z += z * wv[j].z; acc[b].w += z * wv[j].w;
+                }
+        }
+#pragma unroll
+        for (int b = 0; b < FCI_BT; ++b) {
+#pragma unroll
+            for (int off = 4; off <= 32; off <<= 1) {
+                acc[b].x += __shfl_xor(acc[b].x, off); acc[b].y += __shfl_xor(acc[b].y, off);
+                acc[b].z += __shfl_xor(acc[b].z, off); acc[b].w += __shfl_xor(acc[b].w, off);
+            }
+            if (lane < 4) {
+                red[wave][b][4 * lane] = acc[b].x; red[wave][b][4 * lane + 1] = acc[b].y;
+                red[wave][b][4 * lane + 2] = acc[b].z; red[wave][b][4 * lane + 3] = acc[b].w;
+            }
+        }
+        __syncthreads();
+        {
+            const int b = tid >> 4, c = tid & 15;      // 16 rows x 16 columns
+            if (b0 + b < B)
+                dx[(size_t)(b0 + b) * dx_stride + i0 + c] = ((red[0][b][c] + red[1][b][c]) + (red[2][b][c] + red[3][b][c])) * wmul;
+        }
+    }
+}
+
 // dw[o,i] = wmul * sum_b dz[b,o] * x[b,i];  db[o] = bmul * sum_b dz[b,o]
 __global__ __launch_bounds__(256) void fc_bwd_weight_kernel(const float* __restrict__ dout, const float* __restrict__ out,
                                                            const float* __restrict__ x, long long x_stride,
@@ -508,11 +571,18 @@ int spk_fc_bwd(const float* dout, const float* out, const float* x, int64_t x_st
     SPK_REQUIRE(B > 0 && I > 0 && O > 0, "fc_bwd: bad shape");
     hipStream_t s = (hipStream_t)stream;
     if (dx) {
-        SPK_REQUIRE((size_t)FCB_BT * O * sizeof(float) <= 60 * 1024, "fc_bwd: O too large for the LDS tile");
-        hipLaunchKernelGGL(fc_bwd_input_kernel, dim3((unsigned)spk::ceil_div(I, 64)), dim3(256), (size_t)FCB_BT * O * sizeof(float),
-                           s, dout, out, w, dx, (long long)dx_stride, B, I, O, wmul, slope);
-        int rc = spk::check_launch("fc_bwd_input_kernel");
-        if (rc != SPK_OK) return rc;
+        if (O % 512 == 0 && I % 16 == 0 && (size_t)FCI_BT * O * sizeof(float) <= 48 * 1024 && (reinterpret_cast<uintptr_t>(w) & 15) == 0) {
+            hipLaunchKernelGGL(fc_bwd_input_cols_kernel, dim3((unsigned)(I / 16)), dim3(256), (size_t)FCI_BT * O * sizeof(float), s, dout,
+                               out, w, dx, (long long)dx_stride, B, I, O, wmul, slope);
+            int rc = spk::check_launch("fc_bwd_input_cols_kernel");
+            if (rc != SPK_OK) return rc;
+        } else {
+            SPK_REQUIRE((size_t)FCB_BT * O * sizeof(float) <= 60 * 1024, "fc_bwd: O too large for the LDS tile");
+            hipLaunchKernelGGL(fc_bwd_input_kernel, dim3((unsigned)spk::ceil_div(I, 64)), dim3(256), (size_t)FCB_BT * O * sizeof(float),
+                               s, dout, out, w, dx, (long long)dx_stride, B, I, O, wmul, slope);
+            int rc = spk::check_launch("fc_bwd_input_kernel");
+            if (rc != SPK_OK) return rc;
+        }
     }
     if (dw) {
         hipLaunchKernelGGL(fc_bwd_weight_kernel, dim3((unsigned)std::min(spk::ceil_div(I, 256), 8), (unsigned)O), dim3(256), 0,

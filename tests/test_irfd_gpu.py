@@ -1,6 +1,7 @@
 """GPU parity of ``IRFD.forward`` (the D-step use is this forward under
 ``no_grad``) and of the discriminator forward (F2) against the CPU oracle."""
 import importlib
+import re
 
 import pytest
 import torch
@@ -137,20 +138,32 @@ def _check_all_gradients(got, ref32, ref64, pixels, what):
     receptive field -- and which parameter's own fp32 reference evaluation caught a flip is luck (measured, B = 1: the
     oracle's fp32 error on ``Ee.6.2.bn3.bias`` is 3.2e-4, on ``Ee.6.3.bn2.bias`` 1.8e-5; the HIP path's 3.7e-4 and 3.6e-4).
     The yardstick for "the reference's own fp32 noise" is therefore taken per sub-network (the 90th percentile over its
-    parameters of p90|ref32 - ref64| / rms) in addition to the parameter's own; the HIP path may be 4x that, as everywhere."""
+    parameters of p90|ref32 - ref64| / rms) in addition to the parameter's own; the HIP path may be 4x that, as everywhere.
+
+    The same luck decides criterion (1) for the one badly conditioned KIND of parameter here, the noise weights: their gradient
+    is sum_{b, pixel} dt * noise with zero-mean noise -- a cancelling sum -- and the reference's own fp32 evaluation is off by
+    5e-4 .. 5e-3 on the 13 of them (train B=2: layers.5.noise1 5.1e-3, layers.2.noise2 4.3e-3, layers.3.noise2 2.1e-3, layers.0.noise2
+    5e-4), depending only on where rounding fell.  A 1e-7 change anywhere upstream (another summation order in the stem conv)
+    moves the HIP path's error on one of them from under 3x ITS sample to 3.1x.  So err(ref32) of (1) is taken as the larger
+    of the parameter's own and the 90th percentile over the parameters of its kind (names with the layer digits masked)."""
     assert set(got) == set(ref64), sorted(set(got) ^ set(ref64))[:5]
     stats = {k: grad_stats(got[k], ref32[k], ref64[k]) for k in got if float(ref64[k].abs().max()) > 0.0}
     floor = {}
     for gname in GROUPS:
         r = sorted(v[3] for k, v in stats.items() if k.startswith(gname))
         floor[gname] = r[int(0.9 * (len(r) - 1))] if r else 0.0
+    kind = lambda k: re.sub(r"\d+", "#", k)
+    by_kind = {}
+    for k, v in stats.items():
+        by_kind.setdefault(kind(k), []).append(v[1])
+    kind_floor = {kd: sorted(v)[int(0.9 * (len(v) - 1))] for kd, v in by_kind.items()}
     bad, worst = [], 0.0
     for k in sorted(got):
         if k not in stats:
             assert float(got[k].abs().max()) == 0.0, k
             continue
         nf = next((floor[gname] for gname in GROUPS if k.startswith(gname)), 0.0)
-        ok, (e, e32, p90) = grad_close(got[k], ref32[k], ref64[k], pixels=pixels, noise_floor=nf)
+        ok, (e, e32, p90) = grad_close(got[k], ref32[k], ref64[k], pixels=pixels, noise_floor=nf, err_floor=kind_floor[kind(k)])
         worst = max(worst, e)
         if not ok:
             bad.append((k, e, e32, p90, nf))
