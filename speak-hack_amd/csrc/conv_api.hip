@@ -185,6 +185,55 @@ __global__ void pack_weights_kernel(const PackList list, float* __restrict__ wp,
     wp[idx] = v;
 }
 
+// The same image for tf = 0 / 1, one workgroup per (co tile, chunk) block of CO_T x CI_T x taps floats, through LDS: the kernel above
+// reads one float per thread at a stride of Cin * taps floats (64 cache lines per wave-load; 271 us for the 57 MB of the trunk's
+// layer-4 3x3 weights, a tenth of the HBM rate -- 0.54 ms of every generator step, since every weight is re-packed after the
+// optimizer step).  Here the SOURCE is walked in its own order -- runs of CI_T * taps floats per output channel (tf = 0) or of
+// CO_T * taps floats per input channel (tf = 1: the transposed, flipped operator) -- and the packed order is formed in LDS.
+__global__ __launch_bounds__(256) void pack_weights_tiled_kernel(const PackList list, float* __restrict__ wp, int taps, int Cin_orig,
+                                                                int opCin, int opCout, int CO_T, int CI_T, int n_chunks, int tf,
+                                                                long long total) {
+    extern __shared__ float tile[];                       // [CO_T][CI_T * taps] (tf = 0) or [CI_T][CO_T * taps] (tf = 1)
+    const int chunk = blockIdx.x % n_chunks, cot = blockIdx.x / n_chunks;
+    const float* __restrict__ w = list.w[blockIdx.y];
+    const int n = CO_T * CI_T * taps, run = tf ? CO_T * taps : CI_T * taps, pitch = run | 1;      // (odd pitch: bank-conflict-free columns)
+    constexpr int U = 20;                                 // loads per thread, ALL in flight before the first LDS store (n <= 256 U: host)
+    // element e = (row, rem) of the block in SOURCE order: row = co_in (tf = 0) / ci (tf = 1), rem runs over the row's contiguous
+    // floats; stepping e by 256 is an add and a carry, the source offset is row * (Cin_orig * taps) + rem from the block's origin
+    const size_t origin = tf ? ((size_t)chunk * CI_T * Cin_orig + (size_t)cot * CO_T) * taps
+                             : ((size_t)cot * CO_T * Cin_orig + (size_t)chunk * CI_T) * taps;
+    const int rowstride = Cin_orig * taps;
+    const bool edge = (cot + 1) * CO_T > opCout || (chunk + 1) * CI_T > opCin;      // (uniform) ragged channels: per-element checks
+    const int q256 = 256 / run, r256 = 256 - q256 * run;
+    int row = threadIdx.x / run, rem = threadIdx.x - row * run;
+    float v[U];
+    int dst[U];
+#pragma unroll
+    for (int k = 0; k < U; ++k) {
+        bool ok = threadIdx.x + 256 * k < n;
+        if (edge && ok) {
+            const int sub = rem / taps;
+            const int co = cot * CO_T + (tf ? sub : row), cig = chunk * CI_T + (tf ? row : sub);
+            ok = co < opCout && cig < opCin;
+        }
+        const float x = w[ok ? origin + (size_t)row * rowstride + rem : origin];
+        v[k] = ok ? x : 0.f;
+        dst[k] = threadIdx.x + 256 * k < n ? row * pitch + rem : -1;
+        row += q256; rem += r256;
+        if (rem >= run) { rem -= run; ++row; }
+    }
+#pragma unroll
+    for (int k = 0; k < U; ++k)
+        if (dst[k] >= 0) tile[dst[k]] = v[k];
+    __syncthreads();
+    float* out = wp + (size_t)blockIdx.y * total + (size_t)blockIdx.x * n;
+    for (int e = threadIdx.x; e < n; e += 256) {          // packed order: [tap][ci][co_in]
+        const int co_in = e % CO_T, t = e / CO_T;
+        const int ci = t % CI_T, tap = t / CI_T;
+        out[e] = tf ? tile[ci * pitch + co_in * taps + (taps - 1 - tap)] : tile[co_in * pitch + ci * taps + tap];
+    }
+}
+
 // config 12: w[Cout][Cin] -> itself (tf = 0) or its transpose [Cin][Cout] (tf = 1)
 __global__ void pack_rowmajor_kernel(const PackList list, float* __restrict__ wp, int Cin, int Cout, int tf, long long n) {
     const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
@@ -459,6 +508,14 @@ int spk_conv2d_pack_weights_list(const float* const* ws, int n, float* w_packed,
     const int n_chunks = spk::ceil_div(opCin, c.ci_t);
     const long long total = (long long)spk::ceil_div(opCout, c.co_t) * n_chunks * taps * c.ci_t * c.co_t;
     const int threads = 256;
+    const size_t tile_bytes = (transpose_flip ? (size_t)c.ci_t * ((c.co_t * taps) | 1) : (size_t)c.co_t * ((c.ci_t * taps) | 1)) * sizeof(float);
+    if (transpose_flip <= 1 && tile_bytes <= 64 * 1024 && c.co_t * c.ci_t * taps <= 256 * 20) {
+        const long long blocks = (long long)spk::ceil_div(opCout, c.co_t) * n_chunks;
+        SPK_REQUIRE(blocks < (1ll << 31), "pack_weights: too many tiles");
+        hipLaunchKernelGGL(pack_weights_tiled_kernel, dim3((unsigned)blocks, (unsigned)n), dim3(threads), tile_bytes, (hipStream_t)stream, list,
+                           w_packed, taps, Cin, opCin, opCout, c.co_t, c.ci_t, n_chunks, transpose_flip, total);
+        return spk::check_launch("pack_weights_tiled_kernel");
+    }
     hipLaunchKernelGGL(pack_weights_kernel, dim3((unsigned)((total + threads - 1) / threads), (unsigned)n), dim3(threads), 0,
                        (hipStream_t)stream, list, w_packed, taps, transpose_flip == 3 ? Cout : Cin, opCin, opCout, c.co_t, c.ci_t,
                        n_chunks, transpose_flip, total);
