@@ -518,6 +518,8 @@ class ResNet50Trunk(nn.Sequential):
     def _backward(self, recs, dfeat):
         """dfeat [B,2048,1,1] -> {parameter: gradient}."""
         side = ops.side_stream(dfeat.device)           # the weight gradients' stream (joined before the gradients are returned)
+        if side is not None and torch.cuda.is_current_stream_capturing():
+            side = None                                # a stream capture stays on the capturing stream
         stem, blocks = self._plan
         grads = {}
         g, per_plane, g_scale = dfeat.view(dfeat.size(0), -1).contiguous(), True, None
