@@ -195,6 +195,25 @@ def test_wgrad_stride2_wide_form(pkg, dev, B, Cin, Cout, H, W, groups, aff):
     assert rel_l2(acc, base.cpu() + 0.5 * ref) < TOL
 
 
+@pytest.mark.parametrize("B,I,O", [(5, 512, 96), (16, 512, 512), (9, 512, 1024), (8, 6144, 512), (3, 2048, 64), (16, 48, 512), (20, 64, 1024)])
+def test_fc_shape_specialised_kernels(pkg, dev, B, I, O):
+    """The FC forms picked by shape -- 512-wide rows with every load in flight (fc_dot512), four rows per workgroup for long rows
+    (fc_wide4_kernel, I = 1024 U), the input gradient on 16-column slabs (fc_bwd_input_cols_kernel, O % 512 == 0) and the general
+    kernels -- against torch, forward and backward, more rows than one batch tile."""
+    tag = f"fcs.{B}.{I}.{O}"
+    x = recipe_input(tag + ".x", (B, I)).requires_grad_(True)
+    w = recipe_tensor(tag + ".w", (O, I)).requires_grad_(True)
+    b = recipe_tensor(tag + ".b", (O,)).requires_grad_(True)
+    wmul, bmul, slope = 0.37, 1.3, 0.2
+    ref = F.leaky_relu(F.linear(x, w * wmul, b * bmul), slope)
+    g = recipe_input(tag + ".g", ref.shape)
+    ref.backward(g)
+    out = pkg.ops.fc(x.detach().to(dev), w.detach().to(dev), b.detach().to(dev), wmul, bmul, slope)
+    assert rel_l2(out, ref.detach()) < TOL
+    dx, dw, db = pkg.ops.fc_bwd(g.to(dev), out, x.detach().to(dev), w.detach().to(dev), wmul, bmul, slope)
+    assert rel_l2(dx, x.grad) < TOL and rel_l2(dw, w.grad) < TOL and rel_l2(db, b.grad) < TOL
+
+
 def test_pointwise_backward_kernels(pkg, dev, golden):
     # bilinear x2 adjoint, incl. odd sizes and 1x1
     g = golden("decoder_ops.npz")
