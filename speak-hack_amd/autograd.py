@@ -35,6 +35,94 @@ def input_grad_only():
         _INPUT_GRAD_ONLY = prev
 
 
+# ---- weight gradients whose only consumer is SpectralNormAllFn.backward: on the second stream ------------------------------------
+# A discriminator conv's weight is W / sigma, an output of SpectralNormAllFn; its gradient sits untouched in that node's input
+# buffer until the node runs -- after the LAST conv's backward -- as long as the conv is the weight's only user.  An R1 pass
+# adds ConvDgradFn as a second one and the engine would ADD the two gradients on the current stream: those weights are marked
+# ``_spk_shared`` when the differentiable backward is built, and _wgrad_shared lets the second launch accumulate into the
+# first one's tensor instead.  So the
+# weight-gradient launch goes to ops.side_stream behind the producer of its operands, the data-gradient chain never waits for
+# it, and SpectralNormAllFn.backward joins the stream before it reads the gradients (a callback at the end of the backward
+# pass joins it as well, whatever else happens to the graph).  tools/lab_wgrad_overlap.py: 1-5 % of the discriminator's layers.
+_side_pending = set()
+
+
+def _side_join(device):
+    """The current stream waits for every weight gradient queued on the device's second stream so far."""
+    key = torch.device(device).index
+    if key in _side_pending:
+        _side_pending.discard(key)
+        st = ops.side_stream(device)
+        if st is not None:
+            torch.cuda.current_stream(device).wait_stream(st)
+
+
+def _wgrad_aside(dt, x, launch):
+    """``launch()`` (a weight gradient reading the temporaries ``dt`` and ``x``) on the second stream behind everything queued on the
+    current stream so far; in order on the current stream when there is no second stream, under a stream capture, or outside a
+    backward pass (no place to hang the final join)."""
+    side = ops.side_stream(dt.device)
+    if side is None or torch.cuda.is_current_stream_capturing():
+        return launch()
+    key = dt.device.index
+    if key not in _side_pending:
+        try:
+            torch.autograd.Variable._execution_engine.queue_callback(lambda: _side_join(dt.device))
+        except RuntimeError:
+            return launch()
+        _side_pending.add(key)
+    side.wait_stream(torch.cuda.current_stream(dt.device))
+    with torch.cuda.stream(side):
+        dw = launch()
+    dt.record_stream(side)
+    x.record_stream(side)
+    return dw
+
+
+def _wgrad_shared(weight, a, b, make):
+    """The gradient of a normalised weight with TWO users in the graph (an R1 pass: the conv itself and ConvDgradFn).  The first
+    of them to run in a backward pass allocates the gradient; the second ADDS into it inside the weight-gradient kernel
+    (``make(out, accumulate=True)``) and hands autograd nothing.  One tensor reaches SpectralNormAllFn.backward, the engine has
+    nothing to add on the current stream -- so both launches may sit on the second stream, in order among themselves.
+    ``make(out, accumulate)`` launches the kernel; ``a``, ``b`` are its temporaries (see _wgrad_aside)."""
+    task = torch._C._current_graph_task_id()
+    held = getattr(weight, "_spk_dw", None)
+    if held is None or held[0] != task:
+        dw = _wgrad_aside(a, b, lambda: make(None, False))
+        weight._spk_dw = (task, dw)
+        return dw
+    weight._spk_dw = None
+    _wgrad_aside(a, b, lambda: make(held[1], True))
+    return None
+
+
+class WeightGateFn(torch.autograd.Function):
+    """Identity on a module's conv weights, applied ONCE before the first conv of a forward pass (SynthesisNetwork.forward).  It is
+    created first, so in the backward pass it runs after every conv's backward: the one place where the current stream has to
+    wait for the weight gradients that those backwards queued on the second stream, before autograd hands them to the
+    parameters (AccumulateGrad, gradient hooks, the data-parallel reducer).  What SpectralNormAllFn is for the discriminator."""
+
+    @staticmethod
+    def forward(ctx, *weights):
+        ctx.dev = weights[0].device
+        return tuple(w.view_as(w) for w in weights)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, *grads):
+        _side_join(ctx.dev)
+        return grads
+
+
+def gate_weights(weights):
+    """-> the weights behind a WeightGateFn node, each tagged with the parameter it stands for (``_spk_gate_of``: the packed-image
+    caches key on the parameter; FusedConvFn.backward puts the weight gradient of a tagged weight on the second stream)."""
+    outs = WeightGateFn.apply(*weights)
+    for o, w in zip(outs, weights):
+        o._spk_gate_of = w
+    return outs
+
+
 def _needs(ctx, grad_mode):
     """Whether to keep tensors for backward.  Grad mode is always off *inside* Function.forward and
     ``needs_input_grad`` ignores ``torch.no_grad()``, so the caller samples the mode and passes it in."""
@@ -73,12 +161,13 @@ class FusedConvFn(torch.autograd.Function):
         H, W = (2 * Hs, 2 * Ws) if upsample else (Hs, Ws)
         keep = _needs(ctx, grad_mode)
         a = torch.empty((B, Cout, H, W), device=x.device, dtype=torch.float32) if keep else None
+        pw = getattr(weight, "_spk_gate_of", weight)      # (behind a WeightGateFn: the parameter itself keys the packed images)
         if ops.train_bf16x3(B, Cin, Cout, H, W):     # opt-in split-precision training (ops.train_conv_precision)
-            y = ops.conv3x3_bf16x3(x, packed.get_bf16x3(weight), Cout, bias=bias, noise_w=noise_w, noise=noise, style=style,
+            y = ops.conv3x3_bf16x3(x, packed.get_bf16x3(pw), Cout, bias=bias, noise_w=noise_w, noise=noise, style=style,
                                    upsample=upsample, lrelu_slope=slope, out_pre=a, out_scale=w_scale)
         else:
             cfg = ops.conv2d_pick_config(3, 1, B, Cin, Cout, H, W)
-            y = ops.conv2d_fused(x, packed.get(weight, cfg), Cout, 3, 1, bias=bias, noise_w=noise_w, noise=noise,
+            y = ops.conv2d_fused(x, packed.get(pw, cfg), Cout, 3, 1, bias=bias, noise_w=noise_w, noise=noise,
                                  style=style, upsample=upsample, lrelu_slope=slope, config=cfg, out_pre=a, out_scale=w_scale)
         if keep:
             ctx.save_for_backward(x, weight, a, noise, style)
@@ -96,16 +185,21 @@ class FusedConvFn(torch.autograd.Function):
                                     slope if slope is not None else 1.0)
         dstyle, dbias, dnw = _epilogue_param_grads(sums, style is not None, has_bias, has_noise)
         dx = dw = None
+        pw = getattr(weight, "_spk_gate_of", None)
+        if ctx.needs_input_grad[1]:
+            launch = lambda: ops.conv2d_wgrad(dt, x, Cout, Cin, 3, 1, upsample=upsample, scale=w_scale)
+            # behind a WeightGateFn (which joins the second stream before the parameters see their gradients): beside the data gradient
+            dw = _wgrad_aside(dt, x, launch) if pw is not None else launch()
+        if pw is None:
+            pw = weight
         if ctx.needs_input_grad[0]:
             if ops.train_bf16x3(B, Cout, Cin, H, W):
-                dx = ops.conv3x3_bf16x3(dt, packed.get_bf16x3(weight, transpose_flip=True), Cin, out_scale=w_scale)
+                dx = ops.conv3x3_bf16x3(dt, packed.get_bf16x3(pw, transpose_flip=True), Cin, out_scale=w_scale)
             else:
                 cfg = ops.conv2d_pick_config(3, 1, B, Cout, Cin, H, W)
-                dx = ops.conv2d_fused(dt, packed.get(weight, cfg, transpose_flip=True), Cin, 3, 1, config=cfg, out_scale=w_scale)
+                dx = ops.conv2d_fused(dt, packed.get(pw, cfg, transpose_flip=True), Cin, 3, 1, config=cfg, out_scale=w_scale)
             if upsample:
                 dx = ops.upsample2x_bilinear_bwd(dx)
-        if ctx.needs_input_grad[1]:
-            dw = ops.conv2d_wgrad(dt, x, Cout, Cin, 3, 1, upsample=upsample, scale=w_scale)
         return dx, dw, dbias, dnw, None, dstyle, None, None, None, None, None
 
 
@@ -314,8 +408,15 @@ class ConvDgradFn(torch.autograd.Function):
         dt, weight = ctx.saved_tensors
         k, stride = ctx.conf
         g = g.contiguous()
-        ddt = _conv_plain(g, weight, k, stride) if ctx.needs_input_grad[0] else None
-        dw = ops.conv2d_wgrad(dt, g, weight.shape[0], weight.shape[1], k, stride) if ctx.needs_input_grad[1] else None
+        ddt = dw = None
+        if ctx.needs_input_grad[1]:
+            Co, Ci = weight.shape[:2]
+            if getattr(weight, "_spk_sn", None) is not None and getattr(weight, "_spk_shared", False):
+                dw = _wgrad_shared(weight, dt, g, lambda out, acc: ops.conv2d_wgrad(dt, g, Co, Ci, k, stride, out=out, accumulate=acc))
+            else:
+                dw = ops.conv2d_wgrad(dt, g, Co, Ci, k, stride)
+        if ctx.needs_input_grad[0]:
+            ddt = _conv_plain(g, weight, k, stride)
         return ddt, dw, None, None, None
 
 
@@ -350,6 +451,8 @@ class ConvBiasLReLUFn(torch.autograd.Function):
         if torch.is_grad_enabled():        # double backward requested: differentiable data path
             dt = _LReluMaskFn.apply(dy, y, slope) if slope is not None else dy.contiguous()
             if ctx.needs_input_grad[0]:
+                if getattr(weight, "_spk_sn", None) is not None:
+                    weight._spk_shared = True     # a second user of this weight (ConvDgradFn): its gradients will be ADDED on the current stream
                 dx = ConvDgradFn.apply(dt, weight, k, stride, tuple(x.shape[-2:]))
             if not _INPUT_GRAD_ONLY:
                 with torch.no_grad():
@@ -360,10 +463,15 @@ class ConvBiasLReLUFn(torch.autograd.Function):
                         db = dtd.sum((0, 2, 3))
             return dx, dw, db, None, None, None, None
         dt, sums = ops.epilogue_bwd(dy.contiguous(), y, None, None, slope if slope is not None else 1.0)
+        if ctx.needs_input_grad[1]:
+            if getattr(weight, "_spk_sn", None) is None:
+                dw = ops.conv2d_wgrad(dt, x, Cout, Cin, k, stride)
+            elif getattr(weight, "_spk_shared", False):           # an R1 pass: ConvDgradFn contributes to the same gradient
+                dw = _wgrad_shared(weight, dt, x, lambda out, acc: ops.conv2d_wgrad(dt, x, Cout, Cin, k, stride, out=out, accumulate=acc))
+            else:                                                 # consumed by SpectralNormAllFn.backward only: see _wgrad_aside
+                dw = _wgrad_aside(dt, x, lambda: ops.conv2d_wgrad(dt, x, Cout, Cin, k, stride))
         if ctx.needs_input_grad[0]:
             dx = _conv_dgrad(dt, weight, k, stride, tuple(x.shape[-2:]))
-        if ctx.needs_input_grad[1]:
-            dw = ops.conv2d_wgrad(dt, x, Cout, Cin, k, stride)
         if has_bias and ctx.needs_input_grad[2]:
             db = sums[:, 2].sum(0)
         return dx, dw, db, None, None, None, None
@@ -565,6 +673,7 @@ class SpectralNormAllFn(torch.autograd.Function):
     @torch.autograd.function.once_differentiable
     def backward(ctx, *grads):
         u_flat, v_flat, sigma, *weights = ctx.saved_tensors
+        _side_join(sigma.device)              # the convs' weight gradients were queued on the second stream
         ru, cv = ctx.sizes
         us, vs = list(u_flat.split(ru)), list(v_flat.split(cv))
         gs = [None if (g is None or not ctx.needs_input_grad[3 + i]) else g.contiguous() for i, g in enumerate(grads)]

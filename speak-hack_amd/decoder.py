@@ -97,19 +97,21 @@ class SynthesisBlock(nn.Module):
         self.out_channels = out_channels
         self._pk1, self._pk2 = ops.PackedConvWeight(), ops.PackedConvWeight()
 
-    def _half(self, x, conv, pk, noise_mod, noise, style, upsample):
+    def _half(self, x, conv, pk, noise_mod, noise, style, upsample, weight=None):
         B, Cin, Hs, Ws = x.shape
         H, W = (2 * Hs, 2 * Ws) if upsample else (Hs, Ws)
         if noise is None:
             noise = torch.randn(B, 1, H, W, device=x.device, dtype=torch.float32)
-        return AG.fused_conv(x, conv.weight, conv.bias, noise_mod.weight, noise, style, upsample, LRELU, pk)
+        return AG.fused_conv(x, conv.weight if weight is None else weight, conv.bias, noise_mod.weight, noise, style, upsample, LRELU, pk)
 
-    def forward(self, x, w, noise1=None, noise2=None, styles=None):
-        """``w`` is [B,2,512].  ``styles`` (optional) = precomputed ([B,2C],[B,2C]) affine outputs."""
+    def forward(self, x, w, noise1=None, noise2=None, styles=None, weights=None):
+        """``w`` is [B,2,512].  ``styles`` (optional) = precomputed ([B,2C],[B,2C]) affine outputs; ``weights`` (optional) = the two
+        conv weights behind the network's ``AG.gate_weights`` node (SynthesisNetwork.forward)."""
         if styles is None:
             styles = (self.style_mod1.style(w[:, 0]), self.style_mod2.style(w[:, 1]))
-        x = self._half(x.contiguous(), self.conv1, self._pk1, self.noise1, noise1, styles[0], True)
-        x = self._half(x, self.conv2, self._pk2, self.noise2, noise2, styles[1], False)
+        w1, w2 = weights if weights is not None else (None, None)
+        x = self._half(x.contiguous(), self.conv1, self._pk1, self.noise1, noise1, styles[0], True, w1)
+        x = self._half(x, self.conv2, self._pk2, self.noise2, noise2, styles[1], False, w2)
         return x
 
 
@@ -182,9 +184,17 @@ class SynthesisNetwork(nn.Module):
                                         for j, m in enumerate(mods))
         x = AG.bias_noise_style(self.const_input, self.bias, self.noise_input1.weight, noises[0],
                                    styles[0] if styles is not None else self.style_mod.style(w[:, 0]), B)
+        # a training pass: the conv weights go through ONE gate node, whose backward (after every conv's) joins the second stream
+        # that the convs' weight gradients are queued on (autograd.WeightGateFn)
+        gated = None
+        if torch.is_grad_enabled() and w.is_cuda and ops.side_stream(w.device) is not None:
+            cw = [c.weight for layer in self.layers for c in (layer.conv1, layer.conv2)]
+            if all(t.requires_grad for t in cw):
+                gated = AG.gate_weights(cw)
         for i, layer in enumerate(self.layers):
             x = layer(x, w[:, 2 * i + 1:2 * i + 3], noises[1 + 2 * i], noises[2 + 2 * i],
-                      styles=(styles[1 + 2 * i], styles[2 + 2 * i]) if styles is not None else None)
+                      styles=(styles[1 + 2 * i], styles[2 + 2 * i]) if styles is not None else None,
+                      weights=(gated[2 * i], gated[2 * i + 1]) if gated is not None else None)
         return AG.to_rgb(x, self.to_rgb.weight, self.to_rgb.bias)
 
 

@@ -399,3 +399,33 @@ def test_forward_pair_equals_two_calls(pkg, dev, train):
     with torch.no_grad():
         ya2, yb2 = g.forward_pair(fa, fb, na, None)
     assert ya2.shape == yb2.shape == ya0.shape
+
+
+def test_weight_gradients_on_the_second_stream_equal_in_order_launches(pkg, dev, monkeypatch):
+    """A training pass of the decoder routes its conv weights through ``autograd.WeightGateFn`` and queues their weight gradients
+    on ``ops.side_stream``; the gate's backward joins the stream before the parameters see the gradients.  Two calls that share
+    the parameters (the gradients of the second are ADDED to the first's by autograd, after both gates), repeated, bitwise equal
+    to the in-order schedule."""
+    g = pkg.StyleGenerator(6144)
+    g.load_state_dict(fill_state_dict(g.state_dict(), prefix="Gd."))
+    g.to(dev).train(True)
+    g.style_mixing_prob = 0.0
+    B = 4
+    fa, fb = recipe_input("gate.fa", (B, 6144)).to(dev), recipe_input("gate.fb", (B, 6144)).to(dev)
+    na = [n.to(dev) for n in recipe_noises("gate.a", B, 256)]
+    nb = [n.to(dev) for n in recipe_noises("gate.b", B, 256)]
+
+    def grads():
+        g.zero_grad(set_to_none=True)
+        ya, yb = g(fa, na), g(fb, nb)
+        ((ya ** 2).mean() + (yb * ya.detach()).mean()).backward()
+        return {k: p.grad.clone() for k, p in g.named_parameters() if p.grad is not None}
+
+    assert pkg.ops.side_stream(dev) is not None
+    aside = [grads() for _ in range(3)]
+    monkeypatch.setattr(pkg.ops, "side_stream", lambda device: None)
+    inline = grads()
+    for got in aside:
+        bad = [k for k in inline if not torch.equal(got[k], inline[k])]
+        assert not bad, bad[:4]
+

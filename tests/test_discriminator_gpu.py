@@ -92,6 +92,33 @@ def test_discriminator_first_order(disc, res, B, train):
     check(outs["hip"][1], outs["ref32"][1], outs["ref64"][1], "first order", pixels=B * res * res)
 
 
+def test_weight_gradients_on_the_second_stream_equal_in_order_launches(disc, monkeypatch):
+    """The convs' weight gradients are queued on ``ops.side_stream`` and joined by ``SpectralNormAllFn.backward``; in an R1 pass
+    the two contributions to a weight's gradient (the conv and ConvDgradFn) are summed by the second launch.  Several
+    discriminator calls and an R1 penalty in one backward pass (train.py:160-182), repeated, bitwise equal to the in-order
+    schedule."""
+    dev = torch.device("cuda:0")
+    ops = importlib.import_module("speak-hack_amd.ops")
+    d = make(disc, 128, 5, True).to(dev)
+    xs = [recipe_input(f"discs.x{i}", (4, 3, 128, 128), "uniform").to(dev) for i in range(3)]
+    state = copy.deepcopy(d.state_dict())
+
+    def step():
+        d.load_state_dict(state)                      # the power iteration moves u / v: every run starts from the same buffers
+        d.zero_grad(set_to_none=True)
+        loss = sum(d_loss(d(x)) for x in xs) + 10.0 * r1(lambda m, t: m(t), d, xs[0].clone())     # + an R1 pass (train.py:170-182)
+        loss.backward()
+        return {n: p.grad.clone() for n, p in d.named_parameters() if p.grad is not None}
+
+    assert ops.side_stream(dev) is not None
+    aside = [step() for _ in range(3)]
+    monkeypatch.setattr(ops, "side_stream", lambda device: None)
+    inline = step()
+    for got in aside:
+        bad = [k for k in inline if not torch.equal(got[k], inline[k])]
+        assert not bad, bad[:4]
+
+
 @pytest.mark.parametrize("res,B", [(32, 2), (64, 2)])
 def test_discriminator_r1_double_backward(disc, res, B):
     """grad_penalty = mean_b |dD/dx|^2, then its gradient w.r.t. every discriminator parameter."""
