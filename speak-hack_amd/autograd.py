@@ -73,6 +73,7 @@ def _wgrad_aside(dt, x, launch):
         _side_pending.add(key)
     side.wait_stream(torch.cuda.current_stream(dt.device))
     with torch.cuda.stream(side):
+        ops.side_stream_delay()
         dw = launch()
     dt.record_stream(side)
     x.record_stream(side)

@@ -42,6 +42,7 @@ def _wgrad_aside(side, dr, launch):
         return launch()
     side.wait_stream(torch.cuda.current_stream(dr.device))
     with torch.cuda.stream(side):
+        ops.side_stream_delay()
         dw = launch()
     dr.record_stream(side)
     return dw

@@ -177,6 +177,15 @@ def side_stream(device):
     return st
 
 
+def side_stream_delay():
+    """Test hook (``SPK_WGRAD_STREAM_DELAY`` = spin cycles): stall the CURRENT stream before a weight gradient is launched on
+    it.  With the second stream held back by milliseconds, any consumer that does not wait for it reads garbage -- the
+    second-stream equality tests run once this way (tests/test_second_stream_delay_gpu.py)."""
+    n = int(os.environ.get("SPK_WGRAD_STREAM_DELAY", "0"))
+    if n > 0:
+        torch.cuda._sleep(n)
+
+
 def conv_out_size(n, k, stride):
     return (n + 2 * ((k - 1) // 2) - k) // stride + 1
 
