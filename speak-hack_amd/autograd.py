@@ -57,10 +57,10 @@ def _side_join(device):
             torch.cuda.current_stream(device).wait_stream(st)
 
 
-def _wgrad_aside(dt, x, launch):
-    """``launch()`` (a weight gradient reading the temporaries ``dt`` and ``x``) on the second stream behind everything queued on the
-    current stream so far; in order on the current stream when there is no second stream, under a stream capture, or outside a
-    backward pass (no place to hang the final join)."""
+def _wgrad_aside(dt, x, launch, extra=()):
+    """``launch()`` (a weight gradient reading the temporaries ``dt`` and ``x``, and those in ``extra``) on the second stream behind
+    everything queued on the current stream so far; in order on the current stream when there is no second stream, under a
+    stream capture, or outside a backward pass (no place to hang the final join)."""
     side = ops.side_stream(dt.device)
     if side is None or torch.cuda.is_current_stream_capturing():
         return launch()
@@ -77,6 +77,8 @@ def _wgrad_aside(dt, x, launch):
         dw = launch()
     dt.record_stream(side)
     x.record_stream(side)
+    for t in extra:
+        t.record_stream(side)
     return dw
 
 
@@ -520,7 +522,8 @@ class ModConvFn(torch.autograd.Function):
         d = ops.modconv_demod(weight, s, scale) if demodulate else None
         cfg = ops.conv2d_pick_config(3, 1, B, Cin, Cout, H, W)
         cfg = cfg + 4 if cfg < 4 else cfg
-        y = ops.conv2d_fused(x, packed.get(weight, cfg), Cout, 3, 1, bias=bias, noise_w=noise_w, noise=noise, lrelu_slope=slope,
+        pw = getattr(weight, "_spk_gate_of", weight)      # (behind a WeightGateFn: the parameter keys the packed images)
+        y = ops.conv2d_fused(x, packed.get(pw, cfg), Cout, 3, 1, bias=bias, noise_w=noise_w, noise=noise, lrelu_slope=slope,
                              out_scale=scale, batch_scale=s, demod=d, act_gain=gain, config=cfg, upsample=upsample, up_fir=True)
         if _needs(ctx, grad_mode):
             ctx.save_for_backward(x, weight, s, d, y, noise, bias, noise_w)
@@ -543,26 +546,34 @@ class ModConvFn(torch.autograd.Function):
         if need_dx or need_ds:
             cfg = ops.conv2d_pick_config(3, 1, B, Cout, Cin, H, W)
             cfg = cfg + 4 if cfg < 4 else cfg
-            dxt = ops.conv2d_fused(dt, packed.get(weight, cfg, transpose_flip=True), Cin, 3, 1, out_scale=scale,
-                                   batch_scale=dprime, config=cfg)                     # d (up(x) * s), at the output resolution
+            dxt = ops.conv2d_fused(dt, packed.get(getattr(weight, "_spk_gate_of", weight), cfg, transpose_flip=True), Cin, 3, 1,
+                                   out_scale=scale, batch_scale=dprime, config=cfg)    # d (up(x) * s), at the output resolution
             if upsample and (x.shape[-1] % 2 or dxt.data_ptr() % 16):                  # odd widths: the stand-alone adjoint
                 dxu = ops.upfirdn2d(dxt, torch.flip(fir, [0, 1]), up=1, down=2, pad=(1, 1))
                 dx, ds = ops.modconv_dx_finish(dxu, x, s, False, need_dx=need_dx)
             else:
                 dx, ds = ops.modconv_dx_finish(dxt, x, s, upsample, need_dx=need_dx)
+        dw_aside = False
         if need_dw:
             if ops.wgrad_mod_supported(B, Cin, Cout, H, W, upsample) and not (x.data_ptr() % 16 or dt.data_ptr() % 16):
-                dw = ops.conv2d_wgrad(dt, x, Cout, Cin, 3, 1, upsample=upsample, up_fir=True, scale=scale, batch_scale=s,
-                                      g_scale=dprime)
+                def launch():
+                    t = ops.conv2d_wgrad(dt, x, Cout, Cin, 3, 1, upsample=upsample, up_fir=True, scale=scale, batch_scale=s, g_scale=dprime)
+                    if dw_aside and dd is not None:      # the demodulation adjoint's share of dw, behind the kernel on ITS stream
+                        ops.modconv_demod_bwd(weight, s, d, dd, scale, ds=None, dw=t)
+                    return t
+                # behind a WeightGateFn (which joins the second stream before the parameter sees the gradient): beside the data gradient
+                dw_aside = getattr(weight, "_spk_gate_of", None) is not None
+                # (s and d are saved tensors: autograd releases them when this backward returns, the second stream may still be reading)
+                dw = _wgrad_aside(dt, x, launch, extra=[t for t in (s, d, dprime, dd) if t is not None]) if dw_aside else launch()
             else:                # tiny planes (the 4^2 layer): rescale the two (few-KB) operands and run the plain kernel
                 x_up = ops.upfirdn2d(x, fir, up=2, down=1, pad=(2, 1)) if upsample else x
                 g2 = ops.bias_noise_style(dt, B, None, None, None, _scale_rows(dprime))
                 xs = ops.bias_noise_style(x_up, B, None, None, None, _scale_rows(s))
                 dw = ops.conv2d_wgrad(g2, xs, Cout, Cin, 3, 1, scale=scale)
-        if dd is not None and (need_ds or need_dw):
+        if dd is not None and (need_ds or (need_dw and not dw_aside)):
             if need_ds and ds is None:
                 ds = torch.zeros_like(s)
-            ops.modconv_demod_bwd(weight, s, d, dd, scale, ds=ds if need_ds else None, dw=dw if need_dw else None)
+            ops.modconv_demod_bwd(weight, s, d, dd, scale, ds=ds if need_ds else None, dw=dw if (need_dw and not dw_aside) else None)
         return dx, dw, ds, dbias, dnw, None, None, None, None, None, None, None, None, None
 
 

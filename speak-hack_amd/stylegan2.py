@@ -70,7 +70,7 @@ class ModulatedConv2d(nn.Module):
         self._pk = ops.PackedConvWeight()
 
     def forward(self, x, style, bias=None, noise_w=None, noise=None, lrelu=None, act_gain=1.0, upsample=False, s=None, d=None,
-                skip=None):
+                skip=None, weight=None):
         """``s`` / ``d`` (optional): the modulation ``self.modulation(style)`` and the demodulation vector computed
         elsewhere (grouped launches).  ``skip`` (toRGB only): the previous resolution's image; its [1,3,3,1] x2 upsample
         and the sum happen inside the toRGB launch."""
@@ -91,8 +91,9 @@ class ModulatedConv2d(nn.Module):
                                     act_gain=act_gain, config=cfg, upsample=upsample, up_fir=True)
         # upfirdn2d(up=2, [1,3,3,1]) is folded into the conv's input staging: no 4x tensor in HBM; the demodulation vector and
         # its adjoint are kernels inside the Function (spk_modconv_demod / spk_modconv_demod_bwd)
-        return AG.mod_conv(x.contiguous(), self.weight, s.contiguous(), bias, noise_w, noise, self.scale, upsample, lrelu,
-                           act_gain, _UP_FIR, self._pk, demodulate=self.demodulate)
+        # (``weight``: this conv's weight behind the generator's AG.gate_weights node, a training pass)
+        return AG.mod_conv(x.contiguous(), self.weight if weight is None else weight, s.contiguous(), bias, noise_w, noise, self.scale,
+                           upsample, lrelu, act_gain, _UP_FIR, self._pk, demodulate=self.demodulate)
 
 
 _UP_FIR = make_kernel((1, 3, 3, 1)) * 4.0        # host copy of the x2 FIR (gain up^2), for the backward's materialised passes
@@ -118,7 +119,7 @@ class StyledConv(nn.Module):
         self.noise = NoiseInjection()
         self.activate = FusedLeakyReLU(out_channel)
 
-    def forward(self, x, style, noise=None, s=None, d=None):
+    def forward(self, x, style, noise=None, s=None, d=None, weight=None):
         B, _, H, W = x.shape
         if self.upsample:
             H, W = 2 * H, 2 * W
@@ -127,7 +128,7 @@ class StyledConv(nn.Module):
         nw = self.noise.weight.expand(self.conv.out_channel).contiguous()
         # conv*demod + noise_w*noise + bias -> lrelu(0.2) * sqrt2: one launch
         return self.conv(x, style, bias=self.activate.bias, noise_w=nw, noise=noise.contiguous(), lrelu=0.2, act_gain=SQRT2,
-                         upsample=self.upsample, s=s, d=d)
+                         upsample=self.upsample, s=s, d=d, weight=weight)
 
 
 class ToRGB(nn.Module):
@@ -212,11 +213,16 @@ class StyleGAN2Generator(nn.Module):
             s_of = {id(m): sv for m, sv in zip(layers, ss)}
             dd = ops.modconv_demod_grouped((m.conv.weight, s_of[id(m)], m.conv.scale) for m in styled)
         sit, dit = iter(ss), iter(dd)
+        # a training pass: the styled convs' weights go through ONE gate node, whose backward (after every conv's) joins the second
+        # stream that their weight gradients are queued on (autograd.WeightGateFn)
+        git = iter([None] * len(styled))
+        if train and features.is_cuda and ops.side_stream(features.device) is not None and all(m.conv.weight.requires_grad for m in styled):
+            git = iter(AG.gate_weights([m.conv.weight for m in styled]))
         out = self.input.input.expand(B, -1, -1, -1).contiguous()
-        out = self.conv1(out, w, nxt(), s=next(sit), d=next(dit))
+        out = self.conv1(out, w, nxt(), s=next(sit), d=next(dit), weight=next(git))
         skip = self.to_rgb1(out, w, s=next(sit))
         for i, rgb in enumerate(self.to_rgbs):
-            out = self.convs[2 * i](out, w, nxt(), s=next(sit), d=next(dit))
-            out = self.convs[2 * i + 1](out, w, nxt(), s=next(sit), d=next(dit))
+            out = self.convs[2 * i](out, w, nxt(), s=next(sit), d=next(dit), weight=next(git))
+            out = self.convs[2 * i + 1](out, w, nxt(), s=next(sit), d=next(dit), weight=next(git))
             skip = rgb(out, w, skip, s=next(sit))
         return skip

@@ -16,4 +16,4 @@ def test_equality_tests_with_the_second_stream_held_back():
     r = subprocess.run([sys.executable, "-m", "pytest", "tests", "-m", "gpu", "-q", "-x", "-k", "second_stream_equal", "-p", "no:cacheprovider"],
                        cwd=root, env=env, capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-2000:]
-    assert "3 passed" in r.stdout, r.stdout[-1500:]
+    assert "4 passed" in r.stdout, r.stdout[-1500:]

@@ -226,6 +226,34 @@ def test_variant_generator_backward(sg2, dev):
         assert ok, (k, info)
 
 
+def test_weight_gradients_on_the_second_stream_equal_in_order_launches(sg2, ops, dev, monkeypatch):
+    """A training pass of the variant routes the styled convs' weights through ``autograd.WeightGateFn`` and queues each weight
+    gradient AND the demodulation adjoint's share of it on ``ops.side_stream`` (the modulation's share stays on the current
+    stream): bitwise the in-order schedule, where one ``spk_modconv_demod_bwd`` call writes both shares."""
+    B, res = 4, 128
+    torch.manual_seed(3)
+    g = sg2.StyleGAN2Generator(6144, resolution=res).train().to(dev)
+    with torch.no_grad():
+        for n, p in g.named_parameters():
+            if n.endswith("noise.weight"):
+                p.fill_(0.1)
+    feats = recipe_input(f"sg2s.f.{B}", (B, 6144)).to(dev)
+    noises = [recipe_input(f"sg2s.n{i}.{B}.{res}", s).to(dev) for i, s in enumerate(M.noise_shapes(B, res))]
+
+    def grads():
+        g.zero_grad(set_to_none=True)
+        (g(feats, noises) ** 2).mean().backward()
+        return {k: p.grad.clone() for k, p in g.named_parameters() if p.grad is not None}
+
+    assert ops.side_stream(dev) is not None
+    aside = [grads() for _ in range(3)]
+    monkeypatch.setattr(ops, "side_stream", lambda device: None)
+    inline = grads()
+    for got in aside:
+        bad = [k for k in inline if not torch.equal(got[k], inline[k])]
+        assert not bad, bad[:4]
+
+
 def test_variant_launch_plan_equals_launch_by_launch(sg2, dev):
     """The variant's inference forward as one launch list (plan.StyleGAN2Plan) against its launch-by-launch path, which
     runs the skip upsample as the stand-alone upfirdn2d + a torch add when handed a non-matching skip -- here both paths
