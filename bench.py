@@ -60,7 +60,9 @@ BATCH = 8
 RES = 256
 F32_MFMA_PEAK_TFLOPS = 157.3      # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, dense
 BF16_MFMA_PEAK_TFLOPS = 2500.0    # MI355X_MICROARCH.md: ~2.5 PFLOP/s dense bf16 (the headline figures with 2:1 sparsity are not used)
-GFLOP_PER_PAIR = 593.5            # IRFD fwd+bwd, decoder x3, checkpointed encoders x4
+GFLOP_PER_PAIR = 593.5            # IRFD fwd+bwd as the REFERENCE executes it: decoder x3, checkpointed encoders x4
+GFLOP_PER_PAIR_EXECUTED = 593.5 - 6 * 10.677   # what this build executes by default: the encoders' activations are stored
+                                               # (encoder.TrunkFn), so the checkpoint's second forward (6 x 10.677) never runs
 
 
 def decoder_conv_flops(batch, resolution=RES):
@@ -237,7 +239,7 @@ def irfd_steps(pkg, dev, which, B, steps, warmup, precision="f32", sg2=False, ob
     return ms
 
 
-def irfd_dp_steps(pkg, dev, which, B, steps, warmup, dist, rank):
+def irfd_dp_steps(pkg, dev, which, B, steps, warmup, dist, rank, algo="all_reduce"):
     """BASELINE config 4: the generator (or discriminator) step at ``B`` samples per rank with the gradient exchange of
     train.py:333-338,399-401 (accelerate's DDP) done by dp.GradBucketReducer on the initialised backend.  Times the step
     WITH the exchange, then the same step inside ``no_sync()`` (every rank steps on its own gradients: no collective) --
@@ -252,7 +254,7 @@ def irfd_dp_steps(pkg, dev, which, B, steps, warmup, dist, rank):
     for n, p in net.named_parameters():
         p.requires_grad_(n.startswith("D.") == (which == "d"))
     params = [p for p in net.parameters() if p.requires_grad]
-    red = dp.GradBucketReducer(params)
+    red = dp.GradBucketReducer(params, algo=algo)
     with torch.no_grad():
         for b in net.buffers():                # BatchNorm / spectral-norm buffers, as DDP's broadcast_buffers
             dist.broadcast(b, src=0)
@@ -297,17 +299,77 @@ def irfd_dp_steps(pkg, dev, which, B, steps, warmup, dist, rank):
     by_hook, by_finish = list(red.stats["launched_by_hook"]), list(red.stats["launched_by_finish"])
     # (stats are reset by zero_grad(): these are the last timed step's)
     n_buckets, cold = len(red.buckets), [i for i, b in enumerate(red.buckets) if b["cold"]]
+    # one more synchronising step with per-bucket stamps (host: launch / wait entry / wait return; stream events at the same
+    # points): where an exchange that costs more than its bytes spends the time
+    red.profile = True
+    torch.cuda.synchronize()
+    dist.barrier()
+    t_step = time.perf_counter()
+    step()
+    host_ms = (time.perf_counter() - t_step) * 1e3
+    torch.cuda.synchronize()
+    timeline = red.timeline()
+    red.profile = False
     step(False)
     ms_local = timed(False)                    # last: the replicas drift apart from here on
     res = {"ms_per_step": round(ms, 2), "samples_per_rank": B, "pairs_per_s": round(world * B / ms * 1e3, 1),
-           "backend": dist.get_backend(), "world_size": world, "grad_bytes_per_step": red.bytes_per_step(),
+           "backend": dist.get_backend(), "world_size": world, "algo": algo, "grad_bytes_per_step": red.bytes_per_step(),
            "buckets": n_buckets, "bucket_bytes": red.bucket_bytes, "buckets_launched_by_hook": len(by_hook),
            "buckets_launched_by_finish": len(by_finish), "cold_buckets": len(cold),
-           "ms_per_step_no_exchange": round(ms_local, 2), "exposed_comm_ms": round(ms - ms_local, 2)}
+           "ms_per_step_no_exchange": round(ms_local, 2), "exposed_comm_ms": round(ms - ms_local, 2),
+           "bucket_timeline_rank0": {"host_ms_of_the_stamped_step": round(host_ms, 2), "buckets": timeline}}
     red.remove()
     del net, opt, red
     torch.cuda.empty_cache()
     return res
+
+
+def train_iterations(pkg, dev, B, iters=5, warmup_iters=5, precision="f32", dist=None, rank=0, algo="all_reduce"):
+    """The reference's REAL iteration (train.py:150-210, config.yaml:18 G_steps = 5): ``training.train_iteration`` over
+    ``iters`` consecutive steps starting at a multiple of G_steps -- 5 discriminator steps and 1 generator step WITH the
+    adversarial term through model.D, the clip over all parameters, Adam on Gd and on D.  With ``dist``: the data-parallel
+    form (both reducers).  Returns (ms per iteration, pairs/s over all ranks)."""
+    import model as M
+    T = importlib.import_module("speak-hack_amd.training")
+    world = dist.get_world_size() if dist is not None else 1
+    torch.manual_seed(1234 + rank)
+    net = M.IRFD().to(dev).train()
+    red_G = red_D = None
+    if dist is not None:
+        red_G, red_D = T.make_reducers(net, algo=algo)
+    opt_G = torch.optim.Adam(net.Gd.parameters(), lr=2e-4, betas=(0.5, 0.999))          # config.yaml:19-20
+    opt_D = torch.optim.Adam(net.D.parameters(), lr=5e-5, betas=(0.5, 0.999))
+    g = torch.Generator().manual_seed(10 + rank)
+    batch = {"source_image": (torch.rand(B, 3, 256, 256, generator=g) * 2 - 1).to(dev),
+             "target_image": (torch.rand(B, 3, 256, 256, generator=g) * 2 - 1).to(dev),
+             "emotion_labels_s": torch.randint(0, 8, (B,), generator=g).to(dev),
+             "emotion_labels_t": torch.randint(0, 8, (B,), generator=g).to(dev)}
+    kw = dict(G_steps=5, r1_weight=1.0, stylegan_loss_weight=0.1, grad_clip_value=1.0, reducer_G=red_G, reducer_D=red_D)   # config.yaml:18,21,36,43
+
+    def sync():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    with pkg.ops.train_conv_precision(precision):
+        for step in range(warmup_iters):
+            T.train_iteration(net, batch, opt_G, opt_D, step, **kw)
+        sync()
+        t0 = time.perf_counter()
+        for step in range(iters):
+            T.train_iteration(net, batch, opt_G, opt_D, step, **kw)
+        sync()
+        el = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([el], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        el = float(t.item())
+        red_G.remove(), red_D.remove()
+    del net, opt_G, opt_D
+    torch.cuda.empty_cache()
+    ms = el / iters * 1e3
+    return ms, world * B / ms * 1e3
 
 
 def single_frame(pkg, dev, threads):
@@ -359,7 +421,9 @@ def launch_ranks(n):
     """``python bench.py --gpus N`` without a launcher: start N fresh child ranks (one per GPU) through
     torch.distributed.run and relay their output.  Runs BEFORE this process has made any GPU call (importing torch does
     not initialise HIP); the children are new processes, this one is never replaced."""
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
+    env = dict(os.environ)
+    if env.get("SPK_BENCH_ONE_DEVICE") == "1":             # the one-GPU rehearsal shares device 0 between the ranks: the
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # only case this script sets it; RCCL's environment is the caller's
     env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or n) // n)))
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.abspath(__file__), *sys.argv[1:]]
@@ -378,6 +442,9 @@ def main():
     ap.add_argument("--no-graph", action="store_true", help="launch the step's kernels eagerly instead of replaying "
                     "the hipGraph captured from them")
     ap.add_argument("--dp-steps", type=int, default=5, help="timed steps of the data-parallel training steps (N > 1)")
+    ap.add_argument("--dp-algo", default="all_reduce", choices=("all_reduce", "rs_ag"), help="the gradient exchange of the "
+                    "data-parallel steps: one all-reduce per bucket, or reduce-scatter + all-gather (dp.GradBucketReducer algo)")
+    ap.add_argument("--blocks", type=int, default=3, help="timed blocks of --steps steps each; the line reports the median block")
     args = ap.parse_args()
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
@@ -443,16 +510,22 @@ def main():
 
         for _ in range(args.warmup):
             step()
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            step()
-        barrier()
-        elapsed = time.perf_counter() - t0
-        if dist is not None:
-            t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            elapsed = float(t.item())
+        # EXACTLY --steps steps per timed block, barrier + synchronize on both sides, MAX over ranks; --blocks such blocks
+        # back to back, the line carries the MEDIAN block (value / ms_per_step) and every block's figure beside it
+        block_s = []
+        for _ in range(max(1, args.blocks)):
+            barrier()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                step()
+            barrier()
+            el = time.perf_counter() - t0
+            if dist is not None:
+                t = torch.tensor([el], device=dev, dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                el = float(t.item())
+            block_s.append(el)
+        elapsed = sorted(block_s)[len(block_s) // 2]
 
         # ---- eager: the same step as an unchanged caller gets it (no graph) ----
         for _ in range(3):
@@ -581,8 +654,13 @@ def main():
                                         "checkpoint semantics; 2 decoder passes; reconstruction loss; fwd + bwd + global-norm clip + Adam on Gd), "
                                         "batch 16, fp32, eager launches",
                                 "ms_per_step": round(g_ms, 2), "pairs_per_s": round(16 / g_ms * 1e3, 1),
-                                "algorithmic_tflops": round(16 / g_ms * 1e3 * GFLOP_PER_PAIR / 1e3, 1),
-                                "frac_of_f32_mfma_peak": round(16 / g_ms * 1e3 * GFLOP_PER_PAIR / 1e3 / F32_MFMA_PEAK_TFLOPS, 4)}
+                                "executed_gflop_per_pair": round(GFLOP_PER_PAIR_EXECUTED, 1),
+                                "executed_tflops": round(16 / g_ms * 1e3 * GFLOP_PER_PAIR_EXECUTED / 1e3, 1),
+                                "frac_of_f32_mfma_peak": round(16 / g_ms * 1e3 * GFLOP_PER_PAIR_EXECUTED / 1e3 / F32_MFMA_PEAK_TFLOPS, 4),
+                                "algorithmic_tflops_reference_equivalent": round(16 / g_ms * 1e3 * GFLOP_PER_PAIR / 1e3, 1),
+                                "flops_note": "frac_of_f32_mfma_peak counts EXECUTED FLOPs: the encoders' activations are stored, the "
+                                              "checkpoint's recompute (6 x 10.677 of the reference's 593.5 GFLOP per pair) is not run and "
+                                              "not counted; the reference-equivalent figure prices the step at the reference's own work"}
         g_bf = irfd_steps(pkg, dev, "g", 16, steps=5, warmup=2, precision="bf16x3")
         extras["train_step"]["bf16x3_opt_in"] = {
             "what": "OPT-IN ops.train_conv_precision('bf16x3'): the decoder's 3x3 convs forward and their data gradients on the bf16 pipe "
@@ -600,6 +678,16 @@ def main():
                             "pairs_per_s": round(8 / d_ms * 1e3, 1)}
         d_bf = irfd_steps(pkg, dev, "d", 8, steps=5, warmup=2, precision="bf16x3")
         extras["d_step"]["bf16x3_opt_in"] = {"ms_per_step": round(d_bf, 2), "pairs_per_s": round(8 / d_bf * 1e3, 1)}
+
+        it_ms, it_pairs = train_iterations(pkg, dev, 8)
+        it_bf, it_bf_pairs = train_iterations(pkg, dev, 8, precision="bf16x3")
+        extras["train_iteration"] = {
+            "what": "the reference's REAL iteration (train.py:150-210; config.yaml G_steps 5, r1_weight 1, stylegan_loss_weight 0.1, clip 1.0): "
+                    "training.train_iteration over 5 consecutive iterations = 5 discriminator steps (instance noise, BCE, R1 double "
+                    "backward, Adam on D) + 1 generator step WITH the adversarial term through model.D (fwd + bwd, clip over all "
+                    "parameters, Adam on Gd), batch 8, fp32, eager launches",
+            "ms_per_iteration": round(it_ms, 2), "pairs_per_s": round(it_pairs, 1),
+            "bf16x3_opt_in": {"ms_per_iteration": round(it_bf, 2), "pairs_per_s": round(it_bf_pairs, 1)}}
 
         extras["single_frame"] = single_frame(pkg, dev, 0 if args.no_cpu_baseline else host_cores())
 
@@ -620,6 +708,11 @@ def main():
             "unit": "frames/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 4),
+            "timed_blocks": {"what": f"{len(block_s)} timed blocks of {args.steps} steps each (barrier + synchronize around every block, max over "
+                                     "ranks); value / ms_per_step are the median block's",
+                             "ms_per_step": [round(b / args.steps * 1e3, 4) for b in block_s],
+                             "frames_per_s_min": round(world * BATCH * args.steps / max(block_s), 2),
+                             "frames_per_s_max": round(world * BATCH * args.steps / min(block_s), 2)},
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f32", "data": "synthetic",
             "config": {"workload": "StyleGAN decoder (styleganv1.StyleGenerator) 256^2 forward only, batch 8/GPU, "
@@ -645,17 +738,37 @@ def main():
         import threading
         done = threading.Event()
         deadline = float(os.environ.get("SPK_BENCH_DP_DEADLINE_S", "420"))
+        flag = os.path.join("/tmp", f"spk_bench_dp_failed_{os.environ.get('MASTER_PORT', '0')}_{os.getppid()}")   # one node: ranks share /tmp
+        if rank == 0 and os.path.exists(flag):
+            os.unlink(flag)                  # a stale flag of an earlier job with the same port and launcher pid
+        dist.barrier()
 
         def watchdog():
-            if not done.wait(deadline + (0 if rank == 0 else 15)):      # rank 0 reports first; everyone leaves with rc 0
-                if rank == 0:
-                    line.update(extras)
-                    line["train_step_dp"] = {"error": f"the data-parallel steps did not finish within {deadline:.0f} s "
-                                                      f"(backend {args.backend}, {world} ranks); headline fields are complete"}
-                    print(json.dumps(line), flush=True)
-                os._exit(0)
+            # Ends the process when the deadline passes or when ANY rank has flagged a failure.  Rank 0 prints its complete
+            # headline line (with the error) first; EVERY rank then leaves with a NON-ZERO code: a stalled or failed exchange
+            # is a failed config 4 and the driver's rc must say so (no restart, no re-exec: this process has used the GPU).
+            t_end, why = time.monotonic() + deadline, None
+            while not done.wait(0.5):
+                if os.path.exists(flag):
+                    try:
+                        why = open(flag).read()[:600] or "a rank failed"
+                    except OSError:
+                        why = "a rank failed"
+                elif time.monotonic() > t_end:
+                    why = (f"the data-parallel steps did not finish within {deadline:.0f} s (backend {args.backend}, {world} ranks, "
+                           f"algo {args.dp_algo})")
+                if why is not None:
+                    if rank == 0:
+                        line.update(extras)
+                        line["train_step_dp"] = {"error": why + "; headline fields are complete; exit code 3"}
+                        print(json.dumps(line), flush=True)
+                    else:
+                        time.sleep(2.0)          # rank 0 reports first
+                    os._exit(3)
         threading.Thread(target=watchdog, daemon=True).start()
         try:
+            if os.environ.get("SPK_BENCH_DP_FAIL_RANK") == str(rank):      # test hook (tests/test_bench_dp_gpu.py): a rank that fails
+                raise RuntimeError("injected failure (SPK_BENCH_DP_FAIL_RANK)")
             # ---- config 5 per rank: the 512^2 decoder at batch 4 (replicas) ----
             with torch.no_grad():
                 s512 = pkg.SynthesisNetwork(resolution=512).eval().to(dev)
@@ -669,29 +782,47 @@ def main():
                 ms5 = float(t5.item())
                 del s512, g5
             torch.cuda.empty_cache()
-            dp_g = irfd_dp_steps(pkg, dev, "g", BATCH, args.dp_steps, 2, dist, rank)
-            dp_d = irfd_dp_steps(pkg, dev, "d", BATCH, args.dp_steps, 2, dist, rank)
+            dp_g = irfd_dp_steps(pkg, dev, "g", BATCH, args.dp_steps, 2, dist, rank, args.dp_algo)
+            dp_d = irfd_dp_steps(pkg, dev, "d", BATCH, args.dp_steps, 2, dist, rank, args.dp_algo)
+            it_ms, it_pairs = train_iterations(pkg, dev, BATCH, dist=dist, rank=rank, algo=args.dp_algo)
             if rank == 0:
                 extras["decoder_512_b4"] = {"what": "BASELINE config 5: SynthesisNetwork(resolution=512) forward, batch 4 per rank, fp32 "
                                                     "(hipGraph replay, replicas; slowest rank)", "ms_per_step": round(ms5, 4),
                                             "frames_per_s": round(world * 4 / ms5 * 1e3, 2), "frames_per_s_per_gpu": round(4 / ms5 * 1e3, 2)}
                 dp_g["what"] = ("BASELINE config 4: IRFD generator step (3 encoders x 2 images, 2 decoder passes, fwd + bwd + global-norm "
                                 "clip + Adam on Gd), batch 8 per rank, fp32, gradients of every trained parameter exchanged by "
-                                "dp.GradBucketReducer (bucketed all-reduce launched from backward hooks) -- slowest rank")
-                dp_g["algorithmic_tflops"] = round(dp_g["pairs_per_s"] * GFLOP_PER_PAIR / 1e3, 1)
+                                "dp.GradBucketReducer (buckets launched from backward hooks) -- slowest rank")
+                dp_g["executed_tflops"] = round(dp_g["pairs_per_s"] * GFLOP_PER_PAIR_EXECUTED / 1e3, 1)
+                dp_g["algorithmic_tflops_reference_equivalent"] = round(dp_g["pairs_per_s"] * GFLOP_PER_PAIR / 1e3, 1)
                 dp_d["what"] = ("discriminator step of train.py:155-183 at batch 8 per rank with the same exchange (76 MB of gradients, R1 "
                                 "double backward) -- slowest rank")
                 extras["train_step_dp"], extras["d_step_dp"] = dp_g, dp_d
+                extras["train_iteration_dp"] = {
+                    "what": "the reference's whole iteration (train.py:150-210) data-parallel: training.train_iteration with reducer_G / "
+                            "reducer_D over 5 consecutive iterations (5 D steps + 1 G step with the adversarial term; D's share of the "
+                            "clip norm exchanged too), batch 8 per rank -- slowest rank",
+                    "ms_per_iteration": round(it_ms, 2), "pairs_per_s": round(it_pairs, 1), "algo": args.dp_algo,
+                    "backend": dist.get_backend(), "world_size": world}
 
-        except Exception as e:               # a transport error must not cost the headline record either
-            print(f"bench: data-parallel steps failed on rank {rank}: {type(e).__name__}: {e}", file=sys.stderr, flush=True)
+        except Exception as e:               # a transport error must not cost the headline record -- but it IS a failure
+            import traceback
+            print(f"bench: data-parallel steps failed on rank {rank}: {type(e).__name__}: {e}\n{traceback.format_exc()}",
+                  file=sys.stderr, flush=True)
+            try:                             # tell the other ranks' watchdogs (they may sit inside a collective)
+                with open(flag, "w") as f:
+                    f.write(f"rank {rank}: {type(e).__name__}: {e}"[:600])
+            except OSError:
+                pass
             if rank == 0:
                 line.update(extras)
-                line["train_step_dp"] = {"error": f"{type(e).__name__}: {e}"[:600]}
+                line["train_step_dp"] = {"error": f"{type(e).__name__}: {e}"[:600] + "; headline fields are complete; exit code 3"}
                 print(json.dumps(line), flush=True)
-                os._exit(0)
-            threading.Event().wait()         # the other ranks may be inside a collective: leave through the watchdog
+            else:
+                time.sleep(3.0)              # rank 0's watchdog prints the line before the launcher tears the job down
+            os._exit(3)                      # never rc 0, never a re-exec
         done.set()
+        if rank == 0 and os.path.exists(flag):
+            os.unlink(flag)
 
     if rank == 0:
         line.update(extras)

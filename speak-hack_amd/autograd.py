@@ -10,12 +10,14 @@ instead of silently dropping the second-order term.
 """
 from __future__ import annotations
 
+import contextlib
+import weakref
+
 import torch
+from torch.utils.weak import WeakTensorKeyDictionary
 
 from . import ops
 
-
-import contextlib
 
 _INPUT_GRAD_ONLY = False
 
@@ -37,41 +39,45 @@ def input_grad_only():
 
 # ---- weight gradients whose only consumer is SpectralNormAllFn.backward: on the second stream ------------------------------------
 # A discriminator conv's weight is W / sigma, an output of SpectralNormAllFn; its gradient sits untouched in that node's input
-# buffer until the node runs -- after the LAST conv's backward -- as long as the conv is the weight's only user.  An R1 pass
-# adds ConvDgradFn as a second one and the engine would ADD the two gradients on the current stream: those weights are marked
-# ``_spk_shared`` when the differentiable backward is built, and _wgrad_shared lets the second launch accumulate into the
-# first one's tensor instead.  So the
-# weight-gradient launch goes to ops.side_stream behind the producer of its operands, the data-gradient chain never waits for
-# it, and SpectralNormAllFn.backward joins the stream before it reads the gradients (a callback at the end of the backward
-# pass joins it as well, whatever else happens to the graph).  tools/lab_wgrad_overlap.py: 1-5 % of the discriminator's layers.
-_side_pending = set()
+# buffer until the node runs -- after the LAST conv's backward -- as long as ONE tensor is handed to the engine per weight.  An
+# R1 pass adds ConvDgradFn as a second user of the weight and the engine would ADD the two gradients on the current stream, so
+# every gradient of a normalised weight goes through _wgrad_shared: the first user of a backward pass allocates it, later
+# users accumulate into that tensor inside the kernel.  The weight-gradient launches go to ops.side_stream behind the producer
+# of their operands, the data-gradient chain never waits for them, and SpectralNormAllFn.backward joins the stream before it
+# reads the gradients (a callback at the end of the backward pass joins the launching stream as well, whatever else happens
+# to the graph).  tools/lab_wgrad_overlap.py: 1-5 % of the discriminator's layers.
+_side_pending = set()                     # (device index, graph task id) with an end-of-backward join queued
 
 
-def _side_join(device):
-    """The current stream waits for every weight gradient queued on the device's second stream so far."""
-    key = torch.device(device).index
-    if key in _side_pending:
-        _side_pending.discard(key)
-        st = ops.side_stream(device)
-        if st is not None:
-            torch.cuda.current_stream(device).wait_stream(st)
+def _side_join(device, stream=None):
+    """``stream`` (default: the current one) waits for every weight gradient queued on the device's second stream so far.
+    Unconditional -- waiting on a stream with nothing queued costs an event -- so that two backward passes on one device
+    (other threads, other streams) cannot cancel each other's join."""
+    st = ops.side_stream(device)
+    if st is not None:
+        (stream if stream is not None else torch.cuda.current_stream(device)).wait_stream(st)
 
 
 def _wgrad_aside(dt, x, launch, extra=()):
     """``launch()`` (a weight gradient reading the temporaries ``dt`` and ``x``, and those in ``extra``) on the second stream behind
     everything queued on the current stream so far; in order on the current stream when there is no second stream, under a
     stream capture, or outside a backward pass (no place to hang the final join)."""
-    side = ops.side_stream(dt.device)
+    dev = dt.device
+    side = ops.side_stream(dev)
     if side is None or torch.cuda.is_current_stream_capturing():
         return launch()
-    key = dt.device.index
+    cur = torch.cuda.current_stream(dev)
+    key = (dev.index, torch._C._current_graph_task_id())
     if key not in _side_pending:
+        def done(dev=dev, cur=cur, key=key):         # holds the device, the launching stream and the key -- never a tensor
+            _side_pending.discard(key)
+            _side_join(dev, cur)
         try:
-            torch.autograd.Variable._execution_engine.queue_callback(lambda: _side_join(dt.device))
+            torch.autograd.Variable._execution_engine.queue_callback(done)
         except RuntimeError:
             return launch()
         _side_pending.add(key)
-    side.wait_stream(torch.cuda.current_stream(dt.device))
+    side.wait_stream(cur)
     with torch.cuda.stream(side):
         ops.side_stream_delay()
         dw = launch()
@@ -83,18 +89,20 @@ def _wgrad_aside(dt, x, launch, extra=()):
 
 
 def _wgrad_shared(weight, a, b, make):
-    """The gradient of a normalised weight with TWO users in the graph (an R1 pass: the conv itself and ConvDgradFn).  The first
-    of them to run in a backward pass allocates the gradient; the second ADDS into it inside the weight-gradient kernel
-    (``make(out, accumulate=True)``) and hands autograd nothing.  One tensor reaches SpectralNormAllFn.backward, the engine has
-    nothing to add on the current stream -- so both launches may sit on the second stream, in order among themselves.
-    ``make(out, accumulate)`` launches the kernel; ``a``, ``b`` are its temporaries (see _wgrad_aside)."""
+    """The gradient of a spectrally normalised weight (an output of SpectralNormAllFn), however many users it has in the graph
+    -- one in a first-order pass; two in an R1 pass (the conv itself and ConvDgradFn); more if a caller reuses a layer.  The
+    first user to run in a backward pass allocates the gradient and hands it to autograd; every later one ADDS into that
+    tensor inside the weight-gradient kernel (``make(out, accumulate=True)``) and hands autograd nothing.  So exactly one
+    tensor reaches SpectralNormAllFn.backward, the engine never adds two contributions on the current stream, and all the
+    launches may sit on the second stream, in order among themselves.  SpectralNormAllFn.backward drops the note
+    (``_spk_dw``) when it has consumed the gradient.  ``make(out, accumulate)`` launches the kernel; ``a``, ``b`` are its
+    temporaries (see _wgrad_aside)."""
     task = torch._C._current_graph_task_id()
     held = getattr(weight, "_spk_dw", None)
     if held is None or held[0] != task:
         dw = _wgrad_aside(a, b, lambda: make(None, False))
         weight._spk_dw = (task, dw)
         return dw
-    weight._spk_dw = None
     _wgrad_aside(a, b, lambda: make(held[1], True))
     return None
 
@@ -354,12 +362,17 @@ def _packed(weight, cfg, tf=False):
     return _packed_of(weight, cfg, tf), None
 
 
+_PACKS = WeakTensorKeyDictionary()
+
+
 def _packed_of(weight, cfg, tf=False):
     """Packed image of a per-forward weight tensor (the discriminator's W / sigma: a fresh tensor every forward, so the
-    per-parameter cache of ``ops.PackedConvWeight`` cannot hold it).  The images ride on the tensor object itself and die with
+    per-parameter cache of ``ops.PackedConvWeight`` cannot hold it).  The images are held per tensor object (weakly) and die with
     it: the forward pack is reused by the R1 double backward, the data-gradient pack by both backward passes (64 of the 220
     pack launches of a discriminator step)."""
-    cache = weight.__dict__.setdefault("_spk_packs", {}) if hasattr(weight, "__dict__") else {}
+    cache = _PACKS.get(weight)             # weakly keyed by the tensor OBJECT: nothing rides in Parameter.__dict__, which
+    if cache is None:                      # ``torch.save(model)`` / any pickling of Parameters would carry along
+        cache = _PACKS[weight] = {}
     key = (cfg, tf, weight._version, weight.data_ptr())
     hit = cache.get(key)
     if hit is None:
@@ -414,7 +427,7 @@ class ConvDgradFn(torch.autograd.Function):
         ddt = dw = None
         if ctx.needs_input_grad[1]:
             Co, Ci = weight.shape[:2]
-            if getattr(weight, "_spk_sn", None) is not None and getattr(weight, "_spk_shared", False):
+            if getattr(weight, "_spk_sn", None) is not None:
                 dw = _wgrad_shared(weight, dt, g, lambda out, acc: ops.conv2d_wgrad(dt, g, Co, Ci, k, stride, out=out, accumulate=acc))
             else:
                 dw = ops.conv2d_wgrad(dt, g, Co, Ci, k, stride)
@@ -454,9 +467,7 @@ class ConvBiasLReLUFn(torch.autograd.Function):
         if torch.is_grad_enabled():        # double backward requested: differentiable data path
             dt = _LReluMaskFn.apply(dy, y, slope) if slope is not None else dy.contiguous()
             if ctx.needs_input_grad[0]:
-                if getattr(weight, "_spk_sn", None) is not None:
-                    weight._spk_shared = True     # a second user of this weight (ConvDgradFn): its gradients will be ADDED on the current stream
-                dx = ConvDgradFn.apply(dt, weight, k, stride, tuple(x.shape[-2:]))
+                dx = ConvDgradFn.apply(dt, weight, k, stride, tuple(x.shape[-2:]))     # a second user of this weight: see _wgrad_shared
             if not _INPUT_GRAD_ONLY:
                 with torch.no_grad():
                     dtd = dt.detach()
@@ -469,10 +480,8 @@ class ConvBiasLReLUFn(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             if getattr(weight, "_spk_sn", None) is None:
                 dw = ops.conv2d_wgrad(dt, x, Cout, Cin, k, stride)
-            elif getattr(weight, "_spk_shared", False):           # an R1 pass: ConvDgradFn contributes to the same gradient
+            else:                                                 # consumed by SpectralNormAllFn.backward only: second stream
                 dw = _wgrad_shared(weight, dt, x, lambda out, acc: ops.conv2d_wgrad(dt, x, Cout, Cin, k, stride, out=out, accumulate=acc))
-            else:                                                 # consumed by SpectralNormAllFn.backward only: see _wgrad_aside
-                dw = _wgrad_aside(dt, x, lambda: ops.conv2d_wgrad(dt, x, Cout, Cin, k, stride))
         if ctx.needs_input_grad[0]:
             dx = _conv_dgrad(dt, weight, k, stride, tuple(x.shape[-2:]))
         if has_bias and ctx.needs_input_grad[2]:
@@ -679,6 +688,7 @@ class SpectralNormAllFn(torch.autograd.Function):
             ru, cv = [u.numel() for u in us], [v.numel() for v in vs]
             ctx.save_for_backward(torch.cat([u.reshape(-1) for u in us]), torch.cat([v.reshape(-1) for v in vs]), sigma, *weights)
             ctx.sizes = (ru, cv)
+            ctx.hats = [weakref.ref(h) for h in hats]
         return tuple(hats)
 
     @staticmethod
@@ -686,6 +696,10 @@ class SpectralNormAllFn(torch.autograd.Function):
     def backward(ctx, *grads):
         u_flat, v_flat, sigma, *weights = ctx.saved_tensors
         _side_join(sigma.device)              # the convs' weight gradients were queued on the second stream
+        for ref in ctx.hats:                  # _wgrad_shared's notes: consumed here, must not pin a gradient past this pass
+            h = ref()
+            if h is not None and getattr(h, "_spk_dw", None) is not None:
+                h._spk_dw = None
         ru, cv = ctx.sizes
         us, vs = list(u_flat.split(ru)), list(v_flat.split(cv))
         gs = [None if (g is None or not ctx.needs_input_grad[3 + i]) else g.contiguous() for i, g in enumerate(grads)]

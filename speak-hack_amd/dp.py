@@ -23,6 +23,15 @@ training iteration -- summing parameter gradients over ranks -- is done here:
 * ``finish()`` launches, in index order, what the hooks could not (buckets with parameters that got no gradient
   this step: they contribute zeros), waits for the outstanding collectives (stream-side on GPU) and leaves
   ``1/world``-scaled sums in place, exactly what DDP's gradient averaging leaves;
+* ``algo="rs_ag"`` exchanges a bucket as ``reduce_scatter_tensor`` + ``all_gather_into_tensor`` on the (world-padded) flat
+  buffer instead of one ``all_reduce``: on xGMI every GPU is one hop from every other, so a reduce-scatter in which rank r
+  receives its 1/world slice from all 7 peers at once drives all 7 links (S/8 per link and phase) where a single ring is
+  bound by one link.  Same sums, same bucket order, same hooks; on a stream-ordered backend (RCCL) both
+  phases are queued from the hook, on a host-ordered one (gloo) the all-gather is issued when the reduce-scatter is
+  waited for.  ``all_reduce`` stays the default: RCCL's own all-reduce already picks multi-ring / direct algorithms.
+* ``stats["timeline"]``: per launched bucket its bytes, who launched it (hook / finish) and host times of launch, wait
+  entry and wait return relative to the step's re-arm; with ``profile = True`` on device tensors also stream events at
+  the same three points (``timeline()`` resolves them), so an exchange that costs more than its bytes can be read off.
 * ``no_sync()`` / ``GradAccumulator``: the gradient-accumulation schedule of ``accelerator.accumulate``
   (train.py:152,335; config.yaml gradient_accumulation_steps): micro-steps inside ``no_sync`` only accumulate
   locally, the last micro-step exchanges the sums.
@@ -42,7 +51,8 @@ tensors with the ``gloo`` backend (tests/test_dp_gloo.py, world size 2) and on H
 from __future__ import annotations
 
 import contextlib
-from typing import Iterable, List, Optional
+import time
+from typing import Iterable, List, Optional, Sequence
 
 import torch
 import torch.distributed as dist
@@ -51,9 +61,17 @@ import torch.distributed as dist
 class GradBucketReducer:
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 32 << 20,
                  process_group: Optional[dist.ProcessGroup] = None, average: bool = True,
-                 broadcast_parameters: bool = True, rebuild_after_first_step: bool = True):
+                 broadcast_parameters: bool = True, rebuild_after_first_step: bool = True, algo: str = "all_reduce"):
+        if algo not in ("all_reduce", "rs_ag"):
+            raise ValueError(f"GradBucketReducer: algo must be 'all_reduce' or 'rs_ag', not {algo!r}")
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
+        self.algo = algo
+        # RCCL queues collectives on its own stream in issue order: the all-gather may be issued right behind the
+        # reduce-scatter.  gloo runs each collective on a worker thread: the second phase waits for the first on the host.
+        self._stream_ordered = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
+        self.profile = False
         self.average = average
         self.bucket_bytes = int(bucket_bytes)
         plist = [p for p in params if p.requires_grad]
@@ -74,9 +92,10 @@ class GradBucketReducer:
         self._fired: List[int] = []                        # registration indices in hook order (first synced backward)
         self._sync = True
         self._in_flat = False                              # gradients live in the flat buffers (after a finish(), world > 1)
-        self._handles = []
+        self._handles = []                                 # (work, bucket index, second phase to issue after the wait | None)
         self._next = 0                                     # lowest bucket index not launched yet
-        self.stats = {"launched_by_hook": [], "launched_by_finish": []}     # bucket indices, last step
+        self._t0, self._ev0 = time.perf_counter(), None
+        self.stats = self._fresh_stats()                   # bucket indices + timeline, since the last zero_grad()
         self._hooks = [p.register_post_accumulate_grad_hook(self._hook) for p in plist]
         self.zero_grad()
 
@@ -111,14 +130,17 @@ class GradBucketReducer:
 
     def _seal(self, plist, dev, dtype, cold=False):
         total = sum(p.numel() for p in plist)
-        flat = views = None
+        flat = views = shard = None
         if self.world > 1:                     # the communication buffer and each parameter's slice of it
-            flat = torch.zeros(total, device=dev, dtype=dtype)
+            padded = total + (-total) % self.world if self.algo == "rs_ag" else total
+            flat = torch.zeros(padded, device=dev, dtype=dtype)
+            if self.algo == "rs_ag":           # this rank's 1/world slice of the sums, between the two phases
+                shard = torch.zeros(padded // self.world, device=dev, dtype=dtype)
             views, off = [], 0
             for p in plist:
                 views.append(flat[off:off + p.numel()].view_as(p))
                 off += p.numel()
-        self.buckets.append({"params": plist, "flat": flat, "views": views, "numel": total, "pending": len(plist),
+        self.buckets.append({"params": plist, "flat": flat, "views": views, "shard": shard, "numel": total, "pending": len(plist),
                              "n": len(plist), "ready": False, "launched": False, "cold": cold})
 
     # ---- backward-time protocol ----------------------------------------------------------------
@@ -136,15 +158,31 @@ class GradBucketReducer:
     def _drain(self, by_hook):
         """Launch ready buckets strictly in index order: every rank issues the same sequence of collectives."""
         while self._next < len(self.buckets) and self.buckets[self._next]["ready"]:
-            self._launch(self._next)
+            self._launch(self._next, by_hook)
             self.stats["launched_by_hook" if by_hook else "launched_by_finish"].append(self._next)
             self._next += 1
 
-    def _launch(self, bi):
+    def _fresh_stats(self):
+        return {"launched_by_hook": [], "launched_by_finish": [], "timeline": []}
+
+    def _ms(self):
+        return round((time.perf_counter() - self._t0) * 1e3, 3)
+
+    def _event(self, b):
+        if self.profile and b["flat"] is not None and b["flat"].is_cuda:
+            ev = torch.cuda.Event(enable_timing=True)
+            ev.record()
+            return ev
+        return None
+
+    def _launch(self, bi, by_hook=False):
         b = self.buckets[bi]
         b["launched"] = True
         if self.world == 1:
             return
+        rec = {"bucket": bi, "bytes": b["numel"] * b["params"][0].element_size(), "by": "hook" if by_hook else "finish",
+               "launch_ms": self._ms(), "wait_begin_ms": None, "wait_end_ms": None, "_ev_launch": self._event(b), "_ev_done": None}
+        self.stats["timeline"].append(rec)
         have_v, have_g, missing = [], [], []
         for p, v in zip(b["params"], b["views"]):
             if p.grad is None:
@@ -161,14 +199,44 @@ class GradBucketReducer:
                 p.grad = v                     # the optimizer reads the reduced values in place
             if self.average:
                 b["flat"].div_(self.world)
-        self._handles.append(dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        if self.algo == "rs_ag":
+            h = dist.reduce_scatter_tensor(b["shard"], b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            gather = lambda: dist.all_gather_into_tensor(b["flat"], b["shard"], group=self.group, async_op=True)
+            if self._stream_ordered:
+                self._handles.append((h, rec, None))
+                self._handles.append((gather(), rec, None))
+            else:
+                self._handles.append((h, rec, gather))
+        else:
+            self._handles.append((dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True), rec, None))
 
     # ---- step protocol -------------------------------------------------------------------------
     def _wait(self):
         """Outstanding all-reduces complete (stream-side on RCCL) before anything else touches their flat buffers."""
-        for h in self._handles:
+        for h, rec, then in self._handles:
+            if rec["wait_begin_ms"] is None:
+                rec["wait_begin_ms"] = self._ms()
             h.wait()
+            if then is not None:               # host-ordered backend: the second phase goes out once the first is done
+                then().wait()
+            rec["wait_end_ms"] = self._ms()
+            if rec["_ev_launch"] is not None:
+                rec["_ev_done"] = self._event(self.buckets[rec["bucket"]])
         self._handles = []
+
+    def timeline(self):
+        """``stats["timeline"]`` as plain numbers.  With ``profile`` on device tensors: ``gpu_launch_ms`` / ``gpu_done_ms`` =
+        when the launching stream reached the collective's launch point / had the reduced bucket available, relative to the
+        step's re-arm (synchronises the device)."""
+        out = []
+        for rec in self.stats["timeline"]:
+            r = {k: v for k, v in rec.items() if not k.startswith("_")}
+            if rec["_ev_launch"] is not None and rec["_ev_done"] is not None and self._ev0 is not None:
+                rec["_ev_done"].synchronize()
+                r["gpu_launch_ms"] = round(self._ev0.elapsed_time(rec["_ev_launch"]), 3)
+                r["gpu_done_ms"] = round(self._ev0.elapsed_time(rec["_ev_done"]), 3)
+            out.append(r)
+        return out
 
     def _rearm(self):
         self._wait()
@@ -176,15 +244,28 @@ class GradBucketReducer:
             b["pending"], b["ready"], b["launched"] = b["n"], False, False
         self._next = 0
 
-    def zero_grad(self):
-        """Drop the gradients (``set_to_none``) and re-arm the buckets."""
+    def zero_grad(self, params: Optional[Iterable[torch.nn.Parameter]] = None):
+        """Drop the gradients (``set_to_none``) and re-arm the buckets.  ``params``: drop only these (the reference's
+        ``optimizer_G.zero_grad()`` clears ``Gd`` alone, train.py:187 -- the encoders' gradients keep accumulating from
+        one generator step to the next); the others stay where they are, in the flat buffers
+        after a ``finish()``, and the next backward adds to them in place."""
         self._wait()                           # a backward that launched collectives but was never finish()ed
-        for b in self.buckets:
-            for p in b["params"]:
+        if params is None:
+            for b in self.buckets:
+                for p in b["params"]:
+                    p.grad = None
+            self._in_flat = False
+        else:
+            for p in params:
+                if id(p) not in self._bucket_of:
+                    raise ValueError("GradBucketReducer.zero_grad: parameter is not managed by this reducer")
                 p.grad = None
         self._rearm()
-        self._in_flat = False
-        self.stats = {"launched_by_hook": [], "launched_by_finish": []}
+        self.stats = self._fresh_stats()
+        self._t0 = time.perf_counter()
+        if self.profile and self._registration[0].is_cuda:
+            self._ev0 = torch.cuda.Event(enable_timing=True)
+            self._ev0.record()
 
     @contextlib.contextmanager
     def no_sync(self):
@@ -248,21 +329,31 @@ class GradBucketReducer:
     def _grads(self):
         return [p.grad for p in self.params if p.grad is not None]
 
+    def _tensors(self):
+        return [b["flat"] for b in self.buckets] if self._in_flat else self._grads()
+
+    def _partial_norms(self) -> Optional[torch.Tensor]:
+        """fp64 vector of per-tensor L2 norms (one multi-tensor launch), or None when there is no gradient at all."""
+        tensors = self._tensors()
+        return torch.stack(torch._foreach_norm(tensors)).double() if tensors else None
+
     def grad_norm(self) -> torch.Tensor:
         """Global L2 norm of the (already synchronised, hence rank-identical) gradients -- what
         ``clip_grad_norm_`` (train.py:207-208) needs; no further collective and no fp64 copy of the buckets:
         one multi-tensor norm launch, the handful of partial norms combined in fp64."""
-        tensors = [b["flat"] for b in self.buckets] if self._in_flat else self._grads()
-        if not tensors:
+        parts = self._partial_norms()
+        if parts is None:
             return torch.zeros((), device=self.params[0].device)
-        return torch.linalg.vector_norm(torch.stack(torch._foreach_norm(tensors)).double()).float()
+        return torch.linalg.vector_norm(parts).float()
+
+    def scale_(self, coef: torch.Tensor):
+        tensors = self._tensors()
+        if tensors:
+            torch._foreach_mul_(tensors, coef)
 
     def clip_(self, max_norm: float) -> torch.Tensor:
         total = self.grad_norm()
-        coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
-        tensors = [b["flat"] for b in self.buckets] if self._in_flat else self._grads()
-        if tensors:
-            torch._foreach_mul_(tensors, coef)
+        self.scale_(torch.clamp(max_norm / (total + 1e-6), max=1.0))
         return total
 
     def bytes_per_step(self) -> int:
@@ -301,6 +392,21 @@ class GradAccumulator:
         """Only after a synchronised step (gradients of unfinished groups must survive)."""
         if self._micro % self.steps == 0:
             self.reducer.zero_grad()
+
+
+def clip_grad_norm_(reducers: Sequence[GradBucketReducer], max_norm: float) -> torch.Tensor:
+    """``accelerator.clip_grad_norm_(model.parameters(), v)`` (train.py:207-208) when the model's parameters are spread over
+    several reducers (one per network: ``D`` has its own step and its own exchange): ONE global norm over all of them, one
+    coefficient, every reducer's gradients scaled in place.  Every reducer must have been ``finish()``ed since its last
+    backward -- the norm is only rank-identical over exchanged gradients."""
+    parts = [q for q in (r._partial_norms() for r in reducers) if q is not None]
+    if not parts:
+        return torch.zeros((), device=reducers[0].params[0].device)
+    total = torch.linalg.vector_norm(torch.cat(parts)).float()
+    coef = torch.clamp(max_norm / (total + 1e-6), max=1.0)
+    for r in reducers:
+        r.scale_(coef)
+    return total
 
 
 def shard_batch(global_batch: int, rank: int, world: int):

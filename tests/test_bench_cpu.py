@@ -30,6 +30,8 @@ def test_parent_launches_fresh_ranks_before_touching_the_gpu(monkeypatch):
 
     monkeypatch.setattr(bench.subprocess, "run", fake_run)
     monkeypatch.delenv("WORLD_SIZE", raising=False)
+    monkeypatch.delenv("HSA_ENABLE_IPC_MODE_LEGACY", raising=False)
+    monkeypatch.delenv("SPK_BENCH_ONE_DEVICE", raising=False)
     monkeypatch.setattr(sys, "argv", ["bench.py", "--gpus", "4", "--steps", "3", "--warmup", "1"])
     try:
         bench.main()
@@ -41,8 +43,15 @@ def test_parent_launches_fresh_ranks_before_touching_the_gpu(monkeypatch):
     assert cmd[cmd.index("--nproc-per-node") + 1] == "4" and cmd[cmd.index("--master-addr") + 1] == "127.0.0.1"
     assert os.path.samefile(cmd[cmd.index("--master-port") + 2], os.path.join(ROOT, "bench.py"))
     assert cmd[-6:] == ["--gpus", "4", "--steps", "3", "--warmup", "1"]
-    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert "HSA_ENABLE_IPC_MODE_LEGACY" not in seen["env"]        # RCCL ranks get the caller's environment, untouched
     assert not seen["cuda_initialised"]
+    # the one-device rehearsal (all ranks on GPU 0 over gloo) is the only case that sets the IPC mode itself
+    monkeypatch.setenv("SPK_BENCH_ONE_DEVICE", "1")
+    try:
+        bench.main()
+    except SystemExit as e:
+        assert e.code == 7
+    assert seen["env"]["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
 
 
 def test_rank_process_does_not_relaunch(monkeypatch):

@@ -5,6 +5,7 @@ import importlib
 import os
 import socket
 
+import pytest
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -225,3 +226,151 @@ def test_single_process_reducer_is_a_noop_exchange():
     red.zero_grad()
     assert red.bytes_per_step() == sum(p.numel() * 4 for p in model.parameters())
     assert dp.shard_batch(64, 3, 8) == (24, 32)
+
+
+# ---- the whole training iteration (train.py:150-210) through both reducers ---------------------------------------------
+class _ToyIRFD(nn.Module):
+    """The interface ``training.train_iteration`` drives -- ``model(x_s, x_t)`` -> the reference's 10-tuple, ``.D``,
+    ``.Gd`` -- at toy size, with everything that makes the data-parallel schedule delicate: train-mode BatchNorm (per-rank
+    statistics), spectral norm (buffers updated every forward), a host-RNG swap and a noise draw per forward, a head
+    (``Cm``) and an encoder that no optimizer owns."""
+
+    def __init__(self):
+        super().__init__()
+        sn = nn.utils.spectral_norm
+        self.E = nn.Sequential(nn.Conv2d(3, 8, 3, padding=1), nn.BatchNorm2d(8), nn.ReLU(), nn.AdaptiveAvgPool2d(1), nn.Flatten())
+        self.Gd = nn.Sequential(nn.Linear(8, 32), nn.Tanh(), nn.Linear(32, 3 * 8 * 8))
+        self.D = nn.Sequential(sn(nn.Conv2d(3, 6, 3, stride=2, padding=1)), nn.LeakyReLU(0.2), nn.Flatten(), sn(nn.Linear(6 * 16, 1)))
+        self.Cm = nn.Linear(8, 8)
+
+    def forward(self, x_s, x_t):
+        f_s, f_t = self.E(x_s), self.E(x_t)
+        if int(torch.randint(0, 3, (1,))) == 0:                 # the swap of model.py:98-104, host RNG
+            f_s, f_t = f_t, f_s
+        r_s = self.Gd(f_s + 0.01 * torch.randn_like(f_s)).view(-1, 3, 8, 8)
+        r_t = self.Gd(f_t + 0.01 * torch.randn_like(f_t)).view(-1, 3, 8, 8)
+        return (r_s, r_t, f_s, f_s, f_s, f_t, f_t, f_t, torch.softmax(self.Cm(f_s), 1), torch.softmax(self.Cm(f_t), 1))
+
+
+_IT_KW = dict(G_steps=2, r1_weight=1.0, stylegan_loss_weight=0.1, grad_clip_value=0.05)     # small clip value: the clip is active
+_IT_STEPS = (0, 1, 2)
+
+
+def _toy_shard(rank, B=4):
+    g = torch.Generator().manual_seed(10 + rank)
+    return {"source_image": torch.rand(B, 3, 8, 8, generator=g) * 2 - 1, "target_image": torch.rand(B, 3, 8, 8, generator=g) * 2 - 1,
+            "emotion_labels_s": torch.randint(0, 8, (B,), generator=g), "emotion_labels_t": torch.randint(0, 8, (B,), generator=g)}
+
+
+def _toy_optimizers(model):
+    return (torch.optim.Adam(model.Gd.parameters(), lr=1e-2, betas=(0.5, 0.999)),
+            torch.optim.Adam(model.D.parameters(), lr=1e-2, betas=(0.5, 0.999)))
+
+
+def _iteration_worker(rank, world, port, tmp, algo):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    T = importlib.import_module("speak-hack_amd.training")
+    torch.manual_seed(77 + rank)                               # replicas seeded differently: make_reducers broadcasts rank 0
+    model = _ToyIRFD().train()
+    red_G, red_D = T.make_reducers(model, bucket_bytes=2048, algo=algo)
+    assert len(red_G.buckets) >= 2
+    if rank == 0:
+        torch.save(model.state_dict(), os.path.join(tmp, "init.pt"))
+    opt_G, opt_D = _toy_optimizers(model)
+    torch.manual_seed(1000 + rank)                             # this rank's RNG stream from here on
+    shard, log = _toy_shard(rank), []
+    for step in _IT_STEPS:
+        out = T.train_iteration(model, shard, opt_G, opt_D, step, reducer_G=red_G, reducer_D=red_D, **_IT_KW)
+        log.append({k: None if v is None else float(v) for k, v in out.items()})
+    torch.save({"params": {k: v.detach().clone() for k, v in model.named_parameters()},
+                "buffers": {k: v.detach().clone() for k, v in model.named_buffers()},
+                "grads": {k: None if v.grad is None else v.grad.detach().clone() for k, v in model.named_parameters()},
+                "log": log, "timeline_D": red_D.timeline(), "timeline_G": red_G.timeline()}, os.path.join(tmp, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("algo", ["all_reduce", "rs_ag"])
+def test_train_iteration_two_ranks_equals_the_single_process_iteration(tmp_path, algo):
+    """training.train_iteration with both reducers (train.py:150-210 under data parallelism) on 2 ranks: the replicas end
+    rank-identical, and equal to ONE process stepping on the mean of the two shards' gradients (tests/dp_emulation.py) --
+    through three iterations with two generator steps, so that the never-zeroed encoder / Cm gradients, the local
+    contribution of loss_G to D's gradients and the global-norm clip over both reducers are all exercised."""
+    from dp_emulation import emulate
+    world = 2
+    mp.spawn(_iteration_worker, args=(world, _free_port(), str(tmp_path), algo), nprocs=world, join=True)
+    r0 = torch.load(os.path.join(tmp_path, "rank0.pt"))
+    r1 = torch.load(os.path.join(tmp_path, "rank1.pt"))
+    for k in r0["params"]:
+        assert torch.equal(r0["params"][k], r1["params"][k]), k                        # replicas stay identical
+        g0, g1 = r0["grads"][k], r1["grads"][k]
+        assert (g0 is None) == (g1 is None) and (g0 is None or torch.equal(g0, g1)), k     # and so do all gradients, D's included
+    assert any(not torch.equal(r0["buffers"][k], r1["buffers"][k]) for k in r0["buffers"] if "running" in k)   # BatchNorm: per rank
+    for k in r0["buffers"]:
+        if k.endswith(("weight_u", "weight_v")):
+            assert torch.equal(r0["buffers"][k], r1["buffers"][k]), k                  # spectral norm: function of the weights only
+    model = _ToyIRFD().train()
+    model.load_state_dict(torch.load(os.path.join(tmp_path, "init.pt")))
+    opt_G, opt_D = _toy_optimizers(model)
+    log, states = emulate(model, [_toy_shard(0), _toy_shard(1)], opt_G, opt_D, _IT_STEPS, seeds=(1000, 1001), **_IT_KW)
+    for it, rec in enumerate(log):
+        for r, rr in enumerate((r0, r1)):
+            assert abs(rec["loss_D"][r] - rr["log"][it]["loss_D"]) <= 1e-5 * max(1.0, abs(rec["loss_D"][r])), (it, r)
+            if rr["log"][it]["loss_G"] is not None:
+                assert abs(rec["loss_G"][r] - rr["log"][it]["loss_G"]) <= 1e-5 * max(1.0, abs(rec["loss_G"][r])), (it, r)
+    assert [x["loss_G"] is not None for x in r0["log"]] == [True, False, True]
+    for k, p in model.named_parameters():
+        assert torch.allclose(p, r0["params"][k], rtol=1e-4, atol=1e-5), (k, float((p - r0["params"][k]).abs().max()))
+        if p.grad is not None:
+            assert torch.allclose(p.grad, r0["grads"][k], rtol=1e-4, atol=1e-6), (k, float((p.grad - r0["grads"][k]).abs().max()))
+    for r, rr in enumerate((r0, r1)):                                                   # each rank's own BatchNorm statistics too
+        for k, v in states.buffers[r].items():
+            assert torch.allclose(v, rr["buffers"][k], rtol=1e-4, atol=1e-6), (r, k)
+    # the timeline: every launched bucket with its bytes and host times of launch / wait entry / wait return
+    tl = r0["timeline_G"]
+    assert tl and all(t["wait_end_ms"] >= t["wait_begin_ms"] >= t["launch_ms"] >= 0 and t["bytes"] > 0 for t in tl)
+    assert [t["bucket"] for t in tl] == sorted(t["bucket"] for t in tl)
+
+
+def _rs_ag_worker(rank, world, port, tmp):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    dp = importlib.import_module("speak-hack_amd.dp")
+    out = {}
+    for algo in ("all_reduce", "rs_ag"):
+        model = _toy()
+        odd = nn.Parameter(torch.ones(7))                      # bucket sizes that are not multiples of the world size
+        params = list(model.parameters()) + [odd]
+        red = dp.GradBucketReducer(params, bucket_bytes=4096 + 4, algo=algo)
+        g = torch.Generator().manual_seed(100)
+        x_all, y_all = torch.randn(9, 12, generator=g), torch.randn(9, 3, generator=g)
+        lo, hi = rank * 3, rank * 3 + 3
+        for step in range(2):
+            red.zero_grad()
+            (((model(x_all[lo:hi]) - y_all[lo:hi]) ** 2).mean() + (odd * (rank + 1.0)).sum()).backward()
+            red.finish()
+        out[algo] = [p.grad.clone() for p in params]
+        out[algo + "_norm"] = red.grad_norm()
+        if algo == "rs_ag":
+            assert all(b["flat"].numel() % world == 0 and b["shard"].numel() * world == b["flat"].numel() for b in red.buckets)
+            assert any(b["flat"].numel() != b["numel"] for b in red.buckets)           # padding was actually needed somewhere
+        red.remove()
+    torch.save(out, os.path.join(tmp, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_reduce_scatter_all_gather_equals_all_reduce(tmp_path):
+    """GradBucketReducer(algo="rs_ag") -- reduce_scatter_tensor + all_gather_into_tensor on the world-padded buckets, the
+    exchange SURVEY.md 5 asks for on xGMI -- leaves the same gradients as the all-reduce, on 3 ranks (odd sizes)."""
+    world = 3
+    mp.spawn(_rs_ag_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    rs = [torch.load(os.path.join(tmp_path, f"rank{r}.pt")) for r in range(world)]
+    for a, b in zip(rs[0]["all_reduce"], rs[0]["rs_ag"]):
+        assert torch.allclose(a, b, rtol=1e-6, atol=1e-7)
+    for r in rs[1:]:
+        for a, b in zip(rs[0]["rs_ag"], r["rs_ag"]):
+            assert torch.equal(a, b)                                                   # rank-identical
+    assert torch.allclose(rs[0]["all_reduce_norm"], rs[0]["rs_ag_norm"], rtol=1e-6)
+    assert torch.allclose(rs[0]["rs_ag"][-1], torch.full((7,), 2.0))                   # mean of 1, 2, 3

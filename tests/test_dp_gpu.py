@@ -95,3 +95,67 @@ def test_generator_step_with_gradient_accumulation_two_ranks(tmp_path):
     _check_exchange(r0, r1, never_reached=("Cm.",))
     s1 = r0["steps"][1]
     assert s1["by_hook"] == list(range(s1["n_buckets"] - 1)) and s1["by_finish"] == [s1["n_buckets"] - 1]
+
+
+@pytest.mark.parametrize("algo", ["all_reduce", "rs_ag"])
+def test_training_iteration_two_ranks_equals_the_single_process_iteration(tmp_path, algo):
+    """``training.train_iteration(..., reducer_G, reducer_D)`` -- the reference's whole iteration (train.py:150-210) under
+    data parallelism -- on two ranks of the REAL model on the HIP path: three iterations (D, G | D | D, G).  The replicas
+    end bit-identical (parameters AND every gradient, D's included: the global-norm clip of train.py:208 runs over both
+    reducers' exchanged buffers), and equal ONE process stepping on the mean of the two shards' gradients, with each rank's
+    own RNG streams and BatchNorm buffers played back (tests/dp_emulation.py)."""
+    import importlib
+    from dp_emulation import emulate
+    sys.path.insert(0, os.path.join(ROOT, "tests", "workers"))
+    W = importlib.import_module("dp_iteration_worker")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "workers", "dp_iteration_worker.py"), "--out", str(tmp_path),
+           "--backend", "gloo", "--one-device", "--batch", "2", "--algo", algo]
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", OMP_NUM_THREADS="4")
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout[-3000:], r.stderr[-3000:])
+    r0, r1 = (torch.load(tmp_path / f"rank{i}.pt", weights_only=False) for i in (0, 1))
+    for k in r0["params"]:
+        assert torch.equal(r0["params"][k], r1["params"][k]), k
+        g0, g1 = r0["grads"][k], r1["grads"][k]
+        assert (g0 is None) == (g1 is None) and (g0 is None or torch.equal(g0, g1)), k
+    assert [x["loss_G"] is not None for x in r0["log"]] == [True, False, True]
+    assert r0["log"][0]["loss_D"] != r1["log"][0]["loss_D"]                      # different shards, different draws
+    assert any(not torch.equal(r0["buffers"][k], r1["buffers"][k]) for k in r0["buffers"] if k.endswith("running_mean"))
+    for k in r0["buffers"]:
+        if k.endswith(("weight_u", "weight_v")):
+            assert torch.equal(r0["buffers"][k], r1["buffers"][k]), k
+    # ---- the same three iterations in ONE process on the mean of the shards' gradients ----
+    import model as M
+    dev = torch.device("cuda:0")
+    net = M.IRFD().to(dev).train()
+    net.load_state_dict(torch.load(tmp_path / "init.pt", map_location=dev))
+    init = {k: v.detach().clone() for k, v in net.named_parameters()}
+    opt_G, opt_D = W.optimizers(net)
+    shards = [W.shard(r, 2, dev) for r in (0, 1)]
+    log, states = emulate(net, shards, opt_G, opt_D, W.STEPS, seeds=(W.SEED0, W.SEED0 + 1), device=dev, **W.KW)
+    for it, rec in enumerate(log):
+        for r, rr in enumerate((r0, r1)):
+            assert abs(rec["loss_D"][r] - rr["log"][it]["loss_D"]) <= 2e-4 * max(1.0, abs(rec["loss_D"][r])), (it, r, rec, rr["log"][it])
+            if rr["log"][it]["loss_G"] is not None:
+                assert abs(rec["loss_G"][r] - rr["log"][it]["loss_G"]) <= 2e-4 * max(1.0, abs(rec["loss_G"][r])), (it, r, rec, rr["log"][it])
+    # gradients as they stand after the last iteration (encoders / Cm: accumulated over both G steps and clipped twice; Gd:
+    # the last G step's; D: the last D step's mean plus the mean of the G step's contribution, clipped)
+    worst = ("", 0.0)
+    for k, p in net.named_parameters():
+        g = r0["grads"][k]
+        assert (p.grad is None) == (g is None), k
+        if g is not None and float(g.norm()) > 0:
+            e = rel_l2(p.grad.cpu(), g)
+            worst = max(worst, (k, e), key=lambda t: t[1])
+    assert worst[1] < 2e-3, worst
+    # the Adam updates: compare what the steps did to each stepped tensor (delta from the initial weights)
+    for k, p in net.named_parameters():
+        if k.startswith(("Gd.", "D.")):
+            d_ref, d_got = (p.detach() - init[k]).cpu(), r0["params"][k] - init[k].cpu()
+            if float(d_ref.norm()) > 0:
+                assert rel_l2(d_got, d_ref) < 2e-2, (k, rel_l2(d_got, d_ref))
+        else:
+            assert torch.equal(p.detach().cpu(), r0["params"][k]), k                # encoders / Cm: never stepped (train.py:346-347)
+    tl = r0["timeline_G"] + r0["timeline_D"]
+    assert tl and all(t["wait_end_ms"] >= t["wait_begin_ms"] >= t["launch_ms"] >= 0 for t in tl)
