@@ -29,6 +29,14 @@ training iteration -- summing parameter gradients over ranks -- is done here:
   bound by one link.  Same sums, same bucket order, same hooks; on a stream-ordered backend (RCCL) both
   phases are queued from the hook, on a host-ordered one (gloo) the all-gather is issued when the reduce-scatter is
   waited for.  ``all_reduce`` stays the default: RCCL's own all-reduce already picks multi-ring / direct algorithms.
+* transport.  RCCL ("nccl") reduces device buffers in place on its own stream.  Any other backend on device tensors (gloo: the
+  one-GPU rehearsal of the multi-rank path, tests/test_dp_gpu.py) goes through pinned host buffers that THIS class stages
+  (``transport="host"``): the bucket is copied device -> host on a normal-priority copy stream right from the hook, the
+  collective runs on the host copies when the bucket is waited for, the result goes back on the same stream.  torch's gloo
+  backend can take device tensors itself, but it parks a HIGH-priority stream on an event of the launching stream; on this
+  part a waiting high-priority queue starves the process's own normal-priority queues, and a step whose kernels take 45 ms
+  ran for 2.5-10 s (profiles/r04_a_*: the per-bucket timeline shows the launching stream reaching a collective's launch point
+  seconds after the host queued it, and the collective itself done 10-25 ms later).
 * ``stats["timeline"]``: per launched bucket its bytes, who launched it (hook / finish) and host times of launch, wait
   entry and wait return relative to the step's re-arm; with ``profile = True`` on device tensors also stream events at
   the same three points (``timeline()`` resolves them), so an exchange that costs more than its bytes can be read off.
@@ -61,9 +69,12 @@ import torch.distributed as dist
 class GradBucketReducer:
     def __init__(self, params: Iterable[torch.nn.Parameter], bucket_bytes: int = 32 << 20,
                  process_group: Optional[dist.ProcessGroup] = None, average: bool = True,
-                 broadcast_parameters: bool = True, rebuild_after_first_step: bool = True, algo: str = "all_reduce"):
+                 broadcast_parameters: bool = True, rebuild_after_first_step: bool = True, algo: str = "all_reduce",
+                 transport: str = "auto"):
         if algo not in ("all_reduce", "rs_ag"):
             raise ValueError(f"GradBucketReducer: algo must be 'all_reduce' or 'rs_ag', not {algo!r}")
+        if transport not in ("auto", "device", "host"):
+            raise ValueError(f"GradBucketReducer: transport must be 'auto', 'device' or 'host', not {transport!r}")
         self.group = process_group
         self.world = dist.get_world_size(process_group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(process_group) if dist.is_initialized() else 0
@@ -73,6 +84,7 @@ class GradBucketReducer:
         self._stream_ordered = dist.is_initialized() and dist.get_backend(process_group) == "nccl"
         self.profile = False
         self.average = average
+        self._transport_arg, self._copy_stream = transport, None
         self.bucket_bytes = int(bucket_bytes)
         plist = [p for p in params if p.requires_grad]
         if not plist:
@@ -81,6 +93,9 @@ class GradBucketReducer:
         for p in plist:
             if p.device != dev or p.dtype != dtype:
                 raise ValueError("GradBucketReducer: parameters must share device and dtype")
+        self.staged = self.world > 1 and dev.type == "cuda" and (transport == "host" or (transport == "auto" and not self._stream_ordered))
+        if self.staged:
+            self._copy_stream = torch.cuda.Stream(dev)     # normal priority, ours
         self._registration = plist                         # index space of the recorded / broadcast order
         self._index = {id(p): i for i, p in enumerate(plist)}
         self.params = list(reversed(plist))                # ~ the order autograd finishes them (refined after step 1)
@@ -135,12 +150,14 @@ class GradBucketReducer:
             padded = total + (-total) % self.world if self.algo == "rs_ag" else total
             flat = torch.zeros(padded, device=dev, dtype=dtype)
             if self.algo == "rs_ag":           # this rank's 1/world slice of the sums, between the two phases
-                shard = torch.zeros(padded // self.world, device=dev, dtype=dtype)
+                shard = torch.zeros(padded // self.world, device=dev if not self.staged else "cpu", dtype=dtype,
+                                    pin_memory=self.staged)
             views, off = [], 0
             for p in plist:
                 views.append(flat[off:off + p.numel()].view_as(p))
                 off += p.numel()
-        self.buckets.append({"params": plist, "flat": flat, "views": views, "shard": shard, "numel": total, "pending": len(plist),
+        host = torch.empty(flat.numel(), dtype=dtype, pin_memory=True) if (self.staged and flat is not None) else None
+        self.buckets.append({"params": plist, "flat": flat, "views": views, "shard": shard, "host": host, "numel": total, "pending": len(plist),
                              "n": len(plist), "ready": False, "launched": False, "cold": cold})
 
     # ---- backward-time protocol ----------------------------------------------------------------
@@ -199,16 +216,34 @@ class GradBucketReducer:
                 p.grad = v                     # the optimizer reads the reduced values in place
             if self.average:
                 b["flat"].div_(self.world)
+        if self.staged:                        # device -> pinned host now, behind the gradients; the collective at wait time
+            cs = self._copy_stream
+            cs.wait_stream(torch.cuda.current_stream(b["flat"].device))
+            with torch.cuda.stream(cs):
+                b["host"].copy_(b["flat"], non_blocking=True)
+                copied = torch.cuda.Event()
+                copied.record(cs)
+            self._handles.append((_StagedWork(self, b, copied), rec, None))
+            return
+        buf = b["flat"]
         if self.algo == "rs_ag":
-            h = dist.reduce_scatter_tensor(b["shard"], b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-            gather = lambda: dist.all_gather_into_tensor(b["flat"], b["shard"], group=self.group, async_op=True)
+            h = dist.reduce_scatter_tensor(b["shard"], buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            gather = lambda: dist.all_gather_into_tensor(buf, b["shard"], group=self.group, async_op=True)
             if self._stream_ordered:
                 self._handles.append((h, rec, None))
                 self._handles.append((gather(), rec, None))
             else:
                 self._handles.append((h, rec, gather))
         else:
-            self._handles.append((dist.all_reduce(b["flat"], op=dist.ReduceOp.SUM, group=self.group, async_op=True), rec, None))
+            self._handles.append((dist.all_reduce(buf, op=dist.ReduceOp.SUM, group=self.group, async_op=True), rec, None))
+
+    def _host_exchange(self, b):
+        """The bucket's collective on its pinned host copy (blocking: a host-ordered backend)."""
+        if self.algo == "rs_ag":
+            dist.reduce_scatter_tensor(b["shard"], b["host"], op=dist.ReduceOp.SUM, group=self.group)
+            dist.all_gather_into_tensor(b["host"], b["shard"], group=self.group)
+        else:
+            dist.all_reduce(b["host"], op=dist.ReduceOp.SUM, group=self.group)
 
     # ---- step protocol -------------------------------------------------------------------------
     def _wait(self):
@@ -363,6 +398,22 @@ class GradBucketReducer:
         for h in self._hooks:
             h.remove()
         self._hooks = []
+
+
+class _StagedWork:
+    """A bucket on its way through the host (``GradBucketReducer.staged``): ``wait()`` = the copy has landed, the collective
+    runs on the host buffer, the result is queued back to the device and the current stream waits for it."""
+
+    def __init__(self, reducer, bucket, copied):
+        self.reducer, self.bucket, self.copied = reducer, bucket, copied
+
+    def wait(self):
+        r, b = self.reducer, self.bucket
+        self.copied.synchronize()
+        r._host_exchange(b)
+        with torch.cuda.stream(r._copy_stream):
+            b["flat"].copy_(b["host"], non_blocking=True)
+        torch.cuda.current_stream(b["flat"].device).wait_stream(r._copy_stream)
 
 
 class GradAccumulator:
