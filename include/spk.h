@@ -62,6 +62,14 @@ extern "C" {
                                   * exact-f32 matrix rate at ~3e-5 rel-L2 through the whole decoder (csrc/conv3x3_bf16x3.hip).
                                   * w_packed from spk_conv2d_pack_weights_bf16x3; flags: BIAS / NOISE / LRELU / STYLE /
                                   * UPSAMPLE2X (+ UP_FIR1331) / IN_BATCH_SCALE (+ out_scale_bc), y_pre; config / ksplit ignored. */
+#define SPK_CONV_WINOGRAD 16384u  /* 3x3 stride-1 pad-1 convs as Winograd F(2x2, 3x3) on the f32 MFMA pipe (csrc/conv3x3_wino_f32.hip): fp32
+                                  * operands, products and accumulation, 16 multiplies per 2x2 output tile where the direct form
+                                  * spends 36 -- the algorithm the reference's own backend (MIOpen under PyTorch-ROCm) runs for an
+                                  * fp32 3x3 nn.Conv2d (styleganv1.py:615-616,625,630,662-672).  Differs from the direct form in
+                                  * summation order and the +-1 / 0.5 transforms only (1e-6-class rel-L2 per layer).  Plain input
+                                  * (no UPSAMPLE2X / IN_AFFINE_RELU / IN_BATCH_SCALE), ungrouped, H % 8 == 0, W % 32 == 0,
+                                  * Cin % 8 == 0; flags BIAS / NOISE / LRELU / STYLE / ACCUM, y_pre, out_scale(_dev).
+                                  * w_packed from spk_conv2d_pack_weights_wino; config / ksplit ignored. */
 #define SPK_EPI_ACCUM_HALF 8192u     /* y += accum_half at the EVEN pixels: accum_half is [B, groups*Cout, ceil(H/2), ceil(W/2)], element
                                       * (h, w) is added to y(2h, 2w) -- the data gradient of a stride-2 1x1 conv (the
                                       * trunk's downsample.0, model.py:60-62 via torchvision Bottleneck) joins the block input's
@@ -192,6 +200,16 @@ int spk_conv2d_pack_weights_bf16x3(const float* w, void* w_packed, int Cin, int 
 int spk_conv2d_pack_weights_bf16x3_tf(const float* w, void* w_packed, int Cin, int Cout, int transpose_flip, void* stream);
 int spk_conv2d_bf16x3_supported(int B, int Cin, int Cout, int H, int W);
 int spk_conv2d_bf16x3_fwd(const spk_conv2d_desc* desc, void* stream);
+
+/* The SPK_CONV_WINOGRAD path: size in BYTES of the transformed weight image U = G g G^T / the packer (w is the fp32
+ * [Cout,Cin,3,3] parameter; transpose_flip = 1: the data-gradient operator w'[ci][co][ky][kx] = w[co][ci][2-ky][2-kx], whose
+ * image has spk_conv2d_packed_bytes_wino(Cout, Cin) bytes and is run with Cin / Cout exchanged) / whether a shape is served /
+ * the launch itself (spk_conv2d_fwd forwards to it).  replaces: the F.conv2d of styleganv1.py:625,630 (SynthesisBlock conv1 / conv2
+ * after the separate x2 upsampling), styleganv1.py:662 (DiscriminatorBlock conv1) and their data gradients. */
+int64_t spk_conv2d_packed_bytes_wino(int Cin, int Cout);
+int spk_conv2d_pack_weights_wino(const float* w, float* w_packed, int Cin, int Cout, int transpose_flip, void* stream);
+int spk_conv2d_wino_supported(int B, int Cin, int Cout, int H, int W);
+int spk_conv2d_wino_fwd(const spk_conv2d_desc* desc, void* stream);
 
 /* ---- backward of the convolution ---------------------------------------------------------------------
  * Data gradient: spk_conv2d_fwd itself on the output gradient with weights packed transpose_flip = 1

@@ -42,6 +42,7 @@ CONV_DGRAD_S2 = 1024
 CONV_TRANSPOSE4X4_S2 = 2048
 CONV_BF16X3 = 4096
 EPI_ACCUM_HALF = 8192
+CONV_WINOGRAD = 16384
 
 
 FC_MAX_GROUPS = 16
@@ -207,6 +208,10 @@ _PROTOTYPES = {
     "spk_conv2d_pack_weights_bf16x3_tf": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
     "spk_conv2d_bf16x3_supported": (C.c_int, [C.c_int] * 5),
     "spk_conv2d_bf16x3_fwd": (C.c_int, [C.POINTER(Conv2dDesc), C.c_void_p]),
+    "spk_conv2d_packed_bytes_wino": (C.c_int64, [C.c_int, C.c_int]),
+    "spk_conv2d_pack_weights_wino": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "spk_conv2d_wino_supported": (C.c_int, [C.c_int] * 5),
+    "spk_conv2d_wino_fwd": (C.c_int, [C.POINTER(Conv2dDesc), C.c_void_p]),
     "spk_conv2d_stats_slots": (C.c_int, [C.c_int] * 9),
     "spk_bn_finalize": (C.c_int, [C.c_void_p, C.c_int, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_float,
                                   C.c_float, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]),

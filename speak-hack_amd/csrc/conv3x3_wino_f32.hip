@@ -1,0 +1,394 @@
+// 3x3 stride-1 pad-1 convolution as Winograd F(2x2, 3x3) on the gfx950 f32 MFMA pipe -- fp32 operands, fp32 products, fp32
+// accumulation, 16 multiplies per 2x2 output tile and (ci, co) pair where the direct form spends 36: 2.25x fewer matrix
+// instructions for the same convolution.  This is what the reference's own backend does for these layers (PyTorch hands an
+// fp32 3x3 nn.Conv2d -- styleganv1.py:615-616,625,630; the discriminator's conv1 of every block, styleganv1.py:662-672 -- to
+// MIOpen, whose fp32 3x3 solvers are Winograd kernels); the arithmetic differs from the direct form only in summation order
+// and in the +-1, 1/2 transforms: 1e-6-class rel-L2 per layer, asserted in tests/test_wino_gpu.py (bound of the path: 1e-3).
+//
+//   Y = A^T [ (G g G^T) (.) (B^T d B) ] A      per 2x2 output tile, per (co, ci);  d = the 4x4 input patch of the tile
+//     U[xi][co][ci] = G g G^T     -- weights, transformed at PACK time (spk_conv2d_pack_weights_wino), xi = 4 i + j in 0..15
+//     V[xi][ci][t]  = B^T d B     -- input patches, transformed while staging (32 adds per patch)
+//     M[xi][co][t]  = sum_ci U[xi][co][ci] V[xi][ci][t]   -- SIXTEEN independent GEMMs: v_mfma_f32_32x32x2_f32, A = U, B = V
+//     Y = A^T M A                 -- 24 adds per (co, tile), lane-local: the 16 M[xi] of a (co, tile) sit in the same
+//                                    accumulator position of 16 accumulator tiles
+//
+// Block = 64 co x 64 tiles (16 x 4 tiles = 32 x 8 output pixels), 4 waves (2 x 2: 32 co x 32 tiles each), ci chunks of 8.
+// A wave holds 16 accumulator tiles = 256 registers: ONE wave per SIMD, one workgroup per CU, so the wave hides its own
+// latencies (the weight-gradient kernels' situation): everything that feeds chunk i + 1 is interleaved, one piece behind one
+// MFMA, with the 64 MFMAs of chunk i.
+//   * U: LDS-DMA (global_load_lds_dwordx4) of the chunk's contiguous 32 KB packed block, one chunk ahead, 2 slots;
+//   * raw input: `buffer_load_dword ... lds` gathers -- a lane fetches any address, the wave's 64 dwords land consecutively in
+//     LDS; addresses outside the image are out of range of the buffer descriptor and return 0, which IS the zero padding: no
+//     select, no mask, no vector instruction.  Wave w stages the planes of channels w and w + 4 for itself (10 x 34 floats
+//     each, two chunks ahead, 2 slots) and transforms them: no other wave reads its raw tile;
+//   * V: wave w transforms its two planes for all 64 tiles (a lane = a tile: 8 ds_read_b64 + 32 adds + 16 ds_write_b32 per
+//     plane), 2 slots;  one barrier per chunk.
+// LDS: 2 x 32 KB (U) + 2 x 32 KB (V) + 2 x 11 KB (raw) = 150 KB.  Vector instructions per chunk of 64 MFMAs: 64 adds.
+// Epilogue: output transform in registers, the 64 x 256 block through LDS, then the f32 kernel's staged epilogue element for
+// element (out_scale, bias, noise, LeakyReLU, [y_pre], style, [accumulate]; 16-byte stores).
+#include "conv_mfma_f32.hpp"
+
+namespace spkwino {
+
+using spkconv::f32x16;
+using spkconv::lds_f32_t;
+using spkconv::static_for;
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) f32x2 lds_f32x2_t;
+
+constexpr int CO_T = 64, CI_T = 8, RW = 32, RH = 8, TXN = RW / 2, TYN = RH / 2, NTILE = TXN * TYN, NT = 256;
+constexpr int RAW_W = RW + 2, RAW_H = RH + 2, RAW_USED = RAW_W * RAW_H;     // 34 x 10 = 340 floats of a plane
+constexpr int RAW_PLANE = 352, RAW_WAVE = 2 * RAW_PLANE;                    // 704 = 11 x 64: a wave's two planes = 11 gathers
+constexpr int RAW_GATHERS = RAW_WAVE / 64;
+constexpr int U_FLOATS = 16 * CI_T * CO_T, V_FLOATS = 16 * CI_T * NTILE, RAW_FLOATS = 4 * RAW_WAVE;
+constexpr int U_OFF = 0, V_OFF = 2 * U_FLOATS, RAW_OFF = V_OFF + 2 * V_FLOATS;
+constexpr int LDS_FLOATS = RAW_OFF + 2 * RAW_FLOATS;
+constexpr int LDS_BYTES = LDS_FLOATS * 4;                                    // 153 600
+constexpr int OP = RW * RH + 4;                                              // pitch of the epilogue's output block
+static_assert(NTILE == 64 && RAW_GATHERS == 11 && RAW_USED <= RAW_PLANE, "geometry");
+static_assert(CO_T * OP <= LDS_FLOATS, "the epilogue block reuses the ring");
+constexpr int U_DMA = U_FLOATS * 4 / 1024 / 4;                               // 1 KB blocks per wave and chunk (8)
+
+struct Args {
+    const float* x;
+    const float* wp;
+    const float* bias;
+    const float* noise_w;
+    const float* noise;
+    const float* style;
+    float* y;
+    float* y_pre;
+    const float* out_scale_dev;
+    int B, Cin, Cout, H, W;
+    int regions_x, regions_y;
+    int n_chunks;
+    int style_stride;
+    unsigned flags;
+    unsigned x_bytes;
+    float slope, out_scale, act_gain;
+};
+
+// ---- weights: U = G g G^T, image [co tile 64][chunk 8][xi 16][ci 8][co 64] (zero padded), one 32 KB block per (co tile, chunk) ----
+__global__ void pack_wino_kernel(const float* __restrict__ w, float* __restrict__ out, int Cin, int Cout, int opCin, int opCout,
+                                 int transpose_flip, int n_chunks, long long total) {
+    const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int co_l = (int)(idx % CO_T);
+    long long r = idx / CO_T;
+    const int ci_l = (int)(r % CI_T);
+    r /= CI_T;
+    const int xi = (int)(r % 16);
+    r /= 16;
+    const int chunk = (int)(r % n_chunks), co_tile = (int)(r / n_chunks);
+    const int co = co_tile * CO_T + co_l, ci = chunk * CI_T + ci_l;
+    float v = 0.f;
+    if (co < opCout && ci < opCin) {
+        float g[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b)
+                // transpose_flip: the data-gradient operator, w'[co][ci][a][b] = w[ci][co][2-a][2-b] (co indexes the forward conv's Cin)
+                g[a][b] = transpose_flip ? w[(((size_t)ci * Cin + co) * 3 + (2 - a)) * 3 + (2 - b)] : w[(((size_t)co * Cin + ci) * 3 + a) * 3 + b];
+        const int i = xi >> 2, j = xi & 3;
+        // rows of G: [1,0,0], [.5,.5,.5], [.5,-.5,.5], [0,0,1]
+        float t[3];   // (G g)[i][b]
+#pragma unroll
+        for (int b = 0; b < 3; ++b)
+            t[b] = i == 0 ? g[0][b] : (i == 3 ? g[2][b] : 0.5f * ((g[0][b] + g[2][b]) + (i == 1 ? g[1][b] : -g[1][b])));
+        v = j == 0 ? t[0] : (j == 3 ? t[2] : 0.5f * ((t[0] + t[2]) + (j == 1 ? t[1] : -t[1])));
+    }
+    out[idx] = v;
+}
+
+__global__ __launch_bounds__(NT) void wino_kernel(const Args p) {
+    extern __shared__ __attribute__((aligned(16))) float smem[];
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int half = lane >> 5, l32 = lane & 31;
+    const int wm = wave >> 1, wn = wave & 1;
+
+    // XCD-aware region order (as the f32 kernel): every XCD walks one contiguous run of regions
+    int bx;
+    {
+        const int n = (int)gridDim.x, q = n >> 3, r = n & 7;
+        const int xcd = (int)blockIdx.x & 7, k = (int)blockIdx.x >> 3;
+        bx = xcd * q + min(xcd, r) + k;
+    }
+    const int rx = bx % p.regions_x;
+    bx /= p.regions_x;
+    const int ry = bx % p.regions_y, b = bx / p.regions_y;
+    const int y0 = ry * RH, x0 = rx * RW;
+    const int co_tile = blockIdx.y, co0 = co_tile * CO_T;
+    const size_t HW = (size_t)p.H * p.W;
+
+    // ---- the raw gathers: byte offsets of this lane's 11 elements (plane j of channel wave + 4 j), or out of range ----
+    const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
+    unsigned voff[RAW_GATHERS];
+#pragma unroll
+    for (int k = 0; k < RAW_GATHERS; ++k) {
+        const int e = k * 64 + lane;
+        const int j = e >= RAW_PLANE ? 1 : 0, q = e - j * RAW_PLANE;
+        const int r = q / RAW_W, c = q - r * RAW_W;
+        const int yy = y0 - 1 + r, xx = x0 - 1 + c;
+        const bool ok = q < RAW_USED && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+        voff[k] = ok ? (unsigned)((((size_t)b * p.Cin + wave + 4 * j) * HW + (size_t)yy * p.W + xx) * 4) : 0x80000000u;
+    }
+    const unsigned chunk_bytes = (unsigned)(CI_T * HW * 4);
+    const float* wsrc = p.wp + (size_t)co_tile * p.n_chunks * U_FLOATS;
+
+    // LDS-DMA as inline assembly: the compiler treats a pending `... lds` load as a flat access that may complete out of order
+    // with the ds_reads and answers with s_waitcnt lgkmcnt(0) in front of EVERY fragment use until the next vmcnt(0) -- with one
+    // wave per SIMD that is an LDS round trip per four MFMAs.  Issued behind its back, the fragment reads keep their counted
+    // waits (lgkmcnt(6)); completion is this kernel's business: s_waitcnt vmcnt(0) before the chunk barrier.  (LDS base = 0:
+    // the kernel has no static LDS.)
+#define WINO_DMA_RAW(chunk_, slot_, k_)                                                                                 \
+    {   /* (operands through locals: an asm operand inside a lambda does not capture) */                                \
+        const unsigned m0_ = (unsigned)((RAW_OFF + (slot_) * RAW_FLOATS + (k_) * 64) * 4) + raw_m0, vo_ = voff[k_];     \
+        const unsigned so_ = (unsigned)(chunk_) * chunk_bytes;                                                          \
+        const __amdgpu_buffer_rsrc_t rs_ = rsrc;                                                                        \
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" :: "s"(m0_), "v"(vo_), "s"(rs_), "s"(so_)); \
+    }
+#define WINO_DMA_U(chunk_, slot_, k_)                                                                                   \
+    {                                                                                                                   \
+        const unsigned m0_ = (unsigned)((U_OFF + (slot_) * U_FLOATS) * 4 + (k_) * 1024) + u_m0, vo_ = lane16;           \
+        const float* sb_ = wsrc + (size_t)(chunk_) * U_FLOATS + (wave * U_DMA + (k_)) * 256;                            \
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2" :: "s"(m0_), "v"(vo_), "s"(sb_));   \
+    }
+    const unsigned raw_m0 = (unsigned)(wave * RAW_WAVE * 4), u_m0 = (unsigned)(wave * U_DMA * 1024), lane16 = (unsigned)lane * 16u;
+
+    // ---- per-lane LDS bases (floats); everything else is an instruction immediate ----
+    // (made opaque: the compiler then folds only the small compile-time parts into the 16-bit instruction offsets instead of
+    // materialising one address register per constant that does not fit)
+    int a_base = U_OFF + half * CO_T + wm * 32 + l32;               // + slot * U_FLOATS + (xi * 8 + 2 kk) * 64
+    int b_base = V_OFF + half * NTILE + wn * 32 + l32;              // + slot * V_FLOATS + (xi * 8 + 2 kk) * 64
+    const int ty_l = lane >> 4, tx_l = lane & 15;
+    int raw_rd = (RAW_OFF + wave * RAW_WAVE + 2 * ty_l * RAW_W + 2 * tx_l) >> 1;   // in float pairs; + slot * RAW_FLOATS + j * RAW_PLANE + r * 34 + {0, 2}
+    int v_wr = V_OFF + wave * NTILE + lane;                         // + slot * V_FLOATS + (xi * 8 + 4 j) * 64
+    asm volatile("" : "+v"(a_base), "+v"(b_base), "+v"(raw_rd), "+v"(v_wr));
+
+    f32x16 acc[16];
+#pragma unroll
+    for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[xi][r] = 0.f;
+
+    // the input transform of plane j of raw slot rs into V slot vs, in three kinds of pieces (reads, adds, writes)
+    float d[2][16], tq[2][16], tv[2][16];
+#define WINO_T_READ(rs_, j_, r_)                                                                                        \
+    {                                                                                                                   \
+        const f32x2 lo_ = *((const volatile lds_f32x2_t*)0 + (raw_rd + ((rs_) * RAW_FLOATS + (j_) * RAW_PLANE + (r_) * RAW_W) / 2)); \
+        const f32x2 hi_ = *((const volatile lds_f32x2_t*)0 + (raw_rd + ((rs_) * RAW_FLOATS + (j_) * RAW_PLANE + (r_) * RAW_W + 2) / 2)); \
+        d[j_][4 * (r_) + 0] = lo_.x; d[j_][4 * (r_) + 1] = lo_.y; d[j_][4 * (r_) + 2] = hi_.x; d[j_][4 * (r_) + 3] = hi_.y; \
+    }
+    // B^T d over the rows (column c_): t0 = d0 - d2, t1 = d1 + d2, t2 = d2 - d1, t3 = d1 - d3
+#define WINO_T_ROWS(j_, c_)                                                                                             \
+    {                                                                                                                   \
+        tq[j_][c_] = d[j_][c_] - d[j_][8 + (c_)]; tq[j_][4 + (c_)] = d[j_][4 + (c_)] + d[j_][8 + (c_)];                 \
+        tq[j_][8 + (c_)] = d[j_][8 + (c_)] - d[j_][4 + (c_)]; tq[j_][12 + (c_)] = d[j_][4 + (c_)] - d[j_][12 + (c_)];   \
+    }
+    // (.) B over the columns (row i_)
+#define WINO_T_COLS(j_, i_)                                                                                             \
+    {                                                                                                                   \
+        tv[j_][4 * (i_)] = tq[j_][4 * (i_)] - tq[j_][4 * (i_) + 2]; tv[j_][4 * (i_) + 1] = tq[j_][4 * (i_) + 1] + tq[j_][4 * (i_) + 2]; \
+        tv[j_][4 * (i_) + 2] = tq[j_][4 * (i_) + 2] - tq[j_][4 * (i_) + 1]; tv[j_][4 * (i_) + 3] = tq[j_][4 * (i_) + 1] - tq[j_][4 * (i_) + 3]; \
+    }
+#define WINO_T_WRITE(vs_, j_, xi_)                                                                                      \
+    *((volatile lds_f32_t*)0 + (v_wr + ((vs_) * V_FLOATS + ((xi_) * CI_T + 4 * (j_)) * NTILE))) = tv[j_][xi_];
+
+    const int n = p.n_chunks;
+    // ---- prologue: U_0, raw_0, raw_1 in flight; raw_0 -> V_0 ----
+    static_for<0, U_DMA>([&](auto k) { WINO_DMA_U(0, 0, decltype(k)::value); });
+    static_for<0, RAW_GATHERS>([&](auto k) { WINO_DMA_RAW(0, 0, decltype(k)::value); });
+    static_for<0, RAW_GATHERS>([&](auto k) { WINO_DMA_RAW(min(1, n - 1), 1, decltype(k)::value); });
+    __builtin_amdgcn_s_waitcnt(0x0f70);              // vmcnt(0): this wave's DMA has landed (its raw planes are its own)
+    static_for<0, 2>([&](auto j) {
+        static_for<0, 4>([&](auto r) { WINO_T_READ(0, decltype(j)::value, decltype(r)::value); });
+        static_for<0, 4>([&](auto c) { WINO_T_ROWS(decltype(j)::value, decltype(c)::value); });
+        static_for<0, 4>([&](auto i) { WINO_T_COLS(decltype(j)::value, decltype(i)::value); });
+        static_for<0, 16>([&](auto xi) { WINO_T_WRITE(0, decltype(j)::value, decltype(xi)::value); });
+    });
+    __syncthreads();
+
+    // ---- main loop: chunk i out of U / V slot i & 1; during it U_{i+1}, raw_{i+2} are requested and raw_{i+1} becomes V_{i+1} ----
+    constexpr int PD = 4;                            // fragment prefetch distance in MFMAs
+    float fa[PD + 1], fb[PD + 1];
+#define WINO_FRAG(slot_, s_, reg_)                                                                                      \
+    {                                                                                                                   \
+        constexpr int kk_ = (s_) >> 4, xi_ = (s_) & 15;                                                                 \
+        fa[reg_] = *((const volatile lds_f32_t*)0 + (a_base + ((slot_) * U_FLOATS + (xi_ * CI_T + 2 * kk_) * CO_T)));   \
+        fb[reg_] = *((const volatile lds_f32_t*)0 + (b_base + ((slot_) * V_FLOATS + (xi_ * CI_T + 2 * kk_) * NTILE)));  \
+    }
+    auto chunk_body = [&](auto slot_c, const int i) __attribute__((always_inline)) {
+        constexpr int S = decltype(slot_c)::value, O = 1 - S;     // this chunk's slot; the other one receives chunk i + 1
+        // Past the last chunk the requests repeat chunk n - 1 (into slots nobody reads any more) and the transform turns stale
+        // planes into a V slot nobody reads: the body stays ONE basic block, without a uniform branch per piece.
+        const int c1 = min(i + 1, n - 1), c2 = min(i + 2, n - 1);
+        static_for<0, PD>([&](auto s) { WINO_FRAG(S, decltype(s)::value, decltype(s)::value); });
+        static_for<0, 64>([&](auto s_c) {
+            constexpr int s = decltype(s_c)::value;
+            if constexpr (s + PD < 64) { WINO_FRAG(S, s + PD, (s + PD) % (PD + 1)); }
+            acc[s & 15] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s % (PD + 1)], fb[s % (PD + 1)], acc[s & 15], 0, 0, 0);
+            // requests: the next chunk's weights into the other U slot, the raw planes of chunk i + 2 into THIS raw slot
+            // (its planes became V_i during chunk i - 1)
+            if constexpr (s < U_DMA) { WINO_DMA_U(c1, O, s); }
+            else if constexpr (s < U_DMA + RAW_GATHERS) { WINO_DMA_RAW(c2, S, s - U_DMA); }
+            // raw slot O -> V slot O.  plane 0: reads behind MFMAs 2-5, adds 8-15, writes 16-23; plane 1: 12-15, 24-31, 32-39
+            static_for<0, 2>([&](auto j_c) {
+                constexpr int j = decltype(j_c)::value, tr = 2 + 10 * j, ta = 8 + 16 * j;
+                if constexpr (s >= tr && s < tr + 4) { WINO_T_READ(O, j, s - tr); }
+                if constexpr (s >= ta && s < ta + 4) { WINO_T_ROWS(j, s - ta); }
+                if constexpr (s >= ta + 4 && s < ta + 8) { WINO_T_COLS(j, s - ta - 4); }
+                if constexpr (s >= ta + 8 && s < ta + 16) { WINO_T_WRITE(O, j, 2 * (s - ta - 8)); WINO_T_WRITE(O, j, 2 * (s - ta - 8) + 1); }
+            });
+            __builtin_amdgcn_sched_barrier(0);
+        });
+        __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0): U_{i+1} and this wave's raw_{i+2} have landed
+        __syncthreads();                             // V_{i+1} complete, every wave is done with slot S
+    };
+    for (int i = 0; i < n; i += 2) {                 // (host: n is even -- ONE loop body, so that the 256 accumulator registers
+        chunk_body(std::integral_constant<int, 0>{}, i);       //  never cross a control-flow merge and stay in the AGPR file)
+        chunk_body(std::integral_constant<int, 1>{}, i + 1);
+    }
+#undef WINO_FRAG
+#undef WINO_T_WRITE
+#undef WINO_T_COLS
+#undef WINO_T_ROWS
+#undef WINO_T_READ
+#undef WINO_DMA_U
+#undef WINO_DMA_RAW
+
+    // ---- output transform Y = A^T M A (A^T = [1,1,1,0; 0,1,-1,-1]) and the block into LDS as [co][8 rows x 32 pixels] ----
+    float* const ot = smem;
+    const int tile = wn * 32 + l32, oy = 2 * (tile >> 4), ox = 2 * (tile & 15);
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+        float s0[4], s1[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const float m0 = acc[4 * i][r], m1 = acc[4 * i + 1][r], m2 = acc[4 * i + 2][r], m3 = acc[4 * i + 3][r];
+            s0[i] = (m0 + m1) + m2;
+            s1[i] = (m1 - m2) - m3;
+        }
+        const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+        f32x2 top, bot;
+        top.x = (s0[0] + s0[1]) + s0[2]; top.y = (s1[0] + s1[1]) + s1[2];
+        bot.x = (s0[1] - s0[2]) - s0[3]; bot.y = (s1[1] - s1[2]) - s1[3];
+        *reinterpret_cast<f32x2*>(ot + row * OP + oy * RW + ox) = top;
+        *reinterpret_cast<f32x2*>(ot + row * OP + (oy + 1) * RW + ox) = bot;
+    }
+    __syncthreads();
+
+    // ---- the f32 kernel's staged epilogue, element for element: a thread finishes 4 consecutive pixels of a channel ----
+    const bool f_bias = p.flags & SPK_EPI_BIAS, f_noise = p.flags & SPK_EPI_NOISE;
+    const bool f_lrelu = p.flags & SPK_EPI_LRELU, f_style = p.flags & SPK_EPI_STYLE, f_accum = p.flags & SPK_EPI_ACCUM;
+    const float osc = p.out_scale_dev ? p.out_scale * *p.out_scale_dev : p.out_scale;
+    constexpr int F4 = RW * RH / 4, RPI = NT / F4;       // 64 vectors per channel row, 4 rows per pass
+    const int f4 = tid % F4, row0 = tid / F4;
+    const int pt = 4 * f4, px = pt & (RW - 1), py = pt / RW;
+    const size_t pix = (size_t)(y0 + py) * p.W + (x0 + px);
+    const size_t o0 = (size_t)b * p.Cout * HW + pix;
+    float4 nzv = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (f_noise) nzv = *reinterpret_cast<const float4*>(p.noise + (size_t)b * HW + pix);
+    const float* stp = f_style ? p.style + (size_t)b * p.style_stride : nullptr;
+#pragma unroll 2
+    for (int i = 0; i < CO_T / RPI; ++i) {
+        const int cl = row0 + RPI * i, co = co0 + cl;
+        if (co >= p.Cout) continue;
+        float4 v = *reinterpret_cast<const float4*>(ot + cl * OP + pt);
+        v.x *= osc; v.y *= osc; v.z *= osc; v.w *= osc;
+        const float bb = f_bias ? p.bias[co] : 0.f;
+        v.x += bb; v.y += bb; v.z += bb; v.w += bb;
+        if (f_noise) {
+            const float nwc = p.noise_w[co];
+            v.x += nwc * nzv.x; v.y += nwc * nzv.y; v.z += nwc * nzv.z; v.w += nwc * nzv.w;
+        }
+        if (f_lrelu) {
+            v.x = (v.x > 0.f ? v.x : v.x * p.slope) * p.act_gain; v.y = (v.y > 0.f ? v.y : v.y * p.slope) * p.act_gain;
+            v.z = (v.z > 0.f ? v.z : v.z * p.slope) * p.act_gain; v.w = (v.w > 0.f ? v.w : v.w * p.slope) * p.act_gain;
+        }
+        const size_t off = o0 + (size_t)co * HW;
+        if (p.y_pre) *reinterpret_cast<float4*>(p.y_pre + off) = v;
+        if (f_style) {
+            const float s0 = stp[co] + 1.f, s1 = stp[p.Cout + co];
+            v.x = v.x * s0 + s1; v.y = v.y * s0 + s1; v.z = v.z * s0 + s1; v.w = v.w * s0 + s1;
+        }
+        float4* dst = reinterpret_cast<float4*>(p.y + off);
+        if (f_accum) {
+            const float4 old = *dst;
+            v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
+        }
+        *dst = v;
+    }
+}
+
+}  // namespace spkwino
+
+using namespace spkwino;
+
+extern "C" {
+
+int64_t spk_conv2d_packed_bytes_wino(int Cin, int Cout) {
+    if (Cin <= 0 || Cout <= 0) return -1;
+    return (int64_t)spk::ceil_div(Cout, CO_T) * spk::ceil_div(Cin, CI_T) * U_FLOATS * 4;
+}
+
+int spk_conv2d_pack_weights_wino(const float* w, float* w_packed, int Cin, int Cout, int transpose_flip, void* stream) {
+    SPK_REQUIRE(w && w_packed && Cin > 0 && Cout > 0 && (transpose_flip == 0 || transpose_flip == 1), "pack_weights_wino: bad arguments");
+    const int opCin = transpose_flip ? Cout : Cin, opCout = transpose_flip ? Cin : Cout;
+    const int n_chunks = spk::ceil_div(opCin, CI_T);
+    const long long total = (long long)spk::ceil_div(opCout, CO_T) * n_chunks * U_FLOATS;
+    hipLaunchKernelGGL(pack_wino_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, w, w_packed, Cin, Cout,
+                       opCin, opCout, transpose_flip, n_chunks, total);
+    return spk::check_launch("pack_wino_kernel");
+}
+
+int spk_conv2d_wino_supported(int B, int Cin, int Cout, int H, int W) {
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return 0;
+    if (H % RH || W % RW) return 0;
+    if (Cin % (2 * CI_T)) return 0; // whole chunks (the gathers of a ragged last chunk would reach past the tensor), an even number of them
+    if ((long long)B * Cin * H * W * 4 >= (1ll << 31)) return 0;          // 32-bit buffer offsets, bit 31 = "out of range"
+    return 1;
+}
+
+// entered from spk_conv2d_fwd when desc->flags has SPK_CONV_WINOGRAD
+int spk_conv2d_wino_fwd(const spk_conv2d_desc* d, void* stream) {
+    SPK_REQUIRE(d && d->x && d->w_packed && d->y, "conv2d winograd: null pointer");
+    SPK_REQUIRE(d->kh == 3 && d->kw == 3 && d->stride == 1, "conv2d winograd: 3x3 stride-1 kernels only");
+    SPK_REQUIRE(d->groups <= 1, "conv2d winograd: not grouped");
+    const unsigned allowed = SPK_CONV_WINOGRAD | SPK_EPI_BIAS | SPK_EPI_NOISE | SPK_EPI_LRELU | SPK_EPI_STYLE | SPK_EPI_ACCUM;
+    SPK_REQUIRE(!(d->flags & ~allowed) && !d->stats && !d->out_scale_bc && !d->accum_half,
+                "conv2d winograd: plain input; epilogue flags bias, noise, lrelu, style, accum");
+    SPK_REQUIRE(d->H == d->Hin && d->W == d->Win, "conv2d winograd: output size must equal the input size");
+    SPK_REQUIRE(spk_conv2d_wino_supported(d->B, d->Cin, d->Cout, d->H, d->W), "conv2d winograd: %dx%d is not a whole number of 32 x 8 regions "
+                "(or the input exceeds 2 GB)", d->H, d->W);
+    SPK_REQUIRE(!(d->flags & SPK_EPI_BIAS) || d->bias, "conv2d winograd: SPK_EPI_BIAS without bias");
+    SPK_REQUIRE(!(d->flags & SPK_EPI_NOISE) || (d->noise && d->noise_w), "conv2d winograd: SPK_EPI_NOISE without noise");
+    SPK_REQUIRE(!(d->flags & SPK_EPI_STYLE) || d->style, "conv2d winograd: SPK_EPI_STYLE without style");
+    const auto aligned16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
+    SPK_REQUIRE(aligned16(d->w_packed) && aligned16(d->y) && aligned16(d->y_pre) && aligned16(d->noise) && (reinterpret_cast<uintptr_t>(d->x) & 3) == 0,
+                "conv2d winograd: tensors must be 16-byte aligned");
+    Args a;
+    a.x = d->x; a.wp = d->w_packed; a.bias = d->bias; a.noise_w = d->noise_w; a.noise = d->noise; a.style = d->style;
+    a.y = d->y; a.y_pre = d->y_pre; a.out_scale_dev = d->out_scale_dev;
+    a.B = d->B; a.Cin = d->Cin; a.Cout = d->Cout; a.H = d->H; a.W = d->W;
+    a.regions_x = d->W / RW; a.regions_y = d->H / RH;
+    a.n_chunks = spk::ceil_div(d->Cin, CI_T);
+    a.style_stride = d->style_stride; a.flags = d->flags;
+    a.x_bytes = (unsigned)((long long)d->B * d->Cin * d->H * d->W * 4);
+    a.slope = d->lrelu_slope; a.out_scale = d->out_scale; a.act_gain = d->act_gain != 0.f ? d->act_gain : 1.f;
+    static bool raised = false;
+    if (!raised) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        if (e != hipSuccess) return spk::fail(SPK_ELAUNCH, "hipFuncSetAttribute(LDS): %s", hipGetErrorString(e));
+        raised = true;
+    }
+    const long long gx = (long long)a.regions_x * a.regions_y * d->B;
+    SPK_REQUIRE(gx < (1ll << 31), "conv2d winograd: grid too large");
+    dim3 grid((unsigned)gx, (unsigned)spk::ceil_div(d->Cout, CO_T));
+    hipLaunchKernelGGL(wino_kernel, grid, dim3(NT), LDS_BYTES, (hipStream_t)stream, a);
+    return spk::check_launch("wino_kernel");
+}
+
+}  // extern "C"

@@ -1,0 +1,110 @@
+"""The fp32 Winograd F(2x2, 3x3) conv (csrc/conv3x3_wino_f32.hip, SPK_CONV_WINOGRAD) against an fp64 convolution of the same
+operands and against the direct f32 MFMA kernel, through the C ABI.  It replaces the F.conv2d of styleganv1.py:625,630,662
+where the shape allows.  Tolerance: 5e-6 rel-L2 per layer against fp64 (the direct kernel sits at ~1e-7: an fmaf chain; the
+Winograd form adds the rounding of its +-1 / 0.5 transforms -- the path's bound, north_star, is 1e-3)."""
+import importlib
+import os
+import sys
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+TOL = 5e-6
+
+
+@pytest.fixture(scope="module")
+def ops():
+    assert torch.cuda.is_available()
+    return importlib.import_module("speak-hack_amd").ops
+
+
+def _ref(x, w, **kw):
+    y = F.conv2d(x.double(), w.double(), padding=1)
+    if kw.get("out_scale") is not None:
+        y = y * kw["out_scale"]
+    if kw.get("bias") is not None:
+        y = y + kw["bias"].double().view(1, -1, 1, 1)
+    if kw.get("noise") is not None:
+        y = y + kw["noise_w"].double().view(1, -1, 1, 1) * kw["noise"].double()
+    if kw.get("slope") is not None:
+        y = F.leaky_relu(y, kw["slope"])
+    pre = y
+    if kw.get("style") is not None:
+        C = w.shape[0]
+        s = kw["style"].double()
+        y = y * (s[:, :C].view(-1, C, 1, 1) + 1) + s[:, C:].view(-1, C, 1, 1)
+    return y, pre
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 16, 64, 8, 32), (1, 32, 48, 16, 32), (2, 64, 64, 32, 64), (1, 512, 512, 32, 32),
+                                            (3, 128, 64, 24, 96), (1, 16, 200, 8, 64)])
+def test_wino_plain_equals_fp64_conv(ops, B, Cin, Cout, H, W):
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(B * 1000 + Cin + Cout + H)
+    x = torch.randn(B, Cin, H, W, generator=g).to(dev)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)).to(dev)
+    assert ops.wino_supported(B, Cin, Cout, H, W)
+    y = ops.conv3x3_wino(x, ops.pack_conv_weight_wino(w), Cout)
+    ref, _ = _ref(x, w)
+    assert rel_l2(y, ref) < TOL, rel_l2(y, ref)
+    cfg = ops.conv2d_pick_config(3, 1, B, Cin, Cout, H, W)
+    direct = ops.conv2d_fused(x, ops.pack_conv_weight(w, cfg), Cout, 3, 1, config=cfg)
+    assert rel_l2(y, direct) < TOL
+    # every border pixel of every region, not only the aggregate: the zero padding comes from out-of-range gathers
+    err = (y.double() - ref).abs().amax(dim=(0, 1))
+    assert float(err.max()) < 1e-4 * float(ref.abs().max()), float(err.max())
+
+
+def test_wino_full_epilogue_and_pre_style_output(ops):
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(7)
+    B, Cin, Cout, H, W = 2, 64, 128, 16, 64
+    x = torch.randn(B, Cin, H, W, generator=g).to(dev)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)).to(dev)
+    bias, nw = torch.randn(Cout, generator=g).to(dev), torch.randn(Cout, generator=g).to(dev)
+    noise = torch.randn(B, 1, H, W, generator=g).to(dev)
+    style = torch.randn(B, 2 * Cout, generator=g).to(dev)
+    pre = torch.empty(B, Cout, H, W, device=dev)
+    y = ops.conv3x3_wino(x, ops.pack_conv_weight_wino(w), Cout, bias=bias, noise_w=nw, noise=noise, style=style, lrelu_slope=0.2,
+                         out_scale=0.7, out_pre=pre)
+    ref, ref_pre = _ref(x, w, bias=bias, noise_w=nw, noise=noise, style=style, slope=0.2, out_scale=0.7)
+    assert rel_l2(y, ref) < TOL and rel_l2(pre, ref_pre) < TOL
+    # the same through the direct kernel's epilogue: the two agree element for element up to the contraction's rounding
+    cfg = ops.conv2d_pick_config(3, 1, B, Cin, Cout, H, W)
+    d = ops.conv2d_fused(x, ops.pack_conv_weight(w, cfg), Cout, 3, 1, bias=bias, noise_w=nw, noise=noise, style=style, lrelu_slope=0.2,
+                         out_scale=0.7, config=cfg)
+    assert rel_l2(y, d) < TOL
+
+
+def test_wino_accumulate_device_scale_and_data_gradient(ops):
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(11)
+    B, Cin, Cout, H, W = 2, 32, 64, 16, 32
+    x = torch.randn(B, Cin, H, W, generator=g).to(dev).requires_grad_(True)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)).to(dev)
+    base = torch.randn(B, Cout, H, W, generator=g).to(dev)
+    sd = torch.tensor([0.37], device=dev)
+    y = ops.conv3x3_wino(x.detach(), ops.pack_conv_weight_wino(w), Cout, out=base.clone(), accumulate=True, out_scale=2.0, out_scale_dev=sd)
+    ref = base.double() + 2.0 * 0.37 * F.conv2d(x.detach().double(), w.double(), padding=1)
+    assert rel_l2(y, ref) < TOL
+    # data gradient = the same kernel on the transposed, flipped weights (Cin / Cout exchanged)
+    dy = torch.randn(B, Cout, H, W, generator=g).to(dev)
+    (dx_ref,) = torch.autograd.grad(F.conv2d(x.double(), w.double(), padding=1), x, dy.double())
+    dx = ops.conv3x3_wino(dy, ops.pack_conv_weight_wino(w, transpose_flip=True), Cin)
+    assert rel_l2(dx, dx_ref) < TOL
+
+
+def test_wino_rejects_what_it_does_not_serve(ops):
+    assert not ops.wino_supported(1, 24, 64, 8, 32)      # an odd number of 8-channel chunks
+    assert not ops.wino_supported(1, 16, 64, 12, 32)     # not whole 32 x 8 regions
+    assert not ops.wino_supported(1, 16, 64, 8, 16)
+    L = importlib.import_module("speak-hack_amd")._lib
+    dev = torch.device("cuda:0")
+    x, w = torch.randn(1, 16, 12, 32, device=dev), torch.randn(64, 16, 3, 3, device=dev)
+    with pytest.raises(L.SpkError):
+        ops.conv3x3_wino(x, ops.pack_conv_weight_wino(w), 64)
