@@ -542,7 +542,9 @@ enum {
     SPK_OP_BIAS_NOISE_STYLE = 4,  /* desc: spk_bias_noise_style_args-> spk_bias_noise_style_fwd */
     SPK_OP_TORGB = 5,             /* desc: spk_torgb_args           -> spk_conv1x1_small_fwd / spk_torgb_mod_skip_fwd */
     SPK_OP_DEMOD_GROUPED = 6,     /* desc: spk_demod_grouped_args   -> spk_modconv_demod_grouped */
-    SPK_OP_PIXELNORM = 7          /* desc: spk_pixelnorm_args       -> spk_pixelnorm_fwd */
+    SPK_OP_PIXELNORM = 7,         /* desc: spk_pixelnorm_args       -> spk_pixelnorm_fwd */
+    SPK_OP_UPSAMPLE2X = 8         /* desc: spk_upsample2x_args      -> spk_upsample2x_bilinear_fwd (the x2 image of a block whose conv1
+                                   * runs as Winograd, styleganv1.py:621,624) */
 };
 typedef struct spk_op { int32_t kind; int32_t reserved; const void* desc; } spk_op;
 typedef struct spk_fc_args {
@@ -560,6 +562,7 @@ typedef struct spk_torgb_args {   /* mod NULL: plain 1x1 (styleganv1.py:607); el
 } spk_torgb_args;
 typedef struct spk_demod_grouped_args { const spk_demod_group* groups; int32_t n_groups, B; float eps; int32_t reserved; } spk_demod_grouped_args;
 typedef struct spk_pixelnorm_args { const float* x; float* y; int32_t B, C; int64_t HW; float eps; int32_t sqrt_form; } spk_pixelnorm_args;
+typedef struct spk_upsample2x_args { const float* x; float* y; int64_t planes; int32_t Hin, Win; } spk_upsample2x_args;
 int spk_launch_list(const spk_op* ops, int n_ops, uint32_t kind_mask, void* stream);
 
 #ifdef __cplusplus

@@ -80,7 +80,7 @@ class DemodGroup(C.Structure):
 
 
 # ---- launch lists (include/spk.h: spk_launch_list) ----
-OP_CONV2D, OP_FC, OP_FC_GROUPED, OP_BIAS_NOISE_STYLE, OP_TORGB, OP_DEMOD_GROUPED, OP_PIXELNORM = 1, 2, 3, 4, 5, 6, 7
+OP_CONV2D, OP_FC, OP_FC_GROUPED, OP_BIAS_NOISE_STYLE, OP_TORGB, OP_DEMOD_GROUPED, OP_PIXELNORM, OP_UPSAMPLE2X = 1, 2, 3, 4, 5, 6, 7, 8
 ALL_OPS = 0xFFFFFFFF
 
 
@@ -112,6 +112,10 @@ class ToRGBArgs(C.Structure):
 
 class DemodGroupedArgs(C.Structure):
     _fields_ = [("groups", C.c_void_p), ("n_groups", C.c_int32), ("B", C.c_int32), ("eps", C.c_float), ("reserved", C.c_int32)]
+
+
+class Upsample2xArgs(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("planes", C.c_int64), ("Hin", C.c_int32), ("Win", C.c_int32)]
 
 
 class PixelNormArgs(C.Structure):

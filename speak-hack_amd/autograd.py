@@ -176,6 +176,10 @@ class FusedConvFn(torch.autograd.Function):
         if ops.train_bf16x3(B, Cin, Cout, H, W):     # opt-in split-precision training (ops.train_conv_precision)
             y = ops.conv3x3_bf16x3(x, packed.get_bf16x3(pw), Cout, bias=bias, noise_w=noise_w, noise=noise, style=style,
                                    upsample=upsample, lrelu_slope=slope, out_pre=a, out_scale=w_scale)
+        elif ops.use_wino(B, Cin, Cout, H, W):       # fp32 Winograd (ops.CONV3X3_ALGO); a x2 layer reads the materialised x2 image
+            xin = ops.upsample2x_bilinear(x) if upsample else x
+            y = ops.conv3x3_wino(xin, packed.get_wino(pw), Cout, bias=bias, noise_w=noise_w, noise=noise, style=style,
+                                 lrelu_slope=slope, out_pre=a, out_scale=w_scale)
         else:
             cfg = ops.conv2d_pick_config(3, 1, B, Cin, Cout, H, W)
             y = ops.conv2d_fused(x, packed.get(pw, cfg), Cout, 3, 1, bias=bias, noise_w=noise_w, noise=noise,
@@ -206,6 +210,8 @@ class FusedConvFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             if ops.train_bf16x3(B, Cout, Cin, H, W):
                 dx = ops.conv3x3_bf16x3(dt, packed.get_bf16x3(pw, transpose_flip=True), Cin, out_scale=w_scale)
+            elif ops.use_wino(B, Cout, Cin, H, W):
+                dx = ops.conv3x3_wino(dt, packed.get_wino(pw, transpose_flip=True), Cin, out_scale=w_scale)
             else:
                 cfg = ops.conv2d_pick_config(3, 1, B, Cout, Cin, H, W)
                 dx = ops.conv2d_fused(dt, packed.get(pw, cfg, transpose_flip=True), Cin, 3, 1, config=cfg, out_scale=w_scale)
@@ -378,7 +384,9 @@ def _packed_of(weight, cfg, tf=False):
     if hit is None:
         if cache and next(iter(cache))[2:] != key[2:]:
             cache.clear()                 # the tensor was updated in place (a Parameter after an optimizer step): drop old images
-        if cfg == "bf16x3":
+        if cfg == "wino":
+            hit = ops.pack_conv_weight_wino(weight.detach(), transpose_flip=bool(tf))
+        elif cfg == "bf16x3":
             hit = ops.pack_conv_weight_bf16x3(weight.detach(), transpose_flip=bool(tf))
         else:
             hit = ops.pack_conv_weight(weight.detach(), cfg, transpose_flip=tf)
@@ -392,6 +400,9 @@ def _conv_plain(x, weight, k, stride):
     Ho, Wo = ops.conv_out_size(H, k, stride), ops.conv_out_size(W, k, stride)
     if k == 3 and stride == 1 and ops.train_bf16x3(B, Cin, Cout, Ho, Wo):
         return ops.conv3x3_bf16x3(x.contiguous(), _packed(weight, "bf16x3")[0], Cout)
+    if k == 3 and stride == 1 and ops.use_wino(B, Cin, Cout, Ho, Wo):
+        wp, sd = _packed(weight, "wino")
+        return ops.conv3x3_wino(x.contiguous(), wp, Cout, out_scale_dev=sd)
     cfg = ops.conv2d_pick_config(k, stride, B, Cin, Cout, Ho, Wo)
     wp, sd = _packed(weight, cfg)
     return ops.conv2d_fused(x, wp, Cout, k, stride, config=cfg, out_scale_dev=sd)
@@ -402,6 +413,9 @@ def _conv_dgrad(dt, weight, k, stride, in_hw):
     Cin = weight.shape[1]
     if k == 3 and stride == 1 and ops.train_bf16x3(B, Cout, Cin, in_hw[0], in_hw[1]):
         return ops.conv3x3_bf16x3(dt, _packed(weight, "bf16x3", True)[0], Cin)
+    if k == 3 and stride == 1 and ops.use_wino(B, Cout, Cin, in_hw[0], in_hw[1]):
+        wp, sd = _packed(weight, "wino", True)
+        return ops.conv3x3_wino(dt.contiguous(), wp, Cin, out_scale_dev=sd)
     cfg, tf = ops.dgrad_plan(k, stride, B, Cout, Cin, in_hw, dt.shape[-2:])
     wp, sd = _packed(weight, cfg, tf)
     return ops.conv2d_dgrad(dt, wp, Cin, k, stride, in_hw, cfg, out_scale_dev=sd)
@@ -449,6 +463,9 @@ class ConvBiasLReLUFn(torch.autograd.Function):
         Ho, Wo = ops.conv_out_size(H, k, stride), ops.conv_out_size(W, k, stride)
         if k == 3 and stride == 1 and ops.train_bf16x3(B, Cin, Cout, Ho, Wo):
             y = ops.conv3x3_bf16x3(x.contiguous(), _packed(weight, "bf16x3")[0], Cout, bias=bias, lrelu_slope=slope)
+        elif k == 3 and stride == 1 and ops.use_wino(B, Cin, Cout, Ho, Wo):
+            wp, sd = _packed(weight, "wino")
+            y = ops.conv3x3_wino(x.contiguous(), wp, Cout, bias=bias, lrelu_slope=slope, out_scale_dev=sd)
         else:
             cfg = ops.conv2d_pick_config(k, stride, B, Cin, Cout, Ho, Wo)
             wp, sd = _packed(weight, cfg)

@@ -52,6 +52,11 @@ extern "C" int spk_launch_list(const spk_op* ops, int n_ops, uint32_t kind_mask,
                 rc = spk_pixelnorm_fwd(a->x, a->y, a->B, a->C, a->HW, a->eps, a->sqrt_form, stream);
                 break;
             }
+            case SPK_OP_UPSAMPLE2X: {
+                const spk_upsample2x_args* a = static_cast<const spk_upsample2x_args*>(op.desc);
+                rc = spk_upsample2x_bilinear_fwd(a->x, a->y, a->planes, a->Hin, a->Win, stream);
+                break;
+            }
             default:
                 return spk::fail(SPK_EUNSUPPORTED, "launch_list: op %d: unknown kind %d", i, op.kind);
         }

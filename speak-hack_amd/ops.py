@@ -54,6 +54,17 @@ class PackedConvWeight:
         self._cache[key] = (stamp, packed, weakref.ref(weight))
         return packed
 
+    def get_wino(self, weight: torch.Tensor, transpose_flip: bool = False) -> torch.Tensor:
+        """The transformed image U = G g G^T of the fp32 Winograd conv (``conv3x3_wino``), cached the same way."""
+        key = ("wino", bool(transpose_flip))
+        stamp = (weight.data_ptr(), weight._version, tuple(weight.shape))
+        hit = self._cache.get(key)
+        if hit is not None and hit[0] == stamp and hit[2]() is weight:
+            return hit[1]
+        packed = pack_conv_weight_wino(weight.detach(), transpose_flip=transpose_flip)
+        self._cache[key] = (stamp, packed, weakref.ref(weight))
+        return packed
+
     def clear(self):
         self._cache.clear()
 
@@ -358,6 +369,33 @@ def conv3x3_bf16x3(x, w_packed, Cout, *, bias=None, noise_w=None, noise=None, st
 
 
 # ---- Winograd F(2x2, 3x3) on the f32 MFMA pipe (SPK_CONV_WINOGRAD, csrc/conv3x3_wino_f32.hip) ------------------------------------
+# Which fp32 algorithm a 3x3 stride-1 conv runs: "auto" -- Winograd F(2x2, 3x3) where the kernel serves the shape and the launch
+# fills the chip, the direct (fmaf-chain) kernel elsewhere; "direct" -- the direct kernel everywhere (SPK_CONV3X3_ALGO=direct: the
+# previous rounds' arithmetic, bit for bit).  Both are fp32 operands, fp32 products, fp32 accumulation.
+CONV3X3_ALGO = os.environ.get("SPK_CONV3X3_ALGO", "auto")
+WINO_MIN_WORKGROUPS = 192          # one workgroup per CU: below ~3/4 of a round the direct kernel's split-K wins
+
+
+@contextlib.contextmanager
+def conv3x3_algo(algo: str):
+    """``with ops.conv3x3_algo("direct"):`` -- scoped override of ``CONV3X3_ALGO`` (plans are keyed on it)."""
+    global CONV3X3_ALGO
+    if algo not in ("auto", "direct"):
+        raise ValueError("conv3x3 algo must be 'auto' or 'direct'")
+    prev, CONV3X3_ALGO = CONV3X3_ALGO, algo
+    try:
+        yield
+    finally:
+        CONV3X3_ALGO = prev
+
+
+def use_wino(B, Cin, Cout, H, W) -> bool:
+    """Whether a 3x3 stride-1 conv with this OUTPUT shape (plain input) goes to the Winograd kernel under ``CONV3X3_ALGO``."""
+    if CONV3X3_ALGO != "auto" or not wino_supported(B, Cin, Cout, H, W):
+        return False
+    return B * (H // 8) * (W // 32) * ((Cout + 63) // 64) >= WINO_MIN_WORKGROUPS
+
+
 def wino_supported(B, Cin, Cout, H, W) -> bool:
     """Whether the fp32 Winograd kernel serves a 3x3 stride-1 conv with this OUTPUT shape (whole 32 x 8 regions, Cin % 16 == 0)."""
     return bool(L.lib().spk_conv2d_wino_supported(B, Cin, Cout, H, W))

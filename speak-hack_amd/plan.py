@@ -45,6 +45,7 @@ class LaunchPlan:
         self.captured = False    # a hipGraph recorded this plan's launches: its buffers must outlive the plan cache
         self.ws = None
         self._ws_bytes = 0
+        self._up_scratch, self._up_users = None, []   # the x2 image of the Winograd x2 layers (one scratch buffer) and its users
 
     # ---- building ----------------------------------------------------------------------------------
     def buf(self, *shape):
@@ -89,6 +90,39 @@ class LaunchPlan:
                              style_stride=int(style.stride(0)) if style is not None else 0, flags=flags,
                              lrelu_slope=float(slope if slope is not None else 1.0), out_scale=float(out_scale), config=-1,
                              ksplit=1, workspace=None, workspace_bytes=0, groups=1, group_in_stride=0, stats_slots=0)
+            return self.add(L.OP_CONV2D, d)
+        if batch_scale is None and demod is None and ops.use_wino(B, Cin, Cout, H, W):
+            # fp32 Winograd F(2x2, 3x3) (include/spk.h SPK_CONV_WINOGRAD); a x2 layer first writes its upsampled input (one
+            # HBM-bound launch: the separate nn.Upsample of styleganv1.py:621,624) -- the transform would cost more inside the
+            # MFMA kernel than this pass does beside it
+            if upsample:
+                if up_fir:
+                    raise L.SpkError("plan: the Winograd path takes the bilinear x2 only")
+                need = B * Cin * H * W                    # one scratch image for all x2 layers: launches are stream-ordered
+                if self._up_scratch is None or self._up_scratch.numel() < need:
+                    self._up_scratch = self.buf(need)
+                    for a_, n_ in self._up_users:           # earlier, smaller users move into the larger buffer
+                        a_.y = self._up_scratch.data_ptr()
+                        n_.x = self._up_scratch.data_ptr()
+                xu = self._up_scratch[:need].view(B, Cin, H, W)
+                up_op = self.add(L.OP_UPSAMPLE2X, L.Upsample2xArgs(x=x.data_ptr(), y=xu.data_ptr(), planes=B * Cin, Hin=Hs, Win=Ws))
+                x = xu
+            packed = self.buf(L.lib().spk_conv2d_packed_bytes_wino(Cin, Cout) // 4)
+            self._refreshers.append(lambda w=weight, p=packed: ops.pack_conv_weight_wino(w.detach(), out=p))
+            self.track(weight)
+            flags = L.CONV_WINOGRAD | (L.EPI_BIAS if bias is not None else 0) | (L.EPI_NOISE if noise is not None else 0) | \
+                (L.EPI_LRELU if slope is not None else 0) | (L.EPI_STYLE if style is not None else 0)
+            d = L.Conv2dDesc(x=x.data_ptr(), w_packed=packed.data_ptr(), bias=L.dptr(bias, "bias"),
+                             noise_w=L.dptr(noise_w, "noise_w") if noise is not None else None,
+                             noise=noise.data_ptr() if noise is not None else None,
+                             style=style.data_ptr() if style is not None else None, in_scale=None, in_shift=None,
+                             out_scale_bc=None, act_gain=float(act_gain), stats=None,
+                             y=out.data_ptr(), y_pre=None, B=B, Cin=Cin, Cout=Cout, H=H, W=W, Hin=H, Win=W, kh=3, kw=3, stride=1,
+                             style_stride=int(style.stride(0)) if style is not None else 0, flags=flags,
+                             lrelu_slope=float(slope if slope is not None else 1.0), out_scale=float(out_scale), config=-1,
+                             ksplit=1, workspace=None, workspace_bytes=0, groups=1, group_in_stride=0, stats_slots=0)
+            if upsample:
+                self._up_users.append((up_op, d))
             return self.add(L.OP_CONV2D, d)
         cfg = ops.conv2d_pick_config(3, 1, B, Cin, Cout, H, W)
         if batch_scale is not None and cfg < 4:
@@ -324,6 +358,7 @@ def plan_for(owner, key, build):
     buffers stay where the graph's kernels will read and write them (as ``ops._workspace`` retires outgrown scratch).  Such
     a graph replays the weights as they were packed at ITS capture: re-capture after an optimizer step."""
     cache = owner.__dict__.setdefault("_plans", {})
+    key = key + (ops.CONV3X3_ALGO,)
     plan = cache.pop(key, None)
     if plan is None or not plan.valid_for():
         _drop(plan)
