@@ -43,11 +43,12 @@ constexpr int RAW_PLANE = 352, RAW_WAVE = 2 * RAW_PLANE;                    // 7
 constexpr int RAW_GATHERS = RAW_WAVE / 64;
 constexpr int U_FLOATS = 16 * CI_T * CO_T, V_FLOATS = 16 * CI_T * NTILE, RAW_FLOATS = 4 * RAW_WAVE;
 constexpr int U_OFF = 0, V_OFF = 2 * U_FLOATS, RAW_OFF = V_OFF + 2 * V_FLOATS;
-constexpr int LDS_FLOATS = RAW_OFF + 2 * RAW_FLOATS;
-constexpr int LDS_BYTES = LDS_FLOATS * 4;                                    // 153 600
-constexpr int OP = RW * RH + 4;                                              // pitch of the epilogue's output block
+constexpr int PRM_OFF = RAW_OFF + 2 * RAW_FLOATS;                            // [64 co][bias, noise weight, style s0 + 1, style s1] of the region
+constexpr int LDS_FLOATS = PRM_OFF + 4 * CO_T;
+constexpr int LDS_BYTES = LDS_FLOATS * 4;                                    // 154 624
+constexpr int OP = RW * RH;                                                  // pitch of the epilogue's output block: 32 rows x 256 floats = one U slot
 static_assert(NTILE == 64 && RAW_GATHERS == 11 && RAW_USED <= RAW_PLANE, "geometry");
-static_assert(CO_T * OP <= LDS_FLOATS, "the epilogue block reuses the ring");
+static_assert(CO_T / 2 * OP == U_FLOATS, "half of the epilogue block is exactly one U slot");
 constexpr int U_DMA = U_FLOATS * 4 / 1024 / 4;                               // 1 KB blocks per wave and chunk (8)
 
 struct Args {
@@ -102,6 +103,13 @@ __global__ void pack_wino_kernel(const float* __restrict__ w, float* __restrict_
     out[idx] = v;
 }
 
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() is a fence: it waits for vmcnt(0) too, i.e. for every global
+// STORE the wave has issued -- behind the epilogue's stores that is a full HBM write latency (~5 000 cycles, measured with
+// tools/lab_wino_phases.py) with the matrix pipe idle, twice per region.
+__device__ __forceinline__ void lds_barrier() {
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 __global__ __launch_bounds__(NT) void wino_kernel(const Args p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -109,32 +117,42 @@ __global__ __launch_bounds__(NT) void wino_kernel(const Args p) {
     const int half = lane >> 5, l32 = lane & 31;
     const int wm = wave >> 1, wn = wave & 1;
 
-    // XCD-aware region order (as the f32 kernel): every XCD walks one contiguous run of regions
-    int bx;
-    {
-        const int n = (int)gridDim.x, q = n >> 3, r = n & 7;
-        const int xcd = (int)blockIdx.x & 7, k = (int)blockIdx.x >> 3;
-        bx = xcd * q + min(xcd, r) + k;
-    }
-    const int rx = bx % p.regions_x;
-    bx /= p.regions_x;
-    const int ry = bx % p.regions_y, b = bx / p.regions_y;
-    const int y0 = ry * RH, x0 = rx * RW;
+    // PERSISTENT workgroups (one per CU: the kernel holds 512 registers per lane): workgroup w walks regions of its XCD's
+    // contiguous share of the region list (the hardware deals workgroup w to XCD w % 8), neighbours in the list running
+    // side by side on the same L2 -- and, the point of it, the first loads of region r + 1 are requested BEFORE the epilogue
+    // of region r, so that a region's global-load latency hides behind its predecessor's output transform and stores.
+    const int n_regions = p.regions_x * p.regions_y * p.B;
+    const int xcd = (int)blockIdx.x & 7, wk = (int)blockIdx.x >> 3, wpx = (int)gridDim.x >> 3;      // (host: gridDim.x % 8 == 0)
+    const int share_q = n_regions >> 3, share_r = n_regions & 7;
+    const int reg_begin = xcd * share_q + min(xcd, share_r), reg_end = reg_begin + share_q + (xcd < share_r ? 1 : 0);
     const int co_tile = blockIdx.y, co0 = co_tile * CO_T;
     const size_t HW = (size_t)p.H * p.W;
 
     // ---- the raw gathers: byte offsets of this lane's 11 elements (plane j of channel wave + 4 j), or out of range ----
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
-    unsigned voff[RAW_GATHERS];
+    unsigned voff[RAW_GATHERS], voff_next[RAW_GATHERS];   // the gathers of the region being requested / of the region after it
+    auto region_coords = [&](int reg, int& b_, int& y0_, int& x0_) {
+        const int rx_ = reg % p.regions_x;
+        const int t_ = reg / p.regions_x;
+        b_ = t_ / p.regions_y;
+        y0_ = (t_ - b_ * p.regions_y) * RH;
+        x0_ = rx_ * RW;
+    };
+    auto set_voff = [&](unsigned (&vo)[RAW_GATHERS], int b_, int y0_, int x0_) {
+        const unsigned img = (unsigned)b_ * (unsigned)p.Cin * (unsigned)HW;           // (host: the whole tensor is below 2^29 floats)
+        int ln = lane;
+        asm volatile("" : "+v"(ln));     // recompute the element coordinates here: hoisted out of the region loop they are 30 registers, spilled
 #pragma unroll
-    for (int k = 0; k < RAW_GATHERS; ++k) {
-        const int e = k * 64 + lane;
-        const int j = e >= RAW_PLANE ? 1 : 0, q = e - j * RAW_PLANE;
-        const int r = q / RAW_W, c = q - r * RAW_W;
-        const int yy = y0 - 1 + r, xx = x0 - 1 + c;
-        const bool ok = q < RAW_USED && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
-        voff[k] = ok ? (unsigned)((((size_t)b * p.Cin + wave + 4 * j) * HW + (size_t)yy * p.W + xx) * 4) : 0x80000000u;
-    }
+        for (int k = 0; k < RAW_GATHERS; ++k) {
+            const int e = k * 64 + ln;
+            const int j = e >= RAW_PLANE ? 1 : 0, q = e - j * RAW_PLANE;
+            const int r = (int)__umulhi((unsigned)q, 0x07878788u);             // q / 34 for q < 2^16 (ceil(2^32 / 34))
+            const int yy = y0_ - 1 + r, xx = x0_ - 1 + (q - r * RAW_W);
+            const bool ok = q < RAW_USED && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+            const unsigned off = (img + (unsigned)(wave + 4 * j) * (unsigned)HW + (unsigned)(yy * p.W + xx)) * 4u;
+            vo[k] = ok ? off : 0x80000000u;
+        }
+    };
     const unsigned chunk_bytes = (unsigned)(CI_T * HW * 4);
     const float* wsrc = p.wp + (size_t)co_tile * p.n_chunks * U_FLOATS;
 
@@ -143,9 +161,9 @@ __global__ __launch_bounds__(NT) void wino_kernel(const Args p) {
     // wave per SIMD that is an LDS round trip per four MFMAs.  Issued behind its back, the fragment reads keep their counted
     // waits (lgkmcnt(6)); completion is this kernel's business: s_waitcnt vmcnt(0) before the chunk barrier.  (LDS base = 0:
     // the kernel has no static LDS.)
-#define WINO_DMA_RAW(chunk_, slot_, k_)                                                                                 \
+#define WINO_DMA_RAW(vo_in_, chunk_, slot_, k_)                                                                         \
     {   /* (operands through locals: an asm operand inside a lambda does not capture) */                                \
-        const unsigned m0_ = (unsigned)((RAW_OFF + (slot_) * RAW_FLOATS + (k_) * 64) * 4) + raw_m0, vo_ = voff[k_];     \
+        const unsigned m0_ = (unsigned)((RAW_OFF + (slot_) * RAW_FLOATS + (k_) * 64) * 4) + raw_m0, vo_ = (vo_in_);     \
         const unsigned so_ = (unsigned)(chunk_) * chunk_bytes;                                                          \
         const __amdgpu_buffer_rsrc_t rs_ = rsrc;                                                                        \
         asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, %3 offen lds" :: "s"(m0_), "v"(vo_), "s"(rs_), "s"(so_)); \
@@ -169,10 +187,9 @@ __global__ __launch_bounds__(NT) void wino_kernel(const Args p) {
     asm volatile("" : "+v"(a_base), "+v"(b_base), "+v"(raw_rd), "+v"(v_wr));
 
     f32x16 acc[16];
+    f32x16 zero16;
 #pragma unroll
-    for (int xi = 0; xi < 16; ++xi)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[xi][r] = 0.f;
+    for (int r = 0; r < 16; ++r) zero16[r] = 0.f;
 
     // the input transform of plane j of raw slot rs into V slot vs, in three kinds of pieces (reads, adds, writes)
     float d[2][16], tq[2][16], tv[2][16];
@@ -198,10 +215,15 @@ __global__ __launch_bounds__(NT) void wino_kernel(const Args p) {
     *((volatile lds_f32_t*)0 + (v_wr + ((vs_) * V_FLOATS + ((xi_) * CI_T + 4 * (j_)) * NTILE))) = tv[j_][xi_];
 
     const int n = p.n_chunks;
-    // ---- prologue: U_0, raw_0, raw_1 in flight; raw_0 -> V_0 ----
+    int reg = reg_begin + wk;
+    if (reg >= reg_end) return;
+    int b, y0, x0;
+    region_coords(reg, b, y0, x0);
+    set_voff(voff, b, y0, x0);
+    // ---- first region: U_0, raw_0, raw_1 requested; raw_0 -> V_0 ----
     static_for<0, U_DMA>([&](auto k) { WINO_DMA_U(0, 0, decltype(k)::value); });
-    static_for<0, RAW_GATHERS>([&](auto k) { WINO_DMA_RAW(0, 0, decltype(k)::value); });
-    static_for<0, RAW_GATHERS>([&](auto k) { WINO_DMA_RAW(min(1, n - 1), 1, decltype(k)::value); });
+    static_for<0, RAW_GATHERS>([&](auto k) { WINO_DMA_RAW(voff[decltype(k)::value], 0, 0, decltype(k)::value); });
+    static_for<0, RAW_GATHERS>([&](auto k) { WINO_DMA_RAW(voff[decltype(k)::value], 1, 1, decltype(k)::value); });
     __builtin_amdgcn_s_waitcnt(0x0f70);              // vmcnt(0): this wave's DMA has landed (its raw planes are its own)
     static_for<0, 2>([&](auto j) {
         static_for<0, 4>([&](auto r) { WINO_T_READ(0, decltype(j)::value, decltype(r)::value); });
@@ -211,7 +233,10 @@ __global__ __launch_bounds__(NT) void wino_kernel(const Args p) {
     });
     __syncthreads();
 
-    // ---- main loop: chunk i out of U / V slot i & 1; during it U_{i+1}, raw_{i+2} are requested and raw_{i+1} becomes V_{i+1} ----
+    // ---- main loop.  The chunks of ALL the workgroup's regions form one stream: chunk i of a region runs out of U / V slot
+    // i & 1 (n is even: every region starts in slot 0); during it the weights of the stream's next chunk and the raw planes of
+    // the one after that are requested, and the raw planes of the next chunk become its V -- across a region boundary these
+    // belong to the NEXT region, so that a region's first operands are in LDS when its predecessor's epilogue ends ----
     constexpr int PD = 4;                            // fragment prefetch distance in MFMAs
     float fa[PD + 1], fb[PD + 1];
 #define WINO_FRAG(slot_, s_, reg_)                                                                                      \
@@ -220,20 +245,21 @@ __global__ __launch_bounds__(NT) void wino_kernel(const Args p) {
         fa[reg_] = *((const volatile lds_f32_t*)0 + (a_base + ((slot_) * U_FLOATS + (xi_ * CI_T + 2 * kk_) * CO_T)));   \
         fb[reg_] = *((const volatile lds_f32_t*)0 + (b_base + ((slot_) * V_FLOATS + (xi_ * CI_T + 2 * kk_) * NTILE)));  \
     }
-    auto chunk_body = [&](auto slot_c, const int i) __attribute__((always_inline)) {
-        constexpr int S = decltype(slot_c)::value, O = 1 - S;     // this chunk's slot; the other one receives chunk i + 1
-        // Past the last chunk the requests repeat chunk n - 1 (into slots nobody reads any more) and the transform turns stale
-        // planes into a V slot nobody reads: the body stays ONE basic block, without a uniform branch per piece.
-        const int c1 = min(i + 1, n - 1), c2 = min(i + 2, n - 1);
+    auto chunk_body = [&](auto slot_c, auto first_c, const int i) __attribute__((always_inline)) {
+        constexpr int S = decltype(slot_c)::value, O = 1 - S;     // this chunk's slot; the other one receives the next chunk
+        constexpr bool FIRST = decltype(first_c)::value;          // a region's first chunk: its first 16 MFMAs START the accumulators (C = 0)
+        const int c1 = i + 1 < n ? i + 1 : 0;                     // the stream's next chunk (weights: the same channel tile)
+        const int c2 = i + 2 >= n ? i + 2 - n : i + 2;            // the chunk after it (past n: in the next region -- `voff` is that region's by then)
         static_for<0, PD>([&](auto s) { WINO_FRAG(S, decltype(s)::value, decltype(s)::value); });
         static_for<0, 64>([&](auto s_c) {
             constexpr int s = decltype(s_c)::value;
             if constexpr (s + PD < 64) { WINO_FRAG(S, s + PD, (s + PD) % (PD + 1)); }
-            acc[s & 15] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s % (PD + 1)], fb[s % (PD + 1)], acc[s & 15], 0, 0, 0);
-            // requests: the next chunk's weights into the other U slot, the raw planes of chunk i + 2 into THIS raw slot
-            // (its planes became V_i during chunk i - 1)
+            if constexpr (FIRST && s < 16) acc[s & 15] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s % (PD + 1)], fb[s % (PD + 1)], zero16, 0, 0, 0);
+            else acc[s & 15] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[s % (PD + 1)], fb[s % (PD + 1)], acc[s & 15], 0, 0, 0);
+            // requests: the next chunk's weights into the other U slot, the raw planes of the chunk after it into THIS raw
+            // slot (its planes became this chunk's V one chunk ago)
             if constexpr (s < U_DMA) { WINO_DMA_U(c1, O, s); }
-            else if constexpr (s < U_DMA + RAW_GATHERS) { WINO_DMA_RAW(c2, S, s - U_DMA); }
+            else if constexpr (s < U_DMA + RAW_GATHERS) { WINO_DMA_RAW(voff[s - U_DMA], c2, S, s - U_DMA); }
             // raw slot O -> V slot O.  plane 0: reads behind MFMAs 2-5, adds 8-15, writes 16-23; plane 1: 12-15, 24-31, 32-39
             static_for<0, 2>([&](auto j_c) {
                 constexpr int j = decltype(j_c)::value, tr = 2 + 10 * j, ta = 8 + 16 * j;
@@ -244,12 +270,143 @@ __global__ __launch_bounds__(NT) void wino_kernel(const Args p) {
             });
             __builtin_amdgcn_sched_barrier(0);
         });
-        __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0): U_{i+1} and this wave's raw_{i+2} have landed
-        __syncthreads();                             // V_{i+1} complete, every wave is done with slot S
+        __builtin_amdgcn_s_waitcnt(0x0f70);          // vmcnt(0): the requested weights and this wave's raw planes have landed
+        __syncthreads();                             // the next chunk's V is complete, every wave is done with slot S
     };
-    for (int i = 0; i < n; i += 2) {                 // (host: n is even -- ONE loop body, so that the 256 accumulator registers
-        chunk_body(std::integral_constant<int, 0>{}, i);       //  never cross a control-flow merge and stay in the AGPR file)
-        chunk_body(std::integral_constant<int, 1>{}, i + 1);
+    const bool f_bias = p.flags & SPK_EPI_BIAS, f_noise = p.flags & SPK_EPI_NOISE;
+    const bool f_lrelu = p.flags & SPK_EPI_LRELU, f_style = p.flags & SPK_EPI_STYLE, f_accum = p.flags & SPK_EPI_ACCUM;
+    const float osc = p.out_scale_dev ? p.out_scale * *p.out_scale_dev : p.out_scale;
+    const float slope_ = f_lrelu ? p.slope : 1.f, gain_ = f_lrelu ? p.act_gain : 1.f;    // (no LeakyReLU: slope 1, gain 1)
+    // the epilogue's block, HALF of it at a time -- [32 co][8 x 32 pixels] = U slot 1, the one slot of the ring that holds nothing
+    // of the next region when a region's last chunk is done (U slot 0: its first weights; V slot 0: its first V; the raw slots)
+    float* const ot = smem + U_OFF + U_FLOATS;
+    const int tile = wn * 32 + l32, oy = 2 * (tile >> 4), ox = 2 * (tile & 15);
+    const int f4 = lane, pt = 4 * f4, px = pt & (RW - 1), py = pt / RW;       // a wave finishes one channel row per pass: 64 x 4 pixels
+
+    using F_ = std::false_type;
+#ifdef SPK_WINO_LAB      // tools/lab_wino_phases.py: cycle stamps of one workgroup's second region, written over the output's first floats
+    unsigned long long lab_t[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int lab_region = 0;
+#define LAB_STAMP(k_) { if (lab_region == 1) lab_t[k_] = __builtin_readcyclecounter(); }
+#else
+#define LAB_STAMP(k_)
+#endif
+    for (;;) {
+        LAB_STAMP(0)
+#pragma unroll
+        for (int xi = 0; xi < 16; ++xi)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[xi][r] = 0.f;
+        // the region after this one (the last region repeats itself: loads nobody uses)
+        const int cur_b = b, cur_y0 = y0, cur_x0 = x0;
+        // everything the epilogue reads from global memory is requested NOW and lands behind the region's MFMAs: the noise of
+        // this thread's four pixels, and (wave 0: one channel per lane) the channel's bias / noise weight / style pair, which
+        // reach the other waves through a 1 KB LDS table -- no load latency between the last MFMA and the stores
+        const size_t pix = (size_t)(cur_y0 + py) * p.W + (cur_x0 + px);
+        float4 nzv = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (f_noise) nzv = *reinterpret_cast<const float4*>(p.noise + (size_t)cur_b * HW + pix);
+        float4 prm = make_float4(0.f, 0.f, 1.f, 0.f);      // neutral: + 0, + 0 * noise, * 1 + 0 -- the finishing loop applies every stage, unconditionally
+        if (wave == 0 && co0 + lane < p.Cout) {
+            const int c_ = co0 + lane;
+            if (f_bias) prm.x = p.bias[c_];
+            if (f_noise) prm.y = p.noise_w[c_];
+            if (f_style) {
+                const float* stp = p.style + (size_t)cur_b * p.style_stride;
+                prm.z = stp[c_] + 1.f;
+                prm.w = stp[p.Cout + c_];
+            }
+        }
+        const bool more = reg + wpx < reg_end;
+        if (more) {
+            reg += wpx;
+            region_coords(reg, b, y0, x0);
+        }
+        set_voff(voff_next, b, y0, x0);
+
+        // (host: n is even.)  From the last pair of chunks on, every raw request belongs to the next region: its offsets move in,
+        // once, by selects (no branch in the body).
+        // ONE loop body, entered once per region: the 256 accumulator registers never cross a control-flow merge other than the
+        // loop header and stay in the AGPR file.  (Peeling the first pair of chunks so that its MFMAs start from C = 0 -- no
+        // zero fill -- was tried: the compiler then copies all accumulators to VGPRs at the loop exit and spills.)
+        LAB_STAMP(1)
+        for (int i = 0; i < n; i += 2) {
+            const bool last_pair = i + 2 >= n;
+#pragma unroll
+            for (int k = 0; k < RAW_GATHERS; ++k) voff[k] = last_pair ? voff_next[k] : voff[k];
+            chunk_body(std::integral_constant<int, 0>{}, F_{}, i);
+            chunk_body(std::integral_constant<int, 1>{}, F_{}, i + 1);
+        }
+
+        // ---- epilogue, twice: output transform Y = A^T M A (A^T = [1,1,1,0; 0,1,-1,-1]) of half of every wave's channel rows into
+        // the LDS block, then the f32 kernel's staged epilogue element for element (a thread finishes 4 consecutive pixels) ----
+        LAB_STAMP(2)
+        const size_t o0 = (size_t)cur_b * p.Cout * HW + pix;
+        if (wave == 0) *reinterpret_cast<float4*>(smem + PRM_OFF + 4 * lane) = prm;      // (published by the first half's barrier)
+        static_for<0, 2>([&](auto h_c) {
+            constexpr int h = decltype(h_c)::value;
+            // accumulator registers r = 8 h .. 8 h + 7 are the wave's rows 16 h + (r & 3) + 8 ((r >> 2) & 1) + 4 half
+#pragma unroll
+            for (int q = 0; q < 8; ++q) {
+                const int r = 8 * h + q;
+                float s0[4], s1[4];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    const float m0 = acc[4 * i][r], m1 = acc[4 * i + 1][r], m2 = acc[4 * i + 2][r], m3 = acc[4 * i + 3][r];
+                    s0[i] = (m0 + m1) + m2;
+                    s1[i] = (m1 - m2) - m3;
+                }
+                const int row = wm * 16 + (q & 3) + 8 * (q >> 2) + 4 * half;       // row of the HALF block: 16 rows per wave row
+                f32x2 top, bot;
+                top.x = (s0[0] + s0[1]) + s0[2]; top.y = (s1[0] + s1[1]) + s1[2];
+                bot.x = (s0[1] - s0[2]) - s0[3]; bot.y = (s1[1] - s1[2]) - s1[3];
+                *reinterpret_cast<f32x2*>(ot + row * OP + oy * RW + ox) = top;
+                *reinterpret_cast<f32x2*>(ot + row * OP + (oy + 1) * RW + ox) = bot;
+                __builtin_amdgcn_sched_barrier(0);   // one row at a time: hoisted together, the 256 accumulator reads need 256 VGPRs and spill the rest
+            }
+            lds_barrier();
+            LAB_STAMP(3 + 2 * h)
+            // eight channel rows per wave: all their LDS reads first, then arithmetic and stores -- no branch on the epilogue flags
+            // (an absent stage runs with its neutral operand), so nothing serialises on an LDS round trip per row
+            float4 vv[8], qq[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int cl = wave + 4 * i;                                         // row of the half block (wave-uniform)
+                vv[i] = *reinterpret_cast<const float4*>(ot + cl * OP + pt);
+                qq[i] = *reinterpret_cast<const float4*>(smem + PRM_OFF + 4 * ((cl >> 4) * 32 + 16 * h + (cl & 15)));   // (one address per wave: a broadcast)
+            }
+#pragma unroll
+            for (int i = 0; i < 8; ++i) {
+                const int cl = wave + 4 * i;
+                const int co = co0 + (cl >> 4) * 32 + 16 * h + (cl & 15);            // half-block row -> channel: wave row, half, row
+                if (co >= p.Cout) continue;
+                float4 v = vv[i];
+                const float4 q_ = qq[i];
+                v.x = v.x * osc + q_.x; v.y = v.y * osc + q_.x; v.z = v.z * osc + q_.x; v.w = v.w * osc + q_.x;
+                v.x += q_.y * nzv.x; v.y += q_.y * nzv.y; v.z += q_.y * nzv.z; v.w += q_.y * nzv.w;
+                v.x = (v.x > 0.f ? v.x : v.x * slope_) * gain_; v.y = (v.y > 0.f ? v.y : v.y * slope_) * gain_;
+                v.z = (v.z > 0.f ? v.z : v.z * slope_) * gain_; v.w = (v.w > 0.f ? v.w : v.w * slope_) * gain_;
+                const size_t off = o0 + (size_t)co * HW;
+                if (p.y_pre) *reinterpret_cast<float4*>(p.y_pre + off) = v;
+                v.x = v.x * q_.z + q_.w; v.y = v.y * q_.z + q_.w; v.z = v.z * q_.z + q_.w; v.w = v.w * q_.z + q_.w;
+                float4* dst = reinterpret_cast<float4*>(p.y + off);
+                if (f_accum) {
+                    const float4 old = *dst;
+                    v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
+                }
+#ifdef SPK_WINO_NOSTORE   // LAB knock-out: everything but the store itself
+                if (v.x == 12345.678f)
+#endif
+                *dst = v;
+            }
+            lds_barrier();                           // the half block has been read: the next half / the next region's U_1 may land
+            LAB_STAMP(4 + 2 * h)
+        });
+#ifdef SPK_WINO_LAB
+        if (lab_region == 1 && blockIdx.x == 8 && blockIdx.y == 0 && tid == 0)
+            for (int k = 0; k < 7; ++k) p.y[k] = (float)(long long)(lab_t[k] - lab_t[0]);
+        ++lab_region;
+#endif
+        if (!more) break;
     }
 #undef WINO_FRAG
 #undef WINO_T_WRITE
@@ -258,69 +415,6 @@ __global__ __launch_bounds__(NT) void wino_kernel(const Args p) {
 #undef WINO_T_READ
 #undef WINO_DMA_U
 #undef WINO_DMA_RAW
-
-    // ---- output transform Y = A^T M A (A^T = [1,1,1,0; 0,1,-1,-1]) and the block into LDS as [co][8 rows x 32 pixels] ----
-    float* const ot = smem;
-    const int tile = wn * 32 + l32, oy = 2 * (tile >> 4), ox = 2 * (tile & 15);
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-        float s0[4], s1[4];
-#pragma unroll
-        for (int i = 0; i < 4; ++i) {
-            const float m0 = acc[4 * i][r], m1 = acc[4 * i + 1][r], m2 = acc[4 * i + 2][r], m3 = acc[4 * i + 3][r];
-            s0[i] = (m0 + m1) + m2;
-            s1[i] = (m1 - m2) - m3;
-        }
-        const int row = wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-        f32x2 top, bot;
-        top.x = (s0[0] + s0[1]) + s0[2]; top.y = (s1[0] + s1[1]) + s1[2];
-        bot.x = (s0[1] - s0[2]) - s0[3]; bot.y = (s1[1] - s1[2]) - s1[3];
-        *reinterpret_cast<f32x2*>(ot + row * OP + oy * RW + ox) = top;
-        *reinterpret_cast<f32x2*>(ot + row * OP + (oy + 1) * RW + ox) = bot;
-    }
-    __syncthreads();
-
-    // ---- the f32 kernel's staged epilogue, element for element: a thread finishes 4 consecutive pixels of a channel ----
-    const bool f_bias = p.flags & SPK_EPI_BIAS, f_noise = p.flags & SPK_EPI_NOISE;
-    const bool f_lrelu = p.flags & SPK_EPI_LRELU, f_style = p.flags & SPK_EPI_STYLE, f_accum = p.flags & SPK_EPI_ACCUM;
-    const float osc = p.out_scale_dev ? p.out_scale * *p.out_scale_dev : p.out_scale;
-    constexpr int F4 = RW * RH / 4, RPI = NT / F4;       // 64 vectors per channel row, 4 rows per pass
-    const int f4 = tid % F4, row0 = tid / F4;
-    const int pt = 4 * f4, px = pt & (RW - 1), py = pt / RW;
-    const size_t pix = (size_t)(y0 + py) * p.W + (x0 + px);
-    const size_t o0 = (size_t)b * p.Cout * HW + pix;
-    float4 nzv = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (f_noise) nzv = *reinterpret_cast<const float4*>(p.noise + (size_t)b * HW + pix);
-    const float* stp = f_style ? p.style + (size_t)b * p.style_stride : nullptr;
-#pragma unroll 2
-    for (int i = 0; i < CO_T / RPI; ++i) {
-        const int cl = row0 + RPI * i, co = co0 + cl;
-        if (co >= p.Cout) continue;
-        float4 v = *reinterpret_cast<const float4*>(ot + cl * OP + pt);
-        v.x *= osc; v.y *= osc; v.z *= osc; v.w *= osc;
-        const float bb = f_bias ? p.bias[co] : 0.f;
-        v.x += bb; v.y += bb; v.z += bb; v.w += bb;
-        if (f_noise) {
-            const float nwc = p.noise_w[co];
-            v.x += nwc * nzv.x; v.y += nwc * nzv.y; v.z += nwc * nzv.z; v.w += nwc * nzv.w;
-        }
-        if (f_lrelu) {
-            v.x = (v.x > 0.f ? v.x : v.x * p.slope) * p.act_gain; v.y = (v.y > 0.f ? v.y : v.y * p.slope) * p.act_gain;
-            v.z = (v.z > 0.f ? v.z : v.z * p.slope) * p.act_gain; v.w = (v.w > 0.f ? v.w : v.w * p.slope) * p.act_gain;
-        }
-        const size_t off = o0 + (size_t)co * HW;
-        if (p.y_pre) *reinterpret_cast<float4*>(p.y_pre + off) = v;
-        if (f_style) {
-            const float s0 = stp[co] + 1.f, s1 = stp[p.Cout + co];
-            v.x = v.x * s0 + s1; v.y = v.y * s0 + s1; v.z = v.z * s0 + s1; v.w = v.w * s0 + s1;
-        }
-        float4* dst = reinterpret_cast<float4*>(p.y + off);
-        if (f_accum) {
-            const float4 old = *dst;
-            v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
-        }
-        *dst = v;
-    }
 }
 
 }  // namespace spkwino
@@ -384,9 +478,23 @@ int spk_conv2d_wino_fwd(const spk_conv2d_desc* d, void* stream) {
         if (e != hipSuccess) return spk::fail(SPK_ELAUNCH, "hipFuncSetAttribute(LDS): %s", hipGetErrorString(e));
         raised = true;
     }
-    const long long gx = (long long)a.regions_x * a.regions_y * d->B;
-    SPK_REQUIRE(gx < (1ll << 31), "conv2d winograd: grid too large");
-    dim3 grid((unsigned)gx, (unsigned)spk::ceil_div(d->Cout, CO_T));
+    const long long n_regions = (long long)a.regions_x * a.regions_y * d->B;
+    SPK_REQUIRE(n_regions < (1ll << 31), "conv2d winograd: grid too large");
+    // persistent: one workgroup per CU over all channel tiles, a multiple of 8 per channel tile (the XCD shares), at most one per region
+    const int co_tiles = spk::ceil_div(d->Cout, CO_T);
+    static int n_cu = 0;
+    if (n_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return spk::fail(SPK_ELAUNCH, "conv2d winograd: no device properties");
+        n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    long long gx = std::max(8ll, ((long long)n_cu / co_tiles) / 8 * 8);
+    static int lab_mult = -1;       // LAB: SPK_WINO_WGS = workgroups per CU slot (0: one workgroup per region)
+    if (lab_mult < 0) { const char* e = getenv("SPK_WINO_WGS"); lab_mult = e ? atoi(e) : 1; }
+    gx = lab_mult == 0 ? (n_regions + 7) / 8 * 8 : gx * lab_mult;
+    gx = std::min(gx, (n_regions + 7) / 8 * 8);
+    dim3 grid((unsigned)gx, (unsigned)co_tiles);
     hipLaunchKernelGGL(wino_kernel, grid, dim3(NT), LDS_BYTES, (hipStream_t)stream, a);
     return spk::check_launch("wino_kernel");
 }

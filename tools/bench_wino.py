@@ -28,7 +28,10 @@ def main():
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--reps", type=int, default=20)
     args = ap.parse_args()
-    ops = importlib.import_module("speak-hack_amd").ops
+    pkg = importlib.import_module("speak-hack_amd")
+    if os.environ.get("SPK_LAB_LIB"):          # A/B against another build of the library
+        pkg._lib.LIB_PATH = os.path.abspath(os.environ["SPK_LAB_LIB"])
+    ops = pkg.ops
     dev = torch.device("cuda:0")
     B = args.batch
     layers = [(512, 512, 32), (512, 512, 64), (512, 256, 64), (256, 256, 64), (256, 128, 128), (128, 128, 128), (128, 64, 256), (64, 64, 256),
