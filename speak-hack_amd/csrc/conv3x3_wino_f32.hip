@@ -24,8 +24,8 @@
 //   * V: wave w transforms its two planes for all 64 tiles (a lane = a tile: 8 ds_read_b64 + 32 adds + 16 ds_write_b32 per
 //     plane), 2 slots;  one barrier per chunk.
 // LDS: 2 x 32 KB (U) + 2 x 32 KB (V) + 2 x 11 KB (raw) = 150 KB.  Vector instructions per chunk of 64 MFMAs: 64 adds.
-// Epilogue: output transform in registers, the 64 x 256 block through LDS, then the f32 kernel's staged epilogue element for
-// element (out_scale, bias, noise, LeakyReLU, [y_pre], style, [accumulate]; 16-byte stores).
+// Epilogue: output transform and the f32 kernel's epilogue element for element (out_scale, bias, noise, LeakyReLU, [y_pre], style,
+// [accumulate]) in registers; a lane stores its tile's 2 x 2 pixels as two 8-byte stores, 16 lanes a whole 128-byte line.
 #include "conv_mfma_f32.hpp"
 
 namespace spkwino {
@@ -46,9 +46,7 @@ constexpr int U_OFF = 0, V_OFF = 2 * U_FLOATS, RAW_OFF = V_OFF + 2 * V_FLOATS;
 constexpr int PRM_OFF = RAW_OFF + 2 * RAW_FLOATS;                            // [64 co][bias, noise weight, style s0 + 1, style s1] of the region
 constexpr int LDS_FLOATS = PRM_OFF + 4 * CO_T;
 constexpr int LDS_BYTES = LDS_FLOATS * 4;                                    // 154 624
-constexpr int OP = RW * RH;                                                  // pitch of the epilogue's output block: 32 rows x 256 floats = one U slot
 static_assert(NTILE == 64 && RAW_GATHERS == 11 && RAW_USED <= RAW_PLANE, "geometry");
-static_assert(CO_T / 2 * OP == U_FLOATS, "half of the epilogue block is exactly one U slot");
 constexpr int U_DMA = U_FLOATS * 4 / 1024 / 4;                               // 1 KB blocks per wave and chunk (8)
 
 struct Args {
@@ -103,6 +101,11 @@ __global__ void pack_wino_kernel(const float* __restrict__ w, float* __restrict_
     out[idx] = v;
 }
 
+// One vector add / subtract, spelled out: given the whole transform, the compiler pairs the operands for v_pk_add_f32 and pays for
+// it with a v_mov_b32 per pair (24 moves per chunk of 64 MFMAs; a packed op costs its two scalar ones on this part anyway).
+__device__ __forceinline__ float fadd_(float a, float b) { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ float fsub_(float a, float b) { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() is a fence: it waits for vmcnt(0) too, i.e. for every global
 // STORE the wave has issued -- behind the epilogue's stores that is a full HBM write latency (~5 000 cycles, measured with
 // tools/lab_wino_phases.py) with the matrix pipe idle, twice per region.
@@ -138,20 +141,24 @@ __global__ __launch_bounds__(NT) void wino_kernel(const Args p) {
         y0_ = (t_ - b_ * p.regions_y) * RH;
         x0_ = rx_ * RW;
     };
-    auto set_voff = [&](unsigned (&vo)[RAW_GATHERS], int b_, int y0_, int x0_) {
-        const unsigned img = (unsigned)b_ * (unsigned)p.Cin * (unsigned)HW;           // (host: the whole tensor is below 2^29 floats)
-        int ln = lane;
-        asm volatile("" : "+v"(ln));     // recompute the element coordinates here: hoisted out of the region loop they are 30 registers, spilled
+    // per lane and gather, once: the element's byte offset from the region's origin pixel in plane 0 of the image (wraps for the
+    // halo's row -1 / column -1: the sum with the origin is in range whenever the element exists), and which image edges would
+    // put it outside (bit 0: region at the top edge, 1: bottom, 2: left, 3: right, 4: the pitch's padding -- never loaded)
+    unsigned rel[RAW_GATHERS], edge[RAW_GATHERS];
 #pragma unroll
-        for (int k = 0; k < RAW_GATHERS; ++k) {
-            const int e = k * 64 + ln;
-            const int j = e >= RAW_PLANE ? 1 : 0, q = e - j * RAW_PLANE;
-            const int r = (int)__umulhi((unsigned)q, 0x07878788u);             // q / 34 for q < 2^16 (ceil(2^32 / 34))
-            const int yy = y0_ - 1 + r, xx = x0_ - 1 + (q - r * RAW_W);
-            const bool ok = q < RAW_USED && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
-            const unsigned off = (img + (unsigned)(wave + 4 * j) * (unsigned)HW + (unsigned)(yy * p.W + xx)) * 4u;
-            vo[k] = ok ? off : 0x80000000u;
-        }
+    for (int k = 0; k < RAW_GATHERS; ++k) {
+        const int e = k * 64 + lane;
+        const int j = e >= RAW_PLANE ? 1 : 0, q = e - j * RAW_PLANE;
+        const int r = q / RAW_W, c = q - r * RAW_W;
+        rel[k] = ((unsigned)(wave + 4 * j) * (unsigned)HW + (unsigned)((r - 1) * p.W + (c - 1))) * 4u;
+        edge[k] = (r == 0 ? 1u : 0u) | (r == RAW_H - 1 ? 2u : 0u) | (c == 0 ? 4u : 0u) | (c == RAW_W - 1 ? 8u : 0u) | (q >= RAW_USED ? 16u : 0u);
+    }
+    auto set_voff = [&](unsigned (&vo)[RAW_GATHERS], int b_, int y0_, int x0_) {
+        // (host: the whole tensor is below 2^29 floats)
+        const unsigned origin = (((unsigned)b_ * (unsigned)p.Cin) * (unsigned)HW + (unsigned)(y0_ * p.W + x0_)) * 4u;
+        const unsigned at = (y0_ == 0 ? 1u : 0u) | (y0_ + RH >= p.H ? 2u : 0u) | (x0_ == 0 ? 4u : 0u) | (x0_ + RW >= p.W ? 8u : 0u) | 16u;
+#pragma unroll
+        for (int k = 0; k < RAW_GATHERS; ++k) vo[k] = (edge[k] & at) ? 0x80000000u : origin + rel[k];
     };
     const unsigned chunk_bytes = (unsigned)(CI_T * HW * 4);
     const float* wsrc = p.wp + (size_t)co_tile * p.n_chunks * U_FLOATS;
@@ -202,14 +209,14 @@ __global__ __launch_bounds__(NT) void wino_kernel(const Args p) {
     // B^T d over the rows (column c_): t0 = d0 - d2, t1 = d1 + d2, t2 = d2 - d1, t3 = d1 - d3
 #define WINO_T_ROWS(j_, c_)                                                                                             \
     {                                                                                                                   \
-        tq[j_][c_] = d[j_][c_] - d[j_][8 + (c_)]; tq[j_][4 + (c_)] = d[j_][4 + (c_)] + d[j_][8 + (c_)];                 \
-        tq[j_][8 + (c_)] = d[j_][8 + (c_)] - d[j_][4 + (c_)]; tq[j_][12 + (c_)] = d[j_][4 + (c_)] - d[j_][12 + (c_)];   \
+        tq[j_][c_] = fsub_(d[j_][c_], d[j_][8 + (c_)]); tq[j_][4 + (c_)] = fadd_(d[j_][4 + (c_)], d[j_][8 + (c_)]);     \
+        tq[j_][8 + (c_)] = fsub_(d[j_][8 + (c_)], d[j_][4 + (c_)]); tq[j_][12 + (c_)] = fsub_(d[j_][4 + (c_)], d[j_][12 + (c_)]); \
     }
     // (.) B over the columns (row i_)
 #define WINO_T_COLS(j_, i_)                                                                                             \
     {                                                                                                                   \
-        tv[j_][4 * (i_)] = tq[j_][4 * (i_)] - tq[j_][4 * (i_) + 2]; tv[j_][4 * (i_) + 1] = tq[j_][4 * (i_) + 1] + tq[j_][4 * (i_) + 2]; \
-        tv[j_][4 * (i_) + 2] = tq[j_][4 * (i_) + 2] - tq[j_][4 * (i_) + 1]; tv[j_][4 * (i_) + 3] = tq[j_][4 * (i_) + 1] - tq[j_][4 * (i_) + 3]; \
+        tv[j_][4 * (i_)] = fsub_(tq[j_][4 * (i_)], tq[j_][4 * (i_) + 2]); tv[j_][4 * (i_) + 1] = fadd_(tq[j_][4 * (i_) + 1], tq[j_][4 * (i_) + 2]); \
+        tv[j_][4 * (i_) + 2] = fsub_(tq[j_][4 * (i_) + 2], tq[j_][4 * (i_) + 1]); tv[j_][4 * (i_) + 3] = fsub_(tq[j_][4 * (i_) + 1], tq[j_][4 * (i_) + 3]); \
     }
 #define WINO_T_WRITE(vs_, j_, xi_)                                                                                      \
     *((volatile lds_f32_t*)0 + (v_wr + ((vs_) * V_FLOATS + ((xi_) * CI_T + 4 * (j_)) * NTILE))) = tv[j_][xi_];
@@ -230,6 +237,7 @@ __global__ __launch_bounds__(NT) void wino_kernel(const Args p) {
         static_for<0, 4>([&](auto c) { WINO_T_ROWS(decltype(j)::value, decltype(c)::value); });
         static_for<0, 4>([&](auto i) { WINO_T_COLS(decltype(j)::value, decltype(i)::value); });
         static_for<0, 16>([&](auto xi) { WINO_T_WRITE(0, decltype(j)::value, decltype(xi)::value); });
+        __builtin_amdgcn_sched_barrier(0);           // one plane at a time: the register peak of this block decides what is spilled kernel-wide
     });
     __syncthreads();
 
@@ -277,11 +285,15 @@ __global__ __launch_bounds__(NT) void wino_kernel(const Args p) {
     const bool f_lrelu = p.flags & SPK_EPI_LRELU, f_style = p.flags & SPK_EPI_STYLE, f_accum = p.flags & SPK_EPI_ACCUM;
     const float osc = p.out_scale_dev ? p.out_scale * *p.out_scale_dev : p.out_scale;
     const float slope_ = f_lrelu ? p.slope : 1.f, gain_ = f_lrelu ? p.act_gain : 1.f;    // (no LeakyReLU: slope 1, gain 1)
-    // the epilogue's block, HALF of it at a time -- [32 co][8 x 32 pixels] = U slot 1, the one slot of the ring that holds nothing
-    // of the next region when a region's last chunk is done (U slot 0: its first weights; V slot 0: its first V; the raw slots)
-    float* const ot = smem + U_OFF + U_FLOATS;
+    // epilogue geometry: lane = tile of the region (l32 + 32 wn) -> its 2 x 2 output pixels; accumulator register r of the lane's
+    // half = channel row (r & 3) + 8 (r >> 2) + 4 half of the wave's 32
     const int tile = wn * 32 + l32, oy = 2 * (tile >> 4), ox = 2 * (tile & 15);
-    const int f4 = lane, pt = 4 * f4, px = pt & (RW - 1), py = pt / RW;       // a wave finishes one channel row per pass: 64 x 4 pixels
+    const int row_lane = wm * 32 + 4 * half;                              // + (r & 3) + 8 (r >> 2): row of the 64-channel tile
+    // the operand table of the epilogue: thread t fetches operand t & 3 (bias, noise weight, style scale, style shift) of channel t >> 2
+    const int prm_which = tid & 3, prm_c = co0 + (tid >> 2);
+    const bool prm_on = prm_c < p.Cout && (prm_which == 0 ? f_bias : (prm_which == 1 ? f_noise : f_style));
+    const float* const prm_src = (prm_which == 0 ? p.bias : (prm_which == 1 ? p.noise_w : p.style + (prm_which == 3 ? p.Cout : 0))) + prm_c;
+    const float prm_neutral = prm_which == 2 ? 1.f : 0.f;                 // + 0, + 0 * noise, * 1, + 0
 
     using F_ = std::false_type;
 #ifdef SPK_WINO_LAB      // tools/lab_wino_phases.py: cycle stamps of one workgroup's second region, written over the output's first floats
@@ -302,19 +314,18 @@ __global__ __launch_bounds__(NT) void wino_kernel(const Args p) {
         // everything the epilogue reads from global memory is requested NOW and lands behind the region's MFMAs: the noise of
         // this thread's four pixels, and (wave 0: one channel per lane) the channel's bias / noise weight / style pair, which
         // reach the other waves through a 1 KB LDS table -- no load latency between the last MFMA and the stores
-        const size_t pix = (size_t)(cur_y0 + py) * p.W + (cur_x0 + px);
-        float4 nzv = make_float4(0.f, 0.f, 0.f, 0.f);
-        if (f_noise) nzv = *reinterpret_cast<const float4*>(p.noise + (size_t)cur_b * HW + pix);
-        float4 prm = make_float4(0.f, 0.f, 1.f, 0.f);      // neutral: + 0, + 0 * noise, * 1 + 0 -- the finishing loop applies every stage, unconditionally
-        if (wave == 0 && co0 + lane < p.Cout) {
-            const int c_ = co0 + lane;
-            if (f_bias) prm.x = p.bias[c_];
-            if (f_noise) prm.y = p.noise_w[c_];
-            if (f_style) {
-                const float* stp = p.style + (size_t)cur_b * p.style_stride;
-                prm.z = stp[c_] + 1.f;
-                prm.w = stp[p.Cout + c_];
-            }
+        const size_t pix = (size_t)(cur_y0 + oy) * p.W + (cur_x0 + ox);          // this lane's tile: pixels (pix, pix + 1), (pix + W, pix + W + 1)
+        f32x2 nz0, nz1;
+        nz0.x = nz0.y = nz1.x = nz1.y = 0.f;
+        if (f_noise) {
+            nz0 = *reinterpret_cast<const f32x2*>(p.noise + (size_t)cur_b * HW + pix);
+            nz1 = *reinterpret_cast<const f32x2*>(p.noise + (size_t)cur_b * HW + pix + p.W);
+        }
+        // thread t fetches operand t & 3 of channel t >> 2: bias / noise weight / style scale + 1 / style shift, or its neutral value
+        float prm = prm_neutral;
+        if (prm_on) {                                    // ONE load per thread, no branch per operand kind
+            const float t_ = prm_src[prm_which >= 2 ? (size_t)cur_b * p.style_stride : 0];
+            prm = prm_which == 2 ? t_ + 1.f : t_;
         }
         const bool more = reg + wpx < reg_end;
         if (more) {
@@ -337,73 +348,68 @@ __global__ __launch_bounds__(NT) void wino_kernel(const Args p) {
             chunk_body(std::integral_constant<int, 1>{}, F_{}, i + 1);
         }
 
-        // ---- epilogue, twice: output transform Y = A^T M A (A^T = [1,1,1,0; 0,1,-1,-1]) of half of every wave's channel rows into
-        // the LDS block, then the f32 kernel's staged epilogue element for element (a thread finishes 4 consecutive pixels) ----
+        // ---- epilogue, in registers: output transform Y = A^T M A (A^T = [1,1,1,0; 0,1,-1,-1]) of one channel row at a time, then the
+        // f32 kernel's epilogue element for element (out_scale, bias, noise, LeakyReLU, [y_pre], style, [accumulate]) on the lane's
+        // 2 x 2 pixels, and two 8-byte stores: lanes 0-15 / 16-31 of a half-wave cover 32 consecutive pixels of two image rows --
+        // whole 128-byte lines -- so the block needs no trip through LDS (which would also collide with the next region's operands).
+        // Every stage runs unconditionally; an absent one has its neutral operand in the table.
         LAB_STAMP(2)
-        const size_t o0 = (size_t)cur_b * p.Cout * HW + pix;
-        if (wave == 0) *reinterpret_cast<float4*>(smem + PRM_OFF + 4 * lane) = prm;      // (published by the first half's barrier)
-        static_for<0, 2>([&](auto h_c) {
-            constexpr int h = decltype(h_c)::value;
-            // accumulator registers r = 8 h .. 8 h + 7 are the wave's rows 16 h + (r & 3) + 8 ((r >> 2) & 1) + 4 half
+        smem[PRM_OFF + tid] = prm;
+        lds_barrier();
+        unsigned hw_ = (unsigned)HW;                 // (opaque per region: the 16 rows' channel offsets must not be hoisted out of the region
+        asm volatile("" : "+s"(hw_));                //  loop as 32 live registers)
+        const size_t o0 = (size_t)cur_b * p.Cout * hw_ + pix;
+        LAB_STAMP(3)
+        // The accumulators are read out of the AGPR file one element at a time, by hand (v_accvgpr_read_b32 with an "a" operand):
+        // left to the compiler, the first use of element r of a tile copies the whole 16-register tile to VGPRs, a row touches all
+        // 16 tiles, and 256 VGPRs of copies push everything else that is alive into scratch -- whose reloads then queue, in
+        // vmcnt order, behind the epilogue's own stores (25 000 cycles per region, measured).
+#define WINO_ACC(xi_, r_) ({ float v_; asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v_) : "a"(acc[xi_][r_])); v_; })
+        static_for<0, 16>([&](auto r_c) {
+            constexpr int r = decltype(r_c)::value;
+            const int row = row_lane + (r & 3) + 8 * (r >> 2);
+            const float4 q_ = *reinterpret_cast<const float4*>(smem + PRM_OFF + 4 * row);
+            float s0[4], s1[4];
 #pragma unroll
-            for (int q = 0; q < 8; ++q) {
-                const int r = 8 * h + q;
-                float s0[4], s1[4];
-#pragma unroll
-                for (int i = 0; i < 4; ++i) {
-                    const float m0 = acc[4 * i][r], m1 = acc[4 * i + 1][r], m2 = acc[4 * i + 2][r], m3 = acc[4 * i + 3][r];
-                    s0[i] = (m0 + m1) + m2;
-                    s1[i] = (m1 - m2) - m3;
+            for (int i = 0; i < 4; ++i) {
+                const float m0 = WINO_ACC(4 * i, r), m1 = WINO_ACC(4 * i + 1, r), m2 = WINO_ACC(4 * i + 2, r), m3 = WINO_ACC(4 * i + 3, r);
+                s0[i] = (m0 + m1) + m2;
+                s1[i] = (m1 - m2) - m3;
+            }
+            f32x2 top, bot;
+            top.x = (s0[0] + s0[1]) + s0[2]; top.y = (s1[0] + s1[1]) + s1[2];
+            bot.x = (s0[1] - s0[2]) - s0[3]; bot.y = (s1[1] - s1[2]) - s1[3];
+            top.x = top.x * osc + q_.x; top.y = top.y * osc + q_.x; bot.x = bot.x * osc + q_.x; bot.y = bot.y * osc + q_.x;
+            top.x += q_.y * nz0.x; top.y += q_.y * nz0.y; bot.x += q_.y * nz1.x; bot.y += q_.y * nz1.y;
+            top.x = (top.x > 0.f ? top.x : top.x * slope_) * gain_; top.y = (top.y > 0.f ? top.y : top.y * slope_) * gain_;
+            bot.x = (bot.x > 0.f ? bot.x : bot.x * slope_) * gain_; bot.y = (bot.y > 0.f ? bot.y : bot.y * slope_) * gain_;
+            const int co = co0 + row;
+            if (co < p.Cout) {
+                const size_t off = o0 + (size_t)co * hw_;
+                if (p.y_pre) {
+                    *reinterpret_cast<f32x2*>(p.y_pre + off) = top;
+                    *reinterpret_cast<f32x2*>(p.y_pre + off + p.W) = bot;
                 }
-                const int row = wm * 16 + (q & 3) + 8 * (q >> 2) + 4 * half;       // row of the HALF block: 16 rows per wave row
-                f32x2 top, bot;
-                top.x = (s0[0] + s0[1]) + s0[2]; top.y = (s1[0] + s1[1]) + s1[2];
-                bot.x = (s0[1] - s0[2]) - s0[3]; bot.y = (s1[1] - s1[2]) - s1[3];
-                *reinterpret_cast<f32x2*>(ot + row * OP + oy * RW + ox) = top;
-                *reinterpret_cast<f32x2*>(ot + row * OP + (oy + 1) * RW + ox) = bot;
-                __builtin_amdgcn_sched_barrier(0);   // one row at a time: hoisted together, the 256 accumulator reads need 256 VGPRs and spill the rest
-            }
-            lds_barrier();
-            LAB_STAMP(3 + 2 * h)
-            // eight channel rows per wave: all their LDS reads first, then arithmetic and stores -- no branch on the epilogue flags
-            // (an absent stage runs with its neutral operand), so nothing serialises on an LDS round trip per row
-            float4 vv[8], qq[8];
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int cl = wave + 4 * i;                                         // row of the half block (wave-uniform)
-                vv[i] = *reinterpret_cast<const float4*>(ot + cl * OP + pt);
-                qq[i] = *reinterpret_cast<const float4*>(smem + PRM_OFF + 4 * ((cl >> 4) * 32 + 16 * h + (cl & 15)));   // (one address per wave: a broadcast)
-            }
-#pragma unroll
-            for (int i = 0; i < 8; ++i) {
-                const int cl = wave + 4 * i;
-                const int co = co0 + (cl >> 4) * 32 + 16 * h + (cl & 15);            // half-block row -> channel: wave row, half, row
-                if (co >= p.Cout) continue;
-                float4 v = vv[i];
-                const float4 q_ = qq[i];
-                v.x = v.x * osc + q_.x; v.y = v.y * osc + q_.x; v.z = v.z * osc + q_.x; v.w = v.w * osc + q_.x;
-                v.x += q_.y * nzv.x; v.y += q_.y * nzv.y; v.z += q_.y * nzv.z; v.w += q_.y * nzv.w;
-                v.x = (v.x > 0.f ? v.x : v.x * slope_) * gain_; v.y = (v.y > 0.f ? v.y : v.y * slope_) * gain_;
-                v.z = (v.z > 0.f ? v.z : v.z * slope_) * gain_; v.w = (v.w > 0.f ? v.w : v.w * slope_) * gain_;
-                const size_t off = o0 + (size_t)co * HW;
-                if (p.y_pre) *reinterpret_cast<float4*>(p.y_pre + off) = v;
-                v.x = v.x * q_.z + q_.w; v.y = v.y * q_.z + q_.w; v.z = v.z * q_.z + q_.w; v.w = v.w * q_.z + q_.w;
-                float4* dst = reinterpret_cast<float4*>(p.y + off);
+                top.x = top.x * q_.z + q_.w; top.y = top.y * q_.z + q_.w; bot.x = bot.x * q_.z + q_.w; bot.y = bot.y * q_.z + q_.w;
                 if (f_accum) {
-                    const float4 old = *dst;
-                    v.x += old.x; v.y += old.y; v.z += old.z; v.w += old.w;
+                    const f32x2 o_t = *reinterpret_cast<const f32x2*>(p.y + off), o_b = *reinterpret_cast<const f32x2*>(p.y + off + p.W);
+                    top.x += o_t.x; top.y += o_t.y; bot.x += o_b.x; bot.y += o_b.y;
                 }
-#ifdef SPK_WINO_NOSTORE   // LAB knock-out: everything but the store itself
-                if (v.x == 12345.678f)
+#ifdef SPK_WINO_NOSTORE   // LAB knock-out: everything but the stores themselves
+                if (top.x == 12345.678f)
 #endif
-                *dst = v;
+                {
+                    *reinterpret_cast<f32x2*>(p.y + off) = top;
+                    *reinterpret_cast<f32x2*>(p.y + off + p.W) = bot;
+                }
             }
-            lds_barrier();                           // the half block has been read: the next half / the next region's U_1 may land
-            LAB_STAMP(4 + 2 * h)
         });
+#undef WINO_ACC
+        LAB_STAMP(4)
+        lds_barrier();                               // (the table has been read: the next region may rewrite it)
 #ifdef SPK_WINO_LAB
         if (lab_region == 1 && blockIdx.x == 8 && blockIdx.y == 0 && tid == 0)
-            for (int k = 0; k < 7; ++k) p.y[k] = (float)(long long)(lab_t[k] - lab_t[0]);
+            for (int k = 0; k < 5; ++k) p.y[k] = (float)(long long)(lab_t[k] - lab_t[0]);
         ++lab_region;
 #endif
         if (!more) break;

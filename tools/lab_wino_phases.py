@@ -9,7 +9,7 @@ pkg = importlib.import_module("speak-hack_amd")
 pkg._lib.LIB_PATH = os.path.abspath(os.environ["SPK_LAB_LIB"])
 ops = pkg.ops
 dev = torch.device("cuda:0")
-names = ["region start", "K loop start", "K loop end", "half 0 in LDS", "half 0 stored", "half 1 in LDS", "half 1 stored"]
+names = ["region start", "K loop start", "K loop end", "table published", "rows stored"]
 for Cin, Cout, R in ((64, 64, 256), (128, 64, 256), (128, 128, 128), (512, 512, 64)):
     x = torch.randn(8, Cin, R, R, device=dev)
     w = torch.randn(Cout, Cin, 3, 3, device=dev) * 0.05
@@ -19,5 +19,5 @@ for Cin, Cout, R in ((64, 64, 256), (128, 64, 256), (128, 128, 128), (512, 512, 
     for _ in range(3):
         y = ops.conv3x3_wino(x, ww, Cout, bias=bias, noise_w=nw, noise=noise, style=style, lrelu_slope=0.2)
     torch.cuda.synchronize()
-    t = y.flatten()[:7].tolist()
+    t = y.flatten()[:5].tolist()
     print(f"{Cin}->{Cout} @{R}^2: " + "; ".join(f"{n} {int(v)}" for n, v in zip(names, t)) + f"   (chunks {Cin // 8}: MFMA floor {Cin // 8 * 4096} cycles)")
