@@ -75,6 +75,24 @@ def decoder_conv_flops(batch, resolution=RES):
     return total * batch
 
 
+def pair_executed_gflop(ops, frames):
+    """EXECUTED matrix GFLOP of one training pair (x_s, x_t) in the generator step as THIS build runs it: the encoders' activations
+    are stored (no checkpoint recompute: 3 x 10.677 per encoder pass, 6 passes), the decoder's two frames run forward + data
+    gradient + weight gradient (3 x 56.214 each) -- and where a 3x3 layer's forward / data gradient go to the Winograd kernel
+    (ops.use_wino at the step's decoder batch of ``frames``) they execute 16/36 of their algorithmic FLOPs."""
+    saved, r, cin = 0.0, 8, 512
+    while r <= RES:
+        cout = min(int(8192 / (2.0 ** (r.bit_length() - 2))), 512)
+        for ci, co in ((cin, cout), (cout, cout)):
+            fl = 2 * 9 * ci * co * r * r / 1e9                       # per frame
+            if ops.use_wino(frames, ci, co, r, r):
+                saved += fl * (1 - 16.0 / 36.0)                      # forward
+            if ops.use_wino(frames, co, ci, r, r):
+                saved += fl * (1 - 16.0 / 36.0)                      # data gradient
+        cin, r = cout, r * 2
+    return GFLOP_PER_PAIR_EXECUTED - 2 * saved
+
+
 def host_cores():
     """Cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
@@ -123,6 +141,26 @@ def committed_traffic(which, launches):
         return int(t["bytes_per_launch"])
     except (OSError, KeyError, ValueError):
         return None
+
+
+def plan_conv_flops(plan, L):
+    """(algorithmic FLOPs, EXECUTED matrix FLOPs, launches on the Winograd kernel, launches on the direct kernel) of a launch plan's
+    3x3 conv launches.  A Winograd F(2x2, 3x3) launch executes 16 multiply-adds per 2x2 output tile and (ci, co) pair where the
+    direct form executes 36: its matrix instructions do 16/36 of the algorithmic FLOPs."""
+    alg = exe = 0.0
+    n_w = n_d = 0
+    for kind, d in plan.ops:
+        if kind != L.OP_CONV2D:
+            continue
+        fl = 2.0 * d.kh * d.kw * d.Cin * d.Cout * d.H * d.W * d.B
+        alg += fl
+        if d.flags & L.CONV_WINOGRAD:
+            exe += fl * 16.0 / 36.0
+            n_w += 1
+        else:
+            exe += fl
+            n_d += 1
+    return alg, exe, n_w, n_d
 
 
 def event_ms(fn, reps):
@@ -174,13 +212,35 @@ def conv_time_ms(module, feats, L):
     capture(lambda: module(feats))                # make sure the side stream's plan exists and is the most recent one
     plan = plan_of(module)
     if plan is None:
-        return None, None
+        return None, None, None
     g_all, _ = capture(lambda: plan.run(feats))
     g_nc, _ = capture(lambda: plan.run(feats, kind_mask=L.ALL_OPS & ~(1 << L.OP_CONV2D)))
     R = 20
-    ms = event_ms(g_all.replay, R) - event_ms(g_nc.replay, R)
+    t_nc = event_ms(g_nc.replay, R)
+    ms = event_ms(g_all.replay, R) - t_nc
     n = sum(1 for kind, _ in plan.ops if kind == L.OP_CONV2D)
-    return ms, n
+    up_ms = 0.0
+    if any(kind == L.OP_UPSAMPLE2X for kind, _ in plan.ops):     # the x2 images the Winograd x2 layers read: their own launches
+        g_nu, _ = capture(lambda: plan.run(feats, kind_mask=L.ALL_OPS & ~(1 << L.OP_CONV2D) & ~(1 << L.OP_UPSAMPLE2X)))
+        up_ms = t_nc - event_ms(g_nu.replay, R)
+    return ms, n, up_ms
+
+
+def conv_roofline(plan, L, conv_ms, up_ms, kernel, traffic, step_ms, extra=None):
+    """The roofline object of a decoder plan's conv launches: achieved = EXECUTED matrix TFLOP/s (what the MFMA pipe does), with the
+    algorithmic rate beside it -- the two differ on the Winograd launches by 36/16."""
+    alg, exe, n_w, n_d = plan_conv_flops(plan, L)
+    ach = exe / (conv_ms * 1e-3) / 1e12
+    r = {"bound": "mfma", "kernel": kernel, "achieved": round(ach, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+         "frac": round(ach / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+         "achieved_is": "EXECUTED matrix FLOPs / conv time: a Winograd F(2x2,3x3) launch executes 16/36 of its algorithmic FLOPs",
+         "algorithmic_tflops": round(alg / (conv_ms * 1e-3) / 1e12, 2), "algorithmic_gflop_per_step": round(alg / 1e9, 2),
+         "executed_gflop_per_step": round(exe / 1e9, 2), "launches_per_step": n_w + n_d, "launches_winograd": n_w, "launches_direct": n_d,
+         "conv_ms_per_step": round(conv_ms, 4), "conv_share_of_step": round(conv_ms / step_ms, 3),
+         "upsample_ms_per_step": round(up_ms, 4)}
+    if extra:
+        r.update(extra)
+    return r
 
 
 def irfd_steps(pkg, dev, which, B, steps, warmup, precision="f32", sg2=False, observe=None):
@@ -539,7 +599,8 @@ def main():
         eager_ms = (time.perf_counter() - t1) / n_eager * 1e3
 
         # ---- roofline of the dominant kernel ----
-        conv_ms, n_launch = conv_time_ms(gen, feats, L)
+        conv_ms, n_launch, headline_up_ms = conv_time_ms(gen, feats, L)
+        headline_plan = plan_of(gen)
         roof_how = ("HIP events around 20 replays of the step's hipGraph minus 20 replays of the same launch list captured "
                     "without its conv launches (spk_launch_list kind_mask)")
         if conv_ms is None:
@@ -553,7 +614,7 @@ def main():
             try:
                 gb, _ = capture(eager_step)
                 bf_ms = event_ms(gb.replay, max(20, args.steps))
-                cb_ms, nb = conv_time_ms(gen, feats, L)
+                cb_ms, nb, _ = conv_time_ms(gen, feats, L)
                 plan_b = plan_of(gen)
                 fast = [d for kind, d in plan_b.ops if kind == L.OP_CONV2D and d.flags & L.CONV_BF16X3]
                 fl_fast = sum(2 * 9 * d.Cin * d.Cout * d.H * d.W * d.B for d in fast)
@@ -574,6 +635,18 @@ def main():
                              "frac": round((3 * fl_fast + (fl_all - fl_fast)) / (cb_ms * 1e-3) / 1e12 / BF16_MFMA_PEAK_TFLOPS, 4),
                              "traffic": committed_traffic("bf16x3", nb)}}
 
+            # ---- the headline workload on the DIRECT kernel everywhere (rounds 1-3's arithmetic, an fmaf chain per output) ----
+            with pkg.ops.conv3x3_algo("direct"):
+                gd, _ = capture(eager_step)
+                d_ms = event_ms(gd.replay, max(20, args.steps))
+                cd_ms, nd, _ = conv_time_ms(gen, feats, L)
+                extras["f32_direct"] = {
+                    "what": "the headline workload with ops.conv3x3_algo('direct') / SPK_CONV3X3_ALGO=direct: every 3x3 conv on the direct f32 MFMA "
+                            "implicit-GEMM kernel (bilinear x2 folded into staging), no Winograd launch -- the arithmetic of rounds 1-3",
+                    "frames_per_s_per_gpu": round(BATCH / d_ms * 1e3, 2), "ms_per_step": round(d_ms, 4),
+                    "roofline": conv_roofline(plan_of(gen), L, cd_ms, 0.0, "spkconv::conv_kernel<Cfg,3,3,1,MODE> (f32 MFMA implicit GEMM, fused upsample + "
+                                              "epilogue)", committed_traffic("f32", nd), d_ms)}
+                del gd
             # ---- the build-defined StyleGAN2 variant (modulated conv + upfirdn2d, A11) on the same workload ----
             sg2 = importlib.import_module("speak-hack_amd.stylegan2")
             gen2 = sg2.StyleGAN2Generator(6144).eval().to(dev)
@@ -582,7 +655,7 @@ def main():
                     p.fill_(0.1)
             g2, _ = capture(lambda: gen2(feats))
             sg2_ms = event_ms(g2.replay, max(10, args.steps // 2))
-            c2_ms, n2 = conv_time_ms(gen2, feats, L)
+            c2_ms, n2, _ = conv_time_ms(gen2, feats, L)
             t2 = time.perf_counter()
             for _ in range(10):
                 gen2(feats)
@@ -615,12 +688,14 @@ def main():
             w512 = torch.randn(4, 16, 512, device=dev)
             g5, _ = capture(lambda: s512(w512))
             ms5 = event_ms(g5.replay, 20)
-            c5_ms, n5 = conv_time_ms(s512, w512, L)
-            fl5 = decoder_conv_flops(4, 512)
+            c5_ms, n5, up5_ms = conv_time_ms(s512, w512, L)
+            r5 = conv_roofline(plan_of(s512), L, c5_ms, up5_ms, "spkwino::wino_kernel + spkconv::conv_kernel", None, ms5)
             extras["decoder_512_b4"] = {"what": "BASELINE config 5: SynthesisNetwork(resolution=512) forward, batch 4, fp32 (hipGraph replay)",
                                         "ms_per_step": round(ms5, 4), "frames_per_s_per_gpu": round(4 / ms5 * 1e3, 2),
-                                        "conv_ms_per_step": round(c5_ms, 4), "conv_tflops": round(fl5 / (c5_ms * 1e-3) / 1e12, 2),
-                                        "conv_frac_of_f32_mfma_peak": round(fl5 / (c5_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4)}
+                                        "conv_ms_per_step": round(c5_ms, 4), "conv_tflops": r5["achieved"],
+                                        "conv_frac_of_f32_mfma_peak": r5["frac"], "conv_algorithmic_tflops": r5["algorithmic_tflops"],
+                                        "conv_tflops_is": "executed matrix FLOPs (Winograd launches: 16/36 of algorithmic)",
+                                        "upsample_ms_per_step": r5["upsample_ms_per_step"]}
             del s512, g5
         torch.cuda.empty_cache()
         # ---- the weight-gradient kernel over the decoder's 12 conv layers (what a training step's backward runs), B = 8 ----
@@ -654,13 +729,16 @@ def main():
                                         "checkpoint semantics; 2 decoder passes; reconstruction loss; fwd + bwd + global-norm clip + Adam on Gd), "
                                         "batch 16, fp32, eager launches",
                                 "ms_per_step": round(g_ms, 2), "pairs_per_s": round(16 / g_ms * 1e3, 1),
-                                "executed_gflop_per_pair": round(GFLOP_PER_PAIR_EXECUTED, 1),
-                                "executed_tflops": round(16 / g_ms * 1e3 * GFLOP_PER_PAIR_EXECUTED / 1e3, 1),
-                                "frac_of_f32_mfma_peak": round(16 / g_ms * 1e3 * GFLOP_PER_PAIR_EXECUTED / 1e3 / F32_MFMA_PEAK_TFLOPS, 4),
+                                "executed_gflop_per_pair": round(pair_executed_gflop(pkg.ops, 32), 1),
+                                "executed_tflops": round(16 / g_ms * 1e3 * pair_executed_gflop(pkg.ops, 32) / 1e3, 1),
+                                "frac_of_f32_mfma_peak": round(16 / g_ms * 1e3 * pair_executed_gflop(pkg.ops, 32) / 1e3 / F32_MFMA_PEAK_TFLOPS, 4),
+                                "algorithmic_tflops_stored_activations": round(16 / g_ms * 1e3 * GFLOP_PER_PAIR_EXECUTED / 1e3, 1),
                                 "algorithmic_tflops_reference_equivalent": round(16 / g_ms * 1e3 * GFLOP_PER_PAIR / 1e3, 1),
-                                "flops_note": "frac_of_f32_mfma_peak counts EXECUTED FLOPs: the encoders' activations are stored, the "
-                                              "checkpoint's recompute (6 x 10.677 of the reference's 593.5 GFLOP per pair) is not run and "
-                                              "not counted; the reference-equivalent figure prices the step at the reference's own work"}
+                                "flops_note": "frac_of_f32_mfma_peak counts EXECUTED matrix FLOPs: the encoders' activations are stored (the "
+                                              "checkpoint's recompute, 6 x 10.677 of the reference's 593.5 GFLOP per pair, is not run: 529.4), and "
+                                              "the decoder's 3x3 forward / data-gradient convs on the Winograd kernel execute 16/36 of their "
+                                              "algorithmic FLOPs; the two algorithmic figures price the step at the work of the direct algorithm "
+                                              "without / with the reference's recompute"}
         g_bf = irfd_steps(pkg, dev, "g", 16, steps=5, warmup=2, precision="bf16x3")
         extras["train_step"]["bf16x3_opt_in"] = {
             "what": "OPT-IN ops.train_conv_precision('bf16x3'): the decoder's 3x3 convs forward and their data gradients on the bf16 pipe "
@@ -699,8 +777,6 @@ def main():
                 traffic = json.load(f)["bytes_per_launch"]
         except (OSError, KeyError, ValueError):
             pass
-        flops = decoder_conv_flops(BATCH)
-        achieved = flops / (conv_ms * 1e-3) / 1e12
         ms_per_step = elapsed / args.steps * 1e3
         line = {
             "metric": "generator frames/sec at 256^2, batch 8/GPU",
@@ -719,13 +795,12 @@ def main():
                                    "fp32, random-init weights, synthetic [8,6144] latents, device-drawn noise",
                        "global_batch": BATCH * world, "resolution": RES,
                        "parallelism": f"replicas x{world} (no data-path collective)",
-                       "launch": "hipGraph replay of the step" if graph is not None else "eager launches"},
-            "roofline": {"bound": "mfma", "kernel": "spkconv::conv_kernel<Cfg,3,3,1,MODE> (f32 MFMA implicit GEMM, fused upsample + epilogue)",
-                         "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
-                         "launches_per_step": n_launch, "conv_ms_per_step": round(conv_ms, 4),
-                         "conv_share_of_step": round(conv_ms / ms_per_step, 3),
-                         "algorithmic_gflop_per_step": round(flops / 1e9, 2), "measured_by": roof_how},
+                       "launch": "hipGraph replay of the step" if graph is not None else "eager launches",
+                       "conv3x3_algo": pkg.ops.CONV3X3_ALGO + " (fp32 Winograd F(2x2,3x3) where the kernel serves the layer, the direct fmaf-chain "
+                                       "kernel elsewhere; SPK_CONV3X3_ALGO=direct: the direct kernel everywhere)"},
+            "roofline": conv_roofline(headline_plan, L, conv_ms, headline_up_ms, "spkwino::wino_kernel (fp32 Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32, layers >= 32^2) + "
+                                      "spkconv::conv_kernel<Cfg,3,3,1,MODE> (direct f32 MFMA implicit GEMM, the 8^2 / 16^2 layers)", traffic, ms_per_step,
+                                      {"measured_by": roof_how}),
             "eager": {"what": "the same step without the hipGraph: one spk_launch_list call per forward (plan.DecoderPlan), as an "
                               "unchanged `model.Gd(x)` caller runs it", "ms_per_step": round(eager_ms, 4),
                       "frames_per_s_per_gpu": round(BATCH / eager_ms * 1e3, 2), "vs_graph": round(eager_ms / ms_per_step, 3)},
@@ -792,7 +867,8 @@ def main():
                 dp_g["what"] = ("BASELINE config 4: IRFD generator step (3 encoders x 2 images, 2 decoder passes, fwd + bwd + global-norm "
                                 "clip + Adam on Gd), batch 8 per rank, fp32, gradients of every trained parameter exchanged by "
                                 "dp.GradBucketReducer (buckets launched from backward hooks) -- slowest rank")
-                dp_g["executed_tflops"] = round(dp_g["pairs_per_s"] * GFLOP_PER_PAIR_EXECUTED / 1e3, 1)
+                dp_g["executed_tflops"] = round(dp_g["pairs_per_s"] * pair_executed_gflop(pkg.ops, 2 * BATCH) / 1e3, 1)
+                dp_g["algorithmic_tflops_stored_activations"] = round(dp_g["pairs_per_s"] * GFLOP_PER_PAIR_EXECUTED / 1e3, 1)
                 dp_g["algorithmic_tflops_reference_equivalent"] = round(dp_g["pairs_per_s"] * GFLOP_PER_PAIR / 1e3, 1)
                 dp_d["what"] = ("discriminator step of train.py:155-183 at batch 8 per rank with the same exchange (76 MB of gradients, R1 "
                                 "double backward) -- slowest rank")
