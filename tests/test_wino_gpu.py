@@ -108,3 +108,15 @@ def test_wino_rejects_what_it_does_not_serve(ops):
     x, w = torch.randn(1, 16, 12, 32, device=dev), torch.randn(64, 16, 3, 3, device=dev)
     with pytest.raises(L.SpkError):
         ops.conv3x3_wino(x, ops.pack_conv_weight_wino(w), 64)
+
+
+@pytest.mark.parametrize("shape", [(3, 5, 4, 4), (2, 7, 8, 16), (1, 130, 64, 64), (2, 3, 6, 10), (1, 2, 1, 4), (1, 1, 5, 1)])
+def test_upsample2x_launch_equals_torch_bilinear(ops, shape):
+    """spk_upsample2x_bilinear_fwd (nn.Upsample(scale_factor=2, mode='bilinear'), styleganv1.py:621): the 16-byte-access form taken
+    when the source width is a multiple of 4 -- it writes the x2 image a Winograd x2 layer reads -- and the generic form otherwise."""
+    dev = torch.device("cuda:0")
+    x = torch.randn(*shape, generator=torch.Generator().manual_seed(sum(shape))).to(dev)
+    y = ops.upsample2x_bilinear(x)
+    ref = F.interpolate(x.double(), scale_factor=2, mode="bilinear", align_corners=False)
+    assert y.shape == ref.shape
+    assert float((y.double() - ref).abs().max()) <= 2e-6 * max(1.0, float(ref.abs().max()))

@@ -14,6 +14,9 @@ import sys
 from collections import defaultdict
 
 
+UPS = {}
+
+
 def calls(d, counter):
     f = glob.glob(f"{d}/**/*_counter_collection.csv", recursive=True)[0]
     rows = [r for r in csv.DictReader(open(f)) if r["Counter_Name"] == counter]
@@ -21,8 +24,10 @@ def calls(d, counter):
     out, cur = [], []
     for r in rows:
         n = r["Kernel_Name"]
-        if "conv_kernel<" in n and ", 3, 3, 1, " in n or "conv3x3_bf16x3_kernel" in n:
+        if "conv_kernel<" in n and ", 3, 3, 1, " in n or "conv3x3_bf16x3_kernel" in n or "wino_kernel" in n:
             cur.append((n, float(r["Counter_Value"]) * 1024.0))
+        if "upsample2x_kernel" in n:            # the x2 image a Winograd x2 layer reads (its own launch): reported beside the convs
+            UPS.setdefault(counter, []).append(float(r["Counter_Value"]) * 1024.0)
         if "conv1x1_small" in n:
             out.append(cur)
             cur = []
@@ -61,6 +66,10 @@ def main():
         res[tag] = (fb, wb, len(fc))
         print(f"{tag:7s}: {len(fc)} steps counted; per step: FETCH {fb / 1e6:8.1f} MB, WRITE {wb / 1e6:8.1f} MB, "
               f"sum {(fb + wb) / 1e6:8.1f} MB = {(fb + wb) / 12 / 1e6:6.1f} MB per conv launch")
+        if tag == "f32" and UPS:
+            n_all = sum(1 for c in fetch if len(c) == 12)
+            print(f"         + the upsample2x launches of the Winograd x2 layers (all {n_all} forwards of the run, both precisions): "
+                  f"FETCH {sum(UPS.get('FETCH_SIZE', [])) / n_all / 1e6:8.1f} MB, WRITE {sum(UPS.get('WRITE_SIZE', [])) / n_all / 1e6:8.1f} MB per forward")
         per = defaultdict(lambda: [0.0, 0.0, 0])
         for c in fc:
             for n, v in c:
@@ -74,8 +83,8 @@ def main():
     if "--json" in sys.argv:
         fb, wb, n = res["f32"]
         out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python3 tools/pmc_decoder.py` "
-                         "(the headline decoder step launched eagerly through its launch plan); summary in profiles/r03_v_conv_traffic.txt",
-               "kernel": "spkconv::conv_kernel<Cfg,3,3,1,MODE 0|1>", "launches_per_step": 12, "steps_counted": n,
+                         "(the headline decoder step launched eagerly through its launch plan); summary in profiles/r04_e_conv_traffic.txt",
+               "kernel": "spkwino::wino_kernel (8 launches) + spkconv::conv_kernel<Cfg,3,3,1,MODE 0|1> (4 launches)", "launches_per_step": 12, "steps_counted": n,
                "fetch_bytes_per_step": int(fb), "write_bytes_per_step": int(wb), "bytes_per_launch": int((fb + wb) / 12),
                "bf16x3_fetch_bytes_per_step": int(res["bf16x3"][0]), "bf16x3_write_bytes_per_step": int(res["bf16x3"][1]),
                "correction": "FETCH_SIZE / WRITE_SIZE are KiB.  The input gathers are 4-byte-per-lane loads, which FETCH_SIZE counts in full "
