@@ -138,6 +138,8 @@ def committed_traffic(which, launches):
             return int((t["bf16x3_fetch_bytes_per_step"] + t["bf16x3_write_bytes_per_step"]) / max(1, launches))
         if which == "sg2":
             return int(t["sg2_bytes_per_launch"])
+        if which == "f32_direct":
+            return int(t["direct_f32_bytes_per_launch"])
         return int(t["bytes_per_launch"])
     except (OSError, KeyError, ValueError):
         return None
@@ -645,7 +647,7 @@ def main():
                             "implicit-GEMM kernel (bilinear x2 folded into staging), no Winograd launch -- the arithmetic of rounds 1-3",
                     "frames_per_s_per_gpu": round(BATCH / d_ms * 1e3, 2), "ms_per_step": round(d_ms, 4),
                     "roofline": conv_roofline(plan_of(gen), L, cd_ms, 0.0, "spkconv::conv_kernel<Cfg,3,3,1,MODE> (f32 MFMA implicit GEMM, fused upsample + "
-                                              "epilogue)", committed_traffic("f32", nd), d_ms)}
+                                              "epilogue)", committed_traffic("f32_direct", nd), d_ms)}
                 del gd
             # ---- the build-defined StyleGAN2 variant (modulated conv + upfirdn2d, A11) on the same workload ----
             sg2 = importlib.import_module("speak-hack_amd.stylegan2")
