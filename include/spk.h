@@ -349,6 +349,10 @@ int spk_conv1x1_small_fwd(const float* x, const float* w, const float* bias, flo
 /* ---- bilinear x2 upsampling (align_corners = False) -----------------------------------------------
  * replaces: styleganv1.py:621,624 (nn.Upsample) / stylegan.py:168 (F.interpolate) when used un-fused. */
 int spk_upsample2x_bilinear_fwd(const float* x, float* y, int64_t planes, int Hin, int Win, void* stream);
+/* the same x2 image with a choice of border: zero_border = 0 bilinear (edge taps clamped, as above); 1 = upfirdn2d(up = 2, FIR
+ * [1,3,3,1], pad (2,1)) -- the same (.25, .75) taps with neighbours outside the image counted as zero: the x2 of the StyleGAN2
+ * variant's styled convs (reference/styleganv2.txt:1835).  The materialised input of a Winograd x2 layer. */
+int spk_upsample2x_fwd(const float* x, float* y, int64_t planes, int Hin, int Win, int zero_border, void* stream);
 
 /* ---- BatchNorm2d pieces (torchvision ResNet-50 trunk, model.py:60-62) ------------------------------
  * spk_bn_finalize: turns the fp64 batch sums a conv epilogue accumulated (SPK_EPI_STATS) into the affine
@@ -543,7 +547,7 @@ enum {
     SPK_OP_TORGB = 5,             /* desc: spk_torgb_args           -> spk_conv1x1_small_fwd / spk_torgb_mod_skip_fwd */
     SPK_OP_DEMOD_GROUPED = 6,     /* desc: spk_demod_grouped_args   -> spk_modconv_demod_grouped */
     SPK_OP_PIXELNORM = 7,         /* desc: spk_pixelnorm_args       -> spk_pixelnorm_fwd */
-    SPK_OP_UPSAMPLE2X = 8         /* desc: spk_upsample2x_args      -> spk_upsample2x_bilinear_fwd (the x2 image of a block whose conv1
+    SPK_OP_UPSAMPLE2X = 8         /* desc: spk_upsample2x_args      -> spk_upsample2x_fwd (the x2 image of a block whose conv1
                                    * runs as Winograd, styleganv1.py:621,624) */
 };
 typedef struct spk_op { int32_t kind; int32_t reserved; const void* desc; } spk_op;
@@ -562,7 +566,7 @@ typedef struct spk_torgb_args {   /* mod NULL: plain 1x1 (styleganv1.py:607); el
 } spk_torgb_args;
 typedef struct spk_demod_grouped_args { const spk_demod_group* groups; int32_t n_groups, B; float eps; int32_t reserved; } spk_demod_grouped_args;
 typedef struct spk_pixelnorm_args { const float* x; float* y; int32_t B, C; int64_t HW; float eps; int32_t sqrt_form; } spk_pixelnorm_args;
-typedef struct spk_upsample2x_args { const float* x; float* y; int64_t planes; int32_t Hin, Win; } spk_upsample2x_args;
+typedef struct spk_upsample2x_args { const float* x; float* y; int64_t planes; int32_t Hin, Win; int32_t zero_border, reserved; } spk_upsample2x_args;
 int spk_launch_list(const spk_op* ops, int n_ops, uint32_t kind_mask, void* stream);
 
 #ifdef __cplusplus

@@ -115,7 +115,8 @@ class DemodGroupedArgs(C.Structure):
 
 
 class Upsample2xArgs(C.Structure):
-    _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("planes", C.c_int64), ("Hin", C.c_int32), ("Win", C.c_int32)]
+    _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("planes", C.c_int64), ("Hin", C.c_int32), ("Win", C.c_int32),
+                ("zero_border", C.c_int32), ("reserved", C.c_int32)]
 
 
 class PixelNormArgs(C.Structure):
@@ -232,6 +233,7 @@ _PROTOTYPES = {
     "spk_conv1x1_small_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                         C.c_int64, C.c_float, C.c_void_p]),
     "spk_upsample2x_bilinear_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
+    "spk_upsample2x_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
 }
 
 _lib = None

@@ -546,11 +546,18 @@ class ModConvFn(torch.autograd.Function):
         Cout = weight.shape[0]
         H, W = (2 * Hs, 2 * Ws) if upsample else (Hs, Ws)
         d = ops.modconv_demod(weight, s, scale) if demodulate else None
-        cfg = ops.conv2d_pick_config(3, 1, B, Cin, Cout, H, W)
-        cfg = cfg + 4 if cfg < 4 else cfg
         pw = getattr(weight, "_spk_gate_of", weight)      # (behind a WeightGateFn: the parameter keys the packed images)
-        y = ops.conv2d_fused(x, packed.get(pw, cfg), Cout, 3, 1, bias=bias, noise_w=noise_w, noise=noise, lrelu_slope=slope,
-                             out_scale=scale, batch_scale=s, demod=d, act_gain=gain, config=cfg, upsample=upsample, up_fir=True)
+        if ops.use_wino(B, Cin, Cout, H, W) and (not upsample or Ws % 4 == 0):
+            # fp32 Winograd with the modulation applied to the transformed input and the demodulation in the epilogue; a x2 layer
+            # reads the materialised upfirdn2d(up = 2, [1,3,3,1]) image
+            xin = ops.upsample2x(x, zero_border=True) if upsample else x
+            y = ops.conv3x3_wino(xin, packed.get_wino(pw), Cout, bias=bias, noise_w=noise_w, noise=noise, lrelu_slope=slope,
+                                 out_scale=scale, batch_scale=s.contiguous(), demod=d, act_gain=gain)
+        else:
+            cfg = ops.conv2d_pick_config(3, 1, B, Cin, Cout, H, W)
+            cfg = cfg + 4 if cfg < 4 else cfg
+            y = ops.conv2d_fused(x, packed.get(pw, cfg), Cout, 3, 1, bias=bias, noise_w=noise_w, noise=noise, lrelu_slope=slope,
+                                 out_scale=scale, batch_scale=s, demod=d, act_gain=gain, config=cfg, upsample=upsample, up_fir=True)
         if _needs(ctx, grad_mode):
             ctx.save_for_backward(x, weight, s, d, y, noise, bias, noise_w)
             ctx.conf = (scale, upsample, slope, gain, fir, packed)
@@ -570,10 +577,14 @@ class ModConvFn(torch.autograd.Function):
         need_dx, need_dw, need_ds = ctx.needs_input_grad[0], ctx.needs_input_grad[1], ctx.needs_input_grad[2]
         dx = dw = ds = None
         if need_dx or need_ds:
-            cfg = ops.conv2d_pick_config(3, 1, B, Cout, Cin, H, W)
-            cfg = cfg + 4 if cfg < 4 else cfg
-            dxt = ops.conv2d_fused(dt, packed.get(getattr(weight, "_spk_gate_of", weight), cfg, transpose_flip=True), Cin, 3, 1,
-                                   out_scale=scale, batch_scale=dprime, config=cfg)    # d (up(x) * s), at the output resolution
+            if ops.use_wino(B, Cout, Cin, H, W):
+                dxt = ops.conv3x3_wino(dt, packed.get_wino(getattr(weight, "_spk_gate_of", weight), transpose_flip=True), Cin,
+                                       out_scale=scale, batch_scale=dprime.contiguous())
+            else:
+                cfg = ops.conv2d_pick_config(3, 1, B, Cout, Cin, H, W)
+                cfg = cfg + 4 if cfg < 4 else cfg
+                dxt = ops.conv2d_fused(dt, packed.get(getattr(weight, "_spk_gate_of", weight), cfg, transpose_flip=True), Cin, 3, 1,
+                                       out_scale=scale, batch_scale=dprime, config=cfg)    # d (up(x) * s), at the output resolution
             if upsample and (x.shape[-1] % 2 or dxt.data_ptr() % 16):                  # odd widths: the stand-alone adjoint
                 dxu = ops.upfirdn2d(dxt, torch.flip(fir, [0, 1]), up=1, down=2, pad=(1, 1))
                 dx, ds = ops.modconv_dx_finish(dxu, x, s, False, need_dx=need_dx)

@@ -44,8 +44,9 @@ constexpr int RAW_GATHERS = RAW_WAVE / 64;
 constexpr int U_FLOATS = 16 * CI_T * CO_T, V_FLOATS = 16 * CI_T * NTILE, RAW_FLOATS = 4 * RAW_WAVE;
 constexpr int U_OFF = 0, V_OFF = 2 * U_FLOATS, RAW_OFF = V_OFF + 2 * V_FLOATS;
 constexpr int PRM_OFF = RAW_OFF + 2 * RAW_FLOATS;                            // [64 co][bias, noise weight, style s0 + 1, style s1] of the region
-constexpr int LDS_FLOATS = PRM_OFF + 4 * CO_T;
-constexpr int LDS_BYTES = LDS_FLOATS * 4;                                    // 154 624
+constexpr int DEM_OFF = PRM_OFF + 4 * CO_T;                                  // [64 co] demodulation d[b, co] of the region's image (modulated convs)
+constexpr int LDS_FLOATS = DEM_OFF + CO_T;
+constexpr int LDS_BYTES = LDS_FLOATS * 4;                                    // 154 880
 static_assert(NTILE == 64 && RAW_GATHERS == 11 && RAW_USED <= RAW_PLANE, "geometry");
 constexpr int U_DMA = U_FLOATS * 4 / 1024 / 4;                               // 1 KB blocks per wave and chunk (8)
 
@@ -59,6 +60,8 @@ struct Args {
     float* y;
     float* y_pre;
     const float* out_scale_dev;
+    const float* in_scale;       // MOD: [B, Cin] modulation s[b, ci] (SPK_CONV_IN_BATCH_SCALE): the conv runs on x * s
+    const float* out_scale_bc;   // MOD: [B, Cout] demodulation d[b, co] applied right after the contraction, or null
     int B, Cin, Cout, H, W;
     int regions_x, regions_y;
     int n_chunks;
@@ -113,6 +116,10 @@ __device__ __forceinline__ void lds_barrier() {
     asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
 }
 
+// MOD: the modulated convolution of the StyleGAN2 variant.  B^T (d s) B = s B^T d B: the modulation of the
+// plane's channel -- one scalar per plane, the region lies in one image -- multiplies the 16 transformed values (16 more vector ops
+// per plane); the demodulation rides on the epilogue's out_scale through a second LDS table.
+template <bool MOD>
 __global__ __launch_bounds__(NT) void wino_kernel(const Args p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -212,7 +219,9 @@ __global__ __launch_bounds__(NT) void wino_kernel(const Args p) {
         tq[j_][c_] = fsub_(d[j_][c_], d[j_][8 + (c_)]); tq[j_][4 + (c_)] = fadd_(d[j_][4 + (c_)], d[j_][8 + (c_)]);     \
         tq[j_][8 + (c_)] = fsub_(d[j_][8 + (c_)], d[j_][4 + (c_)]); tq[j_][12 + (c_)] = fsub_(d[j_][4 + (c_)], d[j_][12 + (c_)]); \
     }
-    // (.) B over the columns (row i_)
+    // (.) B over the columns (row i_); MOD: times the plane's modulation
+#define WINO_T_SCALE(j_, i_, sc_)                                                                                       \
+    { tv[j_][4 * (i_)] *= (sc_); tv[j_][4 * (i_) + 1] *= (sc_); tv[j_][4 * (i_) + 2] *= (sc_); tv[j_][4 * (i_) + 3] *= (sc_); }
 #define WINO_T_COLS(j_, i_)                                                                                             \
     {                                                                                                                   \
         tv[j_][4 * (i_)] = fsub_(tq[j_][4 * (i_)], tq[j_][4 * (i_) + 2]); tv[j_][4 * (i_) + 1] = fadd_(tq[j_][4 * (i_) + 1], tq[j_][4 * (i_) + 2]); \
@@ -224,8 +233,9 @@ __global__ __launch_bounds__(NT) void wino_kernel(const Args p) {
     const int n = p.n_chunks;
     int reg = reg_begin + wk;
     if (reg >= reg_end) return;
-    int b, y0, x0;
+    int b, y0, x0, b_cur;            // b: the image of the region whose operands are being requested; b_cur: of the region being computed
     region_coords(reg, b, y0, x0);
+    b_cur = b;
     set_voff(voff, b, y0, x0);
     // ---- first region: U_0, raw_0, raw_1 requested; raw_0 -> V_0 ----
     static_for<0, U_DMA>([&](auto k) { WINO_DMA_U(0, 0, decltype(k)::value); });
@@ -236,6 +246,10 @@ __global__ __launch_bounds__(NT) void wino_kernel(const Args p) {
         static_for<0, 4>([&](auto r) { WINO_T_READ(0, decltype(j)::value, decltype(r)::value); });
         static_for<0, 4>([&](auto c) { WINO_T_ROWS(decltype(j)::value, decltype(c)::value); });
         static_for<0, 4>([&](auto i) { WINO_T_COLS(decltype(j)::value, decltype(i)::value); });
+        if constexpr (MOD) {
+            const float sc0_ = p.in_scale[(size_t)b * p.Cin + wave + 4 * decltype(j)::value];
+            static_for<0, 4>([&](auto i) { WINO_T_SCALE(decltype(j)::value, decltype(i)::value, sc0_); });
+        }
         static_for<0, 16>([&](auto xi) { WINO_T_WRITE(0, decltype(j)::value, decltype(xi)::value); });
         __builtin_amdgcn_sched_barrier(0);           // one plane at a time: the register peak of this block decides what is spilled kernel-wide
     });
@@ -258,6 +272,12 @@ __global__ __launch_bounds__(NT) void wino_kernel(const Args p) {
         constexpr bool FIRST = decltype(first_c)::value;          // a region's first chunk: its first 16 MFMAs START the accumulators (C = 0)
         const int c1 = i + 1 < n ? i + 1 : 0;                     // the stream's next chunk (weights: the same channel tile)
         const int c2 = i + 2 >= n ? i + 2 - n : i + 2;            // the chunk after it (past n: in the next region -- `voff` is that region's by then)
+        float msc[2] = {1.f, 1.f};                                // MOD: the modulation of the two planes being transformed (chunk c1)
+        if constexpr (MOD) {
+            const float* ms_ = p.in_scale + (size_t)(i + 1 < n ? b_cur : b) * p.Cin + c1 * CI_T + wave;
+            msc[0] = ms_[0];
+            msc[1] = ms_[4];
+        }
         static_for<0, PD>([&](auto s) { WINO_FRAG(S, decltype(s)::value, decltype(s)::value); });
         static_for<0, 64>([&](auto s_c) {
             constexpr int s = decltype(s_c)::value;
@@ -273,7 +293,7 @@ __global__ __launch_bounds__(NT) void wino_kernel(const Args p) {
                 constexpr int j = decltype(j_c)::value, tr = 2 + 10 * j, ta = 8 + 16 * j;
                 if constexpr (s >= tr && s < tr + 4) { WINO_T_READ(O, j, s - tr); }
                 if constexpr (s >= ta && s < ta + 4) { WINO_T_ROWS(j, s - ta); }
-                if constexpr (s >= ta + 4 && s < ta + 8) { WINO_T_COLS(j, s - ta - 4); }
+                if constexpr (s >= ta + 4 && s < ta + 8) { WINO_T_COLS(j, s - ta - 4); if constexpr (MOD) { WINO_T_SCALE(j, s - ta - 4, msc[j]); } }
                 if constexpr (s >= ta + 8 && s < ta + 16) { WINO_T_WRITE(O, j, 2 * (s - ta - 8)); WINO_T_WRITE(O, j, 2 * (s - ta - 8) + 1); }
             });
             __builtin_amdgcn_sched_barrier(0);
@@ -311,6 +331,7 @@ __global__ __launch_bounds__(NT) void wino_kernel(const Args p) {
             for (int r = 0; r < 16; ++r) acc[xi][r] = 0.f;
         // the region after this one (the last region repeats itself: loads nobody uses)
         const int cur_b = b, cur_y0 = y0, cur_x0 = x0;
+        b_cur = b;
         // everything the epilogue reads from global memory is requested NOW and lands behind the region's MFMAs: the noise of
         // this thread's four pixels, and (wave 0: one channel per lane) the channel's bias / noise weight / style pair, which
         // reach the other waves through a 1 KB LDS table -- no load latency between the last MFMA and the stores
@@ -326,6 +347,10 @@ __global__ __launch_bounds__(NT) void wino_kernel(const Args p) {
         if (prm_on) {                                    // ONE load per thread, no branch per operand kind
             const float t_ = prm_src[prm_which >= 2 ? (size_t)cur_b * p.style_stride : 0];
             prm = prm_which == 2 ? t_ + 1.f : t_;
+        }
+        float dem = 1.f;
+        if constexpr (MOD) {
+            if (p.out_scale_bc && tid < CO_T && co0 + tid < p.Cout) dem = p.out_scale_bc[(size_t)cur_b * p.Cout + co0 + tid];
         }
         const bool more = reg + wpx < reg_end;
         if (more) {
@@ -355,6 +380,7 @@ __global__ __launch_bounds__(NT) void wino_kernel(const Args p) {
         // Every stage runs unconditionally; an absent one has its neutral operand in the table.
         LAB_STAMP(2)
         smem[PRM_OFF + tid] = prm;
+        if constexpr (MOD) { if (tid < CO_T) smem[DEM_OFF + tid] = dem; }
         lds_barrier();
         unsigned hw_ = (unsigned)HW;                 // (opaque per region: the 16 rows' channel offsets must not be hoisted out of the region
         asm volatile("" : "+s"(hw_));                //  loop as 32 live registers)
@@ -379,7 +405,9 @@ __global__ __launch_bounds__(NT) void wino_kernel(const Args p) {
             f32x2 top, bot;
             top.x = (s0[0] + s0[1]) + s0[2]; top.y = (s1[0] + s1[1]) + s1[2];
             bot.x = (s0[1] - s0[2]) - s0[3]; bot.y = (s1[1] - s1[2]) - s1[3];
-            top.x = top.x * osc + q_.x; top.y = top.y * osc + q_.x; bot.x = bot.x * osc + q_.x; bot.y = bot.y * osc + q_.x;
+            float osc_r = osc;
+            if constexpr (MOD) osc_r = osc * smem[DEM_OFF + row];
+            top.x = top.x * osc_r + q_.x; top.y = top.y * osc_r + q_.x; bot.x = bot.x * osc_r + q_.x; bot.y = bot.y * osc_r + q_.x;
             top.x += q_.y * nz0.x; top.y += q_.y * nz0.y; bot.x += q_.y * nz1.x; bot.y += q_.y * nz1.y;
             top.x = (top.x > 0.f ? top.x : top.x * slope_) * gain_; top.y = (top.y > 0.f ? top.y : top.y * slope_) * gain_;
             bot.x = (bot.x > 0.f ? bot.x : bot.x * slope_) * gain_; bot.y = (bot.y > 0.f ? bot.y : bot.y * slope_) * gain_;
@@ -417,6 +445,7 @@ __global__ __launch_bounds__(NT) void wino_kernel(const Args p) {
 #undef WINO_FRAG
 #undef WINO_T_WRITE
 #undef WINO_T_COLS
+#undef WINO_T_SCALE
 #undef WINO_T_ROWS
 #undef WINO_T_READ
 #undef WINO_DMA_U
@@ -457,9 +486,12 @@ int spk_conv2d_wino_fwd(const spk_conv2d_desc* d, void* stream) {
     SPK_REQUIRE(d && d->x && d->w_packed && d->y, "conv2d winograd: null pointer");
     SPK_REQUIRE(d->kh == 3 && d->kw == 3 && d->stride == 1, "conv2d winograd: 3x3 stride-1 kernels only");
     SPK_REQUIRE(d->groups <= 1, "conv2d winograd: not grouped");
-    const unsigned allowed = SPK_CONV_WINOGRAD | SPK_EPI_BIAS | SPK_EPI_NOISE | SPK_EPI_LRELU | SPK_EPI_STYLE | SPK_EPI_ACCUM;
-    SPK_REQUIRE(!(d->flags & ~allowed) && !d->stats && !d->out_scale_bc && !d->accum_half,
-                "conv2d winograd: plain input; epilogue flags bias, noise, lrelu, style, accum");
+    const unsigned allowed = SPK_CONV_WINOGRAD | SPK_EPI_BIAS | SPK_EPI_NOISE | SPK_EPI_LRELU | SPK_EPI_STYLE | SPK_EPI_ACCUM | SPK_CONV_IN_BATCH_SCALE;
+    SPK_REQUIRE(!(d->flags & ~allowed) && !d->stats && !d->accum_half,
+                "conv2d winograd: plain or batch-scaled input; epilogue flags bias, noise, lrelu, style, accum");
+    const bool mod = d->flags & SPK_CONV_IN_BATCH_SCALE;
+    SPK_REQUIRE(!mod || d->in_scale, "conv2d winograd: IN_BATCH_SCALE without in_scale[B,Cin]");
+    SPK_REQUIRE(!d->out_scale_bc || mod, "conv2d winograd: out_scale_bc (demodulation) goes with SPK_CONV_IN_BATCH_SCALE");
     SPK_REQUIRE(d->H == d->Hin && d->W == d->Win, "conv2d winograd: output size must equal the input size");
     SPK_REQUIRE(spk_conv2d_wino_supported(d->B, d->Cin, d->Cout, d->H, d->W), "conv2d winograd: %dx%d is not a whole number of 32 x 8 regions "
                 "(or the input exceeds 2 GB)", d->H, d->W);
@@ -472,17 +504,19 @@ int spk_conv2d_wino_fwd(const spk_conv2d_desc* d, void* stream) {
     Args a;
     a.x = d->x; a.wp = d->w_packed; a.bias = d->bias; a.noise_w = d->noise_w; a.noise = d->noise; a.style = d->style;
     a.y = d->y; a.y_pre = d->y_pre; a.out_scale_dev = d->out_scale_dev;
+    a.in_scale = mod ? d->in_scale : nullptr; a.out_scale_bc = d->out_scale_bc;
     a.B = d->B; a.Cin = d->Cin; a.Cout = d->Cout; a.H = d->H; a.W = d->W;
     a.regions_x = d->W / RW; a.regions_y = d->H / RH;
     a.n_chunks = spk::ceil_div(d->Cin, CI_T);
     a.style_stride = d->style_stride; a.flags = d->flags;
     a.x_bytes = (unsigned)((long long)d->B * d->Cin * d->H * d->W * 4);
     a.slope = d->lrelu_slope; a.out_scale = d->out_scale; a.act_gain = d->act_gain != 0.f ? d->act_gain : 1.f;
-    static bool raised = false;
-    if (!raised) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    auto kern = mod ? &wino_kernel<true> : &wino_kernel<false>;
+    static bool raised[2] = {false, false};
+    if (!raised[mod ? 1 : 0]) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return spk::fail(SPK_ELAUNCH, "hipFuncSetAttribute(LDS): %s", hipGetErrorString(e));
-        raised = true;
+        raised[mod ? 1 : 0] = true;
     }
     const long long n_regions = (long long)a.regions_x * a.regions_y * d->B;
     SPK_REQUIRE(n_regions < (1ll << 31), "conv2d winograd: grid too large");
@@ -501,7 +535,7 @@ int spk_conv2d_wino_fwd(const spk_conv2d_desc* d, void* stream) {
     gx = lab_mult == 0 ? (n_regions + 7) / 8 * 8 : gx * lab_mult;
     gx = std::min(gx, (n_regions + 7) / 8 * 8);
     dim3 grid((unsigned)gx, (unsigned)co_tiles);
-    hipLaunchKernelGGL(wino_kernel, grid, dim3(NT), LDS_BYTES, (hipStream_t)stream, a);
+    hipLaunchKernelGGL(kern, grid, dim3(NT), LDS_BYTES, (hipStream_t)stream, a);
     return spk::check_launch("wino_kernel");
 }
 

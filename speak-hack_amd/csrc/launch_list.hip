@@ -54,7 +54,7 @@ extern "C" int spk_launch_list(const spk_op* ops, int n_ops, uint32_t kind_mask,
             }
             case SPK_OP_UPSAMPLE2X: {
                 const spk_upsample2x_args* a = static_cast<const spk_upsample2x_args*>(op.desc);
-                rc = spk_upsample2x_bilinear_fwd(a->x, a->y, a->planes, a->Hin, a->Win, stream);
+                rc = spk_upsample2x_fwd(a->x, a->y, a->planes, a->Hin, a->Win, a->zero_border, stream);
                 break;
             }
             default:

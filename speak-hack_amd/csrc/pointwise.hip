@@ -235,6 +235,9 @@ __global__ __launch_bounds__(256) void upsample2x_kernel(const float* __restrict
 // use, four 16-byte stores; plane / row / column from the launch grid (no 64-bit division).  Element for element the arithmetic of
 // upsample2x_kernel (same taps, same order).  The x2 image of a Winograd x2 layer (SPK_OP_UPSAMPLE2X) is 270 MB of writes per
 // decoder step at B = 8: the generic kernel above ran it at ~2 TB/s, a step's worth in 0.32 ms.
+// ZB: neighbours outside the image count as zero instead of being clamped -- upfirdn2d(up = 2, FIR [1,3,3,1], pad (2,1)), the x2 of
+// the StyleGAN2 variant's styled convs: the same (.25, .75) taps.
+template <bool ZB>
 __global__ __launch_bounds__(256) void upsample2x_vec_kernel(const float* __restrict__ x, float* __restrict__ y, int Hin, int Win) {
     const int Wq = Win >> 2;
     const int t = blockIdx.x * 256 + threadIdx.x;                 // over Hin * Wq
@@ -245,14 +248,17 @@ __global__ __launch_bounds__(256) void upsample2x_vec_kernel(const float* __rest
     const float4 a = *reinterpret_cast<const float4*>(xp + (size_t)r0 * Win + c0);
     const float4 b = *reinterpret_cast<const float4*>(xp + (size_t)m * Win + c0);
     const float4 c = *reinterpret_cast<const float4*>(xp + (size_t)r2 * Win + c0);
-    const float al = xp[(size_t)r0 * Win + cl], ar = xp[(size_t)r0 * Win + cr];
-    const float bl = xp[(size_t)m * Win + cl], br = xp[(size_t)m * Win + cr];
-    const float cl_ = xp[(size_t)r2 * Win + cl], cr_ = xp[(size_t)r2 * Win + cr];
+    float al = xp[(size_t)r0 * Win + cl], ar = xp[(size_t)r0 * Win + cr];
+    float bl = xp[(size_t)m * Win + cl], br = xp[(size_t)m * Win + cr];
+    float cl_ = xp[(size_t)r2 * Win + cl], cr_ = xp[(size_t)r2 * Win + cr];
+    if constexpr (ZB) {
+        if (c0 + 4 >= Win) ar = br = cr_ = 0.f;          // (the left edge: see hrow)
+    }
     // horizontal taps: output 2c = l0 x[c-1] + l1 x[c] (c = 0: 1 x[0] + 0 x[1]); output 2c+1 = .75 x[c] + .25 x[min(c+1, Win-1)]
     const float e0 = c0 == 0 ? 1.f : 0.25f, e1 = c0 == 0 ? 0.f : 0.75f;
     auto hrow = [&](const float4& v, float l, float r, float (&o)[8]) {
         // (c0 == 0: the first even output is 1 * x[0] + 0 * x[1], exactly as upsample2x_kernel forms it)
-        o[0] = c0 == 0 ? e0 * v.x + e1 * v.y : 0.25f * l + 0.75f * v.x;
+        o[0] = c0 == 0 ? (ZB ? 0.75f * v.x : e0 * v.x + e1 * v.y) : 0.25f * l + 0.75f * v.x;
         o[1] = 0.75f * v.x + 0.25f * v.y;
         o[2] = 0.25f * v.x + 0.75f * v.y;
         o[3] = 0.75f * v.y + 0.25f * v.z;
@@ -270,8 +276,8 @@ __global__ __launch_bounds__(256) void upsample2x_vec_kernel(const float* __rest
 #pragma unroll
     for (int k = 0; k < 8; ++k) {
         // row 2m = .25 H[m-1] + .75 H[m] (m = 0: 1 H[0] + 0 H[1]); row 2m+1 = .75 H[m] + .25 H[min(m+1, Hin-1)]
-        ev[k] = m == 0 ? 1.f * hb[k] + 0.f * hc[k] : 0.25f * ha[k] + 0.75f * hb[k];
-        od[k] = 0.75f * hb[k] + 0.25f * hc[k];
+        ev[k] = m == 0 ? (ZB ? 0.75f * hb[k] : 1.f * hb[k] + 0.f * hc[k]) : 0.25f * ha[k] + 0.75f * hb[k];
+        od[k] = (ZB && m == Hin - 1) ? 0.75f * hb[k] : 0.75f * hb[k] + 0.25f * hc[k];
     }
     *reinterpret_cast<float4*>(yp) = make_float4(ev[0], ev[1], ev[2], ev[3]);
     *reinterpret_cast<float4*>(yp + 4) = make_float4(ev[4], ev[5], ev[6], ev[7]);
@@ -349,11 +355,23 @@ int spk_torgb_mod_skip_fwd(const float* x, const float* w, const float* mod, con
     return conv1x1_small_launch(x, w, mod, bias, y, B, C, O, (int64_t)H * W, in_scale, stream, skip, W);
 }
 
+int spk_upsample2x_fwd(const float* x, float* y, int64_t planes, int Hin, int Win, int zero_border, void* stream) {
+    SPK_REQUIRE(x && y, "upsample2x: null pointer");
+    SPK_REQUIRE(planes > 0 && Hin > 0 && Win > 0, "upsample2x: bad shape");
+    const bool vec = Win % 4 == 0 && planes < 65536 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
+    if (!zero_border && !vec) return spk_upsample2x_bilinear_fwd(x, y, planes, Hin, Win, stream);
+    SPK_REQUIRE(vec, "upsample2x: the zero-border (upfirdn2d [1,3,3,1]) form needs Win %% 4 == 0, 16-byte aligned tensors, < 65536 planes");
+    dim3 grid((unsigned)((Hin * (Win >> 2) + 255) / 256), (unsigned)planes);
+    if (zero_border) hipLaunchKernelGGL(upsample2x_vec_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, y, Hin, Win);
+    else hipLaunchKernelGGL(upsample2x_vec_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, y, Hin, Win);
+    return spk::check_launch("upsample2x_vec_kernel");
+}
+
 int spk_upsample2x_bilinear_fwd(const float* x, float* y, int64_t planes, int Hin, int Win, void* stream) {
     SPK_REQUIRE(x && y, "upsample2x: null pointer");
     SPK_REQUIRE(planes > 0 && Hin > 0 && Win > 0, "upsample2x: bad shape");
     if (Win % 4 == 0 && planes < 65536 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0) {
-        hipLaunchKernelGGL(upsample2x_vec_kernel, dim3((unsigned)((Hin * (Win >> 2) + 255) / 256), (unsigned)planes), dim3(256), 0,
+        hipLaunchKernelGGL(upsample2x_vec_kernel<false>, dim3((unsigned)((Hin * (Win >> 2) + 255) / 256), (unsigned)planes), dim3(256), 0,
                            (hipStream_t)stream, x, y, Hin, Win);
         return spk::check_launch("upsample2x_vec_kernel");
     }

@@ -417,8 +417,18 @@ def pack_conv_weight_wino(weight: torch.Tensor, out=None, transpose_flip=False) 
     return out
 
 
+def upsample2x(x, zero_border=False):
+    """The x2 image: bilinear (edge taps clamped), or -- ``zero_border`` -- upfirdn2d(up=2, [1,3,3,1], pad (2,1)) (the same taps,
+    neighbours outside the image zero).  What a Winograd x2 layer reads."""
+    B, Cc, H, W = x.shape
+    y = torch.empty((B, Cc, 2 * H, 2 * W), device=x.device, dtype=torch.float32)
+    L.check(L.lib().spk_upsample2x_fwd(L.dptr(x.contiguous(), "x"), L.dptr(y), B * Cc, H, W, 1 if zero_border else 0, L.stream_ptr()),
+            "spk_upsample2x_fwd")
+    return y
+
+
 def conv3x3_wino(x, w_packed, Cout, *, bias=None, noise_w=None, noise=None, style=None, style_stride=None, lrelu_slope=None,
-                 out_scale=1.0, act_gain=1.0, out=None, out_pre=None, accumulate=False, out_scale_dev=None):
+                 out_scale=1.0, act_gain=1.0, out=None, out_pre=None, accumulate=False, out_scale_dev=None, batch_scale=None, demod=None):
     """3x3 stride-1 pad-1 conv with the fused decoder epilogue as Winograd F(2x2, 3x3): fp32 throughout, 2.25x fewer matrix
     instructions than the direct form, 1e-6-class rel-L2 against it.  ``w_packed`` from ``pack_conv_weight_wino``."""
     B, Cin, H, W = x.shape
@@ -428,11 +438,17 @@ def conv3x3_wino(x, w_packed, Cout, *, bias=None, noise_w=None, noise=None, styl
         raise L.SpkError(f"conv3x3_wino: noise must be [B,1,H,W]={B, 1, H, W}, got {tuple(noise.shape)}")
     if style is not None and style_stride is None:
         style_stride = style.stride(0) if style.dim() == 2 else 2 * Cout
+    if batch_scale is not None and tuple(batch_scale.shape) != (B, Cin):
+        raise L.SpkError("conv3x3_wino: batch_scale must be [B,Cin]")
+    if demod is not None and (batch_scale is None or tuple(demod.shape) != (B, Cout)):
+        raise L.SpkError("conv3x3_wino: demod must be [B,Cout] and goes with batch_scale")
     flags = L.CONV_WINOGRAD | (L.EPI_BIAS if bias is not None else 0) | (L.EPI_NOISE if noise is not None else 0) | \
-        (L.EPI_LRELU if lrelu_slope is not None else 0) | (L.EPI_STYLE if style is not None else 0) | (L.EPI_ACCUM if accumulate else 0)
+        (L.EPI_LRELU if lrelu_slope is not None else 0) | (L.EPI_STYLE if style is not None else 0) | (L.EPI_ACCUM if accumulate else 0) | \
+        (L.CONV_IN_BATCH_SCALE if batch_scale is not None else 0)
     d = L.Conv2dDesc(x=L.dptr(x, "x"), w_packed=L.dptr(w_packed, "w_packed"), bias=L.dptr(bias, "bias"),
                      noise_w=L.dptr(noise_w, "noise_w") if noise is not None else None, noise=L.dptr(noise, "noise"),
-                     style=_style_ptr(style), in_scale=None, in_shift=None, out_scale_bc=None, act_gain=float(act_gain), stats=None,
+                     style=_style_ptr(style), in_scale=L.dptr(batch_scale, "batch_scale"), in_shift=None, out_scale_bc=L.dptr(demod, "demod"),
+                     act_gain=float(act_gain), stats=None,
                      y=L.dptr(out, "out"), y_pre=L.dptr(out_pre, "out_pre"), B=B, Cin=Cin, Cout=Cout, H=H, W=W, Hin=H, Win=W,
                      kh=3, kw=3, stride=1, style_stride=int(style_stride or 0), flags=flags,
                      lrelu_slope=float(lrelu_slope if lrelu_slope is not None else 1.0), out_scale=float(out_scale), config=-1,

@@ -91,13 +91,11 @@ class LaunchPlan:
                              lrelu_slope=float(slope if slope is not None else 1.0), out_scale=float(out_scale), config=-1,
                              ksplit=1, workspace=None, workspace_bytes=0, groups=1, group_in_stride=0, stats_slots=0)
             return self.add(L.OP_CONV2D, d)
-        if batch_scale is None and demod is None and ops.use_wino(B, Cin, Cout, H, W):
+        if ops.use_wino(B, Cin, Cout, H, W) and (not upsample or Ws % 4 == 0):
             # fp32 Winograd F(2x2, 3x3) (include/spk.h SPK_CONV_WINOGRAD); a x2 layer first writes its upsampled input (one
             # HBM-bound launch: the separate nn.Upsample of styleganv1.py:621,624) -- the transform would cost more inside the
             # MFMA kernel than this pass does beside it
             if upsample:
-                if up_fir:
-                    raise L.SpkError("plan: the Winograd path takes the bilinear x2 only")
                 need = B * Cin * H * W                    # one scratch image for all x2 layers: launches are stream-ordered
                 if self._up_scratch is None or self._up_scratch.numel() < need:
                     self._up_scratch = self.buf(need)
@@ -105,18 +103,21 @@ class LaunchPlan:
                         a_.y = self._up_scratch.data_ptr()
                         n_.x = self._up_scratch.data_ptr()
                 xu = self._up_scratch[:need].view(B, Cin, H, W)
-                up_op = self.add(L.OP_UPSAMPLE2X, L.Upsample2xArgs(x=x.data_ptr(), y=xu.data_ptr(), planes=B * Cin, Hin=Hs, Win=Ws))
+                up_op = self.add(L.OP_UPSAMPLE2X, L.Upsample2xArgs(x=x.data_ptr(), y=xu.data_ptr(), planes=B * Cin, Hin=Hs, Win=Ws,
+                                                                   zero_border=1 if up_fir else 0))
                 x = xu
             packed = self.buf(L.lib().spk_conv2d_packed_bytes_wino(Cin, Cout) // 4)
             self._refreshers.append(lambda w=weight, p=packed: ops.pack_conv_weight_wino(w.detach(), out=p))
             self.track(weight)
             flags = L.CONV_WINOGRAD | (L.EPI_BIAS if bias is not None else 0) | (L.EPI_NOISE if noise is not None else 0) | \
-                (L.EPI_LRELU if slope is not None else 0) | (L.EPI_STYLE if style is not None else 0)
+                (L.EPI_LRELU if slope is not None else 0) | (L.EPI_STYLE if style is not None else 0) | \
+                (L.CONV_IN_BATCH_SCALE if batch_scale is not None else 0)
             d = L.Conv2dDesc(x=x.data_ptr(), w_packed=packed.data_ptr(), bias=L.dptr(bias, "bias"),
                              noise_w=L.dptr(noise_w, "noise_w") if noise is not None else None,
                              noise=noise.data_ptr() if noise is not None else None,
-                             style=style.data_ptr() if style is not None else None, in_scale=None, in_shift=None,
-                             out_scale_bc=None, act_gain=float(act_gain), stats=None,
+                             style=style.data_ptr() if style is not None else None,
+                             in_scale=batch_scale.data_ptr() if batch_scale is not None else None, in_shift=None,
+                             out_scale_bc=demod.data_ptr() if demod is not None else None, act_gain=float(act_gain), stats=None,
                              y=out.data_ptr(), y_pre=None, B=B, Cin=Cin, Cout=Cout, H=H, W=W, Hin=H, Win=W, kh=3, kw=3, stride=1,
                              style_stride=int(style.stride(0)) if style is not None else 0, flags=flags,
                              lrelu_slope=float(slope if slope is not None else 1.0), out_scale=float(out_scale), config=-1,

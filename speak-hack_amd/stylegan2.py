@@ -84,6 +84,10 @@ class ModulatedConv2d(nn.Module):
         if d is not None:        # a demodulation vector computed elsewhere (the grouped launch of the inference path)
             B, Cin, Hs, Ws = x.shape
             H, W = (2 * Hs, 2 * Ws) if upsample else (Hs, Ws)
+            if ops.use_wino(B, Cin, self.out_channel, H, W) and (not upsample or Ws % 4 == 0):
+                xin = ops.upsample2x(x, zero_border=True) if upsample else x.contiguous()
+                return ops.conv3x3_wino(xin, self._pk.get_wino(self.weight), self.out_channel, bias=bias, noise_w=noise_w, noise=noise,
+                                        lrelu_slope=lrelu, out_scale=self.scale, batch_scale=s.contiguous(), demod=d, act_gain=act_gain)
             cfg = ops.conv2d_pick_config(3, 1, B, Cin, self.out_channel, H, W)
             cfg = cfg + 4 if cfg < 4 else cfg
             return ops.conv2d_fused(x.contiguous(), self._pk.get(self.weight, cfg), self.out_channel, 3, 1, bias=bias, noise_w=noise_w,

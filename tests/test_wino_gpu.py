@@ -120,3 +120,43 @@ def test_upsample2x_launch_equals_torch_bilinear(ops, shape):
     ref = F.interpolate(x.double(), scale_factor=2, mode="bilinear", align_corners=False)
     assert y.shape == ref.shape
     assert float((y.double() - ref).abs().max()) <= 2e-6 * max(1.0, float(ref.abs().max()))
+
+
+def test_wino_modulated_conv_equals_fp64(ops):
+    """The StyleGAN2 variant's styled conv on the Winograd kernel (SPK_CONV_WINOGRAD | SPK_CONV_IN_BATCH_SCALE): y = gain * lrelu(d[b,co]
+    * scale * conv3x3(x * s[b,ci], w) + noise_w * noise + bias), the modulation applied to the transformed input, the demodulation in
+    the epilogue -- against the formula in fp64 and against the direct kernel's modulated form."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(23)
+    B, Cin, Cout, H, W = 3, 64, 96, 16, 64
+    x = torch.randn(B, Cin, H, W, generator=g).to(dev)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)).to(dev)
+    s = (torch.rand(B, Cin, generator=g) + 0.5).to(dev)
+    d = (torch.rand(B, Cout, generator=g) + 0.5).to(dev)
+    bias, nw = torch.randn(Cout, generator=g).to(dev), torch.randn(Cout, generator=g).to(dev)
+    noise = torch.randn(B, 1, H, W, generator=g).to(dev)
+    y = ops.conv3x3_wino(x, ops.pack_conv_weight_wino(w), Cout, bias=bias, noise_w=nw, noise=noise, lrelu_slope=0.2, out_scale=0.3,
+                         batch_scale=s, demod=d, act_gain=2 ** 0.5)
+    c = F.conv2d(x.double() * s.double().view(B, Cin, 1, 1), w.double(), padding=1) * 0.3 * d.double().view(B, Cout, 1, 1)
+    ref = F.leaky_relu(c + bias.double().view(1, -1, 1, 1) + nw.double().view(1, -1, 1, 1) * noise.double(), 0.2) * 2 ** 0.5
+    assert rel_l2(y, ref) < TOL, rel_l2(y, ref)
+    cfg = ops.conv2d_pick_config(3, 1, B, Cin, Cout, H, W)
+    cfg = cfg + 4 if cfg < 4 else cfg
+    direct = ops.conv2d_fused(x, ops.pack_conv_weight(w, cfg), Cout, 3, 1, bias=bias, noise_w=nw, noise=noise, lrelu_slope=0.2, out_scale=0.3,
+                              batch_scale=s, demod=d, act_gain=2 ** 0.5, config=cfg)
+    assert rel_l2(y, direct) < TOL
+
+
+@pytest.mark.parametrize("shape", [(2, 5, 4, 8), (1, 3, 16, 32)])
+def test_upsample2x_zero_border_equals_upfirdn2d(ops, shape):
+    """spk_upsample2x_fwd(zero_border = 1) = upfirdn2d(up = 2, [1,3,3,1] * 4 / 64, pad (2,1)): what a modulated Winograd x2 layer reads."""
+    dev = torch.device("cuda:0")
+    x = torch.randn(*shape, generator=torch.Generator().manual_seed(5)).to(dev)
+    y = ops.upsample2x(x, zero_border=True)
+    k1 = torch.tensor([1.0, 3.0, 3.0, 1.0], dtype=torch.float64)
+    k = (k1[:, None] * k1[None, :]) / 64.0 * 4.0
+    C = shape[1]
+    up = torch.zeros(shape[0], C, 2 * shape[2], 2 * shape[3], dtype=torch.float64)
+    up[:, :, ::2, ::2] = x.double().cpu()
+    ref = F.conv2d(F.pad(up, (2, 1, 2, 1)), k.flip(0, 1).view(1, 1, 4, 4).repeat(C, 1, 1, 1), groups=C)
+    assert float((y.double().cpu() - ref).abs().max()) <= 2e-6 * max(1.0, float(ref.abs().max()))
