@@ -657,14 +657,13 @@ def main():
                     p.fill_(0.1)
             g2, _ = capture(lambda: gen2(feats))
             sg2_ms = event_ms(g2.replay, max(10, args.steps // 2))
-            c2_ms, n2, _ = conv_time_ms(gen2, feats, L)
+            c2_ms, n2, up2_ms = conv_time_ms(gen2, feats, L)
+            plan2 = plan_of(gen2)
             t2 = time.perf_counter()
             for _ in range(10):
                 gen2(feats)
             torch.cuda.synchronize()
             sg2_eager = (time.perf_counter() - t2) / 10 * 1e3
-            fl = decoder_conv_flops(BATCH) + 2 * 9 * 16 * 512 * 512 * BATCH        # + the 4x4 styled conv the variant starts with
-            a2 = fl / (c2_ms * 1e-3) / 1e12
             gen2.precision = "bf16x3"                     # the same opt-in split-precision path (tests/test_bf16x3_gpu.py)
             try:
                 g2b, _ = capture(lambda: gen2(feats))
@@ -673,14 +672,14 @@ def main():
             finally:
                 gen2.precision = "f32"
             extras["stylegan2_variant"] = {
-                "what": "speak-hack_amd.stylegan2.StyleGAN2Generator (modulated 3x3 conv + demod, upfirdn2d [1,3,3,1] folded into "
-                        "staging, skip toRGB with the skip upsample + add fused; same channel schedule; parity unpinned by the reference)",
+                "what": "speak-hack_amd.stylegan2.StyleGAN2Generator (modulated 3x3 conv + demod -- the >= 32^2 layers on the fp32 Winograd kernel, "
+                        "their x2 inputs upfirdn2d [1,3,3,1] images written by one launch each; the small layers on the direct kernel with the FIR "
+                        "folded into staging --, skip toRGB with the skip upsample + add fused; same channel schedule; parity unpinned by the reference)",
                 "frames_per_s_per_gpu": round(BATCH / sg2_ms * 1e3, 2), "ms_per_step": round(sg2_ms, 4), "eager_ms_per_step": round(sg2_eager, 4),
                 "bf16x3_opt_in": {"ms_per_step": round(sg2_bf_ms, 4), "frames_per_s_per_gpu": round(BATCH / sg2_bf_ms * 1e3, 2)},
-                "roofline": {"bound": "mfma", "kernel": "spkconv::conv_kernel<Cfg,3,3,1,MODE_(UPSAMPLE_)BATCH_SCALE>", "achieved": round(a2, 2),
-                             "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": round(a2 / F32_MFMA_PEAK_TFLOPS, 4), "traffic": committed_traffic("sg2", n2),
-                             "launches_per_step": n2, "conv_ms_per_step": round(c2_ms, 4), "conv_share_of_step": round(c2_ms / sg2_ms, 3),
-                             "algorithmic_gflop_per_step": round(fl / 1e9, 2)}}
+                "roofline": conv_roofline(plan2, L, c2_ms, up2_ms, "spkwino::wino_kernel<MOD> (fp32 Winograd, modulation on the transformed "
+                                          "input, demodulation in the epilogue) + spkconv::conv_kernel<Cfg,3,3,1,MODE_(UPSAMPLE_)BATCH_SCALE> (the 4^2 - 16^2 "
+                                          "layers)", committed_traffic("sg2", n2), sg2_ms)}
             del gen2, g2
             # ---- config 5: the 512^2 decoder at batch 4 ----
             s512 = pkg.SynthesisNetwork(resolution=512).eval().to(dev)
