@@ -143,11 +143,12 @@ def test_training_iteration_two_ranks_equals_the_single_process_iteration(tmp_pa
     # the last G step's; D: the last D step's mean plus the mean of the G step's contribution, clipped)
     # Criterion.  The two runs execute the same kernels on the same operands except for ONE number: the clip coefficient (a
     # multi-tensor norm over flat buffers here, torch's per-tensor norm there) differs in its last bits, so from the first G step on
-    # every parameter differs by ~1e-7 relative.  That cannot move a gradient -- except through a LeakyReLU / ReLU mask whose
-    # pre-activation lies within 1e-7 of zero: among the ~1e7 activations of a D pass about one does, and one flipped mask moves a
-    # weight gradient by ~1/P of its norm, P = batch x pixels of that layer (128 at the 8^2 block with 2 samples: 0.8 %; observed:
-    # 4e-3 on D.blocks.5.conv1 in one run of three).  So: the bulk of the 600 tensors must agree to rounding, and an outlier is
-    # allowed only at the size ONE flip explains.
+    # every parameter differs by ~1e-7 relative.  That cannot move a gradient -- except through a LeakyReLU mask whose pre-activation
+    # lies within 1e-7 of zero: among the ~1e7 activations of a D pass about one does.  A flipped mask at a layer with P = batch x
+    # pixels positions changes the gradient field behind it over that position's receptive field, i.e. every weight gradient
+    # UPSTREAM of it by ~1/P of its norm -- with 2 samples P is 128 at the 8^2 block and 32 at the 4^2 one.  Measured (deterministic,
+    # the same in every run of one build): median 4.8e-6, p90 8.0e-6 over the 594 tensors, and ~20 tensors of D between 2e-3 and 4e-3.
+    # So: the bulk must agree to rounding, and no tensor may be off by more than one flip at the deepest layer explains (1/32).
     errs = {}
     for k, p in net.named_parameters():
         g = r0["grads"][k]
@@ -155,10 +156,11 @@ def test_training_iteration_two_ranks_equals_the_single_process_iteration(tmp_pa
         if g is not None and float(g.norm()) > 0:
             errs[k] = rel_l2(p.grad.cpu(), g)
     vals = sorted(errs.values())
-    assert vals[len(vals) // 2] < 1e-5, vals[len(vals) // 2]                       # median: rounding
-    assert vals[int(0.9 * len(vals))] < 2e-4, vals[int(0.9 * len(vals))]           # 90 % of the tensors
-    outliers = {k: e for k, e in errs.items() if e >= 2e-3}
-    assert len(outliers) <= 4 and all(e < 5e-2 for e in outliers.values()), outliers
+    print(f"gradient rel-L2 against the emulation over {len(vals)} tensors: median {vals[len(vals) // 2]:.2e}, p90 {vals[int(0.9 * len(vals))]:.2e}, "
+          f"p99 {vals[int(0.99 * len(vals))]:.2e}, max {vals[-1]:.2e}")
+    assert vals[len(vals) // 2] < 2e-5, vals[len(vals) // 2]                       # median: rounding
+    assert vals[int(0.9 * len(vals))] < 2e-4, vals[int(0.9 * len(vals))]           # 90 % of the tensors: rounding
+    assert vals[-1] < 1.0 / 32, max(errs.items(), key=lambda t: t[1])              # the rest: at most one flipped mask's worth
     # the Adam updates: compare what the steps did to each stepped tensor (delta from the initial weights)
     for k, p in net.named_parameters():
         if k.startswith(("Gd.", "D.")):
