@@ -524,11 +524,17 @@ typedef struct spk_sn_group {
     float* sigma;         /* [1]    out: the spectral norm estimate (backward: in) */
     float* dw;            /* backward only: [R, C] out */
     int32_t R, C;
+    int32_t accumulate;   /* backward only: 1 = dw += (a discriminator runs several forwards before one backward, train.py:160-182:
+                           * the passes' gradients of one weight_orig add up inside the kernel instead of as separate tensors) */
+    int32_t reserved;
 } spk_sn_group;
 int64_t spk_spectral_norm_workspace_bytes(const spk_sn_group* groups, int n_groups);
 int spk_spectral_norm_grouped(const spk_sn_group* groups, int n_groups, int power_iteration, float eps, void* workspace,
                               int64_t workspace_bytes, void* stream);
 int spk_spectral_norm_bwd_grouped(const spk_sn_group* groups, int n_groups, void* workspace, int64_t workspace_bytes, void* stream);
+/* out[c] (+)= sum_b sums[b][row][c] over a [B][rows][C] array of per-plane sums (spk_epilogue_bwd's output): the bias gradient of a
+ * conv + bias + LeakyReLU layer (styleganv1.py:662-672), accumulated in place across the passes of one backward. */
+int spk_plane_sums_reduce(const float* sums, int B, int rows, int C, int row, float* out, int accumulate, void* stream);
 
 /* ---- launch lists: a whole module forward per C call ---------------------------------------------------------------
  * The reference's callers run a decoder pass as one Python call (model.py:113-114 `self.Gd(gen_input)`,

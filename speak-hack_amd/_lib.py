@@ -130,7 +130,7 @@ SN_MAX_GROUPS = 24
 class SnGroup(C.Structure):
     """``spk_sn_group`` (include/spk.h)."""
     _fields_ = [("w", C.c_void_p), ("u", C.c_void_p), ("v", C.c_void_p), ("w_hat", C.c_void_p), ("sigma", C.c_void_p),
-                ("dw", C.c_void_p), ("R", C.c_int32), ("C", C.c_int32)]
+                ("dw", C.c_void_p), ("R", C.c_int32), ("C", C.c_int32), ("accumulate", C.c_int32), ("reserved", C.c_int32)]
 
 
 class WgradDesc(C.Structure):
@@ -233,6 +233,7 @@ _PROTOTYPES = {
     "spk_conv1x1_small_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                         C.c_int64, C.c_float, C.c_void_p]),
     "spk_upsample2x_bilinear_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),
+    "spk_plane_sums_reduce": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p]),
     "spk_upsample2x_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_int, C.c_void_p]),
 }
 

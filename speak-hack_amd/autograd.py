@@ -107,6 +107,21 @@ def _wgrad_shared(weight, a, b, make):
     return None
 
 
+def _first_or_add(param, key, make):
+    """One gradient tensor per parameter and backward pass, whatever the number of graph nodes that contribute to it (a
+    discriminator runs six forwards before one backward, train.py:160-182): ``make(None)`` by the first contributor -- that tensor
+    goes to autograd --, ``make(held)`` (accumulate into it, on the current stream) by every later one, which hands autograd nothing.
+    The engine would otherwise add the contributions pairwise: 156 ``add`` launches per discriminator step."""
+    task = torch._C._current_graph_task_id()
+    held = getattr(param, key, None)
+    if held is None or held[0] != task:
+        t = make(None)
+        setattr(param, key, (task, t))
+        return t
+    make(held[1])
+    return None
+
+
 class WeightGateFn(torch.autograd.Function):
     """Identity on a module's conv weights, applied ONCE before the first conv of a forward pass (SynthesisNetwork.forward).  It is
     created first, so in the backward pass it runs after every conv's backward: the one place where the current stream has to
@@ -235,16 +250,50 @@ class FCFn(torch.autograd.Function):
     def backward(ctx, dout):
         x, weight, out = ctx.saved_tensors
         wmul, bmul, slope, has_bias = ctx.conf
-        if torch.is_grad_enabled():        # double backward (R1): [B, <=512] matrices -- differentiable torch algebra
-            dz = dout * torch.where(out > 0, 1.0, float(slope)) if slope != 1.0 else dout
-            dx = (dz @ weight) * wmul if ctx.needs_input_grad[0] else None
-            dw = (dz.t() @ x) * wmul if ctx.needs_input_grad[1] else None
-            db = dz.sum(0) * bmul if (has_bias and ctx.needs_input_grad[2]) else None
+        if torch.is_grad_enabled():        # double backward (R1): the input gradient stays differentiable, on the same HIP kernels
+            dx = FCDgradFn.apply(dout, out, weight, wmul, slope) if ctx.needs_input_grad[0] else None
+            dw = db = None
+            if not _INPUT_GRAD_ONLY and (ctx.needs_input_grad[1] or (has_bias and ctx.needs_input_grad[2])):
+                with torch.no_grad():       # parameter gradients of a recorded pass: plain kernel outputs (as ConvBiasLReLUFn's)
+                    _, dw, db = ops.fc_bwd(dout.detach().contiguous(), out, x, weight, wmul, bmul, slope, need_dx=False,
+                                           need_dw=True, has_bias=has_bias)
             return dx, dw, db, None, None, None, None
         dx, dw, db = ops.fc_bwd(dout.contiguous(), out, x, weight, wmul, bmul, slope,
                                 need_dx=ctx.needs_input_grad[0], need_dw=ctx.needs_input_grad[1] or
                                 (has_bias and ctx.needs_input_grad[2]), has_bias=has_bias)
         return dx, dw, db, None, None, None, None
+
+
+class FCDgradFn(torch.autograd.Function):
+    """dx = wmul * (dout * lrelu'(out)) @ W as a differentiable function of (dout, W): the input gradient of ``FCFn`` inside a recorded
+    backward (the R1 penalty of train.py:246-255 differentiates dD/dx once more).  Its adjoints are kernels that exist already -- with
+    g the gradient w.r.t. dx: d dout = lrelu'(out) * wmul * g @ W^T (``spk_fc_fwd``), d W = wmul * (dout * lrelu'(out))^T @ g (the weight
+    half of ``spk_fc_bwd`` with g in x's place) -- so no GEMM library call sits on the discriminator's path (round 3: 14 Tensile
+    launches per step here)."""
+
+    @staticmethod
+    def forward(ctx, dout, out, weight, wmul, slope):
+        dout = dout.contiguous()
+        ctx.save_for_backward(dout, out, weight)
+        ctx.conf = (wmul, slope)
+        dx, _, _ = ops.fc_bwd(dout, out, dout.new_empty((dout.shape[0], weight.shape[1])), weight, wmul, 0.0, slope, need_dx=True,
+                              need_dw=False, has_bias=False)
+        return dx
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        dout, out, weight = ctx.saved_tensors
+        wmul, slope = ctx.conf
+        g = g.contiguous()
+        ddout = dweight = None
+        if ctx.needs_input_grad[0]:
+            ddout = ops.fc(g, weight, None, wmul, 0.0, 1.0)                  # wmul * g @ W^T ...
+            if slope != 1.0:
+                ddout = ddout * torch.where(out > 0, 1.0, float(slope))     # ... through the same mask
+        if ctx.needs_input_grad[2]:
+            _, dweight, _ = ops.fc_bwd(dout, out, g, weight, wmul, 0.0, slope, need_dx=False, need_dw=True, has_bias=False)
+        return ddout, None, dweight, None, None
 
 
 class StyleFCGroupFn(torch.autograd.Function):
@@ -473,6 +522,7 @@ class ConvBiasLReLUFn(torch.autograd.Function):
         if _needs(ctx, grad_mode):
             ctx.save_for_backward(x, weight, y)
             ctx.conf = (k, stride, slope, bias is not None)
+            ctx.bias_ref = bias               # (the Parameter: its gradient is shared by the passes of one backward, _first_or_add)
         return y
 
     @staticmethod
@@ -502,7 +552,10 @@ class ConvBiasLReLUFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = _conv_dgrad(dt, weight, k, stride, tuple(x.shape[-2:]))
         if has_bias and ctx.needs_input_grad[2]:
-            db = sums[:, 2].sum(0)
+            if isinstance(ctx.bias_ref, torch.nn.Parameter):
+                db = _first_or_add(ctx.bias_ref, "_spk_db", lambda out: ops.plane_sums_reduce(sums, 2, out))
+            else:
+                db = ops.plane_sums_reduce(sums, 2)
         return dx, dw, db, None, None, None, None
 
 
@@ -717,6 +770,7 @@ class SpectralNormAllFn(torch.autograd.Function):
             ctx.save_for_backward(torch.cat([u.reshape(-1) for u in us]), torch.cat([v.reshape(-1) for v in vs]), sigma, *weights)
             ctx.sizes = (ru, cv)
             ctx.hats = [weakref.ref(h) for h in hats]
+            ctx.params = weights              # (the Parameters themselves: their gradients are shared across passes)
         return tuple(hats)
 
     @staticmethod
@@ -731,7 +785,17 @@ class SpectralNormAllFn(torch.autograd.Function):
         ru, cv = ctx.sizes
         us, vs = list(u_flat.split(ru)), list(v_flat.split(cv))
         gs = [None if (g is None or not ctx.needs_input_grad[3 + i]) else g.contiguous() for i, g in enumerate(grads)]
-        dws = ops.spectral_norm_grouped_bwd(gs, weights, us, vs, sigma)
+        # the passes of one backward share ONE gradient tensor per weight_orig (see _first_or_add): the first node's goes to autograd,
+        # the others accumulate into it inside the kernel
+        task = torch._C._current_graph_task_id()
+        into = []
+        for w, g in zip(ctx.params, gs):
+            held = getattr(w, "_spk_sn_dw", None) if (g is not None and isinstance(w, torch.nn.Parameter)) else None
+            into.append(held[1] if (held is not None and held[0] == task) else None)
+        dws = ops.spectral_norm_grouped_bwd(gs, weights, us, vs, sigma, into=into)
+        for w, t in zip(ctx.params, dws):
+            if t is not None and isinstance(w, torch.nn.Parameter):
+                w._spk_sn_dw = (task, t)
         return (None, None, None) + tuple(dws)
 
 

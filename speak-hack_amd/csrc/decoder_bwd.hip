@@ -75,6 +75,16 @@ __global__ __launch_bounds__(256) void epilogue_bwd_kernel(const float* __restri
     }
 }
 
+// out[c] (+)= sum_b sums[b][row][c]: fixed order over the batch
+__global__ __launch_bounds__(256) void plane_sums_reduce_kernel(const float* __restrict__ sums, int B, int rows, int C, int row,
+                                                               float* __restrict__ out, int accumulate) {
+    const int c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float s = 0.f;
+    for (int b = 0; b < B; ++b) s += sums[((size_t)b * rows + row) * C + c];
+    out[c] = accumulate ? out[c] + s : s;
+}
+
 // adjoint of bilinear x2 (align_corners=False): every source pixel gathers from the <= 4x4 upsampled
 // pixels whose forward stencil touches it, re-evaluating the forward index/lambda rule (edges included).
 __global__ __launch_bounds__(256) void upsample2x_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx,
@@ -513,6 +523,13 @@ __global__ __launch_bounds__(256) void fc_grouped_bwd_weight_kernel(const FcBwdG
 }  // namespace
 
 extern "C" {
+
+int spk_plane_sums_reduce(const float* sums, int B, int rows, int C, int row, float* out, int accumulate, void* stream) {
+    SPK_REQUIRE(sums && out && B > 0 && rows > 0 && C > 0 && row >= 0 && row < rows, "plane_sums_reduce: bad arguments");
+    hipLaunchKernelGGL(plane_sums_reduce_kernel, dim3((unsigned)spk::ceil_div(C, 256)), dim3(256), 0, (hipStream_t)stream, sums, B, rows, C, row,
+                       out, accumulate);
+    return spk::check_launch("plane_sums_reduce_kernel");
+}
 
 int spk_epilogue_bwd(const float* dy, const float* a, const float* noise, const float* style, int64_t style_stride,
                      float slope, float* dt, float* sums, int B, int C, int64_t HW, void* stream) {

@@ -164,7 +164,8 @@ __global__ __launch_bounds__(256) void sn_bwd_apply_kernel(const SnGroups a, con
     const size_t n = (size_t)q.R * q.C, i0 = (size_t)(blockIdx.x - a.blk_e[gi]) * 1024 + threadIdx.x * 4;
     for (size_t i = i0; i < std::min(n, i0 + 4); ++i) {
         const int r = (int)(i / q.C), c = (int)(i - (size_t)r * q.C);
-        q.dw[i] = (q.w_hat[i] - coef * q.u[r] * q.v[c]) / sigma;
+        const float d = (q.w_hat[i] - coef * q.u[r] * q.v[c]) / sigma;
+        q.dw[i] = q.accumulate ? q.dw[i] + d : d;
     }
 }
 

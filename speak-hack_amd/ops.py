@@ -717,20 +717,35 @@ def spectral_norm_grouped(weights, us, vs, power_iteration, eps=1e-12):
     return hats, sigma
 
 
-def spectral_norm_grouped_bwd(grads, weights, us, vs, sigma):
-    """dW = (G - <G, W>/sigma u v^T) / sigma for every layer with a gradient (``grads[i]`` None -> None)."""
+def spectral_norm_grouped_bwd(grads, weights, us, vs, sigma, into=None):
+    """dW = (G - <G, W>/sigma u v^T) / sigma for every layer with a gradient (``grads[i]`` None -> None).  ``into[i]`` (a tensor or
+    None): ADD layer i's result into that tensor instead of returning a new one (the entry of the result is then None)."""
     idx = [i for i, g in enumerate(grads) if g is not None]
     out = [None] * len(grads)
     if not idx:
         return out
-    dws = {i: torch.empty_like(weights[i], memory_format=torch.contiguous_format) for i in idx}
+    acc = {i: (into[i] if into is not None else None) for i in idx}
+    dws = {i: (acc[i] if acc[i] is not None else torch.empty_like(weights[i], memory_format=torch.contiguous_format)) for i in idx}
     arr = _sn_groups([(weights[i], us[i], vs[i], grads[i], sigma[i:i + 1], dws[i]) for i in idx])
+    for g, i in zip(arr, idx):
+        g.accumulate = 1 if acc[i] is not None else 0
     nbytes = L.lib().spk_spectral_norm_workspace_bytes(C.cast(arr, C.c_void_p), len(idx))
     ws = _workspace(weights[0].device, nbytes)
     L.check(L.lib().spk_spectral_norm_bwd_grouped(C.cast(arr, C.c_void_p), len(idx), ws.data_ptr(), ws.numel() * 4, L.stream_ptr()),
             "spk_spectral_norm_bwd_grouped")
     for i in idx:
-        out[i] = dws[i]
+        out[i] = dws[i] if acc[i] is None else None
+    return out
+
+
+def plane_sums_reduce(sums, row, out=None):
+    """out[c] (+)= sum_b sums[b, row, c]  (``out`` given: accumulate into it; else a new tensor)."""
+    B, rows, Cc = sums.shape
+    acc = out is not None
+    if out is None:
+        out = torch.empty(Cc, device=sums.device, dtype=torch.float32)
+    L.check(L.lib().spk_plane_sums_reduce(L.dptr(sums, "sums"), B, rows, Cc, int(row), L.dptr(out), 1 if acc else 0, L.stream_ptr()),
+            "spk_plane_sums_reduce")
     return out
 
 
