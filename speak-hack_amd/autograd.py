@@ -116,7 +116,9 @@ def _first_or_add(param, key, make):
     held = getattr(param, key, None)
     if held is None or held[0] != task:
         t = make(None)
-        setattr(param, key, (task, t))
+        # (the note keeps an ALIAS: a second reference to the tensor object itself would stop AccumulateGrad from adopting it --
+        # it clones any gradient whose use count is above one)
+        setattr(param, key, (task, t.detach()))
         return t
     make(held[1])
     return None
@@ -795,7 +797,7 @@ class SpectralNormAllFn(torch.autograd.Function):
         dws = ops.spectral_norm_grouped_bwd(gs, weights, us, vs, sigma, into=into)
         for w, t in zip(ctx.params, dws):
             if t is not None and isinstance(w, torch.nn.Parameter):
-                w._spk_sn_dw = (task, t)
+                w._spk_sn_dw = (task, t.detach())     # (an alias: see _first_or_add)
         return (None, None, None) + tuple(dws)
 
 
