@@ -258,6 +258,19 @@ int spk_conv2d_wgrad(const spk_wgrad_desc* desc, void* stream);
  * low-resolution [B,Cin,H/2,W/2] tensor and the x2 image is never materialised); 0: upsample first. */
 int spk_conv2d_wgrad_up_supported(int B, int Cin, int Cout, int H, int W);
 int spk_conv2d_wgrad_mod_supported(int B, int Cin, int Cout, int H, int W, int upsample);
+/* The same gradient as Winograd F(2x2, 3x3) (wgrad3x3_wino_f32.hip): flags = SPK_CONV_WINOGRAD on a plain 3x3 stride-1 pad-1 problem
+ * (x is the conv's actual input: a x2 layer passes the materialised x2 image, spk_upsample2x_fwd); fp32 throughout, 16/36 of the
+ * direct form's multiply-adds.  Shapes: Cin, Cout multiples of 64, H even, W a multiple of 16 (..._supported); the workspace holds
+ * `splits` slabs [Cout][9][Cin] (..._workspace_bytes; ..._splits returns the split count the kernel will use for `splits` = the
+ * wanted count, 0 = auto), reduced in a fixed order by spk_wgrad_reduce_slabs -- bitwise reproducible. */
+int spk_conv2d_wgrad_wino_supported(int B, int Cin, int Cout, int H, int W);
+int spk_conv2d_wgrad_wino_splits(int splits, int B, int Cin, int Cout, int H, int W);
+int64_t spk_conv2d_wgrad_wino_workspace_bytes(int splits, int B, int Cin, int Cout, int H, int W);
+int spk_conv2d_wgrad_wino(const spk_wgrad_desc* desc, void* stream);
+/* dw[co][ci][tap] (=, or += when accumulate) scale * sum over n_slabs slabs [Cout][taps][Cin], in slab order; fold > 1: rows
+ * co and co + Cout/fold add (see spk_wgrad_desc.fold) */
+int spk_wgrad_reduce_slabs(const float* slabs, float* dw, int n_slabs, int Cout, int Cin, int taps, float scale, int accumulate, int fold,
+                           void* stream);
 
 /* Adjoint of the fused epilogue of spk_conv2d_fwd, one pass.  With y = a*(s0+1)+s1, a = lrelu(t),
  * t = conv + bias + noise_w*noise and dy = dL/dy:

@@ -177,6 +177,11 @@ _PROTOTYPES = {
     "spk_conv2d_wgrad": (C.c_int, [C.POINTER(WgradDesc), C.c_void_p]),
     "spk_conv2d_wgrad_up_supported": (C.c_int, [C.c_int] * 5),
     "spk_conv2d_wgrad_mod_supported": (C.c_int, [C.c_int] * 6),
+    "spk_conv2d_wgrad_wino_supported": (C.c_int, [C.c_int] * 5),
+    "spk_conv2d_wgrad_wino_splits": (C.c_int, [C.c_int] * 6),
+    "spk_conv2d_wgrad_wino_workspace_bytes": (C.c_int64, [C.c_int] * 6),
+    "spk_conv2d_wgrad_wino": (C.c_int, [C.c_void_p, C.c_void_p]),
+    "spk_wgrad_reduce_slabs": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_int, C.c_float, C.c_int, C.c_int, C.c_void_p]),
     "spk_modconv_epi_finish": (C.c_int, [C.c_void_p] * 4 + [C.c_float] + [C.c_void_p] * 4 + [C.c_int, C.c_int, C.c_void_p]),
     "spk_modconv_dx_finish": (C.c_int, [C.c_void_p] * 5 + [C.c_int] * 5 + [C.c_void_p]),
     "spk_modconv_demod_bwd_workspace_bytes": (C.c_int64, [C.c_int] * 3),

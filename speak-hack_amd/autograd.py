@@ -197,6 +197,9 @@ class FusedConvFn(torch.autograd.Function):
             xin = ops.upsample2x_bilinear(x) if upsample else x
             y = ops.conv3x3_wino(xin, packed.get_wino(pw), Cout, bias=bias, noise_w=noise_w, noise=noise, style=style,
                                  lrelu_slope=slope, out_pre=a, out_scale=w_scale)
+            if upsample and keep and ops.use_wgrad_wino(B, Cin, Cout, H, W):
+                x = xin                               # the Winograd weight gradient reads the x2 image too: keep IT, not the source
+                ctx.x_was_up = True
         else:
             cfg = ops.conv2d_pick_config(3, 1, B, Cin, Cout, H, W)
             y = ops.conv2d_fused(x, packed.get(pw, cfg), Cout, 3, 1, bias=bias, noise_w=noise_w, noise=noise,
@@ -211,6 +214,7 @@ class FusedConvFn(torch.autograd.Function):
     def backward(ctx, dy):
         x, weight, a, noise, style = ctx.saved_tensors
         upsample, slope, packed, has_bias, has_noise, w_scale = ctx.conf
+        x_is_up = upsample and getattr(ctx, "x_was_up", False)       # (the saved x is the x2 image already)
         B, Cin = x.shape[:2]
         Cout, H, W = a.shape[1:]
         dt, sums = ops.epilogue_bwd(dy.contiguous(), a, noise if has_noise else None, style,
@@ -219,7 +223,7 @@ class FusedConvFn(torch.autograd.Function):
         dx = dw = None
         pw = getattr(weight, "_spk_gate_of", None)
         if ctx.needs_input_grad[1]:
-            launch = lambda: ops.conv2d_wgrad(dt, x, Cout, Cin, 3, 1, upsample=upsample, scale=w_scale)
+            launch = lambda: ops.conv2d_wgrad(dt, x, Cout, Cin, 3, 1, upsample=upsample and not x_is_up, scale=w_scale)
             # behind a WeightGateFn (which joins the second stream before the parameters see their gradients): beside the data gradient
             dw = _wgrad_aside(dt, x, launch) if pw is not None else launch()
         if pw is None:

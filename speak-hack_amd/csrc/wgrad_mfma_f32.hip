@@ -2202,8 +2202,15 @@ int spk_conv2d_wgrad_mod_supported(int B, int Cin, int Cout, int H, int W, int u
     return (W >= 8 && W % 4 == 0 && H >= 4) ? 1 : 0;
 }
 
+int spk_wgrad_reduce_slabs(const float* slabs, float* dw, int n_slabs, int Cout, int Cin, int taps, float scale, int accumulate, int fold,
+                           void* stream) {
+    SPK_REQUIRE(slabs && dw && n_slabs > 0 && Cout > 0 && Cin > 0 && taps > 0, "wgrad reduce: bad arguments");
+    return launch_wgrad_reduce((hipStream_t)stream, slabs, dw, n_slabs, Cout, Cin, taps, scale, accumulate ? 1 : 0, fold > 1 ? fold : 1);
+}
+
 int spk_conv2d_wgrad(const spk_wgrad_desc* d, void* stream) {
     SPK_REQUIRE(d && d->g && d->x && d->dw, "wgrad: null pointer");
+    if (d->flags & SPK_CONV_WINOGRAD) return spk_conv2d_wgrad_wino(d, stream);
     SPK_REQUIRE(d->B > 0 && d->Cin > 0 && d->Cout > 0 && d->H > 0 && d->W > 0 && d->Hin > 0 && d->Win > 0, "wgrad: bad shape");
     SPK_REQUIRE(wg_supported(d->kh, d->kw, d->stride), "wgrad: unsupported kernel %dx%d stride %d", d->kh, d->kw, d->stride);
     SPK_REQUIRE(d->fold <= 1 || (d->groups > 1 && d->groups % d->fold == 0), "wgrad: fold %d must divide groups %d", d->fold, d->groups);

@@ -160,3 +160,76 @@ def test_upsample2x_zero_border_equals_upfirdn2d(ops, shape):
     up[:, :, ::2, ::2] = x.double().cpu()
     ref = F.conv2d(F.pad(up, (2, 1, 2, 1)), k.flip(0, 1).view(1, 1, 4, 4).repeat(C, 1, 1, 1), groups=C)
     assert float((y.double().cpu() - ref).abs().max()) <= 2e-6 * max(1.0, float(ref.abs().max()))
+
+
+# ---- the weight gradient as Winograd F(2x2, 3x3) (csrc/wgrad3x3_wino_f32.hip) ------------------------------------------------
+def _wgrad_ref(g, x):
+    w = torch.zeros(g.shape[1], x.shape[1], 3, 3, device=g.device, dtype=torch.float64, requires_grad=True)
+    return torch.autograd.grad(F.conv2d(x.double(), w, padding=1), w, g.double())[0]
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,splits", [(1, 64, 64, 8, 32, 1), (1, 64, 64, 8, 32, 2), (2, 64, 64, 4, 16, 0), (1, 128, 64, 8, 64, 1),
+                                                   (4, 64, 128, 16, 32, 0), (3, 64, 64, 6, 48, 0), (2, 192, 128, 32, 32, 0),
+                                                   (1, 64, 64, 2, 64, 0)])
+def test_wgrad_wino_equals_fp64_weight_gradient(ops, B, Cin, Cout, H, W, splits):
+    """Every image border, every chunk boundary between workgroups (splits), ragged chunk counts, and twice: the result is a
+    fixed-order sum (bitwise reproducible)."""
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(B * 100 + Cin + H + W + splits)
+    x = torch.randn(B, Cin, H, W, generator=gen).to(dev)
+    g = torch.randn(B, Cout, H, W, generator=gen).to(dev)
+    assert ops.wgrad_wino_supported(B, Cin, Cout, H, W)
+    dw = ops.conv2d_wgrad_wino(g, x, Cout, Cin, splits=splits)
+    ref = _wgrad_ref(g, x)
+    assert rel_l2(dw, ref) < TOL, rel_l2(dw, ref)
+    assert float((dw.double() - ref).abs().max()) < 2e-5 * float(ref.abs().max())
+    assert torch.equal(dw, ops.conv2d_wgrad_wino(g, x, Cout, Cin, splits=splits))
+    with ops.conv3x3_algo("direct"):
+        direct = ops.conv2d_wgrad(g, x, Cout, Cin, 3, 1)
+    assert rel_l2(dw, direct) < TOL
+
+
+def test_wgrad_wino_border_pixels_one_by_one(ops):
+    """A one-hot output gradient at each border position (and a few inner ones) picks single input pixels: the zero padding
+    (out-of-range LDS-DMA pieces) and the patch addressing, element by element."""
+    dev = torch.device("cuda:0")
+    B, Cin, Cout, H, W = 1, 64, 64, 8, 32
+    x = torch.randn(B, Cin, H, W, generator=torch.Generator().manual_seed(5)).to(dev)
+    spots = [(0, 0), (0, 15), (0, 16), (0, 31), (7, 0), (7, 31), (1, 1), (2, 17), (3, 15), (4, 16), (5, 30), (6, 2)]
+    for h, w_ in spots:
+        g = torch.zeros(B, Cout, H, W, device=dev)
+        g[0, :, h, w_] = 1.0
+        dw = ops.conv2d_wgrad_wino(g, x, Cout, Cin)
+        xp = F.pad(x, (1, 1, 1, 1))[0, :, h:h + 3, w_:w_ + 3]                  # [Cin,3,3]
+        assert float((dw - xp.unsqueeze(0)).abs().max()) < 1e-5, (h, w_)
+
+
+def test_wgrad_wino_scale_accumulate_and_routing(ops):
+    dev = torch.device("cuda:0")
+    B, Cin, Cout, H, W = 4, 128, 64, 32, 32
+    gen = torch.Generator().manual_seed(9)
+    x = torch.randn(B, Cin, H, W, generator=gen).to(dev)
+    g = torch.randn(B, Cout, H, W, generator=gen).to(dev)
+    ref = _wgrad_ref(g, x)
+    out = torch.ones(Cout, Cin, 3, 3, device=dev)
+    ops.conv2d_wgrad_wino(g, x, Cout, Cin, scale=0.5, out=out, accumulate=True)
+    assert rel_l2(out, 1.0 + 0.5 * ref) < TOL
+    # ops.conv2d_wgrad routes a served plain 3x3 problem to the Winograd kernel (bitwise the same call) unless the switch says direct
+    if ops.use_wgrad_wino(B, Cin, Cout, H, W):
+        assert torch.equal(ops.conv2d_wgrad(g, x, Cout, Cin, 3, 1), ops.conv2d_wgrad_wino(g, x, Cout, Cin))
+    # a x2 layer: the same gradient as the in-kernel-interpolating direct form
+    xs = torch.randn(B, Cin, H // 2, W // 2, generator=gen).to(dev)
+    a = ops.conv2d_wgrad(g, xs, Cout, Cin, 3, 1, upsample=True)
+    with ops.conv3x3_algo("direct"):
+        b = ops.conv2d_wgrad(g, xs, Cout, Cin, 3, 1, upsample=True)
+    assert rel_l2(a, b) < TOL
+
+
+def test_wgrad_wino_rejects_what_it_does_not_serve(ops):
+    L = importlib.import_module("speak-hack_amd")._lib
+    assert not ops.wgrad_wino_supported(2, 3, 64, 32, 32) and not ops.wgrad_wino_supported(2, 64, 96, 32, 32)
+    assert not ops.wgrad_wino_supported(2, 64, 64, 32, 24) and not ops.wgrad_wino_supported(2, 64, 64, 7, 32)
+    dev = torch.device("cuda:0")
+    g, x = torch.zeros(2, 96, 32, 32, device=dev), torch.zeros(2, 64, 32, 32, device=dev)
+    with pytest.raises(L.SpkError):
+        ops.conv2d_wgrad_wino(g, x, 96, 64)
