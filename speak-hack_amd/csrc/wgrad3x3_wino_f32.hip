@@ -26,6 +26,8 @@
 // gradient's slabs, so the SAME fixed-order reduce (spk_wgrad_reduce_slabs) finishes: bitwise reproducible, no float atomics.
 #include "conv_mfma_f32.hpp"
 
+#include <cstdlib>
+
 namespace spkwgw {
 
 using spkconv::f32x16;
@@ -48,6 +50,8 @@ struct Args {
     const float* g;
     const float* x;
     float* slabs;            // [splits][Cout][9][Cin]
+    const float* in_scale;   // MOD: s[B][Cin]  -- the conv's input was x * s
+    const float* g_scale;    // MOD: d'[B][Cout] -- the gradient that reaches the conv output is g * d'
     int B, Cin, Cout, H, W;
     int TXB, TY;             // chunks per tile row (W / 16), tile rows (H / 2)
     int chunks_per_wg;       // even; the last workgroup's run may be shorter (the missing chunks count as zero gradients)
@@ -58,6 +62,7 @@ struct Args {
 __device__ __forceinline__ float fadd_(float a, float b) { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float fsub_(float a, float b) { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
+template <bool MOD>
 __global__ __launch_bounds__(NT) void wgrad_wino_kernel(const Args p) {
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
@@ -73,13 +78,17 @@ __global__ __launch_bounds__(NT) void wgrad_wino_kernel(const Args p) {
     // ---- X pieces: the descriptor's base sits one row and four columns BEFORE the tensor, so that every piece's offset from a
     // chunk's origin is non-negative (the range check sees the lane offset only); pieces outside the image are marked out of range
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x) - (p.W + 4), 0, (int)p.x_bytes, 0x00020000);
-    unsigned rel[X_DMA], edge[X_DMA], voff[X_DMA];
+    unsigned rel[X_DMA], voff[X_DMA];
+    unsigned long long e_top[X_DMA], e_bot[X_DMA], e_left[X_DMA], e_right[X_DMA];      // lane masks (SGPR pairs): which lanes' piece k touches an edge
 #pragma unroll
     for (int k = 0; k < X_DMA; ++k) {
         const int q = k * 64 + lane;                         // piece of this wave's tile: [r 4][j 6][channel 16]
         const int c = q & 15, rj = q >> 4, r = rj / 6, j = rj - 6 * r;
         rel[k] = ((unsigned)(16 * wave + c) * HW + (unsigned)(r * p.W + 4 * j)) * 4u;
-        edge[k] = (r == 0 ? 1u : 0u) | (r == 3 ? 2u : 0u) | (j == 0 ? 4u : 0u) | (j == 5 ? 8u : 0u);
+        e_top[k] = __builtin_amdgcn_ballot_w64(r == 0);
+        e_bot[k] = __builtin_amdgcn_ballot_w64(r == 3);
+        e_left[k] = __builtin_amdgcn_ballot_w64(j == 0);
+        e_right[k] = __builtin_amdgcn_ballot_w64(j == 5);
     }
     const unsigned raw_m0 = (unsigned)((RAWX_OFF + wave * RAW_WAVE) * 4);
 #define WGW_DMA_X(k_, soff_)                                                                                            \
@@ -106,9 +115,14 @@ __global__ __launch_bounds__(NT) void wgrad_wino_kernel(const Args p) {
         return (((unsigned)b_ * (unsigned)p.Cin + (unsigned)ci0) * HW + (unsigned)(2 * ty_ * p.W + 16 * tx_)) * 4u;
     };
     auto set_voff = [&](int ty_, int tx_) {
-        const unsigned at = (ty_ == 0 ? 1u : 0u) | (2 * ty_ + 2 >= p.H ? 2u : 0u) | (tx_ == 0 ? 4u : 0u) | (16 * tx_ + 16 >= p.W ? 8u : 0u);
+        const unsigned long long a_top = ty_ == 0 ? ~0ull : 0ull, a_bot = 2 * ty_ + 2 >= p.H ? ~0ull : 0ull;
+        const unsigned long long a_left = tx_ == 0 ? ~0ull : 0ull, a_right = 16 * tx_ + 16 >= p.W ? ~0ull : 0ull;
+        const unsigned oob = 0x80000000u;
 #pragma unroll
-        for (int k = 0; k < X_DMA; ++k) voff[k] = (edge[k] & at) ? 0x80000000u : rel[k];
+        for (int k = 0; k < X_DMA; ++k) {                    // the mask is scalar work; one v_cndmask per piece
+            const unsigned long long m = (e_top[k] & a_top) | (e_bot[k] & a_bot) | (e_left[k] & a_left) | (e_right[k] & a_right);
+            asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(voff[k]) : "v"(rel[k]), "v"(oob), "s"(m));
+        }
     };
     // ---- transform roles: wave w the block's channels 16 w .. 16 w + 15 (of X and of dY); a lane one channel and the tile pair
     // (2 tr_p, 2 tr_p + 1); its dY: the 2 x 4 gradients under the pair
@@ -117,11 +131,15 @@ __global__ __launch_bounds__(NT) void wgrad_wino_kernel(const Args p) {
     auto g_origin = [&](int b_, int ty_, int tx_) -> size_t {
         return ((size_t)b_ * p.Cout * HW + (size_t)(2 * ty_ * p.W + 16 * tx_)) * 4;
     };
-#define WGW_LOAD_G(dst0_, dst1_, org_, valid_)                                                                          \
+#define WGW_LOAD_G(dst0_, dst1_, sx_, sg_, org_, b_, valid_)                                                            \
     if (valid_) {                                                                                                       \
         const char* gp_ = reinterpret_cast<const char*>(p.g) + (org_);                                                  \
         dst0_ = *reinterpret_cast<const f32x4*>(gp_ + g_lane);                                                          \
         dst1_ = *reinterpret_cast<const f32x4*>(gp_ + g_lane + (size_t)p.W * 4);                                        \
+        if constexpr (MOD) {                                                                                            \
+            sx_ = p.in_scale[(size_t)(b_) * p.Cin + ci0 + tr_c];                                                        \
+            sg_ = p.g_scale[(size_t)(b_) * p.Cout + co0 + tr_c];                                                        \
+        }                                                                                                               \
     } else {                                                                                                            \
         dst0_ = f32x4{0.f, 0.f, 0.f, 0.f};                                                                              \
         dst1_ = f32x4{0.f, 0.f, 0.f, 0.f};                                                                              \
@@ -157,6 +175,10 @@ __global__ __launch_bounds__(NT) void wgrad_wino_kernel(const Args p) {
         xr[r_][1] = m_.x; xr[r_][2] = m_.y; xr[r_][3] = m_.z; xr[r_][4] = m_.w;                                         \
         xr[r_][5] = *((const volatile lds_f32_t*)0 + (xr_base + (r_) * RAW_ROW + 2 * RAW_PIECE));                       \
     }
+#define WGW_X_SCALE(r_)                                                                                                 \
+    {                                                                                                                   \
+        _Pragma("unroll") for (int e_ = 0; e_ < 6; ++e_) xr[r_][e_] *= sx_cur;                                          \
+    }
     // V = B^T d B of tile t_ (0 / 1 of the pair: patch columns 2 t_ .. 2 t_ + 3), written to V slot vs_
 #define WGW_V_ROWS(t_, c_)                                                                                              \
     {                                                                                                                   \
@@ -170,14 +192,15 @@ __global__ __launch_bounds__(NT) void wgrad_wino_kernel(const Args p) {
     }
 #define WGW_V_WRITE(vs_, t_, xi_)                                                                                       \
     *((volatile lds_f32_t*)0 + (v_wr + ((vs_) * PV_FLOATS + ((xi_) * TC + (t_)) * 64))) = tv[xi_];
-    // P = A dY A^T of tile t_ (gradients y00 y01 / y10 y11), A = [1 0; 1 1; 1 -1; 0 -1]
+    // P = A dY A^T of tile t_ (gradients y00 y01 / y10 y11), A = [1 0; 1 1; 1 -1; 0 -1] -- stored WITHOUT the minus signs of A's
+    // last row (frequencies 3, 7, 11, 12, 13, 14 hold -P): the epilogue puts them back (P_SIGN), the loop saves ten negations a chunk
 #define WGW_P_MAKE(t_, y00_, y01_, y10_, y11_)                                                                          \
     {                                                                                                                   \
         const float s0_ = fadd_(y00_, y10_), s1_ = fadd_(y01_, y11_), d0_ = fsub_(y00_, y10_), d1_ = fsub_(y01_, y11_); \
-        tq[0] = y00_; tq[1] = fadd_(y00_, y01_); tq[2] = fsub_(y00_, y01_); tq[3] = -(y01_);                            \
-        tq[4] = s0_; tq[5] = fadd_(s0_, s1_); tq[6] = fsub_(s0_, s1_); tq[7] = -s1_;                                    \
-        tq[8] = d0_; tq[9] = fadd_(d0_, d1_); tq[10] = fsub_(d0_, d1_); tq[11] = -d1_;                                  \
-        tq[12] = -(y10_); tq[13] = -fadd_(y10_, y11_); tq[14] = fsub_(y11_, y10_); tq[15] = y11_;                       \
+        tq[0] = y00_; tq[1] = fadd_(y00_, y01_); tq[2] = fsub_(y00_, y01_); tq[3] = y01_;                               \
+        tq[4] = s0_; tq[5] = fadd_(s0_, s1_); tq[6] = fsub_(s0_, s1_); tq[7] = s1_;                                     \
+        tq[8] = d0_; tq[9] = fadd_(d0_, d1_); tq[10] = fsub_(d0_, d1_); tq[11] = d1_;                                   \
+        tq[12] = y10_; tq[13] = fadd_(y10_, y11_); tq[14] = fsub_(y10_, y11_); tq[15] = y11_;                           \
     }
 #define WGW_P_WRITE(ps_, t_, xi_)                                                                                       \
     *((volatile lds_f32_t*)0 + (p_wr + ((ps_) * PV_FLOATS + ((xi_) * TC + (t_)) * 64))) = tq[xi_];
@@ -185,17 +208,20 @@ __global__ __launch_bounds__(NT) void wgrad_wino_kernel(const Args p) {
     // ---- prologue: chunk 0 -> slot 0; chunk 1's X requested, its dY in registers ----
     int b, ty, tx;
     f32x4 ga0, ga1, gb0, gb1;        // dY of the chunk being transformed (a) / of the one after it (b)
+    float sxa = 1.f, sga = 1.f, sxb = 1.f, sgb = 1.f, sx_cur = 1.f;      // MOD: the lane's s[b][ci] / d'[b][co] of those chunks
     chunk_of(c_first, b, ty, tx);
     set_voff(ty, tx);
     {
         const unsigned so = x_origin(b, ty, tx);
         static_for<0, X_DMA>([&](auto k) { WGW_DMA_X(decltype(k)::value, so); });
-        WGW_LOAD_G(ga0, ga1, g_origin(b, ty, tx), true);
+        WGW_LOAD_G(ga0, ga1, sxa, sga, g_origin(b, ty, tx), b, true);
     }
     __builtin_amdgcn_s_waitcnt(0x0f70);
-    auto transform_all = [&](auto slot_c, const f32x4& g0, const f32x4& g1) __attribute__((always_inline)) {
+    auto transform_all = [&](auto slot_c, f32x4 g0, f32x4 g1, const float sx, const float sg) __attribute__((always_inline)) {
         constexpr int SL = decltype(slot_c)::value;
+        if constexpr (MOD) { sx_cur = sx; g0 *= sg; g1 *= sg; }
         static_for<0, 4>([&](auto r) { WGW_X_READ(decltype(r)::value); });
+        if constexpr (MOD) static_for<0, 4>([&](auto r) { WGW_X_SCALE(decltype(r)::value); });
         static_for<0, 2>([&](auto t_c) {
             constexpr int t = decltype(t_c)::value;
             static_for<0, 4>([&](auto c) { WGW_V_ROWS(t, decltype(c)::value); });
@@ -206,7 +232,7 @@ __global__ __launch_bounds__(NT) void wgrad_wino_kernel(const Args p) {
             __builtin_amdgcn_sched_barrier(0);
         });
     };
-    transform_all(std::integral_constant<int, 0>{}, ga0, ga1);
+    transform_all(std::integral_constant<int, 0>{}, ga0, ga1, sxa, sga);
     {
         advance(b, ty, tx, n_valid > 1);
         const int b1 = b, ty1 = ty, tx1 = tx;
@@ -214,7 +240,7 @@ __global__ __launch_bounds__(NT) void wgrad_wino_kernel(const Args p) {
         const unsigned so = x_origin(b1, ty1, tx1);
         __syncthreads();                                     // (P_0 / V_0 published)
         static_for<0, X_DMA>([&](auto k) { WGW_DMA_X(decltype(k)::value, so); });
-        WGW_LOAD_G(ga0, ga1, g_origin(b1, ty1, tx1), n_valid > 1);
+        WGW_LOAD_G(ga0, ga1, sxa, sga, g_origin(b1, ty1, tx1), b1, n_valid > 1);
     }
     __builtin_amdgcn_s_waitcnt(0x0f70);
 
@@ -228,8 +254,10 @@ __global__ __launch_bounds__(NT) void wgrad_wino_kernel(const Args p) {
         fa[reg_] = *((const volatile lds_f32_t*)0 + (a_base[kk_] + ((slot_) * PV_FLOATS + (xi_ * TC + 2 * kk_) * 64)));      \
         fb[reg_] = *((const volatile lds_f32_t*)0 + (b_base[kk_] + ((slot_) * PV_FLOATS + (xi_ * TC + 2 * kk_) * 64)));      \
     }
-    auto chunk_body = [&](auto slot_c, const int i, f32x4& g0, f32x4& g1, f32x4& h0, f32x4& h1) __attribute__((always_inline)) {
+    auto chunk_body = [&](auto slot_c, const int i, f32x4& g0, f32x4& g1, float& gsx, float& gsg, f32x4& h0, f32x4& h1, float& hsx,
+                          float& hsg) __attribute__((always_inline)) {
         constexpr int S = decltype(slot_c)::value, O = 1 - S;
+        if constexpr (MOD) { sx_cur = gsx; g0 *= gsg; g1 *= gsg; }
         // chunk i + 2 (past the run's end: the last chunk's X again, with zero gradients)
         advance(b, ty, tx, i + 2 < n_valid);
         const int b2 = b, ty2 = ty, tx2 = tx;
@@ -244,15 +272,17 @@ __global__ __launch_bounds__(NT) void wgrad_wino_kernel(const Args p) {
             // tile 1: V 29-36 / writes 37-44, P 45 / writes 46-53
 #ifndef WGW_KO_XFORM
             if constexpr (s < 4) { WGW_X_READ(s); }
+            if constexpr (MOD && s >= 2 && s < 6) { WGW_X_SCALE(s - 2); }
 #endif
 #ifndef WGW_KO_LOADS
-            if constexpr (s == 8) { set_voff(ty2, tx2); }
-            if constexpr (s >= 10 && s < 10 + X_DMA) { WGW_DMA_X(s - 10, so2); }        // (the patch rows are in registers: the tile is free)
-            if constexpr (s == 16) { WGW_LOAD_G(h0, h1, go2, i + 2 < n_valid); }
+            if constexpr (s == 6) { set_voff(ty2, tx2); }
+            // (MFMA 8 waited for fragments requested after the last patch-row read: the rows are in registers, the tile is free)
+            if constexpr (s >= 8 && s < 8 + X_DMA) { WGW_DMA_X(s - 8, so2); }
+            if constexpr (s == 14) { WGW_LOAD_G(h0, h1, hsx, hsg, go2, b2, i + 2 < n_valid); }
 #endif
 #ifndef WGW_KO_XFORM
             static_for<0, 2>([&](auto t_c) {
-                constexpr int t = decltype(t_c)::value, t0 = 4 + 25 * t;
+                constexpr int t = decltype(t_c)::value, t0 = (MOD ? 6 : 4) + 25 * t;
                 if constexpr (s >= t0 && s < t0 + 4) { WGW_V_ROWS(t, s - t0); }
                 if constexpr (s >= t0 + 4 && s < t0 + 8) { WGW_V_COLS(s - t0 - 4); }
                 if constexpr (s >= t0 + 8 && s < t0 + 16) { WGW_V_WRITE(O, t, 2 * (s - t0 - 8)); WGW_V_WRITE(O, t, 2 * (s - t0 - 8) + 1); }
@@ -268,8 +298,8 @@ __global__ __launch_bounds__(NT) void wgrad_wino_kernel(const Args p) {
         __syncthreads();                             // P / V of chunk i + 1 complete; every wave is done with slot S
     };
     for (int i = 0; i < n; i += 2) {                 // (host: n is even -- one loop body, the accumulators stay in the AGPR file)
-        chunk_body(std::integral_constant<int, 0>{}, i, ga0, ga1, gb0, gb1);
-        chunk_body(std::integral_constant<int, 1>{}, i + 1, gb0, gb1, ga0, ga1);
+        chunk_body(std::integral_constant<int, 0>{}, i, ga0, ga1, sxa, sga, gb0, gb1, sxb, sgb);
+        chunk_body(std::integral_constant<int, 1>{}, i + 1, gb0, gb1, sxb, sgb, ga0, ga1, sxa, sga);
     }
 
     // ---- epilogue: dg = G^T dU G (G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]) per (co, ci), into the split's slab [co][tap][ci] ----
@@ -285,7 +315,8 @@ __global__ __launch_bounds__(NT) void wgrad_wino_kernel(const Args p) {
         float t[3][4];                               // (G^T M)[a][j]
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const float m0 = WGW_ACC(j, r), m1 = WGW_ACC(4 + j, r), m2 = WGW_ACC(8 + j, r), m3 = WGW_ACC(12 + j, r);
+            const float sj = j == 3 ? -1.f : 1.f;          // P_SIGN: -1 for frequencies (i, 3), i < 3, and (3, j), j < 3
+            const float m0 = sj * WGW_ACC(j, r), m1 = sj * WGW_ACC(4 + j, r), m2 = sj * WGW_ACC(8 + j, r), m3 = -sj * WGW_ACC(12 + j, r);
             const float sm = m1 + m2, df = m1 - m2;
             t[0][j] = m0 + 0.5f * sm;
             t[1][j] = 0.5f * df;
@@ -307,15 +338,25 @@ __global__ __launch_bounds__(NT) void wgrad_wino_kernel(const Args p) {
 #undef WGW_V_WRITE
 #undef WGW_V_COLS
 #undef WGW_V_ROWS
+#undef WGW_X_SCALE
 #undef WGW_X_READ
 #undef WGW_LOAD_G
 #undef WGW_DMA_X
 }
 
-// chunks per workgroup (even) and the split count that follows: near two workgroups per CU over the whole grid, the splits a multiple
-// of 8 when there are that many (workgroups of one split then share an XCD's L2 -- they read the same X / dY chunks)
+// chunks per workgroup (even) and the split count that follows: ONE workgroup per CU over the whole grid (one round: 2.99 ms over the
+// decoder's layers at B = 8 against 3.19 with two rounds of half-length runs -- half the epilogues, half the slabs to reduce), the
+// splits a multiple of 8 when there are that many (workgroups of one split then share an XCD's L2 -- they read the same X / dY chunks)
+static int wgs_target() {
+    static const int v = [] {
+        const char* e = getenv("SPK_WGRAD_WINO_WGS");        // lab override
+        return e && atoi(e) > 0 ? atoi(e) : 256;
+    }();
+    return v;
+}
+
 static void pick_splits(long long n_chunks, int blocks, int want, int& splits, int& per_wg) {
-    long long s = want > 0 ? want : std::max(1, 512 / blocks);
+    long long s = want > 0 ? want : std::max(1, wgs_target() / blocks);
     if (s > 8) s -= s % 8;
     s = std::max(1ll, std::min(s, (n_chunks + 1) / 2));
     per_wg = (int)(2 * ((n_chunks + 2 * s - 1) / (2 * s)));
@@ -352,7 +393,10 @@ int64_t spk_conv2d_wgrad_wino_workspace_bytes(int splits, int B, int Cin, int Co
 int spk_conv2d_wgrad_wino(const spk_wgrad_desc* d, void* stream) {
     SPK_REQUIRE(d && d->g && d->x && d->dw, "wgrad winograd: null pointer");
     SPK_REQUIRE(d->kh == 3 && d->kw == 3 && d->stride == 1 && d->groups <= 1, "wgrad winograd: ungrouped 3x3 stride-1 convs only");
-    SPK_REQUIRE(!(d->flags & ~SPK_CONV_WINOGRAD), "wgrad winograd: plain input (a x2 layer passes the materialised x2 image)");
+    SPK_REQUIRE(!(d->flags & ~(SPK_CONV_WINOGRAD | SPK_CONV_IN_BATCH_SCALE)), "wgrad winograd: plain or batch-scaled input (a x2 layer passes "
+                "the materialised x2 image)");
+    const bool mod = d->flags & SPK_CONV_IN_BATCH_SCALE;
+    SPK_REQUIRE(!mod || (d->in_scale && d->g_scale), "wgrad winograd: IN_BATCH_SCALE needs in_scale = s[B,Cin] and g_scale = d'[B,Cout]");
     SPK_REQUIRE(d->H == d->Hin && d->W == d->Win, "wgrad winograd: output size must equal the input size");
     SPK_REQUIRE(spk_conv2d_wgrad_wino_supported(d->B, d->Cin, d->Cout, d->H, d->W), "wgrad winograd: shape not served (Cin, Cout multiples of 64, "
                 "H even, W a multiple of 16, input below 2 GB)");
@@ -363,6 +407,7 @@ int spk_conv2d_wgrad_wino(const spk_wgrad_desc* d, void* stream) {
     SPK_REQUIRE((reinterpret_cast<uintptr_t>(d->g) & 15) == 0 && (reinterpret_cast<uintptr_t>(d->x) & 15) == 0, "wgrad winograd: 16-byte aligned tensors");
     Args a;
     a.g = d->g; a.x = d->x; a.slabs = static_cast<float*>(d->workspace);
+    a.in_scale = d->in_scale; a.g_scale = d->g_scale;
     a.B = d->B; a.Cin = d->Cin; a.Cout = d->Cout; a.H = d->H; a.W = d->W;
     a.TXB = d->W / 16; a.TY = d->H / 2;
     a.n_chunks = d->B * a.TY * a.TXB;
@@ -370,12 +415,15 @@ int spk_conv2d_wgrad_wino(const spk_wgrad_desc* d, void* stream) {
     a.x_bytes = (unsigned)((long long)d->B * d->Cin * d->H * d->W * 4 + ((long long)d->W + 4) * 4);
     static bool raised = false;
     if (!raised) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&wgrad_wino_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        if (e != hipSuccess) return spk::fail(SPK_ELAUNCH, "hipFuncSetAttribute(LDS): %s", hipGetErrorString(e));
+        for (const void* f : {reinterpret_cast<const void*>(&wgrad_wino_kernel<false>), reinterpret_cast<const void*>(&wgrad_wino_kernel<true>)}) {
+            hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return spk::fail(SPK_ELAUNCH, "hipFuncSetAttribute(LDS): %s", hipGetErrorString(e));
+        }
         raised = true;
     }
     dim3 grid((unsigned)splits, (unsigned)(d->Cout / CO_T), (unsigned)(d->Cin / CI_T));
-    hipLaunchKernelGGL(wgrad_wino_kernel, grid, dim3(NT), LDS_BYTES, (hipStream_t)stream, a);
+    if (mod) hipLaunchKernelGGL(wgrad_wino_kernel<true>, grid, dim3(NT), LDS_BYTES, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(wgrad_wino_kernel<false>, grid, dim3(NT), LDS_BYTES, (hipStream_t)stream, a);
     int rc = spk::check_launch("wgrad_wino_kernel");
     if (rc != SPK_OK) return rc;
     return spk_wgrad_reduce_slabs(static_cast<const float*>(d->workspace), d->dw, splits, d->Cout, d->Cin, 9, d->scale, d->accumulate, 1, stream);

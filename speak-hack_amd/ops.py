@@ -620,10 +620,12 @@ def conv2d_wgrad(g, x, Cout, Cin, k=3, stride=1, *, upsample=False, in_affine=No
     fold = int(fold)
     if fold < 1 or G % fold:
         raise L.SpkError(f"conv2d_wgrad: fold {fold} must divide groups {G}")
-    if (k == 3 and stride == 1 and G == 1 and in_affine is None and batch_scale is None and int(splits) == 0
+    if (k == 3 and stride == 1 and G == 1 and in_affine is None and int(splits) == 0
             and use_wgrad_wino(B, Cin, Cout, H, W) and x.data_ptr() % 16 == 0 and g.data_ptr() % 16 == 0):
         # fp32 Winograd (ops.CONV3X3_ALGO): 16/36 of the multiply-adds; a x2 layer reads the materialised x2 image
-        return conv2d_wgrad_wino(g, upsample2x_bilinear(x) if upsample else x, Cout, Cin, scale=scale, out=out, accumulate=accumulate)
+        if upsample:
+            x = upsample2x(x, zero_border=True) if up_fir else upsample2x_bilinear(x)
+        return conv2d_wgrad_wino(g, x, Cout, Cin, scale=scale, out=out, accumulate=accumulate, batch_scale=batch_scale, g_scale=g_scale)
     if out is None:
         out = torch.empty((G // fold * Cout, Cin, k, k), device=g.device, dtype=torch.float32)
     ws_bytes = L.lib().spk_conv2d_wgrad_workspace_bytes(k, k, stride, int(splits), B, Cin, G * Cout, H, W)
@@ -652,16 +654,21 @@ def use_wgrad_wino(B, Cin, Cout, H, W) -> bool:
     served, and there are enough 16 x 2 pixel chunks for every workgroup to amortise its in-register G^T dU G epilogue."""
     if CONV3X3_ALGO == "direct" or not wgrad_wino_supported(B, Cin, Cout, H, W):
         return False
-    return B * (H // 2) * (W // 16) >= WGRAD_WINO_MIN_CHUNKS * max(1, 512 // ((Cin // 64) * (Cout // 64))) // 8
+    return B * (H // 2) * (W // 16) >= WGRAD_WINO_MIN_CHUNKS * max(1, 256 // ((Cin // 64) * (Cout // 64)))
 
 
-WGRAD_WINO_MIN_CHUNKS = 64
+WGRAD_WINO_MIN_CHUNKS = 8           # per workgroup of the one-round grid (256 workgroups)
 
 
-def conv2d_wgrad_wino(g, x, Cout, Cin, *, scale=1.0, out=None, accumulate=False, splits=0):
+def conv2d_wgrad_wino(g, x, Cout, Cin, *, scale=1.0, out=None, accumulate=False, splits=0, batch_scale=None, g_scale=None):
     """``conv2d_wgrad`` of a plain 3x3 stride-1 pad-1 conv as Winograd F(2x2, 3x3) (csrc/wgrad3x3_wino_f32.hip); x is the conv's
-    actual input (a x2 layer passes the materialised x2 image)."""
+    actual input (a x2 layer passes the materialised x2 image).  ``batch_scale`` [B,Cin] + ``g_scale`` [B,Cout]: the modulated
+    convolution -- x * batch_scale and g * g_scale are formed in registers on the way into the transforms."""
     B, _, H, W = g.shape
+    if (batch_scale is None) != (g_scale is None):
+        raise L.SpkError("conv2d_wgrad_wino: batch_scale goes with g_scale")
+    if batch_scale is not None and (tuple(batch_scale.shape) != (B, Cin) or tuple(g_scale.shape) != (B, Cout)):
+        raise L.SpkError("conv2d_wgrad_wino: batch_scale must be [B,Cin] and g_scale [B,Cout]")
     if tuple(x.shape) != (B, Cin, H, W) or g.shape[1] != Cout:
         raise L.SpkError(f"conv2d_wgrad_wino: g {tuple(g.shape)} / x {tuple(x.shape)} do not fit Cout {Cout}, Cin {Cin}")
     ws_bytes = L.lib().spk_conv2d_wgrad_wino_workspace_bytes(int(splits), B, Cin, Cout, H, W)
@@ -670,10 +677,11 @@ def conv2d_wgrad_wino(g, x, Cout, Cin, *, scale=1.0, out=None, accumulate=False,
     if out is None:
         out = torch.empty((Cout, Cin, 3, 3), device=g.device, dtype=torch.float32)
     ws = _workspace(g.device, ws_bytes)
-    d = L.WgradDesc(g=L.dptr(g, "g"), x=L.dptr(x, "x"), in_scale=None, in_shift=None, dw=L.dptr(out, "dw"), B=B, Cin=Cin, Cout=Cout,
-                    H=H, W=W, Hin=H, Win=W, kh=3, kw=3, stride=1, flags=L.CONV_WINOGRAD, scale=float(scale),
+    d = L.WgradDesc(g=L.dptr(g, "g"), x=L.dptr(x, "x"), in_scale=L.dptr(batch_scale, "batch_scale"), in_shift=None, dw=L.dptr(out, "dw"),
+                    B=B, Cin=Cin, Cout=Cout, H=H, W=W, Hin=H, Win=W, kh=3, kw=3, stride=1,
+                    flags=L.CONV_WINOGRAD | (L.CONV_IN_BATCH_SCALE if batch_scale is not None else 0), scale=float(scale),
                     accumulate=1 if accumulate else 0, splits=int(splits), workspace=ws.data_ptr(), workspace_bytes=ws.numel() * 4,
-                    groups=1, group_in_stride=0, fold=1, g_scale=None)
+                    groups=1, group_in_stride=0, fold=1, g_scale=L.dptr(g_scale, "g_scale"))
     L.check(L.lib().spk_conv2d_wgrad(C.byref(d), L.stream_ptr()), "spk_conv2d_wgrad")
     return out
 

@@ -233,3 +233,27 @@ def test_wgrad_wino_rejects_what_it_does_not_serve(ops):
     g, x = torch.zeros(2, 96, 32, 32, device=dev), torch.zeros(2, 64, 32, 32, device=dev)
     with pytest.raises(L.SpkError):
         ops.conv2d_wgrad_wino(g, x, 96, 64)
+
+
+def test_wgrad_wino_modulated_equals_fp64(ops):
+    """The modulated convolution's weight gradient (StyleGAN2 variant): x * s[b,ci] and g * d'[b,co] formed in registers on the
+    way into the transforms -- against fp64 on explicitly rescaled operands, and, for a x2 layer (upfirdn2d [1,3,3,1] image),
+    against the direct kernel that interpolates in LDS."""
+    dev = torch.device("cuda:0")
+    B, Cin, Cout, H, W = 3, 64, 128, 16, 32
+    gen = torch.Generator().manual_seed(21)
+    x = torch.randn(B, Cin, H, W, generator=gen).to(dev)
+    g = torch.randn(B, Cout, H, W, generator=gen).to(dev)
+    s = (torch.rand(B, Cin, generator=gen) + 0.5).to(dev)
+    dp = (torch.rand(B, Cout, generator=gen) + 0.5).to(dev)
+    dw = ops.conv2d_wgrad_wino(g, x, Cout, Cin, scale=0.7, batch_scale=s, g_scale=dp)
+    ref = 0.7 * _wgrad_ref(g.double() * dp.double().view(B, Cout, 1, 1), x.double() * s.double().view(B, Cin, 1, 1))
+    assert rel_l2(dw, ref) < TOL, rel_l2(dw, ref)
+    xs = torch.randn(B, Cin, H // 2, W // 2, generator=gen).to(dev)
+    a = ops.conv2d_wgrad_wino(g, ops.upsample2x(xs, zero_border=True), Cout, Cin, batch_scale=s, g_scale=dp)
+    with ops.conv3x3_algo("direct"):
+        b = ops.conv2d_wgrad(g, xs, Cout, Cin, 3, 1, upsample=True, up_fir=True, batch_scale=s, g_scale=dp)
+    assert rel_l2(a, b) < TOL, rel_l2(a, b)
+    L = importlib.import_module("speak-hack_amd")._lib
+    with pytest.raises(L.SpkError):
+        ops.conv2d_wgrad_wino(g, x, Cout, Cin, batch_scale=s)

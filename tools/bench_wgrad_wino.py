@@ -43,6 +43,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--batch", type=int, default=8)
     ap.add_argument("--splits", type=int, default=0)
+    ap.add_argument("--wgs", type=int, default=0, help="choose the splits so that the grid has about this many workgroups")
     ap.add_argument("--no-check", action="store_true")
     args = ap.parse_args()
     dev, B = torch.device("cuda:0"), args.batch
@@ -56,9 +57,12 @@ def main():
         if not ops.wgrad_wino_supported(B, ci, co, r, r):
             print(f"{ci:4d}->{co:4d} {r:3d}^2: not served")
             continue
+        if args.wgs:
+            args.splits = max(1, args.wgs // ((ci // 64) * (co // 64)))
         sp = pkg._lib.lib().spk_conv2d_wgrad_wino_splits(args.splits, B, ci, co, r, r)
         dw_w = ops.conv2d_wgrad_wino(g, x, co, ci, splits=args.splits)
-        dw_d = ops.conv2d_wgrad(g, x, co, ci, 3, 1)
+        with ops.conv3x3_algo("direct"):
+            dw_d = ops.conv2d_wgrad(g, x, co, ci, 3, 1)
         torch.cuda.synchronize()
         err = ""
         if not args.no_check:
@@ -68,7 +72,8 @@ def main():
             err = f"  rel-L2 wino {ew:.2e} direct {ed:.2e}"
             del ref
         tw = timed(lambda: ops.conv2d_wgrad_wino(g, x, co, ci, splits=args.splits))
-        td = timed(lambda: ops.conv2d_wgrad(g, x, co, ci, 3, 1))
+        with ops.conv3x3_algo("direct"):
+            td = timed(lambda: ops.conv2d_wgrad(g, x, co, ci, 3, 1))
         fl = 2 * 9 * ci * co * r * r * B
         tot_w += tw
         tot_d += td
