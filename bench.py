@@ -78,8 +78,9 @@ def decoder_conv_flops(batch, resolution=RES):
 def pair_executed_gflop(ops, frames):
     """EXECUTED matrix GFLOP of one training pair (x_s, x_t) in the generator step as THIS build runs it: the encoders' activations
     are stored (no checkpoint recompute: 3 x 10.677 per encoder pass, 6 passes), the decoder's two frames run forward + data
-    gradient + weight gradient (3 x 56.214 each) -- and where a 3x3 layer's forward / data gradient go to the Winograd kernel
-    (ops.use_wino at the step's decoder batch of ``frames``) they execute 16/36 of their algorithmic FLOPs."""
+    gradient + weight gradient (3 x 56.214 each) -- and where a 3x3 layer's forward / data gradient / weight gradient go to the
+    Winograd kernels (ops.use_wino / ops.use_wgrad_wino at the step's decoder batch of ``frames``) they execute 16/36 of their
+    algorithmic FLOPs."""
     saved, r, cin = 0.0, 8, 512
     while r <= RES:
         cout = min(int(8192 / (2.0 ** (r.bit_length() - 2))), 512)
@@ -89,6 +90,8 @@ def pair_executed_gflop(ops, frames):
                 saved += fl * (1 - 16.0 / 36.0)                      # forward
             if ops.use_wino(frames, co, ci, r, r):
                 saved += fl * (1 - 16.0 / 36.0)                      # data gradient
+            if ops.use_wgrad_wino(frames, ci, co, r, r):
+                saved += fl * (1 - 16.0 / 36.0)                      # weight gradient
         cin, r = cout, r * 2
     return GFLOP_PER_PAIR_EXECUTED - 2 * saved
 
@@ -717,15 +720,20 @@ def main():
                 wg_pass()
             wg_ms = event_ms(wg_pass, 5)
             wg_fl = sum(2 * 9 * ci * co * g_.shape[-1] * g_.shape[-2] * BATCH for g_, x_, ci, co, up in tens)
+            wg_ex = sum(2 * 9 * ci * co * g_.shape[-1] * g_.shape[-2] * BATCH *
+                        (16.0 / 36.0 if pkg.ops.use_wgrad_wino(BATCH, ci, co, g_.shape[-2], g_.shape[-1]) else 1.0) for g_, x_, ci, co, up in tens)
             extras["wgrad_decoder_layers"] = {
-                "what": "spk_conv2d_wgrad over the decoder's conv layers at batch 8 (f32 MFMA, exact; the x2 layers read the "
-                        "low-resolution input and fold the bilinear upsampling where that is the faster form), kernel + slab reduce",
-                "layers": len(tens), "ms": round(wg_ms, 4), "tflops": round(wg_fl / (wg_ms * 1e-3) / 1e12, 1),
-                "frac_of_f32_mfma_peak": round(wg_fl / (wg_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4)}
+                "what": "ops.conv2d_wgrad over the decoder's conv layers at batch 8 as a training backward calls it (fp32; Winograd "
+                        "F(2x2,3x3) where the kernel serves the layer -- a x2 layer then reads the x2 image, its pass is in the time -- "
+                        "the direct kernel elsewhere), kernel + slab reduce",
+                "layers": len(tens), "ms": round(wg_ms, 4), "algorithmic_tflops": round(wg_fl / (wg_ms * 1e-3) / 1e12, 1),
+                "executed_tflops": round(wg_ex / (wg_ms * 1e-3) / 1e12, 1),
+                "frac_of_f32_mfma_peak": round(wg_ex / (wg_ms * 1e-3) / 1e12 / F32_MFMA_PEAK_TFLOPS, 4),
+                "frac_is": "EXECUTED matrix FLOPs (16/36 of algorithmic on the Winograd launches) / time"}
             del tens
         torch.cuda.empty_cache()
         # ---- config 3: the IRFD generator step at batch 16; the discriminator step at batch 8 ----
-        g_ms = irfd_steps(pkg, dev, "g", 16, steps=5, warmup=2)
+        g_ms = irfd_steps(pkg, dev, "g", 16, steps=5, warmup=4)
         extras["train_step"] = {"what": "BASELINE config 3: IRFD generator step (3 ResNet-50 encoders x 2 images, train-mode BatchNorm, "
                                         "checkpoint semantics; 2 decoder passes; reconstruction loss; fwd + bwd + global-norm clip + Adam on Gd), "
                                         "batch 16, fp32, eager launches",
@@ -737,25 +745,25 @@ def main():
                                 "algorithmic_tflops_reference_equivalent": round(16 / g_ms * 1e3 * GFLOP_PER_PAIR / 1e3, 1),
                                 "flops_note": "frac_of_f32_mfma_peak counts EXECUTED matrix FLOPs: the encoders' activations are stored (the "
                                               "checkpoint's recompute, 6 x 10.677 of the reference's 593.5 GFLOP per pair, is not run: 529.4), and "
-                                              "the decoder's 3x3 forward / data-gradient convs on the Winograd kernel execute 16/36 of their "
+                                              "the decoder's 3x3 forward / data-gradient / weight-gradient launches on the Winograd kernels execute 16/36 of their "
                                               "algorithmic FLOPs; the two algorithmic figures price the step at the work of the direct algorithm "
                                               "without / with the reference's recompute"}
-        g_bf = irfd_steps(pkg, dev, "g", 16, steps=5, warmup=2, precision="bf16x3")
+        g_bf = irfd_steps(pkg, dev, "g", 16, steps=5, warmup=4, precision="bf16x3")
         extras["train_step"]["bf16x3_opt_in"] = {
             "what": "OPT-IN ops.train_conv_precision('bf16x3'): the decoder's 3x3 convs forward and their data gradients on the bf16 pipe "
                     "(operands split hi + lo, fp32 accumulation), weight gradients and the encoders exact; gradient parity in "
                     "tests/test_bf16x3_gpu.py", "ms_per_step": round(g_bf, 2), "pairs_per_s": round(16 / g_bf * 1e3, 1)}
-        g2_ms = irfd_steps(pkg, dev, "g", 16, steps=5, warmup=2, sg2=True)
+        g2_ms = irfd_steps(pkg, dev, "g", 16, steps=5, warmup=4, sg2=True)
         extras["stylegan2_variant"]["train_step"] = {
             "what": "BASELINE config 3 with the StyleGAN2 decoder variant as IRFD.Gd: the same generator step (encoders + 2 decoder "
                     "passes, fwd + bwd + clip + Adam), batch 16, fp32; the variant's backward runs fused (weight gradient with the "
                     "modulation / demodulation applied while staging, no materialised up(x), no ATen GEMM)",
             "ms_per_step": round(g2_ms, 2), "pairs_per_s": round(16 / g2_ms * 1e3, 1), "vs_stylegan1_decoder_step": round(g2_ms / g_ms, 3)}
-        d_ms = irfd_steps(pkg, dev, "d", 8, steps=5, warmup=2)
+        d_ms = irfd_steps(pkg, dev, "d", 8, steps=5, warmup=4)
         extras["d_step"] = {"what": "discriminator step of train.py:155-183 (4 D fwd+bwd with instance noise + BCE, 2 R1 double backward, "
                                     "Adam on D), batch 8, fp32, eager launches", "ms_per_step": round(d_ms, 2),
                             "pairs_per_s": round(8 / d_ms * 1e3, 1)}
-        d_bf = irfd_steps(pkg, dev, "d", 8, steps=5, warmup=2, precision="bf16x3")
+        d_bf = irfd_steps(pkg, dev, "d", 8, steps=5, warmup=4, precision="bf16x3")
         extras["d_step"]["bf16x3_opt_in"] = {"ms_per_step": round(d_bf, 2), "pairs_per_s": round(8 / d_bf * 1e3, 1)}
 
         it_ms, it_pairs = train_iterations(pkg, dev, 8)

@@ -373,6 +373,7 @@ int spk_conv2d_wgrad_wino_supported(int B, int Cin, int Cout, int H, int W) {
     if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return 0;
     if (Cin % CI_T || Cout % CO_T || H % 2 || W % 16) return 0;
     if ((long long)B * Cin * H * W * 4 + ((long long)W + 4) * 4 >= (1ll << 31)) return 0;     // 32-bit piece offsets, bit 31 = "out of range"
+    if ((long long)Cout * H * W * 4 >= (1ll << 32)) return 0;                                  // a lane's 32-bit offset inside one image of dY
     return 1;
 }
 
