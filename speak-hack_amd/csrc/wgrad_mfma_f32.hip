@@ -1245,12 +1245,70 @@ __global__ __launch_bounds__(256) void wgrad_reduce_vec_kernel(const float* __re
     }
 }
 
+// MANY slabs of a SMALL gradient (the one-round grids of the Winograd weight gradient: 256 slabs of a 64 x 64 x 9 block, 37.7 MB for
+// 36 workgroups of the kernel above -- 256 dependent rounds each): 16 threads share an output element group, thread (e, l) sums the
+// slabs l, l + 16, ... (all of them in flight), the 16 partial sums meet in LDS and are added in lane order -- a fixed order, so the
+// result stays bitwise reproducible (it is NOT the order of the kernels above: a layer always takes the same one of the two).
+constexpr int RD_SL = 16, RD_EL = 16;
+__global__ __launch_bounds__(256) void wgrad_reduce_deep_kernel(const float* __restrict__ slabs, float* __restrict__ dw, int n_slabs,
+                                                               int Cout_all, int Cin, int taps, float scale, int accumulate, int fold) {
+    __shared__ f32x4 part[RD_SL][RD_EL];
+    const int Cout = Cout_all / fold;
+    const size_t total = (size_t)Cout * Cin * taps, slab_stride = (size_t)Cout_all * Cin * taps;
+    const int cin4 = Cin >> 2;
+    const int e = threadIdx.x & (RD_EL - 1), l = threadIdx.x / RD_EL;
+    for (size_t q0 = (size_t)blockIdx.x * RD_EL; q0 < total / 4; q0 += (size_t)gridDim.x * RD_EL) {      // (uniform trip count: barriers inside)
+        const size_t q = q0 + e;
+        const bool live = q < total / 4;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (live)
+            for (int f = 0; f < fold; ++f) {
+                const float* sl = slabs + (size_t)f * total + 4 * q;
+                f32x4 v0 = {0.f, 0.f, 0.f, 0.f}, v1 = v0;
+                int s_ = l;
+                for (; s_ + 7 * RD_SL < n_slabs; s_ += 8 * RD_SL) {
+                    f32x4 a[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) a[j] = *reinterpret_cast<const f32x4*>(sl + (size_t)(s_ + j * RD_SL) * slab_stride);
+#pragma unroll
+                    for (int j = 0; j < 8; j += 2) { v0 += a[j]; v1 += a[j + 1]; }
+                }
+                for (; s_ < n_slabs; s_ += RD_SL) v0 += *reinterpret_cast<const f32x4*>(sl + (size_t)s_ * slab_stride);
+                v += v0 + v1;
+            }
+        part[l][e] = v;
+        __syncthreads();
+        if (l == 0 && live) {
+            f32x4 t = part[0][e];
+#pragma unroll
+            for (int j = 1; j < RD_SL; ++j) t += part[j][e];
+            t *= scale;
+            const int ci = (int)(q % cin4) * 4;
+            const int tap = (int)((q / cin4) % taps);
+            const int co = (int)(q / ((size_t)cin4 * taps));
+            const size_t idx = ((size_t)co * Cin + ci) * taps + tap;
+            if (taps == 1) {
+                f32x4* o = reinterpret_cast<f32x4*>(dw + idx);
+                *o = accumulate ? *o + t : t;
+            } else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) dw[idx + (size_t)j * taps] = accumulate ? dw[idx + (size_t)j * taps] + t[j] : t[j];
+            }
+        }
+        __syncthreads();
+    }
+}
+
 // slabs -> dW on `stream`, after the kernel that wrote them
 inline int launch_wgrad_reduce(hipStream_t stream, const float* slabs, float* dw, int n_slabs, int Cout_all, int Cin, int taps,
                                float scale, int accumulate, int fold) {
     const size_t slab_floats = (size_t)Cout_all * Cin * taps;
     const bool vec = Cin % 4 == 0 && (reinterpret_cast<uintptr_t>(slabs) & 15) == 0 && (reinterpret_cast<uintptr_t>(dw) & 15) == 0;
-    if (vec) {
+    if (vec && n_slabs >= 32 && slab_floats / fold / 4 / 256 < 512) {
+        const unsigned blocks = (unsigned)std::min<size_t>((slab_floats / fold / 4 + RD_EL - 1) / RD_EL, 4096);
+        hipLaunchKernelGGL(wgrad_reduce_deep_kernel, dim3(std::max(blocks, 1u)), dim3(256), 0, stream, slabs, dw, n_slabs, Cout_all, Cin,
+                           taps, scale, accumulate, fold);
+    } else if (vec) {
         const unsigned blocks = (unsigned)std::min<size_t>((slab_floats / fold / 4 + 255) / 256, 4096);
         hipLaunchKernelGGL(wgrad_reduce_vec_kernel, dim3(std::max(blocks, 1u)), dim3(256), 0, stream, slabs, dw, n_slabs, Cout_all, Cin,
                            taps, scale, accumulate, fold);
