@@ -107,3 +107,32 @@ def test_product_path_never_imports_oracle():
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", text, flags=re.M), f
     for f in ("styleganv1.py", "model.py", "stylegan.py"):
         assert "oracle" not in open(os.path.join(ROOT, f)).read()
+
+
+def test_winograd_shape_queries_on_the_host(pkg):
+    """The Winograd entry points' host-side answers (no launch): which shapes the conv / the weight gradient serve, the packed
+    image size, the split rule of the weight gradient's one-round grid and its workspace."""
+    lib = pkg._lib.lib()
+    # forward: regions of 32 x 8 output pixels, input channels in chunks of 8 paired two by two
+    assert lib.spk_conv2d_wino_supported(8, 64, 64, 256, 256) and lib.spk_conv2d_wino_supported(1, 16, 200, 8, 32)
+    assert not lib.spk_conv2d_wino_supported(8, 64, 64, 16, 16)       # W % 32
+    assert not lib.spk_conv2d_wino_supported(8, 64, 64, 12, 32)       # H % 8
+    assert not lib.spk_conv2d_wino_supported(8, 24, 64, 32, 32)       # Cin % 16
+    assert not lib.spk_conv2d_wino_supported(64, 512, 512, 256, 256)  # >= 2 GB: 32-bit gather offsets
+    assert lib.spk_conv2d_packed_bytes_wino(64, 64) == 64 * 64 * 16 * 4 and lib.spk_conv2d_packed_bytes_wino(64, 65) == 64 * 128 * 16 * 4
+    # weight gradient: 64 x 64 (co, ci) blocks, chunks of 16 x 2 output pixels
+    sup = lib.spk_conv2d_wgrad_wino_supported
+    assert sup(8, 64, 64, 256, 256) and sup(1, 64, 128, 2, 16) and sup(3, 192, 64, 6, 48)
+    assert not sup(8, 3, 64, 256, 256) and not sup(8, 64, 96, 32, 32) and not sup(8, 64, 64, 32, 24) and not sup(8, 64, 64, 7, 32)
+    assert not sup(64, 512, 64, 256, 256)
+    for (B, ci, co, H, W) in [(8, 64, 64, 256, 256), (8, 512, 512, 32, 32), (8, 512, 512, 16, 16), (3, 64, 64, 6, 48), (1, 64, 64, 2, 16)]:
+        chunks, blocks = B * (H // 2) * (W // 16), (ci // 64) * (co // 64)
+        s = lib.spk_conv2d_wgrad_wino_splits(0, B, ci, co, H, W)
+        assert 1 <= s <= max(1, 256 // blocks) and s <= (chunks + 1) // 2
+        per = 2 * -(-chunks // (2 * s))
+        assert (s - 1) * per < chunks <= s * per                      # every workgroup has at least one real chunk
+        assert s < 8 or s % 8 == 0 or s * per >= chunks               # (a multiple of 8 where that many are asked for)
+        assert lib.spk_conv2d_wgrad_wino_workspace_bytes(0, B, ci, co, H, W) == s * co * 9 * ci * 4
+        s3 = lib.spk_conv2d_wgrad_wino_splits(3, B, ci, co, H, W)       # an explicit request is honoured up to the chunk count
+        assert 1 <= s3 <= 3
+    assert lib.spk_conv2d_wgrad_wino_splits(0, 8, 64, 96, 32, 32) == -1 and lib.spk_conv2d_wgrad_wino_workspace_bytes(0, 8, 64, 96, 32, 32) == -1
