@@ -258,9 +258,12 @@ int spk_conv2d_wgrad(const spk_wgrad_desc* desc, void* stream);
  * low-resolution [B,Cin,H/2,W/2] tensor and the x2 image is never materialised); 0: upsample first. */
 int spk_conv2d_wgrad_up_supported(int B, int Cin, int Cout, int H, int W);
 int spk_conv2d_wgrad_mod_supported(int B, int Cin, int Cout, int H, int W, int upsample);
-/* The same gradient as Winograd F(2x2, 3x3) (wgrad3x3_wino_f32.hip): flags = SPK_CONV_WINOGRAD on a plain 3x3 stride-1 pad-1 problem
+/* The same gradient as Winograd F(2x2, 3x3) (wgrad3x3_wino_f32.hip): flags = SPK_CONV_WINOGRAD on a 3x3 stride-1 pad-1 problem
  * (x is the conv's actual input: a x2 layer passes the materialised x2 image, spk_upsample2x_fwd); fp32 throughout, 16/36 of the
- * direct form's multiply-adds.  Shapes: Cin, Cout multiples of 64, H even, W a multiple of 16 (..._supported); the workspace holds
+ * direct form's multiply-adds.  With SPK_CONV_IN_BATCH_SCALE (ungrouped: in_scale = s[B,Cin], g_scale = d'[B,Cout]) the modulated
+ * convolution; with SPK_CONV_IN_AFFINE_RELU (in_scale / in_shift per input channel of x) the input was relu(x * scale + shift);
+ * groups / group_in_stride / fold as in spk_wgrad_desc (the shape queries then take Cout = groups * Cout).
+ * Shapes: Cin, Cout multiples of 64, H even, W a multiple of 16 (..._supported); the workspace holds
  * `splits` slabs [Cout][9][Cin] (..._workspace_bytes; ..._splits returns the split count the kernel will use for `splits` = the
  * wanted count, 0 = auto), reduced in a fixed order by spk_wgrad_reduce_slabs -- bitwise reproducible. */
 int spk_conv2d_wgrad_wino_supported(int B, int Cin, int Cout, int H, int W);

@@ -50,8 +50,10 @@ struct Args {
     const float* g;
     const float* x;
     float* slabs;            // [splits][Cout][9][Cin]
-    const float* in_scale;   // MOD: s[B][Cin]  -- the conv's input was x * s
+    const float* in_scale;   // MOD: s[B][Cin]  -- the conv's input was x * s;  AFFINE: scale[Cx] -- it was relu(x * scale + shift)
+    const float* in_shift;   // AFFINE: shift[Cx]
     const float* g_scale;    // MOD: d'[B][Cout] -- the gradient that reaches the conv output is g * d'
+    int G, gin, Cx, Cy;      // groups: Cin / Cout are per group; x has Cx = gin * (G - 1) + Cin channels, g has Cy = G * Cout
     int B, Cin, Cout, H, W;
     int TXB, TY;             // chunks per tile row (W / 16), tile rows (H / 2)
     int chunks_per_wg;       // even; the last workgroup's run may be shorter (the missing chunks count as zero gradients)
@@ -62,14 +64,19 @@ struct Args {
 __device__ __forceinline__ float fadd_(float a, float b) { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 __device__ __forceinline__ float fsub_(float a, float b) { float r; asm("v_sub_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 
-template <bool MOD>
+constexpr int PLAIN = 0, MODULATED = 1, AFFINE_RELU = 2;
+
+template <int MODE>
 __global__ __launch_bounds__(NT) void wgrad_wino_kernel(const Args p) {
+    constexpr bool MOD = MODE == MODULATED, AFF = MODE == AFFINE_RELU;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int half = lane >> 5, l32 = lane & 31;
     const int wm = wave >> 1, wn = wave & 1;
-    const int co0 = blockIdx.y * CO_T, ci0 = blockIdx.z * CI_T;
+    const int co_tiles = p.Cout / CO_T, grp = blockIdx.y / co_tiles;
+    const int co0 = (blockIdx.y - grp * co_tiles) * CO_T, ci0 = blockIdx.z * CI_T;
+    const int xc0 = grp * p.gin + ci0, gc0 = grp * p.Cout + co0;      // first channel of the block in x / in g
     const unsigned HW = (unsigned)p.H * (unsigned)p.W;
     const int n = p.chunks_per_wg;
     const int c_first = blockIdx.x * n;
@@ -112,7 +119,7 @@ __global__ __launch_bounds__(NT) void wgrad_wino_kernel(const Args p) {
         b_ = w2 ? b_ + 1 : b_;
     };
     auto x_origin = [&](int b_, int ty_, int tx_) -> unsigned {
-        return (((unsigned)b_ * (unsigned)p.Cin + (unsigned)ci0) * HW + (unsigned)(2 * ty_ * p.W + 16 * tx_)) * 4u;
+        return (((unsigned)b_ * (unsigned)p.Cx + (unsigned)xc0) * HW + (unsigned)(2 * ty_ * p.W + 16 * tx_)) * 4u;
     };
     auto set_voff = [&](int ty_, int tx_) {
         const unsigned long long a_top = ty_ == 0 ? ~0ull : 0ull, a_bot = 2 * ty_ + 2 >= p.H ? ~0ull : 0ull;
@@ -127,9 +134,9 @@ __global__ __launch_bounds__(NT) void wgrad_wino_kernel(const Args p) {
     // ---- transform roles: wave w the block's channels 16 w .. 16 w + 15 (of X and of dY); a lane one channel and the tile pair
     // (2 tr_p, 2 tr_p + 1); its dY: the 2 x 4 gradients under the pair
     const int tr_c = 16 * wave + (lane & 15), tr_p = lane >> 4;
-    const unsigned g_lane = ((unsigned)(co0 + tr_c) * HW + 4u * tr_p) * 4u;
+    const unsigned g_lane = ((unsigned)(gc0 + tr_c) * HW + 4u * tr_p) * 4u;
     auto g_origin = [&](int b_, int ty_, int tx_) -> size_t {
-        return ((size_t)b_ * p.Cout * HW + (size_t)(2 * ty_ * p.W + 16 * tx_)) * 4;
+        return ((size_t)b_ * p.Cy * HW + (size_t)(2 * ty_ * p.W + 16 * tx_)) * 4;
     };
 #define WGW_LOAD_G(dst0_, dst1_, sx_, sg_, org_, b_, valid_)                                                            \
     if (valid_) {                                                                                                       \
@@ -137,7 +144,7 @@ __global__ __launch_bounds__(NT) void wgrad_wino_kernel(const Args p) {
         dst0_ = *reinterpret_cast<const f32x4*>(gp_ + g_lane);                                                          \
         dst1_ = *reinterpret_cast<const f32x4*>(gp_ + g_lane + (size_t)p.W * 4);                                        \
         if constexpr (MOD) {                                                                                            \
-            sx_ = p.in_scale[(size_t)(b_) * p.Cin + ci0 + tr_c];                                                        \
+            sx_ = p.in_scale[(size_t)(b_) * p.Cin + ci0 + tr_c];   /* (MOD is ungrouped) */                                                        \
             sg_ = p.g_scale[(size_t)(b_) * p.Cout + co0 + tr_c];                                                        \
         }                                                                                                               \
     } else {                                                                                                            \
@@ -178,6 +185,33 @@ __global__ __launch_bounds__(NT) void wgrad_wino_kernel(const Args p) {
 #define WGW_X_SCALE(r_)                                                                                                 \
     {                                                                                                                   \
         _Pragma("unroll") for (int e_ = 0; e_ < 6; ++e_) xr[r_][e_] *= sx_cur;                                          \
+    }
+    // AFFINE: the conv's input was relu(x * a + sh) (a BatchNorm folded into its consumer).  The zero padding must stay zero: a
+    // position outside the image arrives as x = 0, so only its SHIFT is masked (rows by a scalar condition, the left / right column
+    // by a lane mask) -- ten vector ops per chunk for the masks, fma + max per value
+    float af_a = 0.f, af_sh = 0.f, sh_row[4], sh_l[4], sh_r[4];
+    if constexpr (AFF) {
+        af_a = p.in_scale[xc0 + tr_c];
+        af_sh = p.in_shift[xc0 + tr_c];
+    }
+    const unsigned long long m_pair0 = __builtin_amdgcn_ballot_w64(tr_p == 0), m_pair3 = __builtin_amdgcn_ballot_w64(tr_p == 3);
+    auto affine_masks = [&](int ty_, int tx_) {
+        const unsigned long long ml = tx_ == 0 ? m_pair0 : 0ull, mr = 16 * tx_ + 16 >= p.W ? m_pair3 : 0ull;
+        const float zero = 0.f;
+        sh_row[1] = sh_row[2] = af_sh;
+        sh_row[0] = ty_ == 0 ? 0.f : af_sh;
+        sh_row[3] = 2 * ty_ + 2 >= p.H ? 0.f : af_sh;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+            asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(sh_l[r]) : "v"(sh_row[r]), "v"(zero), "s"(ml));
+            asm("v_cndmask_b32_e64 %0, %1, %2, %3" : "=v"(sh_r[r]) : "v"(sh_row[r]), "v"(zero), "s"(mr));
+        }
+    };
+#define WGW_X_AFFINE(r_)                                                                                                \
+    {                                                                                                                   \
+        xr[r_][0] = fmaxf(fmaf(xr[r_][0], af_a, sh_l[r_]), 0.f);                                                        \
+        _Pragma("unroll") for (int e_ = 1; e_ < 5; ++e_) xr[r_][e_] = fmaxf(fmaf(xr[r_][e_], af_a, sh_row[r_]), 0.f);   \
+        xr[r_][5] = fmaxf(fmaf(xr[r_][5], af_a, sh_r[r_]), 0.f);                                                        \
     }
     // V = B^T d B of tile t_ (0 / 1 of the pair: patch columns 2 t_ .. 2 t_ + 3), written to V slot vs_
 #define WGW_V_ROWS(t_, c_)                                                                                              \
@@ -222,6 +256,10 @@ __global__ __launch_bounds__(NT) void wgrad_wino_kernel(const Args p) {
         if constexpr (MOD) { sx_cur = sx; g0 *= sg; g1 *= sg; }
         static_for<0, 4>([&](auto r) { WGW_X_READ(decltype(r)::value); });
         if constexpr (MOD) static_for<0, 4>([&](auto r) { WGW_X_SCALE(decltype(r)::value); });
+        if constexpr (AFF) {
+            affine_masks(ty, tx);
+            static_for<0, 4>([&](auto r) { WGW_X_AFFINE(decltype(r)::value); });
+        }
         static_for<0, 2>([&](auto t_c) {
             constexpr int t = decltype(t_c)::value;
             static_for<0, 4>([&](auto c) { WGW_V_ROWS(t, decltype(c)::value); });
@@ -258,6 +296,7 @@ __global__ __launch_bounds__(NT) void wgrad_wino_kernel(const Args p) {
                           float& hsg) __attribute__((always_inline)) {
         constexpr int S = decltype(slot_c)::value, O = 1 - S;
         if constexpr (MOD) { sx_cur = gsx; g0 *= gsg; g1 *= gsg; }
+        const int ty1 = ty, tx1 = tx;                // (chunk i + 1: the one in the raw tile)
         // chunk i + 2 (past the run's end: the last chunk's X again, with zero gradients)
         advance(b, ty, tx, i + 2 < n_valid);
         const int b2 = b, ty2 = ty, tx2 = tx;
@@ -273,6 +312,8 @@ __global__ __launch_bounds__(NT) void wgrad_wino_kernel(const Args p) {
 #ifndef WGW_KO_XFORM
             if constexpr (s < 4) { WGW_X_READ(s); }
             if constexpr (MOD && s >= 2 && s < 6) { WGW_X_SCALE(s - 2); }
+            if constexpr (AFF && s == 1) { affine_masks(ty1, tx1); }
+            if constexpr (AFF && s >= 2 && s < 6) { WGW_X_AFFINE(s - 2); }
 #endif
 #ifndef WGW_KO_LOADS
             if constexpr (s == 6) { set_voff(ty2, tx2); }
@@ -282,7 +323,7 @@ __global__ __launch_bounds__(NT) void wgrad_wino_kernel(const Args p) {
 #endif
 #ifndef WGW_KO_XFORM
             static_for<0, 2>([&](auto t_c) {
-                constexpr int t = decltype(t_c)::value, t0 = (MOD ? 6 : 4) + 25 * t;
+                constexpr int t = decltype(t_c)::value, t0 = (MODE != PLAIN ? 6 : 4) + 25 * t;
                 if constexpr (s >= t0 && s < t0 + 4) { WGW_V_ROWS(t, s - t0); }
                 if constexpr (s >= t0 + 4 && s < t0 + 8) { WGW_V_COLS(s - t0 - 4); }
                 if constexpr (s >= t0 + 8 && s < t0 + 16) { WGW_V_WRITE(O, t, 2 * (s - t0 - 8)); WGW_V_WRITE(O, t, 2 * (s - t0 - 8) + 1); }
@@ -303,7 +344,7 @@ __global__ __launch_bounds__(NT) void wgrad_wino_kernel(const Args p) {
     }
 
     // ---- epilogue: dg = G^T dU G (G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1]) per (co, ci), into the split's slab [co][tap][ci] ----
-    float* slab = p.slabs + (size_t)blockIdx.x * p.Cout * 9 * p.Cin;
+    float* slab = p.slabs + ((size_t)blockIdx.x * p.Cy + (size_t)grp * p.Cout) * 9 * p.Cin;
     const int ci = ci0 + wn * 32 + l32;
 #define WGW_ACC(xi_, r_) ({ float v_; asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v_) : "a"(acc[xi_][r_])); v_; })
 #ifdef WGW_KO_EPI
@@ -338,6 +379,7 @@ __global__ __launch_bounds__(NT) void wgrad_wino_kernel(const Args p) {
 #undef WGW_V_WRITE
 #undef WGW_V_COLS
 #undef WGW_V_ROWS
+#undef WGW_X_AFFINE
 #undef WGW_X_SCALE
 #undef WGW_X_READ
 #undef WGW_LOAD_G
@@ -393,41 +435,51 @@ int64_t spk_conv2d_wgrad_wino_workspace_bytes(int splits, int B, int Cin, int Co
 // entered from spk_conv2d_wgrad when desc->flags has SPK_CONV_WINOGRAD
 int spk_conv2d_wgrad_wino(const spk_wgrad_desc* d, void* stream) {
     SPK_REQUIRE(d && d->g && d->x && d->dw, "wgrad winograd: null pointer");
-    SPK_REQUIRE(d->kh == 3 && d->kw == 3 && d->stride == 1 && d->groups <= 1, "wgrad winograd: ungrouped 3x3 stride-1 convs only");
-    SPK_REQUIRE(!(d->flags & ~(SPK_CONV_WINOGRAD | SPK_CONV_IN_BATCH_SCALE)), "wgrad winograd: plain or batch-scaled input (a x2 layer passes "
-                "the materialised x2 image)");
-    const bool mod = d->flags & SPK_CONV_IN_BATCH_SCALE;
+    SPK_REQUIRE(d->kh == 3 && d->kw == 3 && d->stride == 1, "wgrad winograd: 3x3 stride-1 convs only");
+    SPK_REQUIRE(!(d->flags & ~(SPK_CONV_WINOGRAD | SPK_CONV_IN_BATCH_SCALE | SPK_CONV_IN_AFFINE_RELU)), "wgrad winograd: plain, batch-scaled or "
+                "affine + ReLU input (a x2 layer passes the materialised x2 image)");
+    const bool mod = d->flags & SPK_CONV_IN_BATCH_SCALE, aff = d->flags & SPK_CONV_IN_AFFINE_RELU;
+    const int G = d->groups > 1 ? d->groups : 1, fold = d->fold > 1 ? d->fold : 1;
+    SPK_REQUIRE(!(mod && aff) && !(mod && G > 1), "wgrad winograd: IN_BATCH_SCALE is ungrouped and excludes IN_AFFINE_RELU");
     SPK_REQUIRE(!mod || (d->in_scale && d->g_scale), "wgrad winograd: IN_BATCH_SCALE needs in_scale = s[B,Cin] and g_scale = d'[B,Cout]");
+    SPK_REQUIRE(!aff || (d->in_scale && d->in_shift), "wgrad winograd: IN_AFFINE_RELU without in_scale / in_shift");
+    SPK_REQUIRE(G % fold == 0, "wgrad winograd: fold %d must divide groups %d", fold, G);
     SPK_REQUIRE(d->H == d->Hin && d->W == d->Win, "wgrad winograd: output size must equal the input size");
-    SPK_REQUIRE(spk_conv2d_wgrad_wino_supported(d->B, d->Cin, d->Cout, d->H, d->W), "wgrad winograd: shape not served (Cin, Cout multiples of 64, "
-                "H even, W a multiple of 16, input below 2 GB)");
+    const int gin = G > 1 ? d->group_in_stride : 0, Cx = gin * (G - 1) + d->Cin, Cy = G * d->Cout;
+    SPK_REQUIRE(gin >= 0 && (G == 1 || gin == 0 || gin >= d->Cin), "wgrad winograd: group_in_stride %d", gin);
+    SPK_REQUIRE(spk_conv2d_wgrad_wino_supported(d->B, d->Cin, Cy, d->H, d->W) && d->Cout % CO_T == 0 &&
+                    (long long)d->B * Cx * d->H * d->W * 4 + ((long long)d->W + 4) * 4 < (1ll << 31),
+                "wgrad winograd: shape not served (Cin, Cout multiples of 64, H even, W a multiple of 16, input below 2 GB)");
     int splits, per_wg;
-    pick_splits((long long)d->B * (d->H / 2) * (d->W / 16), (d->Cin / CI_T) * (d->Cout / CO_T), d->splits, splits, per_wg);
-    const int64_t need = (int64_t)splits * d->Cout * 9 * d->Cin * 4;
+    pick_splits((long long)d->B * (d->H / 2) * (d->W / 16), (d->Cin / CI_T) * (Cy / CO_T), d->splits, splits, per_wg);
+    const int64_t need = (int64_t)splits * Cy * 9 * d->Cin * 4;
     SPK_REQUIRE(d->workspace && d->workspace_bytes >= need, "wgrad winograd: workspace too small (%lld < %lld bytes)", (long long)d->workspace_bytes, (long long)need);
     SPK_REQUIRE((reinterpret_cast<uintptr_t>(d->g) & 15) == 0 && (reinterpret_cast<uintptr_t>(d->x) & 15) == 0, "wgrad winograd: 16-byte aligned tensors");
     Args a;
     a.g = d->g; a.x = d->x; a.slabs = static_cast<float*>(d->workspace);
-    a.in_scale = d->in_scale; a.g_scale = d->g_scale;
+    a.in_scale = d->in_scale; a.in_shift = d->in_shift; a.g_scale = d->g_scale;
+    a.G = G; a.gin = gin; a.Cx = Cx; a.Cy = Cy;
     a.B = d->B; a.Cin = d->Cin; a.Cout = d->Cout; a.H = d->H; a.W = d->W;
     a.TXB = d->W / 16; a.TY = d->H / 2;
     a.n_chunks = d->B * a.TY * a.TXB;
     a.chunks_per_wg = per_wg;
-    a.x_bytes = (unsigned)((long long)d->B * d->Cin * d->H * d->W * 4 + ((long long)d->W + 4) * 4);
+    a.x_bytes = (unsigned)((long long)d->B * Cx * d->H * d->W * 4 + ((long long)d->W + 4) * 4);
     static bool raised = false;
     if (!raised) {
-        for (const void* f : {reinterpret_cast<const void*>(&wgrad_wino_kernel<false>), reinterpret_cast<const void*>(&wgrad_wino_kernel<true>)}) {
+        for (const void* f : {reinterpret_cast<const void*>(&wgrad_wino_kernel<PLAIN>), reinterpret_cast<const void*>(&wgrad_wino_kernel<MODULATED>),
+                              reinterpret_cast<const void*>(&wgrad_wino_kernel<AFFINE_RELU>)}) {
             hipError_t e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return spk::fail(SPK_ELAUNCH, "hipFuncSetAttribute(LDS): %s", hipGetErrorString(e));
         }
         raised = true;
     }
-    dim3 grid((unsigned)splits, (unsigned)(d->Cout / CO_T), (unsigned)(d->Cin / CI_T));
-    if (mod) hipLaunchKernelGGL(wgrad_wino_kernel<true>, grid, dim3(NT), LDS_BYTES, (hipStream_t)stream, a);
-    else hipLaunchKernelGGL(wgrad_wino_kernel<false>, grid, dim3(NT), LDS_BYTES, (hipStream_t)stream, a);
+    dim3 grid((unsigned)splits, (unsigned)(Cy / CO_T), (unsigned)(d->Cin / CI_T));
+    if (mod) hipLaunchKernelGGL(wgrad_wino_kernel<MODULATED>, grid, dim3(NT), LDS_BYTES, (hipStream_t)stream, a);
+    else if (aff) hipLaunchKernelGGL(wgrad_wino_kernel<AFFINE_RELU>, grid, dim3(NT), LDS_BYTES, (hipStream_t)stream, a);
+    else hipLaunchKernelGGL(wgrad_wino_kernel<PLAIN>, grid, dim3(NT), LDS_BYTES, (hipStream_t)stream, a);
     int rc = spk::check_launch("wgrad_wino_kernel");
     if (rc != SPK_OK) return rc;
-    return spk_wgrad_reduce_slabs(static_cast<const float*>(d->workspace), d->dw, splits, d->Cout, d->Cin, 9, d->scale, d->accumulate, 1, stream);
+    return spk_wgrad_reduce_slabs(static_cast<const float*>(d->workspace), d->dw, splits, Cy, d->Cin, 9, d->scale, d->accumulate, fold, stream);
 }
 
 }  // extern "C"

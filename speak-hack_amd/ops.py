@@ -184,7 +184,7 @@ def side_stream(device):
     key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
     st = _side_streams.get(key)
     if st is None:
-        st = _side_streams[key] = torch.cuda.Stream(device)
+        st = _side_streams[key] = torch.cuda.Stream(device, priority=int(os.environ.get("SPK_WGRAD_STREAM_PRIORITY", "0")))
     return st
 
 
@@ -620,12 +620,13 @@ def conv2d_wgrad(g, x, Cout, Cin, k=3, stride=1, *, upsample=False, in_affine=No
     fold = int(fold)
     if fold < 1 or G % fold:
         raise L.SpkError(f"conv2d_wgrad: fold {fold} must divide groups {G}")
-    if (k == 3 and stride == 1 and G == 1 and in_affine is None and int(splits) == 0
-            and use_wgrad_wino(B, Cin, Cout, H, W) and x.data_ptr() % 16 == 0 and g.data_ptr() % 16 == 0):
+    if (k == 3 and stride == 1 and int(splits) == 0 and Cout % 64 == 0 and (G == 1 or (batch_scale is None and not upsample))
+            and use_wgrad_wino(B, Cin, G * Cout, H, W) and x.data_ptr() % 16 == 0 and g.data_ptr() % 16 == 0):
         # fp32 Winograd (ops.CONV3X3_ALGO): 16/36 of the multiply-adds; a x2 layer reads the materialised x2 image
         if upsample:
             x = upsample2x(x, zero_border=True) if up_fir else upsample2x_bilinear(x)
-        return conv2d_wgrad_wino(g, x, Cout, Cin, scale=scale, out=out, accumulate=accumulate, batch_scale=batch_scale, g_scale=g_scale)
+        return conv2d_wgrad_wino(g, x, Cout, Cin, scale=scale, out=out, accumulate=accumulate, batch_scale=batch_scale, g_scale=g_scale,
+                                 in_affine=in_affine, groups=G, shared_input=shared_input, fold=fold)
     if out is None:
         out = torch.empty((G // fold * Cout, Cin, k, k), device=g.device, dtype=torch.float32)
     ws_bytes = L.lib().spk_conv2d_wgrad_workspace_bytes(k, k, stride, int(splits), B, Cin, G * Cout, H, W)
@@ -660,28 +661,38 @@ def use_wgrad_wino(B, Cin, Cout, H, W) -> bool:
 WGRAD_WINO_MIN_CHUNKS = 8           # per workgroup of the one-round grid (256 workgroups)
 
 
-def conv2d_wgrad_wino(g, x, Cout, Cin, *, scale=1.0, out=None, accumulate=False, splits=0, batch_scale=None, g_scale=None):
-    """``conv2d_wgrad`` of a plain 3x3 stride-1 pad-1 conv as Winograd F(2x2, 3x3) (csrc/wgrad3x3_wino_f32.hip); x is the conv's
+def conv2d_wgrad_wino(g, x, Cout, Cin, *, scale=1.0, out=None, accumulate=False, splits=0, batch_scale=None, g_scale=None,
+                      in_affine=None, groups=1, shared_input=False, fold=1):
+    """``conv2d_wgrad`` of a 3x3 stride-1 pad-1 conv as Winograd F(2x2, 3x3) (csrc/wgrad3x3_wino_f32.hip); x is the conv's
     actual input (a x2 layer passes the materialised x2 image).  ``batch_scale`` [B,Cin] + ``g_scale`` [B,Cout]: the modulated
-    convolution -- x * batch_scale and g * g_scale are formed in registers on the way into the transforms."""
+    convolution -- x * batch_scale and g * g_scale are formed in registers on the way into the transforms.  ``in_affine`` =
+    (scale, shift) per input channel: the conv's input was relu(x * scale + shift) (a folded BatchNorm).  ``groups`` / ``fold`` /
+    ``shared_input`` as in ``conv2d_wgrad``."""
     B, _, H, W = g.shape
+    G, fold = int(groups), int(fold)
+    if fold < 1 or G % fold:
+        raise L.SpkError(f"conv2d_wgrad_wino: fold {fold} must divide groups {G}")
     if (batch_scale is None) != (g_scale is None):
         raise L.SpkError("conv2d_wgrad_wino: batch_scale goes with g_scale")
-    if batch_scale is not None and (tuple(batch_scale.shape) != (B, Cin) or tuple(g_scale.shape) != (B, Cout)):
-        raise L.SpkError("conv2d_wgrad_wino: batch_scale must be [B,Cin] and g_scale [B,Cout]")
-    if tuple(x.shape) != (B, Cin, H, W) or g.shape[1] != Cout:
-        raise L.SpkError(f"conv2d_wgrad_wino: g {tuple(g.shape)} / x {tuple(x.shape)} do not fit Cout {Cout}, Cin {Cin}")
-    ws_bytes = L.lib().spk_conv2d_wgrad_wino_workspace_bytes(int(splits), B, Cin, Cout, H, W)
+    if batch_scale is not None and (tuple(batch_scale.shape) != (B, Cin) or tuple(g_scale.shape) != (B, Cout) or G > 1 or in_affine is not None):
+        raise L.SpkError("conv2d_wgrad_wino: batch_scale must be [B,Cin] and g_scale [B,Cout], ungrouped, without in_affine")
+    gin = 0 if (shared_input or G == 1) else Cin
+    Cx = gin * (G - 1) + Cin
+    if tuple(x.shape) != (B, Cx, H, W) or g.shape[1] != G * Cout:
+        raise L.SpkError(f"conv2d_wgrad_wino: g {tuple(g.shape)} / x {tuple(x.shape)} do not fit {G} groups of Cout {Cout}, Cin {Cin}")
+    ws_bytes = L.lib().spk_conv2d_wgrad_wino_workspace_bytes(int(splits), B, Cin, G * Cout, H, W) if Cout % 64 == 0 else -1
     if ws_bytes < 0:
         raise L.SpkError("conv2d_wgrad_wino: shape not served (Cin, Cout multiples of 64, H even, W a multiple of 16)")
     if out is None:
-        out = torch.empty((Cout, Cin, 3, 3), device=g.device, dtype=torch.float32)
+        out = torch.empty((G // fold * Cout, Cin, 3, 3), device=g.device, dtype=torch.float32)
     ws = _workspace(g.device, ws_bytes)
-    d = L.WgradDesc(g=L.dptr(g, "g"), x=L.dptr(x, "x"), in_scale=L.dptr(batch_scale, "batch_scale"), in_shift=None, dw=L.dptr(out, "dw"),
-                    B=B, Cin=Cin, Cout=Cout, H=H, W=W, Hin=H, Win=W, kh=3, kw=3, stride=1,
-                    flags=L.CONV_WINOGRAD | (L.CONV_IN_BATCH_SCALE if batch_scale is not None else 0), scale=float(scale),
+    flags = L.CONV_WINOGRAD | (L.CONV_IN_BATCH_SCALE if batch_scale is not None else 0) | (L.CONV_IN_AFFINE_RELU if in_affine is not None else 0)
+    d = L.WgradDesc(g=L.dptr(g, "g"), x=L.dptr(x, "x"),
+                    in_scale=(L.dptr(in_affine[0], "in_scale") if in_affine is not None else L.dptr(batch_scale, "batch_scale")),
+                    in_shift=L.dptr(in_affine[1], "in_shift") if in_affine is not None else None, dw=L.dptr(out, "dw"),
+                    B=B, Cin=Cin, Cout=Cout, H=H, W=W, Hin=H, Win=W, kh=3, kw=3, stride=1, flags=flags, scale=float(scale),
                     accumulate=1 if accumulate else 0, splits=int(splits), workspace=ws.data_ptr(), workspace_bytes=ws.numel() * 4,
-                    groups=1, group_in_stride=0, fold=1, g_scale=L.dptr(g_scale, "g_scale"))
+                    groups=G, group_in_stride=gin, fold=fold, g_scale=L.dptr(g_scale, "g_scale"))
     L.check(L.lib().spk_conv2d_wgrad(C.byref(d), L.stream_ptr()), "spk_conv2d_wgrad")
     return out
 

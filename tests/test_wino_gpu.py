@@ -257,3 +257,27 @@ def test_wgrad_wino_modulated_equals_fp64(ops):
     L = importlib.import_module("speak-hack_amd")._lib
     with pytest.raises(L.SpkError):
         ops.conv2d_wgrad_wino(g, x, Cout, Cin, batch_scale=s)
+
+
+@pytest.mark.parametrize("B,G,fold,Cin,Cout,H,W,shared", [(2, 6, 2, 64, 64, 16, 32, False), (1, 3, 1, 128, 64, 8, 16, False),
+                                                          (2, 2, 2, 64, 128, 6, 48, True), (3, 1, 1, 64, 64, 8, 32, False)])
+def test_wgrad_wino_grouped_folded_with_a_folded_batchnorm_input(ops, B, G, fold, Cin, Cout, H, W, shared):
+    """The trunk's form (model.py:60-62 + :84-90: G encoder passes as groups, a pass pair sharing weights folded, the conv's input =
+    relu(bn(x)) formed from the saved pre-BatchNorm tensor): against fp64 on the explicit tensors -- in particular the ZERO padding
+    of the activated input (an affine + ReLU of a padded zero is not zero)."""
+    dev = torch.device("cuda:0")
+    gen = torch.Generator().manual_seed(G * 10 + fold + H)
+    Cx = Cin if shared else G * Cin
+    x = torch.randn(B, Cx, H, W, generator=gen).to(dev)
+    g = torch.randn(B, G * Cout, H, W, generator=gen).to(dev)
+    sc = (torch.rand(Cx, generator=gen) + 0.5).to(dev)
+    sh = (torch.randn(Cx, generator=gen) * 0.5 + 0.3).to(dev)         # mostly positive: a padded zero would become relu(shift) > 0
+    dw = ops.conv2d_wgrad_wino(g, x, Cout, Cin, in_affine=(sc, sh), groups=G, shared_input=shared, fold=fold, scale=0.5)
+    xa = torch.relu(x.double() * sc.double().view(1, -1, 1, 1) + sh.double().view(1, -1, 1, 1))
+    per = [_wgrad_ref(g[:, q * Cout:(q + 1) * Cout], xa[:, (0 if shared else q * Cin):(0 if shared else q * Cin) + Cin]) for q in range(G)]
+    n = G // fold
+    ref = 0.5 * torch.cat([sum(per[q + f * n] for f in range(fold)) for q in range(n)], 0)
+    assert dw.shape == ref.shape and rel_l2(dw, ref) < TOL, rel_l2(dw, ref)
+    with ops.conv3x3_algo("direct"):
+        direct = ops.conv2d_wgrad(g, x, Cout, Cin, 3, 1, in_affine=(sc, sh), groups=G, shared_input=shared, fold=fold, scale=0.5)
+    assert rel_l2(dw, direct) < TOL

@@ -128,6 +128,11 @@ def main():
         torch.cuda.synchronize()
         graph.replay()
     else:
+        if os.environ.get("SPK_MAIN_PRIO"):               # LAB: the whole step on a stream of this priority (-1 = high)
+            print("stream priority range", torch.cuda.Stream.priority_range(), file=sys.stderr)
+            main = torch.cuda.Stream(priority=int(os.environ["SPK_MAIN_PRIO"]))
+            main.wait_stream(torch.cuda.current_stream())
+            torch.cuda.set_stream(main)
         for _ in range(args.warmup):
             step()
     torch.cuda.synchronize()
