@@ -675,7 +675,7 @@ def main():
             finally:
                 gen2.precision = "f32"
             extras["stylegan2_variant"] = {
-                "what": "speak-hack_amd.stylegan2.StyleGAN2Generator (modulated 3x3 conv + demod -- the >= 32^2 layers on the fp32 Winograd kernel, "
+                "what": "speak-hack_amd.stylegan2.StyleGAN2Generator (modulated 3x3 conv + demod -- the >= 16^2 layers on the fp32 Winograd kernel (the 16^2 ones with the contraction in 4 slices), "
                         "their x2 inputs upfirdn2d [1,3,3,1] images written by one launch each; the small layers on the direct kernel with the FIR "
                         "folded into staging --, skip toRGB with the skip upsample + add fused; same channel schedule; parity unpinned by the reference)",
                 "frames_per_s_per_gpu": round(BATCH / sg2_ms * 1e3, 2), "ms_per_step": round(sg2_ms, 4), "eager_ms_per_step": round(sg2_eager, 4),
@@ -807,8 +807,8 @@ def main():
                        "launch": "hipGraph replay of the step" if graph is not None else "eager launches",
                        "conv3x3_algo": pkg.ops.CONV3X3_ALGO + " (fp32 Winograd F(2x2,3x3) where the kernel serves the layer, the direct fmaf-chain "
                                        "kernel elsewhere; SPK_CONV3X3_ALGO=direct: the direct kernel everywhere)"},
-            "roofline": conv_roofline(headline_plan, L, conv_ms, headline_up_ms, "spkwino::wino_kernel (fp32 Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32, layers >= 32^2) + "
-                                      "spkconv::conv_kernel<Cfg,3,3,1,MODE> (direct f32 MFMA implicit GEMM, the 8^2 / 16^2 layers)", traffic, ms_per_step,
+            "roofline": conv_roofline(headline_plan, L, conv_ms, headline_up_ms, "spkwino::wino_kernel (fp32 Winograd F(2x2,3x3) on v_mfma_f32_32x32x2_f32, layers >= 16^2; the 16^2 ones run their contraction in 4 slices + the split-K finisher) + "
+                                      "spkconv::conv_kernel<Cfg,3,3,1,MODE> (direct f32 MFMA implicit GEMM, the 8^2 layers)", traffic, ms_per_step,
                                       {"measured_by": roof_how}),
             "eager": {"what": "the same step without the hipGraph: one spk_launch_list call per forward (plan.DecoderPlan), as an "
                               "unchanged `model.Gd(x)` caller runs it", "ms_per_step": round(eager_ms, 4),

@@ -209,6 +209,12 @@ int spk_conv2d_bf16x3_fwd(const spk_conv2d_desc* desc, void* stream);
 int64_t spk_conv2d_packed_bytes_wino(int Cin, int Cout);
 int spk_conv2d_pack_weights_wino(const float* w, float* w_packed, int Cin, int Cout, int transpose_flip, void* stream);
 int spk_conv2d_wino_supported(int B, int Cin, int Cout, int H, int W);
+/* Regions are 32 x 8 output pixels, or 16 x 16 where the image is narrower than 32.  A problem with too few (region, channel tile)
+ * pairs to fill the CUs runs its channel contraction in `ksplit` slices: spk_conv2d_wino_ksplit(want, ...) = the count the launch
+ * will use for desc->ksplit = want (0 = automatic; 1 = no split), ..._workspace_bytes the partial-sum workspace it then needs in
+ * desc->workspace ([ksplit][B][Cout][H][W]; 0 when not split); the epilogue then runs in the direct kernels' split-K finisher. */
+int spk_conv2d_wino_ksplit(int want, int B, int Cin, int Cout, int H, int W);
+int64_t spk_conv2d_wino_workspace_bytes(int ksplit, int B, int Cin, int Cout, int H, int W);
 int spk_conv2d_wino_fwd(const spk_conv2d_desc* desc, void* stream);
 
 /* ---- backward of the convolution ---------------------------------------------------------------------

@@ -37,8 +37,12 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef __attribute__((address_space(3))) f32x2 lds_f32x2_t;
 
-constexpr int CO_T = 64, CI_T = 8, RW = 32, RH = 8, TXN = RW / 2, TYN = RH / 2, NTILE = TXN * TYN, NT = 256;
-constexpr int RAW_W = RW + 2, RAW_H = RH + 2, RAW_USED = RAW_W * RAW_H;     // 34 x 10 = 340 floats of a plane
+constexpr int CO_T = 64, CI_T = 8, NTILE = 64, NT = 256;
+// region shapes (64 tiles each): WIDE = 32 x 8 output pixels (16 x 4 tiles) -- whole 128-byte output lines; SQUARE = 16 x 16 (8 x 8 tiles)
+// for images narrower than 32 pixels.  Raw plane with its halo: 34 x 10 = 340 / 18 x 18 = 324 floats, both within the 352-float pitch.
+constexpr int WIDE = 0, SQUARE = 1;
+constexpr int region_w(int shape) { return shape == SQUARE ? 16 : 32; }
+constexpr int region_h(int shape) { return shape == SQUARE ? 16 : 8; }
 constexpr int RAW_PLANE = 352, RAW_WAVE = 2 * RAW_PLANE;                    // 704 = 11 x 64: a wave's two planes = 11 gathers
 constexpr int RAW_GATHERS = RAW_WAVE / 64;
 constexpr int U_FLOATS = 16 * CI_T * CO_T, V_FLOATS = 16 * CI_T * NTILE, RAW_FLOATS = 4 * RAW_WAVE;
@@ -47,7 +51,7 @@ constexpr int PRM_OFF = RAW_OFF + 2 * RAW_FLOATS;                            // 
 constexpr int DEM_OFF = PRM_OFF + 4 * CO_T;                                  // [64 co] demodulation d[b, co] of the region's image (modulated convs)
 constexpr int LDS_FLOATS = DEM_OFF + CO_T;
 constexpr int LDS_BYTES = LDS_FLOATS * 4;                                    // 154 880
-static_assert(NTILE == 64 && RAW_GATHERS == 11 && RAW_USED <= RAW_PLANE, "geometry");
+static_assert(RAW_GATHERS == 11 && 34 * 10 <= RAW_PLANE && 18 * 18 <= RAW_PLANE, "geometry");
 constexpr int U_DMA = U_FLOATS * 4 / 1024 / 4;                               // 1 KB blocks per wave and chunk (8)
 
 struct Args {
@@ -64,7 +68,9 @@ struct Args {
     const float* out_scale_bc;   // MOD: [B, Cout] demodulation d[b, co] applied right after the contraction, or null
     int B, Cin, Cout, H, W;
     int regions_x, regions_y;
-    int n_chunks;
+    int n_chunks;                // of the whole contraction (the packed image's chunk count)
+    int ksplit, cps;             // the contraction in `ksplit` slices of `cps` chunks (even), a work item = (region, slice)
+    size_t slice_floats;         // ksplit > 1: slice z writes its partial sums at y + z * slice_floats (the caller's split-K workspace)
     int style_stride;
     unsigned flags;
     unsigned x_bytes;
@@ -119,8 +125,9 @@ __device__ __forceinline__ void lds_barrier() {
 // MOD: the modulated convolution of the StyleGAN2 variant.  B^T (d s) B = s B^T d B: the modulation of the
 // plane's channel -- one scalar per plane, the region lies in one image -- multiplies the 16 transformed values (16 more vector ops
 // per plane); the demodulation rides on the epilogue's out_scale through a second LDS table.
-template <bool MOD>
+template <bool MOD, int SHAPE>
 __global__ __launch_bounds__(NT) void wino_kernel(const Args p) {
+    constexpr int RW = region_w(SHAPE), RH = region_h(SHAPE), TXN = RW / 2, RAW_W = RW + 2, RAW_H = RH + 2, RAW_USED = RAW_W * RAW_H;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -131,7 +138,7 @@ __global__ __launch_bounds__(NT) void wino_kernel(const Args p) {
     // contiguous share of the region list (the hardware deals workgroup w to XCD w % 8), neighbours in the list running
     // side by side on the same L2 -- and, the point of it, the first loads of region r + 1 are requested BEFORE the epilogue
     // of region r, so that a region's global-load latency hides behind its predecessor's output transform and stores.
-    const int n_regions = p.regions_x * p.regions_y * p.B;
+    const int n_regions = p.regions_x * p.regions_y * p.B * p.ksplit;      // work items: (region, contraction slice), slice fastest
     const int xcd = (int)blockIdx.x & 7, wk = (int)blockIdx.x >> 3, wpx = (int)gridDim.x >> 3;      // (host: gridDim.x % 8 == 0)
     const int share_q = n_regions >> 3, share_r = n_regions & 7;
     const int reg_begin = xcd * share_q + min(xcd, share_r), reg_end = reg_begin + share_q + (xcd < share_r ? 1 : 0);
@@ -141,7 +148,9 @@ __global__ __launch_bounds__(NT) void wino_kernel(const Args p) {
     // ---- the raw gathers: byte offsets of this lane's 11 elements (plane j of channel wave + 4 j), or out of range ----
     const __amdgpu_buffer_rsrc_t rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.x), 0, (int)p.x_bytes, 0x00020000);
     unsigned voff[RAW_GATHERS], voff_next[RAW_GATHERS];   // the gathers of the region being requested / of the region after it
-    auto region_coords = [&](int reg, int& b_, int& y0_, int& x0_) {
+    auto region_coords = [&](int item, int& b_, int& y0_, int& x0_, int& kb_) {
+        const int reg = item / p.ksplit;
+        kb_ = (item - reg * p.ksplit) * p.cps;               // first chunk of the item's slice
         const int rx_ = reg % p.regions_x;
         const int t_ = reg / p.regions_x;
         b_ = t_ / p.regions_y;
@@ -195,7 +204,7 @@ __global__ __launch_bounds__(NT) void wino_kernel(const Args p) {
     // materialising one address register per constant that does not fit)
     int a_base = U_OFF + half * CO_T + wm * 32 + l32;               // + slot * U_FLOATS + (xi * 8 + 2 kk) * 64
     int b_base = V_OFF + half * NTILE + wn * 32 + l32;              // + slot * V_FLOATS + (xi * 8 + 2 kk) * 64
-    const int ty_l = lane >> 4, tx_l = lane & 15;
+    const int ty_l = lane / TXN, tx_l = lane % TXN;
     int raw_rd = (RAW_OFF + wave * RAW_WAVE + 2 * ty_l * RAW_W + 2 * tx_l) >> 1;   // in float pairs; + slot * RAW_FLOATS + j * RAW_PLANE + r * 34 + {0, 2}
     int v_wr = V_OFF + wave * NTILE + lane;                         // + slot * V_FLOATS + (xi * 8 + 4 j) * 64
     asm volatile("" : "+v"(a_base), "+v"(b_base), "+v"(raw_rd), "+v"(v_wr));
@@ -230,24 +239,25 @@ __global__ __launch_bounds__(NT) void wino_kernel(const Args p) {
 #define WINO_T_WRITE(vs_, j_, xi_)                                                                                      \
     *((volatile lds_f32_t*)0 + (v_wr + ((vs_) * V_FLOATS + ((xi_) * CI_T + 4 * (j_)) * NTILE))) = tv[j_][xi_];
 
-    const int n = p.n_chunks;
+    const int n = p.cps;
     int reg = reg_begin + wk;
     if (reg >= reg_end) return;
-    int b, y0, x0, b_cur;            // b: the image of the region whose operands are being requested; b_cur: of the region being computed
-    region_coords(reg, b, y0, x0);
+    int b, y0, x0, kb, b_cur, kb_cur;   // b, kb: image / first chunk of the item whose operands are being requested; *_cur: of the item being computed
+    region_coords(reg, b, y0, x0, kb);
     b_cur = b;
+    kb_cur = kb;
     set_voff(voff, b, y0, x0);
     // ---- first region: U_0, raw_0, raw_1 requested; raw_0 -> V_0 ----
-    static_for<0, U_DMA>([&](auto k) { WINO_DMA_U(0, 0, decltype(k)::value); });
-    static_for<0, RAW_GATHERS>([&](auto k) { WINO_DMA_RAW(voff[decltype(k)::value], 0, 0, decltype(k)::value); });
-    static_for<0, RAW_GATHERS>([&](auto k) { WINO_DMA_RAW(voff[decltype(k)::value], 1, 1, decltype(k)::value); });
+    static_for<0, U_DMA>([&](auto k) { WINO_DMA_U(kb, 0, decltype(k)::value); });
+    static_for<0, RAW_GATHERS>([&](auto k) { WINO_DMA_RAW(voff[decltype(k)::value], kb, 0, decltype(k)::value); });
+    static_for<0, RAW_GATHERS>([&](auto k) { WINO_DMA_RAW(voff[decltype(k)::value], kb + 1, 1, decltype(k)::value); });
     __builtin_amdgcn_s_waitcnt(0x0f70);              // vmcnt(0): this wave's DMA has landed (its raw planes are its own)
     static_for<0, 2>([&](auto j) {
         static_for<0, 4>([&](auto r) { WINO_T_READ(0, decltype(j)::value, decltype(r)::value); });
         static_for<0, 4>([&](auto c) { WINO_T_ROWS(decltype(j)::value, decltype(c)::value); });
         static_for<0, 4>([&](auto i) { WINO_T_COLS(decltype(j)::value, decltype(i)::value); });
         if constexpr (MOD) {
-            const float sc0_ = p.in_scale[(size_t)b * p.Cin + wave + 4 * decltype(j)::value];
+            const float sc0_ = p.in_scale[(size_t)b * p.Cin + kb * CI_T + wave + 4 * decltype(j)::value];
             static_for<0, 4>([&](auto i) { WINO_T_SCALE(decltype(j)::value, decltype(i)::value, sc0_); });
         }
         static_for<0, 16>([&](auto xi) { WINO_T_WRITE(0, decltype(j)::value, decltype(xi)::value); });
@@ -270,8 +280,8 @@ __global__ __launch_bounds__(NT) void wino_kernel(const Args p) {
     auto chunk_body = [&](auto slot_c, auto first_c, const int i) __attribute__((always_inline)) {
         constexpr int S = decltype(slot_c)::value, O = 1 - S;     // this chunk's slot; the other one receives the next chunk
         constexpr bool FIRST = decltype(first_c)::value;          // a region's first chunk: its first 16 MFMAs START the accumulators (C = 0)
-        const int c1 = i + 1 < n ? i + 1 : 0;                     // the stream's next chunk (weights: the same channel tile)
-        const int c2 = i + 2 >= n ? i + 2 - n : i + 2;            // the chunk after it (past n: in the next region -- `voff` is that region's by then)
+        const int c1 = i + 1 < n ? kb_cur + i + 1 : kb;           // the stream's next chunk (weights: the same channel tile; past n: the next item's first)
+        const int c2 = i + 2 >= n ? kb + i + 2 - n : kb_cur + i + 2;      // the chunk after it (past n: in the next item -- `voff` is that item's by then)
         float msc[2] = {1.f, 1.f};                                // MOD: the modulation of the two planes being transformed (chunk c1)
         if constexpr (MOD) {
             const float* ms_ = p.in_scale + (size_t)(i + 1 < n ? b_cur : b) * p.Cin + c1 * CI_T + wave;
@@ -307,7 +317,7 @@ __global__ __launch_bounds__(NT) void wino_kernel(const Args p) {
     const float slope_ = f_lrelu ? p.slope : 1.f, gain_ = f_lrelu ? p.act_gain : 1.f;    // (no LeakyReLU: slope 1, gain 1)
     // epilogue geometry: lane = tile of the region (l32 + 32 wn) -> its 2 x 2 output pixels; accumulator register r of the lane's
     // half = channel row (r & 3) + 8 (r >> 2) + 4 half of the wave's 32
-    const int tile = wn * 32 + l32, oy = 2 * (tile >> 4), ox = 2 * (tile & 15);
+    const int tile = wn * 32 + l32, oy = 2 * (tile / TXN), ox = 2 * (tile % TXN);
     const int row_lane = wm * 32 + 4 * half;                              // + (r & 3) + 8 (r >> 2): row of the 64-channel tile
     // the operand table of the epilogue: thread t fetches operand t & 3 (bias, noise weight, style scale, style shift) of channel t >> 2
     const int prm_which = tid & 3, prm_c = co0 + (tid >> 2);
@@ -332,6 +342,7 @@ __global__ __launch_bounds__(NT) void wino_kernel(const Args p) {
         // the region after this one (the last region repeats itself: loads nobody uses)
         const int cur_b = b, cur_y0 = y0, cur_x0 = x0;
         b_cur = b;
+        kb_cur = kb;
         // everything the epilogue reads from global memory is requested NOW and lands behind the region's MFMAs: the noise of
         // this thread's four pixels, and (wave 0: one channel per lane) the channel's bias / noise weight / style pair, which
         // reach the other waves through a 1 KB LDS table -- no load latency between the last MFMA and the stores
@@ -355,7 +366,7 @@ __global__ __launch_bounds__(NT) void wino_kernel(const Args p) {
         const bool more = reg + wpx < reg_end;
         if (more) {
             reg += wpx;
-            region_coords(reg, b, y0, x0);
+            region_coords(reg, b, y0, x0, kb);
         }
         set_voff(voff_next, b, y0, x0);
 
@@ -384,7 +395,7 @@ __global__ __launch_bounds__(NT) void wino_kernel(const Args p) {
         lds_barrier();
         unsigned hw_ = (unsigned)HW;                 // (opaque per region: the 16 rows' channel offsets must not be hoisted out of the region
         asm volatile("" : "+s"(hw_));                //  loop as 32 live registers)
-        const size_t o0 = (size_t)cur_b * p.Cout * hw_ + pix;
+        const size_t o0 = (size_t)cur_b * p.Cout * hw_ + pix + (size_t)(kb_cur / p.cps) * p.slice_floats;
         LAB_STAMP(3)
         // The accumulators are read out of the AGPR file one element at a time, by hand (v_accvgpr_read_b32 with an "a" operand):
         // left to the compiler, the first use of element r of a tile copies the whole 16-register tile to VGPRs, a row touches all
@@ -473,12 +484,43 @@ int spk_conv2d_pack_weights_wino(const float* w, float* w_packed, int Cin, int C
     return spk::check_launch("pack_wino_kernel");
 }
 
+static int wino_shape(int H, int W) {         // -1: no region shape tiles the image
+    if (H % region_h(WIDE) == 0 && W % region_w(WIDE) == 0) return WIDE;
+    if (H % region_h(SQUARE) == 0 && W % region_w(SQUARE) == 0) return SQUARE;
+    return -1;
+}
+
 int spk_conv2d_wino_supported(int B, int Cin, int Cout, int H, int W) {
     if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return 0;
-    if (H % RH || W % RW) return 0;
+    if (wino_shape(H, W) < 0) return 0;     // whole 32 x 8 or 16 x 16 pixel regions
     if (Cin % (2 * CI_T)) return 0; // whole chunks (the gathers of a ragged last chunk would reach past the tensor), an even number of them
     if ((long long)B * Cin * H * W * 4 >= (1ll << 31)) return 0;          // 32-bit buffer offsets, bit 31 = "out of range"
     return 1;
+}
+
+// Slices of the channel contraction (split-K) for a problem with too few (region, channel tile) pairs to fill the CUs: the smallest
+// power of two that brings the grid to >= 3/4 of a workgroup per CU while a slice keeps >= 4 chunks (an even number); `want` > 0: that
+// many if the chunk count allows.  1 = no split.  A split launch writes partial sums [ksplit][B][Cout][H][W] into the workspace and
+// the direct kernels' split-K finisher applies the epilogue.
+int spk_conv2d_wino_ksplit(int want, int B, int Cin, int Cout, int H, int W) {
+    if (!spk_conv2d_wino_supported(B, Cin, Cout, H, W)) return -1;
+    const int shape = wino_shape(H, W), n_chunks = Cin / CI_T;
+    const long long pairs = (long long)B * (H / region_h(shape)) * (W / region_w(shape)) * spk::ceil_div(Cout, CO_T);
+    auto ok = [&](int ks) { return ks >= 1 && n_chunks % (2 * ks) == 0 && n_chunks / ks >= 4; };
+    if (want > 0) {
+        int ks = want;
+        while (ks > 1 && !ok(ks)) --ks;
+        return ks;
+    }
+    int ks = 1;
+    while (pairs * ks < 192 && ok(2 * ks)) ks *= 2;
+    return ks;
+}
+
+int64_t spk_conv2d_wino_workspace_bytes(int ksplit, int B, int Cin, int Cout, int H, int W) {
+    const int ks = spk_conv2d_wino_ksplit(ksplit, B, Cin, Cout, H, W);
+    if (ks < 0) return -1;
+    return ks > 1 ? (int64_t)ks * B * Cout * H * W * 4 : 0;
 }
 
 // entered from spk_conv2d_fwd when desc->flags has SPK_CONV_WINOGRAD
@@ -486,41 +528,56 @@ int spk_conv2d_wino_fwd(const spk_conv2d_desc* d, void* stream) {
     SPK_REQUIRE(d && d->x && d->w_packed && d->y, "conv2d winograd: null pointer");
     SPK_REQUIRE(d->kh == 3 && d->kw == 3 && d->stride == 1, "conv2d winograd: 3x3 stride-1 kernels only");
     SPK_REQUIRE(d->groups <= 1, "conv2d winograd: not grouped");
-    const unsigned allowed = SPK_CONV_WINOGRAD | SPK_EPI_BIAS | SPK_EPI_NOISE | SPK_EPI_LRELU | SPK_EPI_STYLE | SPK_EPI_ACCUM | SPK_CONV_IN_BATCH_SCALE;
+    const unsigned epi = SPK_EPI_BIAS | SPK_EPI_NOISE | SPK_EPI_LRELU | SPK_EPI_STYLE | SPK_EPI_ACCUM;
+    const unsigned allowed = SPK_CONV_WINOGRAD | epi | SPK_CONV_IN_BATCH_SCALE;
     SPK_REQUIRE(!(d->flags & ~allowed) && !d->stats && !d->accum_half,
                 "conv2d winograd: plain or batch-scaled input; epilogue flags bias, noise, lrelu, style, accum");
     const bool mod = d->flags & SPK_CONV_IN_BATCH_SCALE;
     SPK_REQUIRE(!mod || d->in_scale, "conv2d winograd: IN_BATCH_SCALE without in_scale[B,Cin]");
     SPK_REQUIRE(!d->out_scale_bc || mod, "conv2d winograd: out_scale_bc (demodulation) goes with SPK_CONV_IN_BATCH_SCALE");
     SPK_REQUIRE(d->H == d->Hin && d->W == d->Win, "conv2d winograd: output size must equal the input size");
-    SPK_REQUIRE(spk_conv2d_wino_supported(d->B, d->Cin, d->Cout, d->H, d->W), "conv2d winograd: %dx%d is not a whole number of 32 x 8 regions "
-                "(or the input exceeds 2 GB)", d->H, d->W);
+    SPK_REQUIRE(spk_conv2d_wino_supported(d->B, d->Cin, d->Cout, d->H, d->W), "conv2d winograd: %dx%d is not a whole number of 32 x 8 or 16 x 16 "
+                "regions (or the input exceeds 2 GB)", d->H, d->W);
     SPK_REQUIRE(!(d->flags & SPK_EPI_BIAS) || d->bias, "conv2d winograd: SPK_EPI_BIAS without bias");
     SPK_REQUIRE(!(d->flags & SPK_EPI_NOISE) || (d->noise && d->noise_w), "conv2d winograd: SPK_EPI_NOISE without noise");
     SPK_REQUIRE(!(d->flags & SPK_EPI_STYLE) || d->style, "conv2d winograd: SPK_EPI_STYLE without style");
     const auto aligned16 = [](const void* q) { return (reinterpret_cast<uintptr_t>(q) & 15) == 0; };
     SPK_REQUIRE(aligned16(d->w_packed) && aligned16(d->y) && aligned16(d->y_pre) && aligned16(d->noise) && (reinterpret_cast<uintptr_t>(d->x) & 3) == 0,
                 "conv2d winograd: tensors must be 16-byte aligned");
+    const int shape = wino_shape(d->H, d->W);
+    const int ks = spk_conv2d_wino_ksplit(d->ksplit, d->B, d->Cin, d->Cout, d->H, d->W);
+    const size_t out_floats = (size_t)d->B * d->Cout * d->H * d->W;
+    if (ks > 1)
+        SPK_REQUIRE(d->workspace && aligned16(d->workspace) && d->workspace_bytes >= (int64_t)ks * (int64_t)out_floats * 4,
+                    "conv2d winograd: %d contraction slices need a workspace of %lld bytes (spk_conv2d_wino_workspace_bytes)", ks,
+                    (long long)ks * (long long)out_floats * 4);
     Args a;
     a.x = d->x; a.wp = d->w_packed; a.bias = d->bias; a.noise_w = d->noise_w; a.noise = d->noise; a.style = d->style;
     a.y = d->y; a.y_pre = d->y_pre; a.out_scale_dev = d->out_scale_dev;
     a.in_scale = mod ? d->in_scale : nullptr; a.out_scale_bc = d->out_scale_bc;
     a.B = d->B; a.Cin = d->Cin; a.Cout = d->Cout; a.H = d->H; a.W = d->W;
-    a.regions_x = d->W / RW; a.regions_y = d->H / RH;
+    a.regions_x = d->W / region_w(shape); a.regions_y = d->H / region_h(shape);
     a.n_chunks = spk::ceil_div(d->Cin, CI_T);
+    a.ksplit = ks; a.cps = a.n_chunks / ks; a.slice_floats = 0;
     a.style_stride = d->style_stride; a.flags = d->flags;
     a.x_bytes = (unsigned)((long long)d->B * d->Cin * d->H * d->W * 4);
     a.slope = d->lrelu_slope; a.out_scale = d->out_scale; a.act_gain = d->act_gain != 0.f ? d->act_gain : 1.f;
-    auto kern = mod ? &wino_kernel<true> : &wino_kernel<false>;
-    static bool raised[2] = {false, false};
-    if (!raised[mod ? 1 : 0]) {
+    if (ks > 1) {       // partial sums, raw: the whole epilogue (and the demodulation) belongs to the finisher
+        a.y = static_cast<float*>(d->workspace); a.y_pre = nullptr; a.out_scale_dev = nullptr; a.out_scale_bc = nullptr;
+        a.flags = d->flags & ~epi; a.out_scale = 1.f; a.slice_floats = out_floats;
+    }
+    void (*kern)(const Args) = mod ? (shape == SQUARE ? &wino_kernel<true, SQUARE> : &wino_kernel<true, WIDE>)
+                                   : (shape == SQUARE ? &wino_kernel<false, SQUARE> : &wino_kernel<false, WIDE>);
+    static bool raised[4] = {false, false, false, false};
+    const int which = (mod ? 2 : 0) + (shape == SQUARE ? 1 : 0);
+    if (!raised[which]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return spk::fail(SPK_ELAUNCH, "hipFuncSetAttribute(LDS): %s", hipGetErrorString(e));
-        raised[mod ? 1 : 0] = true;
+        raised[which] = true;
     }
-    const long long n_regions = (long long)a.regions_x * a.regions_y * d->B;
-    SPK_REQUIRE(n_regions < (1ll << 31), "conv2d winograd: grid too large");
-    // persistent: one workgroup per CU over all channel tiles, a multiple of 8 per channel tile (the XCD shares), at most one per region
+    const long long n_items = (long long)a.regions_x * a.regions_y * d->B * ks;
+    SPK_REQUIRE(n_items < (1ll << 31), "conv2d winograd: grid too large");
+    // persistent: one workgroup per CU over all channel tiles, a multiple of 8 per channel tile (the XCD shares), at most one per item
     const int co_tiles = spk::ceil_div(d->Cout, CO_T);
     static int n_cu = 0;
     if (n_cu == 0) {
@@ -530,13 +587,20 @@ int spk_conv2d_wino_fwd(const spk_conv2d_desc* d, void* stream) {
         n_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
     }
     long long gx = std::max(8ll, ((long long)n_cu / co_tiles) / 8 * 8);
-    static int lab_mult = -1;       // LAB: SPK_WINO_WGS = workgroups per CU slot (0: one workgroup per region)
+    static int lab_mult = -1;       // LAB: SPK_WINO_WGS = workgroups per CU slot (0: one workgroup per item)
     if (lab_mult < 0) { const char* e = getenv("SPK_WINO_WGS"); lab_mult = e ? atoi(e) : 1; }
-    gx = lab_mult == 0 ? (n_regions + 7) / 8 * 8 : gx * lab_mult;
-    gx = std::min(gx, (n_regions + 7) / 8 * 8);
+    gx = lab_mult == 0 ? (n_items + 7) / 8 * 8 : gx * lab_mult;
+    gx = std::min(gx, (n_items + 7) / 8 * 8);
     dim3 grid((unsigned)gx, (unsigned)co_tiles);
     hipLaunchKernelGGL(kern, grid, dim3(NT), LDS_BYTES, (hipStream_t)stream, a);
-    return spk::check_launch("wino_kernel");
+    int rc = spk::check_launch("wino_kernel");
+    if (rc != SPK_OK || ks == 1) return rc;
+    spkconv::ConvArgs f = {};
+    f.bias = d->bias; f.noise_w = d->noise_w; f.noise = d->noise; f.style = d->style; f.out_scale_bc = d->out_scale_bc;
+    f.y = d->y; f.y_pre = d->y_pre; f.B = d->B; f.Cin = d->Cin; f.Cout = d->Cout; f.Cy = d->Cout; f.Cx = d->Cin; f.G = 1; f.H = d->H; f.W = d->W;
+    f.style_stride = d->style_stride; f.flags = d->flags & epi; f.slope = d->lrelu_slope; f.out_scale = d->out_scale;
+    f.act_gain = a.act_gain; f.out_scale_dev = d->out_scale_dev;
+    return spkconv::launch_splitk_epilogue(f, static_cast<const float*>(d->workspace), ks, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -390,10 +390,17 @@ def conv3x3_algo(algo: str):
 
 
 def use_wino(B, Cin, Cout, H, W) -> bool:
-    """Whether a 3x3 stride-1 conv with this OUTPUT shape (plain input) goes to the Winograd kernel under ``CONV3X3_ALGO``."""
+    """Whether a 3x3 stride-1 conv with this OUTPUT shape (plain input) goes to the Winograd kernel under ``CONV3X3_ALGO``: the
+    kernel serves the shape and -- with the contraction split into the slices ``wino_ksplit`` picks -- fills the chip."""
     if CONV3X3_ALGO != "auto" or not wino_supported(B, Cin, Cout, H, W):
         return False
-    return B * (H // 8) * (W // 32) * ((Cout + 63) // 64) >= WINO_MIN_WORKGROUPS
+    rw, rh = (32, 8) if (W % 32 == 0 and H % 8 == 0) else (16, 16)
+    return B * (H // rh) * (W // rw) * ((Cout + 63) // 64) * wino_ksplit(B, Cin, Cout, H, W) >= WINO_MIN_WORKGROUPS
+
+
+def wino_ksplit(B, Cin, Cout, H, W, want=0) -> int:
+    """Slices of the channel contraction the Winograd launch will use (1: none; > 1: partial sums through the split-K workspace)."""
+    return int(L.lib().spk_conv2d_wino_ksplit(int(want), B, Cin, Cout, H, W))
 
 
 def wino_supported(B, Cin, Cout, H, W) -> bool:
@@ -428,7 +435,8 @@ def upsample2x(x, zero_border=False):
 
 
 def conv3x3_wino(x, w_packed, Cout, *, bias=None, noise_w=None, noise=None, style=None, style_stride=None, lrelu_slope=None,
-                 out_scale=1.0, act_gain=1.0, out=None, out_pre=None, accumulate=False, out_scale_dev=None, batch_scale=None, demod=None):
+                 out_scale=1.0, act_gain=1.0, out=None, out_pre=None, accumulate=False, out_scale_dev=None, batch_scale=None, demod=None,
+                 ksplit=0):
     """3x3 stride-1 pad-1 conv with the fused decoder epilogue as Winograd F(2x2, 3x3): fp32 throughout, 2.25x fewer matrix
     instructions than the direct form, 1e-6-class rel-L2 against it.  ``w_packed`` from ``pack_conv_weight_wino``."""
     B, Cin, H, W = x.shape
@@ -452,8 +460,12 @@ def conv3x3_wino(x, w_packed, Cout, *, bias=None, noise_w=None, noise=None, styl
                      y=L.dptr(out, "out"), y_pre=L.dptr(out_pre, "out_pre"), B=B, Cin=Cin, Cout=Cout, H=H, W=W, Hin=H, Win=W,
                      kh=3, kw=3, stride=1, style_stride=int(style_stride or 0), flags=flags,
                      lrelu_slope=float(lrelu_slope if lrelu_slope is not None else 1.0), out_scale=float(out_scale), config=-1,
-                     ksplit=1, workspace=None, workspace_bytes=0, groups=1, group_in_stride=0, stats_slots=0,
+                     ksplit=int(ksplit), workspace=None, workspace_bytes=0, groups=1, group_in_stride=0, stats_slots=0,
                      accum_half=None, out_scale_dev=L.dptr(out_scale_dev, "out_scale_dev"))
+    ws_bytes = L.lib().spk_conv2d_wino_workspace_bytes(int(ksplit), B, Cin, Cout, H, W)
+    if ws_bytes > 0:                        # few regions: the contraction runs in slices, partial sums through the split-K workspace
+        ws = _workspace(x.device, ws_bytes)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     _launch_conv2d(d)
     return out
 

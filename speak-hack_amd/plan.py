@@ -121,7 +121,9 @@ class LaunchPlan:
                              y=out.data_ptr(), y_pre=None, B=B, Cin=Cin, Cout=Cout, H=H, W=W, Hin=H, Win=W, kh=3, kw=3, stride=1,
                              style_stride=int(style.stride(0)) if style is not None else 0, flags=flags,
                              lrelu_slope=float(slope if slope is not None else 1.0), out_scale=float(out_scale), config=-1,
-                             ksplit=1, workspace=None, workspace_bytes=0, groups=1, group_in_stride=0, stats_slots=0)
+                             ksplit=0, workspace=None, workspace_bytes=0, groups=1, group_in_stride=0, stats_slots=0)
+            # (few regions: the contraction runs in slices through the plan's split-K workspace, spk_conv2d_wino_ksplit)
+            self._ws_bytes = max(self._ws_bytes, L.lib().spk_conv2d_wino_workspace_bytes(0, B, Cin, Cout, H, W))
             if upsample:
                 self._up_users.append((up_op, d))
             return self.add(L.OP_CONV2D, d)

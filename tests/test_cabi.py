@@ -113,10 +113,19 @@ def test_winograd_shape_queries_on_the_host(pkg):
     """The Winograd entry points' host-side answers (no launch): which shapes the conv / the weight gradient serve, the packed
     image size, the split rule of the weight gradient's one-round grid and its workspace."""
     lib = pkg._lib.lib()
-    # forward: regions of 32 x 8 output pixels, input channels in chunks of 8 paired two by two
+    # forward: regions of 32 x 8 output pixels (16 x 16 where the image is narrower), input channels in chunks of 8 paired two by two
     assert lib.spk_conv2d_wino_supported(8, 64, 64, 256, 256) and lib.spk_conv2d_wino_supported(1, 16, 200, 8, 32)
-    assert not lib.spk_conv2d_wino_supported(8, 64, 64, 16, 16)       # W % 32
+    assert lib.spk_conv2d_wino_supported(8, 64, 64, 16, 16) and lib.spk_conv2d_wino_supported(1, 64, 64, 32, 48)
+    assert not lib.spk_conv2d_wino_supported(8, 64, 64, 8, 8) and not lib.spk_conv2d_wino_supported(8, 64, 64, 8, 16)
     assert not lib.spk_conv2d_wino_supported(8, 64, 64, 12, 32)       # H % 8
+    # the sliced contraction: few (region, channel tile) pairs -> the smallest power of two that fills 3/4 of the CUs, >= 4 chunks a slice
+    ks = lib.spk_conv2d_wino_ksplit
+    assert ks(0, 8, 512, 512, 16, 16) == 4 and ks(0, 8, 512, 512, 32, 32) == 1 and ks(0, 1, 512, 512, 32, 32) == 8
+    assert ks(0, 1, 64, 64, 16, 16) == 2 and ks(0, 1, 16, 64, 16, 16) == 1           # (8 / 2 chunks: at most 2 / 1 slices)
+    assert ks(3, 8, 512, 512, 16, 16) == 2 and ks(16, 8, 512, 512, 16, 16) == 16 and ks(1, 8, 512, 512, 16, 16) == 1
+    assert ks(0, 8, 64, 64, 8, 8) == -1
+    wsb = lib.spk_conv2d_wino_workspace_bytes
+    assert wsb(0, 8, 512, 512, 16, 16) == 4 * 8 * 512 * 256 * 4 and wsb(0, 8, 512, 512, 32, 32) == 0 and wsb(0, 8, 64, 64, 8, 8) == -1
     assert not lib.spk_conv2d_wino_supported(8, 24, 64, 32, 32)       # Cin % 16
     assert not lib.spk_conv2d_wino_supported(64, 512, 512, 256, 256)  # >= 2 GB: 32-bit gather offsets
     assert lib.spk_conv2d_packed_bytes_wino(64, 64) == 64 * 64 * 16 * 4 and lib.spk_conv2d_packed_bytes_wino(64, 65) == 64 * 128 * 16 * 4

@@ -101,8 +101,9 @@ def test_wino_accumulate_device_scale_and_data_gradient(ops):
 
 def test_wino_rejects_what_it_does_not_serve(ops):
     assert not ops.wino_supported(1, 24, 64, 8, 32)      # an odd number of 8-channel chunks
-    assert not ops.wino_supported(1, 16, 64, 12, 32)     # not whole 32 x 8 regions
+    assert not ops.wino_supported(1, 16, 64, 12, 32)     # not whole 32 x 8 (or 16 x 16) regions
     assert not ops.wino_supported(1, 16, 64, 8, 16)
+    assert ops.wino_supported(1, 16, 64, 16, 16) and ops.wino_supported(1, 16, 64, 32, 48)      # 16 x 16 regions
     L = importlib.import_module("speak-hack_amd")._lib
     dev = torch.device("cuda:0")
     x, w = torch.randn(1, 16, 12, 32, device=dev), torch.randn(64, 16, 3, 3, device=dev)
@@ -281,3 +282,51 @@ def test_wgrad_wino_grouped_folded_with_a_folded_batchnorm_input(ops, B, G, fold
     with ops.conv3x3_algo("direct"):
         direct = ops.conv2d_wgrad(g, x, Cout, Cin, 3, 1, in_affine=(sc, sh), groups=G, shared_input=shared, fold=fold, scale=0.5)
     assert rel_l2(dw, direct) < TOL
+
+
+# ---- 16 x 16 regions and the sliced contraction (few regions: partial sums through the split-K workspace) ------------------------
+@pytest.mark.parametrize("B,Cin,Cout,H,W,ksplit", [(8, 512, 512, 16, 16, 0), (1, 64, 64, 16, 16, 0), (2, 64, 128, 48, 16, 1), (1, 128, 64, 32, 48, 2),
+                                                   (1, 512, 512, 32, 32, 0), (2, 256, 64, 8, 64, 4), (1, 64, 200, 16, 32, 2)])
+def test_wino_square_regions_and_sliced_contraction(ops, B, Cin, Cout, H, W, ksplit):
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(B + Cin + Cout + H + W + ksplit)
+    x = torch.randn(B, Cin, H, W, generator=g).to(dev)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)).to(dev)
+    bias, nw = torch.randn(Cout, generator=g).to(dev), torch.randn(Cout, generator=g).to(dev)
+    noise = torch.randn(B, 1, H, W, generator=g).to(dev)
+    style = torch.randn(B, 2 * Cout, generator=g).to(dev)
+    base = torch.randn(B, Cout, H, W, generator=g).to(dev)
+    assert ops.wino_supported(B, Cin, Cout, H, W)
+    ks = ops.wino_ksplit(B, Cin, Cout, H, W, ksplit)
+    assert ks >= 1 and (Cin // 8) % (2 * ks) == 0
+    if ksplit == 0 and (B, H) in ((8, 16), (1, 32)):
+        assert ks > 1                                   # the cases this form exists for: 64 / 32 (region, channel tile) pairs
+    wp = ops.pack_conv_weight_wino(w)
+    y = ops.conv3x3_wino(x, wp, Cout, ksplit=ksplit)
+    ref, _ = _ref(x, w)
+    assert rel_l2(y, ref) < TOL, rel_l2(y, ref)
+    assert float((y.double() - ref).abs().max()) < 1e-4 * float(ref.abs().max())
+    # the whole epilogue, the pre-style output and accumulate -- in the kernel (ks = 1) or in the split-K finisher (ks > 1)
+    pre = torch.empty(B, Cout, H, W, device=dev)
+    y2 = ops.conv3x3_wino(x, wp, Cout, bias=bias, noise_w=nw, noise=noise, style=style, lrelu_slope=0.2, out_scale=0.7, out_pre=pre,
+                          out=base.clone(), accumulate=True, ksplit=ksplit)
+    ref2, ref_pre = _ref(x, w, bias=bias, noise_w=nw, noise=noise, style=style, slope=0.2, out_scale=0.7)
+    assert rel_l2(y2, ref2 + base.double()) < TOL and rel_l2(pre, ref_pre) < TOL
+    assert torch.equal(y, ops.conv3x3_wino(x, wp, Cout, ksplit=ksplit))
+
+
+def test_wino_modulated_sliced(ops):
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(31)
+    B, Cin, Cout, H, W = 2, 128, 64, 16, 16
+    x = torch.randn(B, Cin, H, W, generator=g).to(dev)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)).to(dev)
+    s_ = (torch.rand(B, Cin, generator=g) + 0.5).to(dev)
+    dm = (torch.rand(B, Cout, generator=g) + 0.5).to(dev)
+    bias = torch.randn(Cout, generator=g).to(dev)
+    for ks in (1, 2, 4):
+        y = ops.conv3x3_wino(x, ops.pack_conv_weight_wino(w), Cout, bias=bias, lrelu_slope=0.2, act_gain=2 ** 0.5, out_scale=0.3,
+                             batch_scale=s_, demod=dm, ksplit=ks)
+        ref = F.conv2d(x.double() * s_.double().view(B, Cin, 1, 1), w.double(), padding=1) * 0.3 * dm.double().view(B, Cout, 1, 1)
+        ref = F.leaky_relu(ref + bias.double().view(1, -1, 1, 1), 0.2) * 2 ** 0.5
+        assert rel_l2(y, ref) < TOL, (ks, rel_l2(y, ref))
