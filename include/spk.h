@@ -74,6 +74,10 @@ extern "C" {
                                       * (h, w) is added to y(2h, 2w) -- the data gradient of a stride-2 1x1 conv (the
                                       * trunk's downsample.0, model.py:60-62 via torchvision Bottleneck) joins the block input's
                                       * gradient without ever being dilated in memory.  1x1 stride-1 GEMM form (configs 14, 15). */
+#define SPK_EPI_TORGB 32768u         /* SPK_CONV_WINOGRAD launches with Cout <= 64 only: the 1x1 conv to 3 channels that follows the last
+                                      * synthesis block (styleganv1.py:607: self.to_rgb) runs inside the epilogue -- rgb_y[b,o] = rgb_bias[o] +
+                                      * sum_co rgb_w[o,co] * y[b,co] on the epilogue's own registers; y may then be NULL (the activation is
+                                      * neither stored nor re-read).  No y_pre / ACCUM / modulation, ksplit 1. */
 #define SPK_CONV_UP_FIR1331 512u     /* with UPSAMPLE2X: the x2 interpolation is upfirdn2d(up=2, FIR [1,3,3,1], pad (2,1)) --
                                       * the same (.75,.25) taps as bilinear, but neighbours outside the image are zero */
 
@@ -146,6 +150,12 @@ typedef struct spk_conv2d_desc {
     const float* out_scale_dev; /* optional DEVICE scalar multiplied into out_scale (NULL = 1): 1 / sigma of a spectrally normalised
                                  * weight (styleganv1.py:644-672 wraps every discriminator layer), so that weight_orig is packed once
                                  * per optimizer step instead of W / sigma once per forward.  Tap kernels and SPK_CONV_DGRAD_S2. */
+    /* SPK_EPI_TORGB: rgb_w [rgb_channels = 3][Cout], rgb_bias [3] or NULL, rgb_y [B,3,H,W] (8-byte aligned) */
+    const float* rgb_w;
+    const float* rgb_bias;
+    float* rgb_y;
+    int32_t rgb_channels;
+    int32_t reserved;
 } spk_conv2d_desc;
 
 int spk_conv2d_num_configs(void);

@@ -33,7 +33,8 @@ class Conv2dDesc(C.Structure):
                 ("workspace", C.c_void_p), ("workspace_bytes", C.c_int64),
                 ("out_scale_bc", C.c_void_p), ("act_gain", C.c_float),
                 ("groups", C.c_int32), ("group_in_stride", C.c_int32), ("stats_slots", C.c_int32),
-                ("accum_half", C.c_void_p), ("out_scale_dev", C.c_void_p)]
+                ("accum_half", C.c_void_p), ("out_scale_dev", C.c_void_p),
+                ("rgb_w", C.c_void_p), ("rgb_bias", C.c_void_p), ("rgb_y", C.c_void_p), ("rgb_channels", C.c_int32), ("reserved", C.c_int32)]
 
 
 CONV_IN_BATCH_SCALE = 256
@@ -43,6 +44,7 @@ CONV_TRANSPOSE4X4_S2 = 2048
 CONV_BF16X3 = 4096
 EPI_ACCUM_HALF = 8192
 CONV_WINOGRAD = 16384
+EPI_TORGB = 32768
 
 
 FC_MAX_GROUPS = 16

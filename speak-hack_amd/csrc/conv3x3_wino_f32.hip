@@ -49,8 +49,10 @@ constexpr int U_FLOATS = 16 * CI_T * CO_T, V_FLOATS = 16 * CI_T * NTILE, RAW_FLO
 constexpr int U_OFF = 0, V_OFF = 2 * U_FLOATS, RAW_OFF = V_OFF + 2 * V_FLOATS;
 constexpr int PRM_OFF = RAW_OFF + 2 * RAW_FLOATS;                            // [64 co][bias, noise weight, style s0 + 1, style s1] of the region
 constexpr int DEM_OFF = PRM_OFF + 4 * CO_T;                                  // [64 co] demodulation d[b, co] of the region's image (modulated convs)
-constexpr int LDS_FLOATS = DEM_OFF + CO_T;
-constexpr int LDS_BYTES = LDS_FLOATS * 4;                                    // 154 880
+constexpr int RGBW_OFF = DEM_OFF + CO_T;                                     // [3][64 co] weights of a fused toRGB (SPK_EPI_TORGB)
+constexpr int LDS_FLOATS = RGBW_OFF + 3 * CO_T;
+constexpr int LDS_BYTES = LDS_FLOATS * 4;                                    // 155 648
+constexpr int RGB_PART_OFF = V_OFF + V_FLOATS;                               // toRGB partial sums [4 channel groups][64 tiles][3][4 px]: V slot 1, idle during an epilogue
 static_assert(RAW_GATHERS == 11 && 34 * 10 <= RAW_PLANE && 18 * 18 <= RAW_PLANE, "geometry");
 constexpr int U_DMA = U_FLOATS * 4 / 1024 / 4;                               // 1 KB blocks per wave and chunk (8)
 
@@ -66,6 +68,9 @@ struct Args {
     const float* out_scale_dev;
     const float* in_scale;       // MOD: [B, Cin] modulation s[b, ci] (SPK_CONV_IN_BATCH_SCALE): the conv runs on x * s
     const float* out_scale_bc;   // MOD: [B, Cout] demodulation d[b, co] applied right after the contraction, or null
+    const float* rgb_w;          // RGB: [3][Cout] weights / [3] bias of the 1x1 conv fused behind the epilogue, its output [B,3,H,W]
+    const float* rgb_bias;
+    float* rgb_y;
     int B, Cin, Cout, H, W;
     int regions_x, regions_y;
     int n_chunks;                // of the whole contraction (the packed image's chunk count)
@@ -125,7 +130,10 @@ __device__ __forceinline__ void lds_barrier() {
 // MOD: the modulated convolution of the StyleGAN2 variant.  B^T (d s) B = s B^T d B: the modulation of the
 // plane's channel -- one scalar per plane, the region lies in one image -- multiplies the 16 transformed values (16 more vector ops
 // per plane); the demodulation rides on the epilogue's out_scale through a second LDS table.
-template <bool MOD, int SHAPE>
+// RGB (SPK_EPI_TORGB): the layer's 64 output channels sit in ONE workgroup (Cout <= 64), so the 1x1 conv to 3 channels that follows the
+// last block (styleganv1.py:607) is a reduction over the epilogue's own registers: 12 fused multiply-adds per channel row, the four
+// channel groups (2 waves x 2 half-waves) meet through LDS.  The 134 MB activation is then neither re-read nor -- y == NULL -- written.
+template <bool MOD, int SHAPE, bool RGB = false>
 __global__ __launch_bounds__(NT) void wino_kernel(const Args p) {
     constexpr int RW = region_w(SHAPE), RH = region_h(SHAPE), TXN = RW / 2, RAW_W = RW + 2, RAW_H = RH + 2, RAW_USED = RAW_W * RAW_H;
     extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -239,6 +247,9 @@ __global__ __launch_bounds__(NT) void wino_kernel(const Args p) {
 #define WINO_T_WRITE(vs_, j_, xi_)                                                                                      \
     *((volatile lds_f32_t*)0 + (v_wr + ((vs_) * V_FLOATS + ((xi_) * CI_T + 4 * (j_)) * NTILE))) = tv[j_][xi_];
 
+    if constexpr (RGB) {             // (published by the first chunk barrier, long before the first epilogue)
+        if (tid < 3 * CO_T) smem[RGBW_OFF + tid] = (tid & (CO_T - 1)) < p.Cout ? p.rgb_w[(tid >> 6) * p.Cout + (tid & (CO_T - 1))] : 0.f;
+    }
     const int n = p.cps;
     int reg = reg_begin + wk;
     if (reg >= reg_end) return;
@@ -402,6 +413,11 @@ __global__ __launch_bounds__(NT) void wino_kernel(const Args p) {
         // 16 tiles, and 256 VGPRs of copies push everything else that is alive into scratch -- whose reloads then queue, in
         // vmcnt order, behind the epilogue's own stores (25 000 cycles per region, measured).
 #define WINO_ACC(xi_, r_) ({ float v_; asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v_) : "a"(acc[xi_][r_])); v_; })
+        float rgb[3][4];                                 // RGB: this lane's share (its 16 channel rows) of its tile's 2 x 2 pixels x 3 channels
+#pragma unroll
+        for (int o = 0; o < 3; ++o)
+#pragma unroll
+            for (int q = 0; q < 4; ++q) rgb[o][q] = 0.f;
         static_for<0, 16>([&](auto r_c) {
             constexpr int r = decltype(r_c)::value;
             const int row = row_lane + (r & 3) + 8 * (r >> 2);
@@ -423,7 +439,20 @@ __global__ __launch_bounds__(NT) void wino_kernel(const Args p) {
             top.x = (top.x > 0.f ? top.x : top.x * slope_) * gain_; top.y = (top.y > 0.f ? top.y : top.y * slope_) * gain_;
             bot.x = (bot.x > 0.f ? bot.x : bot.x * slope_) * gain_; bot.y = (bot.y > 0.f ? bot.y : bot.y * slope_) * gain_;
             const int co = co0 + row;
-            if (co < p.Cout) {
+            if constexpr (RGB) {                     // (no y_pre / accumulate with a fused toRGB: host)
+                top.x = top.x * q_.z + q_.w; top.y = top.y * q_.z + q_.w; bot.x = bot.x * q_.z + q_.w; bot.y = bot.y * q_.z + q_.w;
+#pragma unroll
+                for (int o = 0; o < 3; ++o) {
+                    const float w_ = smem[RGBW_OFF + o * CO_T + row];      // (rows past Cout: 0)
+                    rgb[o][0] += w_ * top.x; rgb[o][1] += w_ * top.y; rgb[o][2] += w_ * bot.x; rgb[o][3] += w_ * bot.y;
+                }
+                if (p.y && co < p.Cout) {
+                    const size_t off = o0 + (size_t)co * hw_;
+                    *reinterpret_cast<f32x2*>(p.y + off) = top;
+                    *reinterpret_cast<f32x2*>(p.y + off + p.W) = bot;
+                }
+                __builtin_amdgcn_sched_barrier(0);       // one channel row at a time: hoisted table reads of 16 rows would not fit the registers
+            } else if (co < p.Cout) {
                 const size_t off = o0 + (size_t)co * hw_;
                 if (p.y_pre) {
                     *reinterpret_cast<f32x2*>(p.y_pre + off) = top;
@@ -444,6 +473,29 @@ __global__ __launch_bounds__(NT) void wino_kernel(const Args p) {
             }
         });
 #undef WINO_ACC
+        if constexpr (RGB) {
+            // the four channel groups of a tile: (wm, half) -> LDS [group][tile][3][4], summed in group order by thread (tile, channel)
+            float* part = smem + RGB_PART_OFF + ((wm * 2 + half) * NTILE + tile) * 12;
+#pragma unroll
+            for (int o = 0; o < 3; ++o) *reinterpret_cast<float4*>(part + 4 * o) = make_float4(rgb[o][0], rgb[o][1], rgb[o][2], rgb[o][3]);
+            lds_barrier();
+            if (tid < 3 * NTILE) {
+                const int o = tid >> 6, t = tid & (NTILE - 1);
+                const float* ps = smem + RGB_PART_OFF + t * 12 + 4 * o;
+                float4 v = *reinterpret_cast<const float4*>(ps);
+#pragma unroll
+                for (int g = 1; g < 4; ++g) {
+                    const float4 u = *reinterpret_cast<const float4*>(ps + g * NTILE * 12);
+                    v.x += u.x; v.y += u.y; v.z += u.z; v.w += u.w;
+                }
+                const float bo = p.rgb_bias ? p.rgb_bias[o] : 0.f;
+                const size_t off = ((size_t)cur_b * 3 + o) * hw_ + (size_t)(cur_y0 + 2 * (t / TXN)) * p.W + (cur_x0 + 2 * (t % TXN));
+                f32x2 a_, b_;
+                a_.x = v.x + bo; a_.y = v.y + bo; b_.x = v.z + bo; b_.y = v.w + bo;
+                *reinterpret_cast<f32x2*>(p.rgb_y + off) = a_;
+                *reinterpret_cast<f32x2*>(p.rgb_y + off + p.W) = b_;
+            }
+        }
         LAB_STAMP(4)
         lds_barrier();                               // (the table has been read: the next region may rewrite it)
 #ifdef SPK_WINO_LAB
@@ -525,14 +577,19 @@ int64_t spk_conv2d_wino_workspace_bytes(int ksplit, int B, int Cin, int Cout, in
 
 // entered from spk_conv2d_fwd when desc->flags has SPK_CONV_WINOGRAD
 int spk_conv2d_wino_fwd(const spk_conv2d_desc* d, void* stream) {
-    SPK_REQUIRE(d && d->x && d->w_packed && d->y, "conv2d winograd: null pointer");
+    SPK_REQUIRE(d && d->x && d->w_packed, "conv2d winograd: null pointer");
     SPK_REQUIRE(d->kh == 3 && d->kw == 3 && d->stride == 1, "conv2d winograd: 3x3 stride-1 kernels only");
     SPK_REQUIRE(d->groups <= 1, "conv2d winograd: not grouped");
     const unsigned epi = SPK_EPI_BIAS | SPK_EPI_NOISE | SPK_EPI_LRELU | SPK_EPI_STYLE | SPK_EPI_ACCUM;
-    const unsigned allowed = SPK_CONV_WINOGRAD | epi | SPK_CONV_IN_BATCH_SCALE;
+    const unsigned allowed = SPK_CONV_WINOGRAD | epi | SPK_CONV_IN_BATCH_SCALE | SPK_EPI_TORGB;
     SPK_REQUIRE(!(d->flags & ~allowed) && !d->stats && !d->accum_half,
-                "conv2d winograd: plain or batch-scaled input; epilogue flags bias, noise, lrelu, style, accum");
-    const bool mod = d->flags & SPK_CONV_IN_BATCH_SCALE;
+                "conv2d winograd: plain or batch-scaled input; epilogue flags bias, noise, lrelu, style, accum, torgb");
+    const bool mod = d->flags & SPK_CONV_IN_BATCH_SCALE, rgb = d->flags & SPK_EPI_TORGB;
+    SPK_REQUIRE(d->y || rgb, "conv2d winograd: null pointer");
+    if (rgb)
+        SPK_REQUIRE(d->rgb_w && d->rgb_y && d->rgb_channels == 3 && d->Cout <= CO_T && !mod && !d->y_pre && !(d->flags & SPK_EPI_ACCUM) &&
+                        (reinterpret_cast<uintptr_t>(d->rgb_y) & 7) == 0,
+                    "conv2d winograd: SPK_EPI_TORGB needs rgb_w [3][Cout], rgb_y [B,3,H,W], Cout <= 64 (one channel tile), no y_pre / accumulate / modulation");
     SPK_REQUIRE(!mod || d->in_scale, "conv2d winograd: IN_BATCH_SCALE without in_scale[B,Cin]");
     SPK_REQUIRE(!d->out_scale_bc || mod, "conv2d winograd: out_scale_bc (demodulation) goes with SPK_CONV_IN_BATCH_SCALE");
     SPK_REQUIRE(d->H == d->Hin && d->W == d->Win, "conv2d winograd: output size must equal the input size");
@@ -555,6 +612,7 @@ int spk_conv2d_wino_fwd(const spk_conv2d_desc* d, void* stream) {
     a.x = d->x; a.wp = d->w_packed; a.bias = d->bias; a.noise_w = d->noise_w; a.noise = d->noise; a.style = d->style;
     a.y = d->y; a.y_pre = d->y_pre; a.out_scale_dev = d->out_scale_dev;
     a.in_scale = mod ? d->in_scale : nullptr; a.out_scale_bc = d->out_scale_bc;
+    a.rgb_w = d->rgb_w; a.rgb_bias = d->rgb_bias; a.rgb_y = d->rgb_y;
     a.B = d->B; a.Cin = d->Cin; a.Cout = d->Cout; a.H = d->H; a.W = d->W;
     a.regions_x = d->W / region_w(shape); a.regions_y = d->H / region_h(shape);
     a.n_chunks = spk::ceil_div(d->Cin, CI_T);
@@ -562,14 +620,16 @@ int spk_conv2d_wino_fwd(const spk_conv2d_desc* d, void* stream) {
     a.style_stride = d->style_stride; a.flags = d->flags;
     a.x_bytes = (unsigned)((long long)d->B * d->Cin * d->H * d->W * 4);
     a.slope = d->lrelu_slope; a.out_scale = d->out_scale; a.act_gain = d->act_gain != 0.f ? d->act_gain : 1.f;
+    SPK_REQUIRE(!rgb || ks == 1, "conv2d winograd: SPK_EPI_TORGB with a sliced contraction (%d slices): pass ksplit = 1 or run the 1x1 separately", ks);
     if (ks > 1) {       // partial sums, raw: the whole epilogue (and the demodulation) belongs to the finisher
         a.y = static_cast<float*>(d->workspace); a.y_pre = nullptr; a.out_scale_dev = nullptr; a.out_scale_bc = nullptr;
         a.flags = d->flags & ~epi; a.out_scale = 1.f; a.slice_floats = out_floats;
     }
     void (*kern)(const Args) = mod ? (shape == SQUARE ? &wino_kernel<true, SQUARE> : &wino_kernel<true, WIDE>)
-                                   : (shape == SQUARE ? &wino_kernel<false, SQUARE> : &wino_kernel<false, WIDE>);
-    static bool raised[4] = {false, false, false, false};
-    const int which = (mod ? 2 : 0) + (shape == SQUARE ? 1 : 0);
+                               : rgb ? (shape == SQUARE ? &wino_kernel<false, SQUARE, true> : &wino_kernel<false, WIDE, true>)
+                                     : (shape == SQUARE ? &wino_kernel<false, SQUARE> : &wino_kernel<false, WIDE>);
+    static bool raised[6] = {false, false, false, false, false, false};
+    const int which = (mod ? 2 : rgb ? 4 : 0) + (shape == SQUARE ? 1 : 0);
     if (!raised[which]) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         if (e != hipSuccess) return spk::fail(SPK_ELAUNCH, "hipFuncSetAttribute(LDS): %s", hipGetErrorString(e));

@@ -526,6 +526,7 @@ int spk_conv2d_fwd(const spk_conv2d_desc* d, void* stream) {
     SPK_REQUIRE(d, "conv2d: null descriptor");
     if (d->flags & SPK_CONV_BF16X3) return spk_conv2d_bf16x3_fwd(d, stream);
     if (d->flags & SPK_CONV_WINOGRAD) return spk_conv2d_wino_fwd(d, stream);
+    SPK_REQUIRE(!(d->flags & SPK_EPI_TORGB), "conv2d: SPK_EPI_TORGB is an epilogue of the SPK_CONV_WINOGRAD launches only");
     SPK_REQUIRE(d->x && d->w_packed && d->y, "conv2d: null tensor pointer");
     SPK_REQUIRE(d->B > 0 && d->Cin > 0 && d->Cout > 0 && d->H > 0 && d->W > 0 && d->Hin > 0 && d->Win > 0, "conv2d: bad shape");
     if (d->flags & SPK_CONV_TRANSPOSE4X4_S2) {

@@ -436,11 +436,19 @@ def upsample2x(x, zero_border=False):
 
 def conv3x3_wino(x, w_packed, Cout, *, bias=None, noise_w=None, noise=None, style=None, style_stride=None, lrelu_slope=None,
                  out_scale=1.0, act_gain=1.0, out=None, out_pre=None, accumulate=False, out_scale_dev=None, batch_scale=None, demod=None,
-                 ksplit=0):
+                 ksplit=0, rgb=None, rgb_out=None, store_out=True):
     """3x3 stride-1 pad-1 conv with the fused decoder epilogue as Winograd F(2x2, 3x3): fp32 throughout, 2.25x fewer matrix
-    instructions than the direct form, 1e-6-class rel-L2 against it.  ``w_packed`` from ``pack_conv_weight_wino``."""
+    instructions than the direct form, 1e-6-class rel-L2 against it.  ``w_packed`` from ``pack_conv_weight_wino``.
+    ``rgb`` = (weight [3,Cout,1,1], bias [3] | None): the 1x1 conv of styleganv1.py:607 inside the epilogue (Cout <= 64, unsliced);
+    returns (out, rgb image), and with ``store_out=False`` (None, rgb image) -- the activation is then never written."""
     B, Cin, H, W = x.shape
-    if out is None:
+    if rgb is not None:
+        if Cout > 64 or out_pre is not None or accumulate or batch_scale is not None or tuple(rgb[0].shape[:2]) != (3, Cout):
+            raise L.SpkError("conv3x3_wino: a fused toRGB needs Cout <= 64, weight [3,Cout,1,1], no out_pre / accumulate / modulation")
+        if rgb_out is None:
+            rgb_out = torch.empty((B, 3, H, W), device=x.device, dtype=torch.float32)
+        ksplit = 1
+    if out is None and (rgb is None or store_out):
         out = torch.empty((B, Cout, H, W), device=x.device, dtype=torch.float32)
     if noise is not None and (noise_w is None or noise.numel() != B * H * W):
         raise L.SpkError(f"conv3x3_wino: noise must be [B,1,H,W]={B, 1, H, W}, got {tuple(noise.shape)}")
@@ -452,7 +460,7 @@ def conv3x3_wino(x, w_packed, Cout, *, bias=None, noise_w=None, noise=None, styl
         raise L.SpkError("conv3x3_wino: demod must be [B,Cout] and goes with batch_scale")
     flags = L.CONV_WINOGRAD | (L.EPI_BIAS if bias is not None else 0) | (L.EPI_NOISE if noise is not None else 0) | \
         (L.EPI_LRELU if lrelu_slope is not None else 0) | (L.EPI_STYLE if style is not None else 0) | (L.EPI_ACCUM if accumulate else 0) | \
-        (L.CONV_IN_BATCH_SCALE if batch_scale is not None else 0)
+        (L.CONV_IN_BATCH_SCALE if batch_scale is not None else 0) | (L.EPI_TORGB if rgb is not None else 0)
     d = L.Conv2dDesc(x=L.dptr(x, "x"), w_packed=L.dptr(w_packed, "w_packed"), bias=L.dptr(bias, "bias"),
                      noise_w=L.dptr(noise_w, "noise_w") if noise is not None else None, noise=L.dptr(noise, "noise"),
                      style=_style_ptr(style), in_scale=L.dptr(batch_scale, "batch_scale"), in_shift=None, out_scale_bc=L.dptr(demod, "demod"),
@@ -461,13 +469,16 @@ def conv3x3_wino(x, w_packed, Cout, *, bias=None, noise_w=None, noise=None, styl
                      kh=3, kw=3, stride=1, style_stride=int(style_stride or 0), flags=flags,
                      lrelu_slope=float(lrelu_slope if lrelu_slope is not None else 1.0), out_scale=float(out_scale), config=-1,
                      ksplit=int(ksplit), workspace=None, workspace_bytes=0, groups=1, group_in_stride=0, stats_slots=0,
-                     accum_half=None, out_scale_dev=L.dptr(out_scale_dev, "out_scale_dev"))
+                     accum_half=None, out_scale_dev=L.dptr(out_scale_dev, "out_scale_dev"),
+                     rgb_w=L.dptr(rgb[0].reshape(3, Cout), "rgb weight") if rgb is not None else None,
+                     rgb_bias=L.dptr(rgb[1], "rgb bias") if rgb is not None and rgb[1] is not None else None,
+                     rgb_y=L.dptr(rgb_out, "rgb_out") if rgb is not None else None, rgb_channels=3 if rgb is not None else 0)
     ws_bytes = L.lib().spk_conv2d_wino_workspace_bytes(int(ksplit), B, Cin, Cout, H, W)
     if ws_bytes > 0:                        # few regions: the contraction runs in slices, partial sums through the split-K workspace
         ws = _workspace(x.device, ws_bytes)
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     _launch_conv2d(d)
-    return out
+    return (out, rgb_out) if rgb is not None else out
 
 
 # 3x3 stride-1 spellings used by the decoder

@@ -18,6 +18,7 @@ goes through the autograd Functions.
 from __future__ import annotations
 
 import ctypes as C
+import os
 
 import torch
 
@@ -25,6 +26,7 @@ from . import _lib as L
 from . import ops
 
 LRELU = 0.2
+FUSE_TORGB = os.environ.get("SPK_FUSE_TORGB", "1") != "0"     # toRGB inside the last Winograd launch's epilogue (SPK_EPI_TORGB)
 MAX_PLANS = 4        # per module: (batch, device, stream, entry) combinations kept
 
 
@@ -298,9 +300,19 @@ class DecoderPlan(LaunchPlan):
         self.track(s.to_rgb.weight, s.to_rgb.bias)
         O, Cc = s.to_rgb.weight.shape[:2]
         self.out_shape = (B, O, x.shape[2], x.shape[3])
-        self.torgb = self.add(L.OP_TORGB, L.ToRGBArgs(x=x.data_ptr(), w=L.dptr(s.to_rgb.weight, "weight"), mod=None,
-                                                      bias=L.dptr(s.to_rgb.bias, "bias"), skip=None, y=None, B=B, C=Cc, O=O,
-                                                      H=x.shape[2], W=x.shape[3], in_scale=1.0))
+        last = d                    # the last block's conv2 launch
+        self.rgb_fused = None
+        if (FUSE_TORGB and O == 3 and Cc <= 64 and (last.flags & L.CONV_WINOGRAD)
+                and ops.wino_ksplit(B, last.Cin, Cc, x.shape[2], x.shape[3]) == 1):
+            # the 1x1 rides in that launch's epilogue (SPK_EPI_TORGB): the last activation is neither written nor read back
+            last.flags |= L.EPI_TORGB
+            last.rgb_w, last.rgb_bias, last.rgb_channels = L.dptr(s.to_rgb.weight, "weight"), L.dptr(s.to_rgb.bias, "bias"), 3
+            last.y, last.ksplit = None, 1
+            self.rgb_fused = last
+        else:
+            self.torgb = self.add(L.OP_TORGB, L.ToRGBArgs(x=x.data_ptr(), w=L.dptr(s.to_rgb.weight, "weight"), mod=None,
+                                                          bias=L.dptr(s.to_rgb.bias, "bias"), skip=None, y=None, B=B, C=Cc, O=O,
+                                                          H=x.shape[2], W=x.shape[3], in_scale=1.0))
         self.finish(*([synthesis] + ([generator] if generator is not None else [])))
 
     @staticmethod
@@ -341,7 +353,10 @@ class DecoderPlan(LaunchPlan):
                     raise L.SpkError(f"noise must be {tuple(nv.shape)}, got {tuple(nz.shape)}")
                 d.noise = L.dptr(nz, "noise")
         y = torch.empty(self.out_shape, device=self.device, dtype=torch.float32)
-        self.torgb.y = y.data_ptr()
+        if self.rgb_fused is not None:
+            self.rgb_fused.rgb_y = y.data_ptr()
+        else:
+            self.torgb.y = y.data_ptr()
         self.launch(kind_mask)
         return y
 

@@ -281,8 +281,27 @@ def test_launch_plan_equals_launch_by_launch(pkg, dev):
     feats = recipe_input("plan.features", (B, 6144)).to(dev)
     noises = [n.to(dev) for n in recipe_noises("plan", B, 256)]
     syn = g.synthesis
+    PL = importlib.import_module("speak-hack_amd.plan")
+    with torch.no_grad():
+        # the plan's one extra fusion -- toRGB inside the last Winograd launch's epilogue (SPK_EPI_TORGB) -- sums the 64 channels in
+        # another order than the stand-alone 1x1: equal to rounding, checked first; the bit-for-bit part then runs without it
+        y_fused = g(feats, noises)
+        plan0 = next(iter(g.__dict__["_plans"].values()))
+        assert plan0.rgb_fused is not None or not pkg.ops.use_wino(B, 64, 64, 256, 256)
+        g.__dict__["_plans"].clear()
+        fuse, PL.FUSE_TORGB = PL.FUSE_TORGB, False
+    try:
+        _plan_equals_launches(pkg, dev, g, syn, feats, noises, y_fused)
+    finally:
+        PL.FUSE_TORGB = fuse
+        g.__dict__["_plans"].clear()
+        syn.__dict__["_plans"].clear()
+
+
+def _plan_equals_launches(pkg, dev, g, syn, feats, noises, y_fused):
     with torch.no_grad():
         y_plan = g(feats, noises)
+        assert rel_l2(y_fused, y_plan) < 2e-6 and next(iter(g.__dict__["_plans"].values())).rgb_fused is None
         assert any(k[3] == "features" for k in g.__dict__["_plans"])
         type(syn).use_plan = False
         try:

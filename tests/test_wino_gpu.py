@@ -330,3 +330,30 @@ def test_wino_modulated_sliced(ops):
         ref = F.conv2d(x.double() * s_.double().view(B, Cin, 1, 1), w.double(), padding=1) * 0.3 * dm.double().view(B, Cout, 1, 1)
         ref = F.leaky_relu(ref + bias.double().view(1, -1, 1, 1), 0.2) * 2 ** 0.5
         assert rel_l2(y, ref) < TOL, (ks, rel_l2(y, ref))
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(2, 64, 64, 16, 64), (1, 128, 64, 32, 32), (2, 64, 48, 16, 16), (8, 64, 64, 64, 64)])
+def test_wino_fused_torgb_equals_conv_then_1x1(ops, B, Cin, Cout, H, W):
+    """SPK_EPI_TORGB: the 1x1 conv of styleganv1.py:607 inside the last launch's epilogue -- against fp64 conv -> epilogue -> 1x1, with
+    and without the activation store."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(B + Cin + Cout + H)
+    x = torch.randn(B, Cin, H, W, generator=g).to(dev)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)).to(dev)
+    bias, nw = torch.randn(Cout, generator=g).to(dev), torch.randn(Cout, generator=g).to(dev)
+    noise = torch.randn(B, 1, H, W, generator=g).to(dev)
+    style = torch.randn(B, 2 * Cout, generator=g).to(dev)
+    rw = (torch.randn(3, Cout, 1, 1, generator=g) / Cout ** 0.5).to(dev)
+    rb = torch.randn(3, generator=g).to(dev)
+    wp = ops.pack_conv_weight_wino(w)
+    ref, _ = _ref(x, w, bias=bias, noise_w=nw, noise=noise, style=style, slope=0.2)
+    ref_rgb = F.conv2d(ref, rw.double(), rb.double())
+    y, rgb = ops.conv3x3_wino(x, wp, Cout, bias=bias, noise_w=nw, noise=noise, style=style, lrelu_slope=0.2, rgb=(rw, rb))
+    assert rel_l2(y, ref) < TOL and rel_l2(rgb, ref_rgb) < TOL, (rel_l2(y, ref), rel_l2(rgb, ref_rgb))
+    none, rgb2 = ops.conv3x3_wino(x, wp, Cout, bias=bias, noise_w=nw, noise=noise, style=style, lrelu_slope=0.2, rgb=(rw, rb), store_out=False)
+    assert none is None and torch.equal(rgb, rgb2)
+    _, rgb3 = ops.conv3x3_wino(x, wp, Cout, rgb=(rw, None))                           # no epilogue stage, no bias
+    assert rel_l2(rgb3, F.conv2d(_ref(x, w)[0], rw.double())) < TOL
+    L = importlib.import_module("speak-hack_amd")._lib
+    with pytest.raises(L.SpkError):
+        ops.conv3x3_wino(x, wp, Cout, rgb=(rw, rb), accumulate=True, out=torch.zeros(B, Cout, H, W, device=dev))
