@@ -285,6 +285,109 @@ __global__ __launch_bounds__(256) void upsample2x_vec_kernel(const float* __rest
     *reinterpret_cast<float4*>(yp + 2 * Win + 4) = make_float4(od[4], od[5], od[6], od[7]);
 }
 
+// The same image with FULLY contiguous stores: a thread owns TWO input columns = one 16-byte group of each of its two output rows, so a
+// store instruction of the wave writes 1 KB without gaps (the 4-column form above writes 32 bytes per thread as two 16-byte halves: every
+// instruction touches every other 16 bytes -- 3.8 TB/s of the ~7 TB/s a plain fill reaches).  Same taps, same expressions, same bits.
+template <bool ZB>
+__global__ __launch_bounds__(256) void upsample2x_vec2_kernel(const float* __restrict__ x, float* __restrict__ y, int Hin, int Win) {
+    const int Wq = Win >> 1;
+    const int t_raw = blockIdx.x * 256 + threadIdx.x;             // over Hin * Wq
+    const bool live = t_raw < Hin * Wq;
+    const int t = live ? t_raw : Hin * Wq - 1;                    // (idle lanes of the last wave shadow the last element: they take part in the shuffles)
+    const int m = t / Wq, qb = t - m * Wq, c0 = 2 * qb, lane = threadIdx.x & 63;
+    const float* xp = x + (size_t)blockIdx.y * Hin * Win;
+    const int r0 = max(m - 1, 0), r2 = min(m + 1, Hin - 1), cl = max(c0 - 1, 0), cr = min(c0 + 2, Win - 1);
+    const float2 a = *reinterpret_cast<const float2*>(xp + (size_t)r0 * Win + c0);
+    const float2 b = *reinterpret_cast<const float2*>(xp + (size_t)m * Win + c0);
+    const float2 c = *reinterpret_cast<const float2*>(xp + (size_t)r2 * Win + c0);
+    // the column left / right of the pair: the neighbour lane's value (three 8-byte loads per thread instead of nine loads); the
+    // lanes at a row's or the wave's edge load theirs
+    float al = __shfl_up(a.y, 1), bl = __shfl_up(b.y, 1), cl_ = __shfl_up(c.y, 1);
+    float ar = __shfl_down(a.x, 1), br = __shfl_down(b.x, 1), cr_ = __shfl_down(c.x, 1);
+    if (qb == 0 || lane == 0) {
+        al = xp[(size_t)r0 * Win + cl]; bl = xp[(size_t)m * Win + cl]; cl_ = xp[(size_t)r2 * Win + cl];
+    }
+    if (qb == Wq - 1 || lane == 63) {
+        ar = xp[(size_t)r0 * Win + cr]; br = xp[(size_t)m * Win + cr]; cr_ = xp[(size_t)r2 * Win + cr];
+    }
+    if constexpr (ZB) {
+        if (c0 + 2 >= Win) ar = br = cr_ = 0.f;
+    }
+    const float e0 = c0 == 0 ? 1.f : 0.25f, e1 = c0 == 0 ? 0.f : 0.75f;
+    auto hrow = [&](const float2& v, float l, float r, float (&o)[4]) {
+        o[0] = c0 == 0 ? (ZB ? 0.75f * v.x : e0 * v.x + e1 * v.y) : 0.25f * l + 0.75f * v.x;
+        o[1] = 0.75f * v.x + 0.25f * v.y;
+        o[2] = 0.25f * v.x + 0.75f * v.y;
+        o[3] = 0.75f * v.y + 0.25f * r;
+    };
+    float ha[4], hb[4], hc[4];
+    hrow(a, al, ar, ha);
+    hrow(b, bl, br, hb);
+    hrow(c, cl_, cr_, hc);
+    float* yp = y + (size_t)blockIdx.y * 4 * Hin * Win + (size_t)(2 * m) * (2 * Win) + 2 * c0;
+    float ev[4], od[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        ev[k] = m == 0 ? (ZB ? 0.75f * hb[k] : 1.f * hb[k] + 0.f * hc[k]) : 0.25f * ha[k] + 0.75f * hb[k];
+        od[k] = (ZB && m == Hin - 1) ? 0.75f * hb[k] : 0.75f * hb[k] + 0.25f * hc[k];
+    }
+    if (!live) return;
+    *reinterpret_cast<float4*>(yp) = make_float4(ev[0], ev[1], ev[2], ev[3]);
+    *reinterpret_cast<float4*>(yp + 2 * Win) = make_float4(od[0], od[1], od[2], od[3]);
+}
+
+// ... and TWO input rows per thread (Hin even): four row loads feed four output rows (1 load per 16-byte store instead of 1.5).
+template <bool ZB>
+__global__ __launch_bounds__(256) void upsample2x_vec2x2_kernel(const float* __restrict__ x, float* __restrict__ y, int Hin, int Win) {
+    const int Wq = Win >> 1, Hq = Hin >> 1;
+    const int t_raw = blockIdx.x * 256 + threadIdx.x;             // over Hq * Wq
+    const bool live = t_raw < Hq * Wq;
+    const int t = live ? t_raw : Hq * Wq - 1;
+    const int mp = t / Wq, qb = t - mp * Wq, c0 = 2 * qb, lane = threadIdx.x & 63, m0 = 2 * mp;
+    const float* xp = x + (size_t)blockIdx.y * Hin * Win;
+    const int cl = max(c0 - 1, 0), cr = min(c0 + 2, Win - 1);
+    const int rows[4] = {max(m0 - 1, 0), m0, m0 + 1, min(m0 + 2, Hin - 1)};
+    float2 v[4];
+    float vl[4], vr[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = *reinterpret_cast<const float2*>(xp + (size_t)rows[k] * Win + c0);
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { vl[k] = __shfl_up(v[k].y, 1); vr[k] = __shfl_down(v[k].x, 1); }
+    if (qb == 0 || lane == 0) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) vl[k] = xp[(size_t)rows[k] * Win + cl];
+    }
+    if (qb == Wq - 1 || lane == 63) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) vr[k] = xp[(size_t)rows[k] * Win + cr];
+    }
+    if constexpr (ZB) {
+        if (c0 + 2 >= Win) { vr[0] = vr[1] = vr[2] = vr[3] = 0.f; }
+    }
+    const float e0 = c0 == 0 ? 1.f : 0.25f, e1 = c0 == 0 ? 0.f : 0.75f;
+    float h[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        h[k][0] = c0 == 0 ? (ZB ? 0.75f * v[k].x : e0 * v[k].x + e1 * v[k].y) : 0.25f * vl[k] + 0.75f * v[k].x;
+        h[k][1] = 0.75f * v[k].x + 0.25f * v[k].y;
+        h[k][2] = 0.25f * v[k].x + 0.75f * v[k].y;
+        h[k][3] = 0.75f * v[k].y + 0.25f * vr[k];
+    }
+    if (!live) return;
+    float* yp = y + (size_t)blockIdx.y * 4 * Hin * Win + (size_t)(2 * m0) * (2 * Win) + 2 * c0;
+    float o[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        // input row m0 (h[1], above h[0], below h[2]) and row m0 + 1 (h[2], above h[1], below h[3])
+        o[0][k] = m0 == 0 ? (ZB ? 0.75f * h[1][k] : 1.f * h[1][k] + 0.f * h[2][k]) : 0.25f * h[0][k] + 0.75f * h[1][k];
+        o[1][k] = 0.75f * h[1][k] + 0.25f * h[2][k];
+        o[2][k] = 0.25f * h[1][k] + 0.75f * h[2][k];
+        o[3][k] = (ZB && m0 + 1 == Hin - 1) ? 0.75f * h[2][k] : 0.75f * h[2][k] + 0.25f * h[3][k];
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) *reinterpret_cast<float4*>(yp + (size_t)r * 2 * Win) = make_float4(o[r][0], o[r][1], o[r][2], o[r][3]);
+}
+
 inline unsigned stream_grid(long long work_items, int threads) {
     const long long blocks = (work_items + threads - 1) / threads;
     return (unsigned)std::max(1ll, std::min(blocks, 256ll * 8));
@@ -361,6 +464,19 @@ int spk_upsample2x_fwd(const float* x, float* y, int64_t planes, int Hin, int Wi
     const bool vec = Win % 4 == 0 && planes < 65536 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0;
     if (!zero_border && !vec) return spk_upsample2x_bilinear_fwd(x, y, planes, Hin, Win, stream);
     SPK_REQUIRE(vec, "upsample2x: the zero-border (upfirdn2d [1,3,3,1]) form needs Win %% 4 == 0, 16-byte aligned tensors, < 65536 planes");
+    static const int form = [] { const char* e = getenv("SPK_UPSAMPLE_FORM"); return e ? atoi(e) : 22; }();    // lab: 4 = the 4-column threads, 2 = two columns x one row
+    if (form == 22 && Hin % 2 == 0) {
+        dim3 grid3((unsigned)(((Hin >> 1) * (Win >> 1) + 255) / 256), (unsigned)planes);
+        if (zero_border) hipLaunchKernelGGL(upsample2x_vec2x2_kernel<true>, grid3, dim3(256), 0, (hipStream_t)stream, x, y, Hin, Win);
+        else hipLaunchKernelGGL(upsample2x_vec2x2_kernel<false>, grid3, dim3(256), 0, (hipStream_t)stream, x, y, Hin, Win);
+        return spk::check_launch("upsample2x_vec2x2_kernel");
+    }
+    if (form == 2 || form == 22) {
+        dim3 grid2((unsigned)((Hin * (Win >> 1) + 255) / 256), (unsigned)planes);
+        if (zero_border) hipLaunchKernelGGL(upsample2x_vec2_kernel<true>, grid2, dim3(256), 0, (hipStream_t)stream, x, y, Hin, Win);
+        else hipLaunchKernelGGL(upsample2x_vec2_kernel<false>, grid2, dim3(256), 0, (hipStream_t)stream, x, y, Hin, Win);
+        return spk::check_launch("upsample2x_vec2_kernel");
+    }
     dim3 grid((unsigned)((Hin * (Win >> 2) + 255) / 256), (unsigned)planes);
     if (zero_border) hipLaunchKernelGGL(upsample2x_vec_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, x, y, Hin, Win);
     else hipLaunchKernelGGL(upsample2x_vec_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, x, y, Hin, Win);
@@ -370,11 +486,8 @@ int spk_upsample2x_fwd(const float* x, float* y, int64_t planes, int Hin, int Wi
 int spk_upsample2x_bilinear_fwd(const float* x, float* y, int64_t planes, int Hin, int Win, void* stream) {
     SPK_REQUIRE(x && y, "upsample2x: null pointer");
     SPK_REQUIRE(planes > 0 && Hin > 0 && Win > 0, "upsample2x: bad shape");
-    if (Win % 4 == 0 && planes < 65536 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0) {
-        hipLaunchKernelGGL(upsample2x_vec_kernel<false>, dim3((unsigned)((Hin * (Win >> 2) + 255) / 256), (unsigned)planes), dim3(256), 0,
-                           (hipStream_t)stream, x, y, Hin, Win);
-        return spk::check_launch("upsample2x_vec_kernel");
-    }
+    if (Win % 4 == 0 && planes < 65536 && (reinterpret_cast<uintptr_t>(x) & 15) == 0 && (reinterpret_cast<uintptr_t>(y) & 15) == 0)
+        return spk_upsample2x_fwd(x, y, planes, Hin, Win, 0, stream);      // (one kernel for both entry points: the same bits)
     hipLaunchKernelGGL(upsample2x_kernel, dim3(stream_grid(planes * 2ll * Hin * ((2 * Win + 3) / 4), 256)), dim3(256), 0,
                        (hipStream_t)stream, x, y, (long long)planes, Hin, Win);
     return spk::check_launch("upsample2x_kernel");
