@@ -173,6 +173,65 @@ __global__ __launch_bounds__(256) void upsample2x_bwd_vec_kernel(const float* __
     }
 }
 
+// ... and TWO source rows per thread (Hin even): six upsampled rows feed two output rows (3 row reads per output row instead of 4),
+// the columns left / right of a thread's eight by lane shuffle (twelve 16-byte loads per thread and no dword gathers: the form above
+// issues sixteen loads per output row and ran the 256^2 layer's 335 MB at 1.9 TB/s).
+__global__ __launch_bounds__(256) void upsample2x_bwd_vec2_kernel(const float* __restrict__ dy, float* __restrict__ dx,
+                                                                 long long planes, int Hin, int Win) {
+    const int Ho = 2 * Hin, Wo = 2 * Win, W4 = Win >> 2, H2 = Hin >> 1, lane = threadIdx.x & 63;
+    const long long total = planes * H2 * W4;
+    const long long rounds = (total + (long long)gridDim.x * blockDim.x - 1) / ((long long)gridDim.x * blockDim.x);
+    for (long long it = 0; it < rounds; ++it) {          // (every lane runs every round: the shuffles below are wave-wide)
+        const long long idx_raw = it * (long long)gridDim.x * blockDim.x + (long long)blockIdx.x * blockDim.x + threadIdx.x;
+        const bool live = idx_raw < total;
+        const long long idx = live ? idx_raw : total - 1;
+        const int q = (int)(idx % W4), ix = q * 4, iy = (int)((idx / W4) % H2) * 2;
+        const long long pl = idx / ((long long)W4 * H2);
+        const float* g = dy + pl * Ho * Wo;
+        float4 a[6], b[6];
+        float l[6], r[6];
+#pragma unroll
+        for (int ky = 0; ky < 6; ++ky) {
+            const float* row = g + (size_t)min(max(2 * iy - 1 + ky, 0), Ho - 1) * Wo + 2 * ix;
+            a[ky] = *reinterpret_cast<const float4*>(row);
+            b[ky] = *reinterpret_cast<const float4*>(row + 4);
+        }
+#pragma unroll
+        for (int ky = 0; ky < 6; ++ky) { l[ky] = __shfl_up(b[ky].w, 1); r[ky] = __shfl_down(a[ky].x, 1); }
+        if (q == 0 || lane == 0) {                       // (a row's first thread: weight 0; a wave's first lane: its own load)
+#pragma unroll
+            for (int ky = 0; ky < 6; ++ky) l[ky] = (g + (size_t)min(max(2 * iy - 1 + ky, 0), Ho - 1) * Wo + 2 * ix)[ix > 0 ? -1 : 0];
+        }
+        if (q == W4 - 1 || lane == 63) {
+#pragma unroll
+            for (int ky = 0; ky < 6; ++ky) r[ky] = (g + (size_t)min(max(2 * iy - 1 + ky, 0), Ho - 1) * Wo + 2 * ix)[ix + 4 < Win ? 8 : 7];
+        }
+        float h[6][4];
+#pragma unroll
+        for (int ky = 0; ky < 6; ++ky) {
+            const float e[10] = {l[ky], a[ky].x, a[ky].y, a[ky].z, a[ky].w, b[ky].x, b[ky].y, b[ky].z, b[ky].w, r[ky]};
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                const int i = ix + j;
+                h[ky][j] = (i > 0 ? 0.25f : 0.f) * e[2 * j] + (i > 0 ? 0.75f : 1.f) * e[2 * j + 1] +
+                           (i < Win - 1 ? 0.75f : 1.f) * e[2 * j + 2] + (i < Win - 1 ? 0.25f : 0.f) * e[2 * j + 3];
+            }
+        }
+        if (!live) continue;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int y = iy + rr;
+            const float wy[4] = {y > 0 ? 0.25f : 0.f, y > 0 ? 0.75f : 1.f, y < Hin - 1 ? 0.75f : 1.f, y < Hin - 1 ? 0.25f : 0.f};
+            float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ky = 0; ky < 4; ++ky)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[j] += wy[ky] * h[2 * rr + ky][j];
+            *reinterpret_cast<float4*>(dx + (pl * Hin + y) * (long long)Win + ix) = make_float4(acc[0], acc[1], acc[2], acc[3]);
+        }
+    }
+}
+
 // toRGB backward, data half: dx[b,c,p] = in_scale * sum_o w[o,c] * dy[b,o,p]   (one streaming pass, 16-B accesses)
 template <bool VEC>
 __global__ __launch_bounds__(256) void conv1x1_small_bwd_data_kernel(const float* __restrict__ w, const float* __restrict__ dy,
@@ -543,6 +602,12 @@ int spk_epilogue_bwd(const float* dy, const float* a, const float* noise, const 
 int spk_upsample2x_bilinear_bwd(const float* dy, float* dx, int64_t planes, int Hin, int Win, void* stream) {
     SPK_REQUIRE(dy && dx && planes > 0 && Hin > 0 && Win > 0, "upsample2x_bwd: bad arguments");
     const long long total = planes * Hin * Win;
+    static const int form = [] { const char* e = getenv("SPK_UPSAMPLE_BWD_FORM"); return e ? atoi(e) : 2; }();       // lab: 1 = one source row per thread
+    if (form == 2 && Win % 4 == 0 && Hin % 2 == 0 && ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0) {
+        hipLaunchKernelGGL(upsample2x_bwd_vec2_kernel, dim3((unsigned)std::min((total / 8 + 255) / 256, 256ll * 256)), dim3(256), 0,
+                           (hipStream_t)stream, dy, dx, (long long)planes, Hin, Win);
+        return spk::check_launch("upsample2x_bwd_vec2_kernel");
+    }
     if (Win % 4 == 0 && ((reinterpret_cast<uintptr_t>(dy) | reinterpret_cast<uintptr_t>(dx)) & 15) == 0) {
         hipLaunchKernelGGL(upsample2x_bwd_vec_kernel, dim3((unsigned)std::min((total / 4 + 255) / 256, 256ll * 256)), dim3(256), 0,
                            (hipStream_t)stream, dy, dx, (long long)planes, Hin, Win);
