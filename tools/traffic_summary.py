@@ -4,7 +4,7 @@
 
     python tools/traffic_summary.py gpurun_out/r2/pmc_fetch gpurun_out/r2/pmc_write [--json profiles/conv_traffic.json]
 
-Calls are told apart by their toRGB launch (the last kernel of a decoder forward); the first call of each precision builds
+Calls are told apart by their prologue launch (the first kernel of a decoder forward); the first call of each precision builds
 the launch plan and is dropped.  FETCH_SIZE / WRITE_SIZE are in KiB (MI355X_MICROARCH.md, HBM section).
 """
 import csv
@@ -26,11 +26,13 @@ def calls(d, counter):
         n = r["Kernel_Name"]
         if "conv_kernel<" in n and ", 3, 3, 1, " in n or "conv3x3_bf16x3_kernel" in n or "wino_kernel" in n:
             cur.append((n, float(r["Counter_Value"]) * 1024.0))
-        if "upsample2x_kernel" in n:            # the x2 image a Winograd x2 layer reads (its own launch): reported beside the convs
+        if "upsample2x_" in n and "bwd" not in n:      # the x2 image a Winograd x2 layer reads (its own launch): reported beside the convs
             UPS.setdefault(counter, []).append(float(r["Counter_Value"]) * 1024.0)
-        if "conv1x1_small" in n:
-            out.append(cur)
+        if "bias_noise_style_kernel" in n and cur:     # a forward's FIRST launch (the const-input prologue): the previous one is complete
+            out.append(cur)                            # (its last launch used to be toRGB -- now inside the last conv's epilogue)
             cur = []
+    if cur:
+        out.append(cur)
     return out
 
 
@@ -83,8 +85,8 @@ def main():
     if "--json" in sys.argv:
         fb, wb, n = res["f32"]
         out = {"source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over `python3 tools/pmc_decoder.py` "
-                         "(the headline decoder step launched eagerly through its launch plan); summary in profiles/r04_e_conv_traffic.txt",
-               "kernel": "spkwino::wino_kernel (8 launches) + spkconv::conv_kernel<Cfg,3,3,1,MODE 0|1> (4 launches)", "launches_per_step": 12, "steps_counted": n,
+                         "(the headline decoder step launched eagerly through its launch plan); summary in profiles/r04_g_conv_traffic_final.txt",
+               "kernel": "spkwino::wino_kernel (10 launches: 8 with 32 x 8 regions -- the last with toRGB in its epilogue --, 2 with 16 x 16 regions and a sliced contraction) + spkconv::conv_kernel<Cfg,3,3,1,MODE 0|1> (the two 8^2 layers)", "launches_per_step": 12, "steps_counted": n,
                "fetch_bytes_per_step": int(fb), "write_bytes_per_step": int(wb), "bytes_per_launch": int((fb + wb) / 12),
                "bf16x3_fetch_bytes_per_step": int(res["bf16x3"][0]), "bf16x3_write_bytes_per_step": int(res["bf16x3"][1]),
                "correction": "FETCH_SIZE / WRITE_SIZE are KiB.  The input gathers are 4-byte-per-lane loads, which FETCH_SIZE counts in full "
