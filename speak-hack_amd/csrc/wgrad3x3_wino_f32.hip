@@ -7,7 +7,8 @@
 // -- 16 multiply-adds per tile (4 output pixels) and (co, ci) pair where the direct weight gradient spends 36.  fp32 operands,
 // products and accumulation; replaces the weight-gradient half of F.conv2d's backward for styleganv1.py:625,630 (SynthesisBlock conv1 /
 // conv2; a x2 layer passes the materialised x2 image) and styleganv1.py:662 (DiscriminatorBlock conv1), first-order and inside the
-// R1 double backward (train.py:246-255).
+// R1 double backward (train.py:246-255); and -- groups + folded pass pairs + a BatchNorm-folded input, wgrad_wino_kernel<AFFINE_RELU> --
+// for conv2 of the torchvision Bottlenecks of the three encoders (model.py:60-62, :84-90) at 64^2 / 32^2 / 16^2.
 //
 // One workgroup owns a 64 co x 64 ci block of dU for a contiguous run of CHUNKS of 8 tiles (one row of 8 tiles = 2 x 16 output
 // pixels); the MFMA loop is the forward kernel's -- A = P[xi][tile][co], B = V[xi][tile][ci], k = the tile pair, 64 MFMAs per chunk,
@@ -49,7 +50,7 @@ constexpr int X_DMA = 6;                                   // 16-byte pieces per
 struct Args {
     const float* g;
     const float* x;
-    float* slabs;            // [splits][Cout][9][Cin]
+    float* slabs;            // [splits][G * Cout][9][Cin]
     const float* in_scale;   // MOD: s[B][Cin]  -- the conv's input was x * s;  AFFINE: scale[Cx] -- it was relu(x * scale + shift)
     const float* in_shift;   // AFFINE: shift[Cx]
     const float* g_scale;    // MOD: d'[B][Cout] -- the gradient that reaches the conv output is g * d'
