@@ -280,7 +280,10 @@ __global__ __launch_bounds__(NT) void wino_kernel(const Args p) {
     // i & 1 (n is even: every region starts in slot 0); during it the weights of the stream's next chunk and the raw planes of
     // the one after that are requested, and the raw planes of the next chunk become its V -- across a region boundary these
     // belong to the NEXT region, so that a region's first operands are in LDS when its predecessor's epilogue ends ----
-    constexpr int PD = 4;                            // fragment prefetch distance in MFMAs
+#ifndef SPK_WINO_PD
+#define SPK_WINO_PD 4
+#endif
+    constexpr int PD = SPK_WINO_PD;                  // fragment prefetch distance in MFMAs (lab: -DSPK_WINO_PD=n)
     float fa[PD + 1], fb[PD + 1];
 #define WINO_FRAG(slot_, s_, reg_)                                                                                      \
     {                                                                                                                   \
