@@ -169,6 +169,10 @@ int spk_conv2d_pick_config(int kh, int kw, int stride, int B, int Cin, int Cout,
  * Cin = channels of the output-side gradient, Cout = channels of the input-side one, Hin x Win = the gradient's size):
  * 13 = the exact-tap kernel, else one of 0-3 */
 int spk_conv2d_dgrad_s2_config(int B, int Cin, int Cout, int Hin, int Win);
+/* SPK_CONV_DGRAD_S2 with the exact-tap kernel (config 13) and few workgroups (small gradient planes): with desc->ksplit != 1 and a
+ * workspace of this many bytes (0: none needed) the contraction runs in slices and the split-K finisher adds them up.  Arguments as
+ * the DGRAD_S2 descriptor's: Cin / Hin / Win describe the output-side gradient, Cout / H / W the input-side one. */
+int64_t spk_conv2d_dgrad_s2_workspace_bytes(int B, int Cin, int Cout, int Hin, int Win, int H, int W, int groups);
 /* CO_T / CI_T / PIX_T of a config (any out pointer may be NULL) */
 int spk_conv2d_config_info(int config, int* co_tile, int* ci_tile, int* pix_tile);
 /* number of floats of the packed image of a [Cout,Cin,kh,kw] weight for `config` (<0 = bad args) */

@@ -206,6 +206,7 @@ _PROTOTYPES = {
     "spk_conv2d_config_valid": (C.c_int, [C.c_int] * 4),
     "spk_conv2d_pick_config": (C.c_int, [C.c_int] * 8),
     "spk_conv2d_dgrad_s2_config": (C.c_int, [C.c_int] * 5),
+    "spk_conv2d_dgrad_s2_workspace_bytes": (C.c_int64, [C.c_int] * 8),
     "spk_conv2d_config_info": (C.c_int, [C.c_int, C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     "spk_conv2d_packed_floats": (C.c_int64, [C.c_int] * 5),
     "spk_conv2d_workspace_bytes": (C.c_int64, [C.c_int] * 10),

@@ -451,6 +451,13 @@ int64_t spk_conv2d_workspace_bytes_grouped(int config, int ksplit, int kh, int k
     return ks > 1 ? (int64_t)ks * B * groups * Cout * H * W * (int64_t)sizeof(float) : 0;
 }
 
+int64_t spk_conv2d_dgrad_s2_workspace_bytes(int B, int Cin, int Cout, int Hin, int Win, int H, int W, int groups) {
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || Hin <= 0 || Win <= 0 || H <= 0 || W <= 0 || groups < 1) return -1;
+    if (spk_conv2d_dgrad_s2_config(B, Cin, Cout, Hin, Win) != kDgradS2Config) return 0;
+    const int ks = dgrad_s2_ksplit(B, Cin, Cout, Hin, Win, groups);
+    return ks > 1 ? (int64_t)ks * B * groups * Cout * H * W * (int64_t)sizeof(float) : 0;
+}
+
 int spk_conv2d_stats_slots(int config, int kh, int kw, int stride, int B, int Cin, int Cout, int H, int W) {
     if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0 || !supported_kernel(kh, kw, stride)) return -1;
     if (config < 0) config = pick_config(kh, stride, B, Cin, Cout, H, W);

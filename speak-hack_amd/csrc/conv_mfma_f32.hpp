@@ -969,6 +969,7 @@ int run_2x2_parity(int cfg, const spk_conv2d_desc* d, int Hd, int Wd, int pshift
 int run_1x1_gemm(const spk_conv2d_desc* d, hipStream_t s);                                // id 12
 int run_dgrad_s2_fused(const spk_conv2d_desc* d, hipStream_t s);                          // id 13
 bool dgrad_s2_fused_takes(int B, int K, int Cc, int Hg, int Wg);
+int dgrad_s2_ksplit(int B, int K, int Cc, int Hg, int Wg, int G);         // contraction slices of the exact-tap kernel (1 = none)
 long long dgrad_s2_fused_packed_floats(int K, int Cc);
 bool gemm1x1_takes(int kh, int stride, int Cin, int H, int W);
 long long gemm1x1_pixel_tiles(int B, int H, int W);

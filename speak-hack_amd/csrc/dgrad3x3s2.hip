@@ -16,7 +16,7 @@
 // replaces: the input-gradient half of F.conv2d's backward for the stride-2 3x3 convs on the path -- conv2 of the first
 // bottleneck of layer2-4 of the torchvision trunk (model.py:60-62), conv2 of every StyleDiscriminator block
 // (styleganv1.py:644-657).
-#include "spk_common.hpp"
+#include "conv_mfma_f32.hpp"      // (ConvArgs + launch_splitk_epilogue for the sliced form)
 
 #include <algorithm>
 #include <type_traits>
@@ -41,6 +41,8 @@ struct Args {
     float* y;                // [B, G*Cc, Hd, Wd]  input-side gradient
     int B, K, Cc, Hg, Wg, Hd, Wd;      // K / Cc per group
     int G, gin, Cg, Cy, co_tiles_g, n_chunks;
+    int cps;                 // chunks per contraction slice (blockIdx.z): slice z writes its partial sums at y + z * slice_floats
+    size_t slice_floats;
     int tiles_x, tiles_y;
     int accumulate;
     float out_scale;
@@ -70,6 +72,7 @@ __global__ __launch_bounds__(256, 2) void dgrad3x3s2_kernel(const Args p) {
     const int grp = (int)blockIdx.y / p.co_tiles_g;
     const int co0 = ((int)blockIdx.y - grp * p.co_tiles_g) * CO_T;          // within the group
     const size_t HWg = (size_t)p.Hg * p.Wg;
+    const int c_begin = (int)blockIdx.z * p.cps, c_end = min(c_begin + p.cps, p.n_chunks);      // (host: c_begin < n_chunks)
 
     // ---- gradient-tile staging roles: element e = tid + 256 i of the [8][9][17] tile (LDS offset = e) ----
     int g_off[GROUNDS], g_k[GROUNDS];
@@ -120,10 +123,10 @@ __global__ __launch_bounds__(256, 2) void dgrad3x3s2_kernel(const Args p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[q][n][r] = 0.f;
 
-    // ---- prologue: chunk 0 -> stage 0 ----
-    w_dma(smem, 0);
-    g_issue(0);
-    g_store(smem, 0);
+    // ---- prologue: the slice's first chunk -> stage 0 ----
+    w_dma(smem, c_begin);
+    g_issue(c_begin);
+    g_store(smem, c_begin);
     __builtin_amdgcn_s_waitcnt(0x0f70);                    // vmcnt(0): this wave's LDS-DMA blocks have landed
     __syncthreads();
 
@@ -133,10 +136,10 @@ __global__ __launch_bounds__(256, 2) void dgrad3x3s2_kernel(const Args p) {
 #pragma unroll
     for (int n = 0; n < 2; ++n) b_base[n] = W_FLOATS + half * PLANE + (2 * (2 * wpix + n) + (l32 >> 4)) * PW + (l32 & 15);   // + 2 s PLANE + a PW + b
 
-    for (int i = 0; i < p.n_chunks; ++i) {
-        const float* cur = smem + (i & 1) * STAGE;
-        float* nxt = smem + ((i + 1) & 1) * STAGE;
-        const bool more = i + 1 < p.n_chunks;                                   // uniform
+    for (int i = c_begin; i < c_end; ++i) {
+        const float* cur = smem + ((i - c_begin) & 1) * STAGE;
+        float* nxt = smem + ((i - c_begin + 1) & 1) * STAGE;
+        const bool more = i + 1 < c_end;                                        // uniform
         if (more) {
             w_dma(nxt, i + 1);
             g_issue(i + 1);
@@ -189,7 +192,7 @@ __global__ __launch_bounds__(256, 2) void dgrad3x3s2_kernel(const Args p) {
             for (int r = 0; r < 16; ++r) {
                 const int c = co0 + wc * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
                 if (c >= p.Cc) continue;
-                float* dst = p.y + (((size_t)b * p.Cy + (size_t)grp * p.Cc + c) * p.Hd + Y) * p.Wd + X;
+                float* dst = p.y + (size_t)blockIdx.z * p.slice_floats + (((size_t)b * p.Cy + (size_t)grp * p.Cc + c) * p.Hd + Y) * p.Wd + X;
                 float v0 = acc[2 * qy][n][r] * osc, v1 = acc[2 * qy + 1][n][r] * osc;
                 if (pair_ok) {                             // Wd even: X + 1 exists and the pair is 8-byte aligned
                     if (p.accumulate) {
@@ -239,9 +242,33 @@ int run_dgrad_s2_fused(const spk_conv2d_desc* d, hipStream_t stream) {
     SPK_REQUIRE((reinterpret_cast<uintptr_t>(d->w_packed) & 15) == 0, "conv2d: DGRAD_S2 (config 13): w_packed must be 16-byte aligned");
     const long long gx = (long long)a.tiles_x * a.tiles_y * d->B;
     SPK_REQUIRE(gx < (1ll << 31) && a.G * a.co_tiles_g < 65536, "conv2d: grid too large");
-    dim3 grid((unsigned)gx, (unsigned)(a.G * a.co_tiles_g));
+    // few workgroups (a 16^2 gradient at B = 8: 16 pixel tiles x 8 channel tiles for 512 slots of two per CU): the contraction runs in
+    // slices, partial sums through the caller's split-K workspace, the direct kernels' finisher adds them up (scale, accumulate)
+    const int ks = dgrad_s2_ksplit(d->B, d->Cin, d->Cout, d->Hin, d->Win, a.G);
+    const size_t out_floats = (size_t)d->B * a.Cy * d->H * d->W;
+    const bool split = ks > 1 && d->ksplit != 1 && d->workspace && (reinterpret_cast<uintptr_t>(d->workspace) & 15) == 0 &&
+                       d->workspace_bytes >= (int64_t)ks * (int64_t)out_floats * 4;
+    a.cps = split ? spk::ceil_div(a.n_chunks, ks) : a.n_chunks;
+    a.slice_floats = split ? out_floats : 0;
+    const int nz = split ? spk::ceil_div(a.n_chunks, a.cps) : 1;
+    if (split) { a.y = static_cast<float*>(d->workspace); a.accumulate = 0; a.out_scale = 1.f; a.out_scale_dev = nullptr; }
+    dim3 grid((unsigned)gx, (unsigned)(a.G * a.co_tiles_g), (unsigned)nz);
     hipLaunchKernelGGL(dgrad3x3s2_kernel, grid, dim3(256), 2 * STAGE * sizeof(float), stream, a);
-    return spk::check_launch("dgrad3x3s2_kernel");
+    int rc = spk::check_launch("dgrad3x3s2_kernel");
+    if (rc != SPK_OK || !split) return rc;
+    ConvArgs f = {};
+    f.y = static_cast<float*>(d->y); f.B = d->B; f.Cin = d->Cin; f.Cout = d->Cout; f.Cy = a.Cy; f.Cx = a.Cg; f.G = a.G; f.H = d->H; f.W = d->W;
+    f.flags = d->flags & SPK_EPI_ACCUM; f.slope = 1.f; f.out_scale = d->out_scale; f.act_gain = 1.f; f.out_scale_dev = d->out_scale_dev;
+    return launch_splitk_epilogue(f, static_cast<const float*>(d->workspace), nz, stream);
+}
+
+// slices of the contraction for the exact-tap kernel: 1 unless the grid fills less than half of the 512 workgroup slots
+int dgrad_s2_ksplit(int B, int K, int Cc, int Hg, int Wg, int G) {
+    const long long wgs = (long long)spk::ceil_div(Wg, spkdg::TW) * spk::ceil_div(Hg, spkdg::TH) * B * G * spk::ceil_div(Cc, spkdg::CO_T);
+    const int n_chunks = spk::ceil_div(K, spkdg::CI_T);
+    int ks = 1;
+    while (wgs * ks < 256 && n_chunks / (2 * ks) >= 8) ks *= 2;
+    return ks;
 }
 
 }  // namespace spkconv

@@ -1134,8 +1134,12 @@ def _dgrad_s2_parity(g, weight_packed, Cin, in_hw, config, out, accumulate, grou
     d = L.Conv2dDesc(x=L.dptr(g, "g"), w_packed=L.dptr(weight_packed, "w_packed"), y=L.dptr(out, "out"), B=B, Cin=Cg // G,
                      Cout=Cin, H=H, W=W, Hin=Hg, Win=Wg, kh=3, kw=3, stride=2,
                      flags=L.CONV_DGRAD_S2 | (L.EPI_ACCUM if accumulate else 0), lrelu_slope=1.0, out_scale=1.0,
-                     config=int(config), ksplit=1, groups=G, group_in_stride=0 if G == 1 else Cg // G,
+                     config=int(config), ksplit=0, groups=G, group_in_stride=0 if G == 1 else Cg // G,
                      out_scale_dev=L.dptr(out_scale_dev, "out_scale_dev"))
+    ws_bytes = L.lib().spk_conv2d_dgrad_s2_workspace_bytes(B, Cg // G, Cin, Hg, Wg, H, W, G)
+    if ws_bytes > 0:                # a small gradient plane: the exact-tap kernel runs its contraction in slices
+        ws = _workspace(g.device, ws_bytes)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4
     _launch_conv2d(d)
     return out
 
