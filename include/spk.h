@@ -379,6 +379,11 @@ int spk_bias_noise_style_fwd(const float* x, int64_t x_batch_stride, const float
 /* ---- 1x1 convolution with few output channels (toRGB) -------------------------------------------
  * y[b,o,p] = sum_c w[o*C + c] * x[b,c,p] * in_scale + bias[o],  O <= 4.  HBM-bound streaming kernel.
  * replaces: styleganv1.py:607 (to_rgb = nn.Conv2d(64,3,1)); stylegan.py:138-140,175-176 (rgb layers). */
+/* 1x1 conv FROM C <= 4 channels with bias and LeakyReLU (slope 1 = none) fused: y[b,o] = lrelu(bias[o] + scale * sum_c w[o,c] x[b,c]); w is
+ * the plain [O][C] matrix, scale_dev an optional DEVICE scalar on it (1 / sigma of a spectrally normalised layer).  A store stream:
+ * HW % 4 == 0, 16-byte aligned tensors.  replaces: StyleDiscriminator.fromrgb + leaky_relu (styleganv1.py:675,684), 3 -> 64 at 256^2. */
+int spk_conv1x1_expand_fwd(const float* x, const float* w, const float* bias, const float* scale_dev, float* y, int B, int C, int O,
+                           int64_t HW, float slope, void* stream);
 int spk_conv1x1_small_fwd(const float* x, const float* w, const float* bias, float* y, int B, int C, int O,
                           int64_t HW, float in_scale, void* stream);
 

@@ -240,6 +240,7 @@ _PROTOTYPES = {
     "spk_fc_grouped_bwd": (C.c_int, [C.c_void_p, C.c_int, C.c_int, C.c_void_p]),
     "spk_bias_noise_style_fwd": (C.c_int, [C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
                                            C.c_int64, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "spk_conv1x1_expand_fwd": (C.c_int, [C.c_void_p] * 5 + [C.c_int, C.c_int, C.c_int, C.c_int64, C.c_float, C.c_void_p]),
     "spk_conv1x1_small_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int,
                                         C.c_int64, C.c_float, C.c_void_p]),
     "spk_upsample2x_bilinear_fwd": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_int, C.c_void_p]),

@@ -449,10 +449,19 @@ def _packed_of(weight, cfg, tf=False):
     return hit
 
 
+def _sn_parts(weight):
+    """(weight_orig, 1 / sigma as a device scalar) of a spectrally normalised weight, or (the weight, None)."""
+    sn = getattr(weight, "_spk_sn", None)
+    return (sn[0].detach(), sn[1]) if sn is not None else (weight.detach(), None)
+
+
 def _conv_plain(x, weight, k, stride):
     B, Cin, H, W = x.shape
     Cout = weight.shape[0]
     Ho, Wo = ops.conv_out_size(H, k, stride), ops.conv_out_size(W, k, stride)
+    if ops.conv1x1_expand_ok(x, Cin, k, stride):                 # fromRGB: a store stream, not a contraction
+        w0, sd = _sn_parts(weight)
+        return ops.conv1x1_expand(x.contiguous(), w0, None, sd)
     if k == 3 and stride == 1 and ops.train_bf16x3(B, Cin, Cout, Ho, Wo):
         return ops.conv3x3_bf16x3(x.contiguous(), _packed(weight, "bf16x3")[0], Cout)
     if k == 3 and stride == 1 and ops.use_wino(B, Cin, Cout, Ho, Wo):
@@ -466,6 +475,8 @@ def _conv_plain(x, weight, k, stride):
 def _conv_dgrad(dt, weight, k, stride, in_hw):
     B, Cout = dt.shape[:2]
     Cin = weight.shape[1]
+    if k == 1 and stride == 1 and Cin <= 4:                      # fromRGB's data gradient: a 1x1 conv TO <= 4 channels (the toRGB kernel)
+        return ops.conv1x1_small(dt.contiguous(), weight.detach().reshape(Cout, Cin).t().contiguous().view(Cin, Cout, 1, 1))
     if k == 3 and stride == 1 and ops.train_bf16x3(B, Cout, Cin, in_hw[0], in_hw[1]):
         return ops.conv3x3_bf16x3(dt, _packed(weight, "bf16x3", True)[0], Cin)
     if k == 3 and stride == 1 and ops.use_wino(B, Cout, Cin, in_hw[0], in_hw[1]):
@@ -516,7 +527,10 @@ class ConvBiasLReLUFn(torch.autograd.Function):
         B, Cin, H, W = x.shape
         Cout = weight.shape[0]
         Ho, Wo = ops.conv_out_size(H, k, stride), ops.conv_out_size(W, k, stride)
-        if k == 3 and stride == 1 and ops.train_bf16x3(B, Cin, Cout, Ho, Wo):
+        if ops.conv1x1_expand_ok(x, Cin, k, stride):             # fromRGB (3 -> 64 at 256^2): a store stream, not a contraction
+            w0, sd = _sn_parts(weight)
+            y = ops.conv1x1_expand(x.contiguous(), w0, bias, sd, slope)
+        elif k == 3 and stride == 1 and ops.train_bf16x3(B, Cin, Cout, Ho, Wo):
             y = ops.conv3x3_bf16x3(x.contiguous(), _packed(weight, "bf16x3")[0], Cout, bias=bias, lrelu_slope=slope)
         elif k == 3 and stride == 1 and ops.use_wino(B, Cin, Cout, Ho, Wo):
             wp, sd = _packed(weight, "wino")

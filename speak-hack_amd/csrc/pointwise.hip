@@ -388,6 +388,41 @@ __global__ __launch_bounds__(256) void upsample2x_vec2x2_kernel(const float* __r
     for (int r = 0; r < 4; ++r) *reinterpret_cast<float4*>(yp + (size_t)r * 2 * Win) = make_float4(o[r][0], o[r][1], o[r][2], o[r][3]);
 }
 
+// 1x1 conv FROM <= 4 channels (the discriminator's fromRGB, styleganv1.py:675: 3 -> 64 at 256^2): a pure store stream -- 134 MB of
+// output for 6 MB of input at B = 8 -- that the tap kernel ran at 1.8 TB/s (its tiles are built for long contractions).  A thread owns
+// four pixels: C 16-byte loads, then one fully contiguous 16-byte store per output channel (bias, LeakyReLU fused); `scale_dev`: an
+// optional device scalar on the weights (1 / sigma of a spectrally normalised layer).
+__global__ __launch_bounds__(256) void conv1x1_expand_kernel(const float* __restrict__ x, const float* __restrict__ w, const float* __restrict__ bias,
+                                                            const float* __restrict__ scale_dev, float* __restrict__ y, int C, int O,
+                                                            long long HW, float slope) {
+    extern __shared__ float w_s[];                       // [O][4] weights (zero padded to 4 inputs) + [O] bias
+    const float sc = scale_dev ? *scale_dev : 1.f;
+    for (int i = threadIdx.x; i < O * 4; i += blockDim.x) w_s[i] = (i & 3) < C ? w[(i >> 2) * C + (i & 3)] * sc : 0.f;
+    for (int i = threadIdx.x; i < O; i += blockDim.x) w_s[4 * O + i] = bias ? bias[i] : 0.f;
+    __syncthreads();
+    const int b = blockIdx.y;
+    const long long p4 = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (p4 >= HW / 4) return;
+    float4 xv[4];
+#pragma unroll
+    for (int c = 0; c < 4; ++c) xv[c] = c < C ? reinterpret_cast<const float4*>(x + ((size_t)b * C + c) * HW)[p4] : make_float4(0.f, 0.f, 0.f, 0.f);
+    float4* yb = reinterpret_cast<float4*>(y + (size_t)b * O * HW) + p4;
+    const size_t plane4 = (size_t)(HW / 4);
+#pragma unroll 4
+    for (int o = 0; o < O; ++o) {
+        const float4 wv = *reinterpret_cast<const float4*>(w_s + 4 * o);
+        const float bo = w_s[4 * O + o];
+        float4 v;
+        v.x = bo + wv.x * xv[0].x + wv.y * xv[1].x + wv.z * xv[2].x + wv.w * xv[3].x;
+        v.y = bo + wv.x * xv[0].y + wv.y * xv[1].y + wv.z * xv[2].y + wv.w * xv[3].y;
+        v.z = bo + wv.x * xv[0].z + wv.y * xv[1].z + wv.z * xv[2].z + wv.w * xv[3].z;
+        v.w = bo + wv.x * xv[0].w + wv.y * xv[1].w + wv.z * xv[2].w + wv.w * xv[3].w;
+        v.x = v.x > 0.f ? v.x : v.x * slope; v.y = v.y > 0.f ? v.y : v.y * slope;
+        v.z = v.z > 0.f ? v.z : v.z * slope; v.w = v.w > 0.f ? v.w : v.w * slope;
+        yb[(size_t)o * plane4] = v;
+    }
+}
+
 inline unsigned stream_grid(long long work_items, int threads) {
     const long long blocks = (work_items + threads - 1) / threads;
     return (unsigned)std::max(1ll, std::min(blocks, 256ll * 8));
@@ -438,6 +473,17 @@ static int conv1x1_small_launch(const float* x, const float* w, const float* mod
                            (long long)HW, in_scale, mod, skip, W);
     }
     return spk::check_launch("conv1x1_small_kernel");
+}
+
+int spk_conv1x1_expand_fwd(const float* x, const float* w, const float* bias, const float* scale_dev, float* y, int B, int C, int O,
+                           int64_t HW, float slope, void* stream) {
+    SPK_REQUIRE(x && w && y, "conv1x1_expand: null pointer");
+    SPK_REQUIRE(B > 0 && B < 65536 && C > 0 && C <= 4 && O > 0 && O <= 2048 && HW > 0 && HW % 4 == 0, "conv1x1_expand: C <= 4 inputs, HW a multiple of 4");
+    SPK_REQUIRE(((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(y)) & 15) == 0, "conv1x1_expand: 16-byte aligned tensors");
+    dim3 grid((unsigned)((HW / 4 + 255) / 256), (unsigned)B);
+    hipLaunchKernelGGL(conv1x1_expand_kernel, grid, dim3(256), (size_t)O * 5 * sizeof(float), (hipStream_t)stream, x, w, bias, scale_dev, y, C, O,
+                       (long long)HW, slope);
+    return spk::check_launch("conv1x1_expand_kernel");
 }
 
 int spk_conv1x1_small_fwd(const float* x, const float* w, const float* bias, float* y, int B, int C, int O, int64_t HW,

@@ -604,6 +604,21 @@ def conv1x1_small(x, weight, bias=None, in_scale=1.0):
     return out
 
 
+def conv1x1_expand(x, weight, bias=None, scale_dev=None, slope=None):
+    """1x1 conv from <= 4 channels (fromRGB) + bias + LeakyReLU as one store stream (csrc/pointwise.hip conv1x1_expand_kernel)."""
+    B, Cc, H, W = x.shape
+    O = weight.shape[0]
+    out = torch.empty((B, O, H, W), device=x.device, dtype=torch.float32)
+    L.check(L.lib().spk_conv1x1_expand_fwd(L.dptr(x, "x"), L.dptr(weight.reshape(O, Cc), "weight"), L.dptr(bias, "bias"),
+                                           L.dptr(scale_dev, "scale_dev"), L.dptr(out), B, Cc, O, H * W,
+                                           float(slope if slope is not None else 1.0), L.stream_ptr()), "spk_conv1x1_expand_fwd")
+    return out
+
+
+def conv1x1_expand_ok(x, Cin, k, stride) -> bool:
+    return k == 1 and stride == 1 and Cin <= 4 and (x.shape[-1] * x.shape[-2]) % 4 == 0 and x.data_ptr() % 16 == 0 and x.shape[0] < 65536
+
+
 def upsample2x_bilinear(x):
     B, Cc, H, W = x.shape
     out = torch.empty((B, Cc, 2 * H, 2 * W), device=x.device, dtype=torch.float32)

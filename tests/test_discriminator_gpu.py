@@ -217,3 +217,32 @@ def test_grouped_spectral_norm_vs_torch_hook():
     loss_ref.backward()
     for m, r in zip(mods, ref):
         assert rel_l2(m.weight_orig.grad, r.weight_orig.grad) < 5e-6
+
+
+@pytest.mark.parametrize("B,C,O,H,W", [(2, 3, 64, 16, 16), (1, 4, 33, 8, 12), (3, 1, 128, 4, 8)])
+def test_fromrgb_expand_kernel_and_its_data_gradient(B, C, O, H, W):
+    """StyleDiscriminator.fromrgb (styleganv1.py:675) = a 1x1 conv from 3 channels + LeakyReLU: the store-stream kernel
+    (spk_conv1x1_expand_fwd) against fp64, with and without the device scalar of a spectrally normalised weight; its data gradient (a 1x1
+    to <= 4 channels) through the same autograd Function the discriminator uses."""
+    assert torch.cuda.is_available()
+    pkg = importlib.import_module("speak-hack_amd")
+    ops, AG = pkg.ops, importlib.import_module("speak-hack_amd.autograd")
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(B + C + O)
+    x = torch.randn(B, C, H, W, generator=g).to(dev)
+    w = torch.randn(O, C, 1, 1, generator=g).to(dev)
+    b = torch.randn(O, generator=g).to(dev)
+    sd = torch.tensor([0.37], device=dev)
+    y = ops.conv1x1_expand(x, w, b, sd, 0.2)
+    ref = F.leaky_relu(F.conv2d(x.double(), w.double() * 0.37, b.double()), 0.2)
+    assert rel_l2(y, ref) < 1e-6
+    assert rel_l2(ops.conv1x1_expand(x, w), F.conv2d(x.double(), w.double())) < 1e-6
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    out = AG.conv_bias_lrelu(xr, wr, b, 1, 1, 0.2)
+    assert rel_l2(out, F.leaky_relu(F.conv2d(x.double(), w.double(), b.double()), 0.2)) < 1e-6
+    dy = torch.randn(B, O, H, W, generator=g).to(dev)
+    out.backward(dy)
+    x64, w64 = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    F.leaky_relu(F.conv2d(x64, w64, b.double()), 0.2).backward(dy.double())
+    assert rel_l2(xr.grad, x64.grad) < 2e-6 and rel_l2(wr.grad, w64.grad) < 5e-6
