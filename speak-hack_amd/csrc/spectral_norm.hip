@@ -145,7 +145,12 @@ __global__ __launch_bounds__(256) void sn_bwd_dot_kernel(const SnGroups a, float
     const int b = blockIdx.x - a.blk_e[gi];
     const size_t n = (size_t)q.R * q.C, i0 = (size_t)b * 1024 + threadIdx.x * 4;
     float d = 0.f;
-    for (size_t i = i0; i < std::min(n, i0 + 4); ++i) d += q.w_hat[i] * q.w[i];     // w_hat slot = the incoming gradient G
+    if ((n & 3) == 0 && i0 + 3 < n) {                                               // (16-byte accesses; the same summation order)
+        const float4 gq = *reinterpret_cast<const float4*>(q.w_hat + i0), wq = *reinterpret_cast<const float4*>(q.w + i0);
+        d += gq.x * wq.x; d += gq.y * wq.y; d += gq.z * wq.z; d += gq.w * wq.w;
+    } else {
+        for (size_t i = i0; i < std::min(n, i0 + 4); ++i) d += q.w_hat[i] * q.w[i];     // w_hat slot = the incoming gradient G
+    }
     const float tot = sn_block_sum(d, red);
     if (threadIdx.x == 0) ws[a.off_q[gi] + b] = tot;
 }
@@ -162,6 +167,16 @@ __global__ __launch_bounds__(256) void sn_bwd_apply_kernel(const SnGroups a, con
     const float sigma = *q.sigma;
     const float coef = dot / sigma;
     const size_t n = (size_t)q.R * q.C, i0 = (size_t)(blockIdx.x - a.blk_e[gi]) * 1024 + threadIdx.x * 4;
+    if ((q.C & 3) == 0 && i0 + 3 < n) {              // rows are a multiple of 4 floats: the four elements share a row, 16-byte accesses
+        const int r = (int)(i0 / q.C), c = (int)(i0 - (size_t)r * q.C);
+        const float4 gq = *reinterpret_cast<const float4*>(q.w_hat + i0), vq = *reinterpret_cast<const float4*>(q.v + c);
+        const float cu = coef * q.u[r];
+        float4 d4 = make_float4((gq.x - cu * vq.x) / sigma, (gq.y - cu * vq.y) / sigma, (gq.z - cu * vq.z) / sigma, (gq.w - cu * vq.w) / sigma);
+        float4* o = reinterpret_cast<float4*>(q.dw + i0);
+        if (q.accumulate) { const float4 old = *o; d4.x += old.x; d4.y += old.y; d4.z += old.z; d4.w += old.w; }
+        *o = d4;
+        return;
+    }
     for (size_t i = i0; i < std::min(n, i0 + 4); ++i) {
         const int r = (int)(i / q.C), c = (int)(i - (size_t)r * q.C);
         const float d = (q.w_hat[i] - coef * q.u[r] * q.v[c]) / sigma;
