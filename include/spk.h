@@ -222,6 +222,11 @@ int spk_conv2d_bf16x3_fwd(const spk_conv2d_desc* desc, void* stream);
  * after the separate x2 upsampling), styleganv1.py:662 (DiscriminatorBlock conv1) and their data gradients. */
 int64_t spk_conv2d_packed_bytes_wino(int Cin, int Cout);
 int spk_conv2d_pack_weights_wino(const float* w, float* w_packed, int Cin, int Cout, int transpose_flip, void* stream);
+/* n <= SPK_WINO_PACK_MAX weights in one launch (host arrays of length n; the same bits as n single calls): what a training step does
+ * after every optimizer step for both images of each decoder layer */
+#define SPK_WINO_PACK_MAX 32
+int spk_conv2d_pack_weights_wino_list(const float* const* w, float* const* w_packed, const int* Cin, const int* Cout, const int* transpose_flip,
+                                      int n, void* stream);
 int spk_conv2d_wino_supported(int B, int Cin, int Cout, int H, int W);
 /* Regions are 32 x 8 output pixels, or 16 x 16 where the image is narrower than 32.  A problem with too few (region, channel tile)
  * pairs to fill the CUs runs its channel contraction in `ksplit` slices: spk_conv2d_wino_ksplit(want, ...) = the count the launch

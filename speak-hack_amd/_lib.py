@@ -223,6 +223,7 @@ _PROTOTYPES = {
     "spk_conv2d_bf16x3_fwd": (C.c_int, [C.POINTER(Conv2dDesc), C.c_void_p]),
     "spk_conv2d_packed_bytes_wino": (C.c_int64, [C.c_int, C.c_int]),
     "spk_conv2d_pack_weights_wino": (C.c_int, [C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.c_int, C.c_void_p]),
+    "spk_conv2d_pack_weights_wino_list": (C.c_int, [C.c_void_p] * 5 + [C.c_int, C.c_void_p]),
     "spk_conv2d_wino_supported": (C.c_int, [C.c_int] * 5),
     "spk_conv2d_wino_ksplit": (C.c_int, [C.c_int] * 6),
     "spk_conv2d_wino_workspace_bytes": (C.c_int64, [C.c_int] * 6),

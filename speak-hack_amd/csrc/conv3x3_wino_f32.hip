@@ -115,6 +115,50 @@ __global__ void pack_wino_kernel(const float* __restrict__ w, float* __restrict_
     out[idx] = v;
 }
 
+// the same for up to 32 weights in ONE launch (blockIdx.y = item): a training step re-packs both images of every decoder layer after
+// each optimizer step -- 20 launches of 26-35 us beside a busy second stream
+struct PackWinoList {
+    const float* w[SPK_WINO_PACK_MAX];
+    float* out[SPK_WINO_PACK_MAX];
+    int Cin[SPK_WINO_PACK_MAX], Cout[SPK_WINO_PACK_MAX], tf[SPK_WINO_PACK_MAX];
+};
+
+__global__ void pack_wino_list_kernel(const PackWinoList a) {
+    const int it = blockIdx.y;
+    const float* __restrict__ w = a.w[it];
+    float* __restrict__ out = a.out[it];
+    const int Cin = a.Cin[it], Cout = a.Cout[it], transpose_flip = a.tf[it];
+    const int opCin = transpose_flip ? Cout : Cin, opCout = transpose_flip ? Cin : Cout;
+    const int n_chunks = (opCin + CI_T - 1) / CI_T;
+    const long long total = (long long)((opCout + CO_T - 1) / CO_T) * n_chunks * U_FLOATS;
+    for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+        const int co_l = (int)(idx % CO_T);
+        long long r = idx / CO_T;
+        const int ci_l = (int)(r % CI_T);
+        r /= CI_T;
+        const int xi = (int)(r % 16);
+        r /= 16;
+        const int chunk = (int)(r % n_chunks), co_tile = (int)(r / n_chunks);
+        const int co = co_tile * CO_T + co_l, ci = chunk * CI_T + ci_l;
+        float v = 0.f;
+        if (co < opCout && ci < opCin) {            // (the arithmetic of pack_wino_kernel, expression for expression)
+            float g[3][3];
+#pragma unroll
+            for (int p = 0; p < 3; ++p)
+#pragma unroll
+                for (int q = 0; q < 3; ++q)
+                    g[p][q] = transpose_flip ? w[(((size_t)ci * Cin + co) * 3 + (2 - p)) * 3 + (2 - q)] : w[(((size_t)co * Cin + ci) * 3 + p) * 3 + q];
+            const int i = xi >> 2, j = xi & 3;
+            float t[3];
+#pragma unroll
+            for (int q = 0; q < 3; ++q)
+                t[q] = i == 0 ? g[0][q] : (i == 3 ? g[2][q] : 0.5f * ((g[0][q] + g[2][q]) + (i == 1 ? g[1][q] : -g[1][q])));
+            v = j == 0 ? t[0] : (j == 3 ? t[2] : 0.5f * ((t[0] + t[2]) + (j == 1 ? t[1] : -t[1])));
+        }
+        out[idx] = v;
+    }
+}
+
 // One vector add / subtract, spelled out: given the whole transform, the compiler pairs the operands for v_pk_add_f32 and pays for
 // it with a v_mov_b32 per pair (24 moves per chunk of 64 MFMAs; a packed op costs its two scalar ones on this part anyway).
 __device__ __forceinline__ float fadd_(float a, float b) { float r; asm("v_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
@@ -543,6 +587,21 @@ static int wino_shape(int H, int W) {         // -1: no region shape tiles the i
     if (H % region_h(WIDE) == 0 && W % region_w(WIDE) == 0) return WIDE;
     if (H % region_h(SQUARE) == 0 && W % region_w(SQUARE) == 0) return SQUARE;
     return -1;
+}
+
+int spk_conv2d_pack_weights_wino_list(const float* const* w, float* const* w_packed, const int* Cin, const int* Cout, const int* transpose_flip,
+                                      int n, void* stream) {
+    SPK_REQUIRE(w && w_packed && Cin && Cout && transpose_flip && n > 0 && n <= SPK_WINO_PACK_MAX, "pack_weights_wino_list: 1..%d items", SPK_WINO_PACK_MAX);
+    PackWinoList a;
+    long long most = 0;
+    for (int i = 0; i < n; ++i) {
+        SPK_REQUIRE(w[i] && w_packed[i] && Cin[i] > 0 && Cout[i] > 0 && (transpose_flip[i] == 0 || transpose_flip[i] == 1), "pack_weights_wino_list: item %d", i);
+        a.w[i] = w[i]; a.out[i] = w_packed[i]; a.Cin[i] = Cin[i]; a.Cout[i] = Cout[i]; a.tf[i] = transpose_flip[i];
+        most = std::max<long long>(most, (transpose_flip[i] ? spk_conv2d_packed_bytes_wino(Cout[i], Cin[i]) : spk_conv2d_packed_bytes_wino(Cin[i], Cout[i])) / 4);
+    }
+    dim3 grid((unsigned)std::min<long long>((most + 255) / 256, 2048), (unsigned)n);
+    hipLaunchKernelGGL(pack_wino_list_kernel, grid, dim3(256), 0, (hipStream_t)stream, a);
+    return spk::check_launch("pack_wino_list_kernel");
 }
 
 int spk_conv2d_wino_supported(int B, int Cin, int Cout, int H, int W) {

@@ -191,6 +191,20 @@ class SynthesisNetwork(nn.Module):
             cw = [c.weight for layer in self.layers for c in (layer.conv1, layer.conv2)]
             if all(t.requires_grad for t in cw):
                 gated = AG.gate_weights(cw)
+        if w.is_cuda:
+            # every stale Winograd weight image of the pass (forward and, under autograd, data-gradient orientation) in ONE launch: after
+            # an optimizer step that is all of them -- 20 launches otherwise
+            items, res, grad = [], 4, torch.is_grad_enabled()
+            for layer in self.layers:
+                res *= 2
+                for conv, pk in ((layer.conv1, layer._pk1), (layer.conv2, layer._pk2)):
+                    Co, Ci = conv.weight.shape[:2]
+                    if not ops.train_bf16x3(B, Ci, Co, res, res) and ops.use_wino(B, Ci, Co, res, res):
+                        items.append((pk, conv.weight, False))
+                    if grad and not ops.train_bf16x3(B, Co, Ci, res, res) and ops.use_wino(B, Co, Ci, res, res):
+                        items.append((pk, conv.weight, True))
+            if items:
+                ops.prepack_wino(items)
         for i, layer in enumerate(self.layers):
             x = layer(x, w[:, 2 * i + 1:2 * i + 3], noises[1 + 2 * i], noises[2 + 2 * i],
                       styles=(styles[1 + 2 * i], styles[2 + 2 * i]) if styles is not None else None,

@@ -424,6 +424,35 @@ def pack_conv_weight_wino(weight: torch.Tensor, out=None, transpose_flip=False) 
     return out
 
 
+WINO_PACK_MAX = 32
+
+
+def prepack_wino(items):
+    """``items`` = [(PackedConvWeight cache, weight, transpose_flip), ...]: fill every STALE Winograd image in ONE launch
+    (spk_conv2d_pack_weights_wino_list) -- the same bits ``get_wino`` would produce one launch at a time."""
+    todo = []
+    for pk, w, tf in items:
+        key = ("wino", bool(tf))
+        stamp = (w.data_ptr(), w._version, tuple(w.shape))
+        hit = pk._cache.get(key)
+        if hit is not None and hit[0] == stamp and hit[2]() is w:
+            continue
+        Cout, Cin = w.shape[:2]
+        n = (L.lib().spk_conv2d_packed_bytes_wino(Cout, Cin) if tf else L.lib().spk_conv2d_packed_bytes_wino(Cin, Cout)) // 4
+        todo.append((pk, key, stamp, w, bool(tf), torch.empty(n, device=w.device, dtype=torch.float32)))
+    for i in range(0, len(todo), WINO_PACK_MAX):
+        part = todo[i:i + WINO_PACK_MAX]
+        n = len(part)
+        ws = (C.c_void_p * n)(*[L.dptr(t[3].detach().contiguous(), "weight") for t in part])
+        outs = (C.c_void_p * n)(*[t[5].data_ptr() for t in part])
+        cin = (C.c_int * n)(*[t[3].shape[1] for t in part])
+        cout = (C.c_int * n)(*[t[3].shape[0] for t in part])
+        tfs = (C.c_int * n)(*[1 if t[4] else 0 for t in part])
+        L.check(L.lib().spk_conv2d_pack_weights_wino_list(ws, outs, cin, cout, tfs, n, L.stream_ptr()), "spk_conv2d_pack_weights_wino_list")
+        for pk, key, stamp, w, tf, out in part:
+            pk._cache[key] = (stamp, out, weakref.ref(w))
+
+
 def upsample2x(x, zero_border=False):
     """The x2 image: bilinear (edge taps clamped), or -- ``zero_border`` -- upfirdn2d(up=2, [1,3,3,1], pad (2,1)) (the same taps,
     neighbours outside the image zero).  What a Winograd x2 layer reads."""

@@ -357,3 +357,25 @@ def test_wino_fused_torgb_equals_conv_then_1x1(ops, B, Cin, Cout, H, W):
     L = importlib.import_module("speak-hack_amd")._lib
     with pytest.raises(L.SpkError):
         ops.conv3x3_wino(x, wp, Cout, rgb=(rw, rb), accumulate=True, out=torch.zeros(B, Cout, H, W, device=dev))
+
+
+def test_wino_list_pack_equals_single_packs_bit_for_bit(ops):
+    """ops.prepack_wino: every stale image of a decoder pass in ONE launch (spk_conv2d_pack_weights_wino_list), both orientations --
+    the bits of the one-at-a-time packer; a second call packs nothing; an in-place update re-packs."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(3)
+    ws = [torch.randn(co, ci, 3, 3, generator=g).to(dev) for co, ci in ((64, 64), (64, 128), (200, 48), (512, 256))]
+    pks = [ops.PackedConvWeight() for _ in ws]
+    items = [(pk, w, tf) for pk, w in zip(pks, ws) for tf in (False, True)]
+    ops.prepack_wino(items)
+    for pk, w in zip(pks, ws):
+        for tf in (False, True):
+            got = pk._cache[("wino", tf)][1]
+            assert pk.get_wino(w, transpose_flip=tf) is got                      # served from the cache the list call filled
+            assert torch.equal(got, ops.pack_conv_weight_wino(w, transpose_flip=tf))
+    before = [pk._cache[("wino", False)][1] for pk in pks]
+    ops.prepack_wino(items)
+    assert all(pk._cache[("wino", False)][1] is b for pk, b in zip(pks, before))
+    ws[1].mul_(2.0)
+    ops.prepack_wino(items)
+    assert pks[1]._cache[("wino", True)][1] is not before[1] and torch.equal(pks[1].get_wino(ws[1]), ops.pack_conv_weight_wino(ws[1]))
