@@ -93,7 +93,17 @@ def pair_executed_gflop(ops, frames):
             if ops.use_wgrad_wino(frames, ci, co, r, r):
                 saved += fl * (1 - 16.0 / 36.0)                      # weight gradient
         cin, r = cout, r * 2
-    return GFLOP_PER_PAIR_EXECUTED - 2 * saved
+    # the encoders: conv2 of every stride-1 Bottleneck (torchvision ResNet-50: 3 / 3 / 5 / 2 of them at 64 / 128 / 256 / 512 channels and
+    # 64^2 / 32^2 / 16^2 / 8^2 pixels for a 256^2 input) -- data gradient and weight gradient on the Winograd kernels where they serve
+    # the shape (6 passes as groups of one launch, `frames` / 2 images each); the forward stays on the direct kernel
+    saved_enc = 0.0
+    for n_blocks, c, r in ((3, 64, 64), (3, 128, 32), (5, 256, 16), (2, 512, 8)):
+        fl = n_blocks * 2 * 9 * c * c * r * r / 1e9               # per image and pass
+        if ops.use_wino(frames // 2, c, c, r, r, groups=6):
+            saved_enc += fl * (1 - 16.0 / 36.0)                       # data gradient
+        if ops.use_wgrad_wino(frames // 2, c, 6 * c, r, r):
+            saved_enc += fl * (1 - 16.0 / 36.0)                       # weight gradient
+    return GFLOP_PER_PAIR_EXECUTED - 2 * saved - 6 * saved_enc
 
 
 def host_cores():
@@ -745,7 +755,7 @@ def main():
                                 "algorithmic_tflops_reference_equivalent": round(16 / g_ms * 1e3 * GFLOP_PER_PAIR / 1e3, 1),
                                 "flops_note": "frac_of_f32_mfma_peak counts EXECUTED matrix FLOPs: the encoders' activations are stored (the "
                                               "checkpoint's recompute, 6 x 10.677 of the reference's 593.5 GFLOP per pair, is not run: 529.4), and "
-                                              "the decoder's 3x3 forward / data-gradient / weight-gradient launches on the Winograd kernels execute 16/36 of their "
+                                              "the decoder's 3x3 forward / data-gradient / weight-gradient launches and the encoders' 3x3 data / weight gradients on the Winograd kernels execute 16/36 of their "
                                               "algorithmic FLOPs; the two algorithmic figures price the step at the work of the direct algorithm "
                                               "without / with the reference's recompute"}
         g_bf = irfd_steps(pkg, dev, "g", 16, steps=5, warmup=4, precision="bf16x3")

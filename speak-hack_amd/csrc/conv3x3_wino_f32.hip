@@ -72,6 +72,8 @@ struct Args {
     const float* rgb_bias;
     float* rgb_y;
     int B, Cin, Cout, H, W;
+    int G, gin, Cx, Cy, co_tiles_g;   // groups (the encoders' passes side by side): Cin / Cout per group; x has Cx = gin * (G - 1) + Cin channels,
+                                 // y has Cy = G * Cout; blockIdx.y = group * co_tiles_g + channel tile; the groups' images one after another
     int regions_x, regions_y;
     int n_chunks;                // of the whole contraction (the packed image's chunk count)
     int ksplit, cps;             // the contraction in `ksplit` slices of `cps` chunks (even), a work item = (region, slice)
@@ -194,7 +196,7 @@ __global__ __launch_bounds__(NT) void wino_kernel(const Args p) {
     const int xcd = (int)blockIdx.x & 7, wk = (int)blockIdx.x >> 3, wpx = (int)gridDim.x >> 3;      // (host: gridDim.x % 8 == 0)
     const int share_q = n_regions >> 3, share_r = n_regions & 7;
     const int reg_begin = xcd * share_q + min(xcd, share_r), reg_end = reg_begin + share_q + (xcd < share_r ? 1 : 0);
-    const int co_tile = blockIdx.y, co0 = co_tile * CO_T;
+    const int grp = (int)blockIdx.y / p.co_tiles_g, co_tile = (int)blockIdx.y - grp * p.co_tiles_g, co0 = co_tile * CO_T;     // co0: within the group
     const size_t HW = (size_t)p.H * p.W;
 
     // ---- the raw gathers: byte offsets of this lane's 11 elements (plane j of channel wave + 4 j), or out of range ----
@@ -223,13 +225,13 @@ __global__ __launch_bounds__(NT) void wino_kernel(const Args p) {
     }
     auto set_voff = [&](unsigned (&vo)[RAW_GATHERS], int b_, int y0_, int x0_) {
         // (host: the whole tensor is below 2^29 floats)
-        const unsigned origin = (((unsigned)b_ * (unsigned)p.Cin) * (unsigned)HW + (unsigned)(y0_ * p.W + x0_)) * 4u;
+        const unsigned origin = (((unsigned)b_ * (unsigned)p.Cx + (unsigned)(grp * p.gin)) * (unsigned)HW + (unsigned)(y0_ * p.W + x0_)) * 4u;
         const unsigned at = (y0_ == 0 ? 1u : 0u) | (y0_ + RH >= p.H ? 2u : 0u) | (x0_ == 0 ? 4u : 0u) | (x0_ + RW >= p.W ? 8u : 0u) | 16u;
 #pragma unroll
         for (int k = 0; k < RAW_GATHERS; ++k) vo[k] = (edge[k] & at) ? 0x80000000u : origin + rel[k];
     };
     const unsigned chunk_bytes = (unsigned)(CI_T * HW * 4);
-    const float* wsrc = p.wp + (size_t)co_tile * p.n_chunks * U_FLOATS;
+    const float* wsrc = p.wp + (size_t)blockIdx.y * p.n_chunks * U_FLOATS;
 
     // LDS-DMA as inline assembly: the compiler treats a pending `... lds` load as a flat access that may complete out of order
     // with the ds_reads and answers with s_waitcnt lgkmcnt(0) in front of EVERY fragment use until the next vmcnt(0) -- with one
@@ -453,7 +455,7 @@ __global__ __launch_bounds__(NT) void wino_kernel(const Args p) {
         lds_barrier();
         unsigned hw_ = (unsigned)HW;                 // (opaque per region: the 16 rows' channel offsets must not be hoisted out of the region
         asm volatile("" : "+s"(hw_));                //  loop as 32 live registers)
-        const size_t o0 = (size_t)cur_b * p.Cout * hw_ + pix + (size_t)(kb_cur / p.cps) * p.slice_floats;
+        const size_t o0 = ((size_t)cur_b * p.Cy + (size_t)grp * p.Cout) * hw_ + pix + (size_t)(kb_cur / p.cps) * p.slice_floats;
         LAB_STAMP(3)
         // The accumulators are read out of the AGPR file one element at a time, by hand (v_accvgpr_read_b32 with an "a" operand):
         // left to the compiler, the first use of element r of a tile copies the whole 16-register tile to VGPRs, a row touches all
@@ -641,7 +643,11 @@ int64_t spk_conv2d_wino_workspace_bytes(int ksplit, int B, int Cin, int Cout, in
 int spk_conv2d_wino_fwd(const spk_conv2d_desc* d, void* stream) {
     SPK_REQUIRE(d && d->x && d->w_packed, "conv2d winograd: null pointer");
     SPK_REQUIRE(d->kh == 3 && d->kw == 3 && d->stride == 1, "conv2d winograd: 3x3 stride-1 kernels only");
-    SPK_REQUIRE(d->groups <= 1, "conv2d winograd: not grouped");
+    const int G = d->groups > 1 ? d->groups : 1;
+    SPK_REQUIRE(G == 1 || !(d->flags & ~(SPK_CONV_WINOGRAD | SPK_EPI_ACCUM)), "conv2d winograd: a grouped launch takes SPK_EPI_ACCUM only (the encoders' "
+                "data gradients)");
+    const int gin = G > 1 ? d->group_in_stride : d->Cin, Cx = gin * (G - 1) + d->Cin, Cy = G * d->Cout;
+    SPK_REQUIRE(G == 1 || gin >= d->Cin, "conv2d winograd: groups read disjoint channels");
     const unsigned epi = SPK_EPI_BIAS | SPK_EPI_NOISE | SPK_EPI_LRELU | SPK_EPI_STYLE | SPK_EPI_ACCUM;
     const unsigned allowed = SPK_CONV_WINOGRAD | epi | SPK_CONV_IN_BATCH_SCALE | SPK_EPI_TORGB;
     SPK_REQUIRE(!(d->flags & ~allowed) && !d->stats && !d->accum_half,
@@ -655,8 +661,8 @@ int spk_conv2d_wino_fwd(const spk_conv2d_desc* d, void* stream) {
     SPK_REQUIRE(!mod || d->in_scale, "conv2d winograd: IN_BATCH_SCALE without in_scale[B,Cin]");
     SPK_REQUIRE(!d->out_scale_bc || mod, "conv2d winograd: out_scale_bc (demodulation) goes with SPK_CONV_IN_BATCH_SCALE");
     SPK_REQUIRE(d->H == d->Hin && d->W == d->Win, "conv2d winograd: output size must equal the input size");
-    SPK_REQUIRE(spk_conv2d_wino_supported(d->B, d->Cin, d->Cout, d->H, d->W), "conv2d winograd: %dx%d is not a whole number of 32 x 8 or 16 x 16 "
-                "regions (or the input exceeds 2 GB)", d->H, d->W);
+    SPK_REQUIRE(spk_conv2d_wino_supported(d->B, d->Cin, d->Cout, d->H, d->W) && (long long)d->B * Cx * d->H * d->W * 4 < (1ll << 31),
+                "conv2d winograd: %dx%d is not a whole number of 32 x 8 or 16 x 16 regions (or the input exceeds 2 GB)", d->H, d->W);
     SPK_REQUIRE(!(d->flags & SPK_EPI_BIAS) || d->bias, "conv2d winograd: SPK_EPI_BIAS without bias");
     SPK_REQUIRE(!(d->flags & SPK_EPI_NOISE) || (d->noise && d->noise_w), "conv2d winograd: SPK_EPI_NOISE without noise");
     SPK_REQUIRE(!(d->flags & SPK_EPI_STYLE) || d->style, "conv2d winograd: SPK_EPI_STYLE without style");
@@ -664,8 +670,8 @@ int spk_conv2d_wino_fwd(const spk_conv2d_desc* d, void* stream) {
     SPK_REQUIRE(aligned16(d->w_packed) && aligned16(d->y) && aligned16(d->y_pre) && aligned16(d->noise) && (reinterpret_cast<uintptr_t>(d->x) & 3) == 0,
                 "conv2d winograd: tensors must be 16-byte aligned");
     const int shape = wino_shape(d->H, d->W);
-    const int ks = spk_conv2d_wino_ksplit(d->ksplit, d->B, d->Cin, d->Cout, d->H, d->W);
-    const size_t out_floats = (size_t)d->B * d->Cout * d->H * d->W;
+    const int ks = spk_conv2d_wino_ksplit(d->ksplit, d->B, d->Cin, Cy, d->H, d->W);       // (the groups' channel tiles count towards the grid)
+    const size_t out_floats = (size_t)d->B * Cy * d->H * d->W;
     if (ks > 1)
         SPK_REQUIRE(d->workspace && aligned16(d->workspace) && d->workspace_bytes >= (int64_t)ks * (int64_t)out_floats * 4,
                     "conv2d winograd: %d contraction slices need a workspace of %lld bytes (spk_conv2d_wino_workspace_bytes)", ks,
@@ -676,11 +682,12 @@ int spk_conv2d_wino_fwd(const spk_conv2d_desc* d, void* stream) {
     a.in_scale = mod ? d->in_scale : nullptr; a.out_scale_bc = d->out_scale_bc;
     a.rgb_w = d->rgb_w; a.rgb_bias = d->rgb_bias; a.rgb_y = d->rgb_y;
     a.B = d->B; a.Cin = d->Cin; a.Cout = d->Cout; a.H = d->H; a.W = d->W;
+    a.G = G; a.gin = gin; a.Cx = Cx; a.Cy = Cy; a.co_tiles_g = spk::ceil_div(d->Cout, CO_T);
     a.regions_x = d->W / region_w(shape); a.regions_y = d->H / region_h(shape);
     a.n_chunks = spk::ceil_div(d->Cin, CI_T);
     a.ksplit = ks; a.cps = a.n_chunks / ks; a.slice_floats = 0;
     a.style_stride = d->style_stride; a.flags = d->flags;
-    a.x_bytes = (unsigned)((long long)d->B * d->Cin * d->H * d->W * 4);
+    a.x_bytes = (unsigned)((long long)d->B * Cx * d->H * d->W * 4);
     a.slope = d->lrelu_slope; a.out_scale = d->out_scale; a.act_gain = d->act_gain != 0.f ? d->act_gain : 1.f;
     SPK_REQUIRE(!rgb || ks == 1, "conv2d winograd: SPK_EPI_TORGB with a sliced contraction (%d slices): pass ksplit = 1 or run the 1x1 separately", ks);
     if (ks > 1) {       // partial sums, raw: the whole epilogue (and the demodulation) belongs to the finisher
@@ -700,7 +707,7 @@ int spk_conv2d_wino_fwd(const spk_conv2d_desc* d, void* stream) {
     const long long n_items = (long long)a.regions_x * a.regions_y * d->B * ks;
     SPK_REQUIRE(n_items < (1ll << 31), "conv2d winograd: grid too large");
     // persistent: one workgroup per CU over all channel tiles, a multiple of 8 per channel tile (the XCD shares), at most one per item
-    const int co_tiles = spk::ceil_div(d->Cout, CO_T);
+    const int co_tiles = G * spk::ceil_div(d->Cout, CO_T);
     static int n_cu = 0;
     if (n_cu == 0) {
         int dev = 0;
@@ -719,7 +726,7 @@ int spk_conv2d_wino_fwd(const spk_conv2d_desc* d, void* stream) {
     if (rc != SPK_OK || ks == 1) return rc;
     spkconv::ConvArgs f = {};
     f.bias = d->bias; f.noise_w = d->noise_w; f.noise = d->noise; f.style = d->style; f.out_scale_bc = d->out_scale_bc;
-    f.y = d->y; f.y_pre = d->y_pre; f.B = d->B; f.Cin = d->Cin; f.Cout = d->Cout; f.Cy = d->Cout; f.Cx = d->Cin; f.G = 1; f.H = d->H; f.W = d->W;
+    f.y = d->y; f.y_pre = d->y_pre; f.B = d->B; f.Cin = d->Cin; f.Cout = d->Cout; f.Cy = Cy; f.Cx = Cx; f.G = G; f.H = d->H; f.W = d->W;
     f.style_stride = d->style_stride; f.flags = d->flags & epi; f.slope = d->lrelu_slope; f.out_scale = d->out_scale;
     f.act_gain = a.act_gain; f.out_scale_dev = d->out_scale_dev;
     return spkconv::launch_splitk_epilogue(f, static_cast<const float*>(d->workspace), ks, (hipStream_t)stream);

@@ -134,6 +134,10 @@ class _ConvBN:
                                                                             in_affine=rec["in_affine"]))
         if not need_dx:
             return None
+        if (self.k == 3 and self.stride == 1 and half is None and ops.use_wino(B, Cout, Cin, H, W)
+                and dr.data_ptr() % 16 == 0 and (dx_out is None or dx_out.data_ptr() % 16 == 0)):
+            # fp32 Winograd F(2x2, 3x3) data gradient (ops.CONV3X3_ALGO)
+            return ops.conv3x3_wino(dr.contiguous(), self.packed.get_wino(conv.weight, transpose_flip=True), Cin, out=dx_out, accumulate=accumulate)
         cfg, tf = ops.dgrad_plan(self.k, self.stride, B, Cout, Cin, (H, W), dr.shape[-2:], dx_out, accumulate)
         if half is not None and (cfg not in ops.GEMM2_CONFIGS or W % 4):
             dx_out, accumulate, half = ops.dilate2x(half, H, W), True, None     # the form that cannot add it in its epilogue
@@ -180,6 +184,20 @@ class _GroupPacked:
         # one launch into the previous image's storage (same key = same size): no per-tensor packs, no concatenation
         packed = ops.pack_conv_weights_list([w.detach() for w in weights], config, transpose_flip,
                                             out=hit[1] if hit is not None else None)
+        self._cache[key] = (stamp, packed)
+        return packed
+
+    def get_wino(self, weights, transpose_flip=False):
+        """The groups' Winograd images U = G g G^T one after another (one list-pack launch), cached the same way."""
+        key = ("wino", bool(transpose_flip))
+        stamp = tuple((w.data_ptr(), w._version) for w in weights)
+        hit = self._cache.get(key)
+        if hit is not None and hit[0] == stamp:
+            return hit[1]
+        Cout, Cin = weights[0].shape[:2]
+        n = (ops.L.lib().spk_conv2d_packed_bytes_wino(Cout, Cin) if transpose_flip else ops.L.lib().spk_conv2d_packed_bytes_wino(Cin, Cout)) // 4
+        packed = hit[1] if hit is not None else torch.empty(len(weights) * n, device=weights[0].device, dtype=torch.float32)
+        ops.pack_conv_weights_wino_into([w.detach() for w in weights], [packed[i * n:(i + 1) * n] for i in range(len(weights))], transpose_flip)
         self._cache[key] = (stamp, packed)
         return packed
 
@@ -284,6 +302,11 @@ class _GroupedConvBN:
             grads[self.convs[q].weight] = dw[q]
         if not need_dx:
             return None
+        if (self.k == 3 and self.stride == 1 and half is None and not self.shared_input and ops.use_wino(B, Cout, Cin, H, W, groups=G)
+                and dr.data_ptr() % 16 == 0 and (dx_out is None or dx_out.data_ptr() % 16 == 0)):
+            # fp32 Winograd F(2x2, 3x3) data gradient, the G trunks as groups of one launch (ops.CONV3X3_ALGO)
+            return ops.conv3x3_wino(dr.contiguous(), self.packed.get_wino(self._weights(), transpose_flip=True), Cin, groups=G,
+                                    out=dx_out, accumulate=accumulate)
         cfg, tf = ops.dgrad_plan(self.k, self.stride, B, Cout, Cin, (H, W), dr.shape[-2:], dx_out, accumulate)
         if half is not None and (cfg not in ops.GEMM2_CONFIGS or W % 4):
             dx_out, accumulate, half = ops.dilate2x(half, H, W), True, None     # the form that cannot add it in its epilogue

@@ -389,13 +389,15 @@ def conv3x3_algo(algo: str):
         CONV3X3_ALGO = prev
 
 
-def use_wino(B, Cin, Cout, H, W) -> bool:
+def use_wino(B, Cin, Cout, H, W, groups=1) -> bool:
     """Whether a 3x3 stride-1 conv with this OUTPUT shape (plain input) goes to the Winograd kernel under ``CONV3X3_ALGO``: the
-    kernel serves the shape and -- with the contraction split into the slices ``wino_ksplit`` picks -- fills the chip."""
+    kernel serves the shape and -- with the contraction split into the slices ``wino_ksplit`` picks -- fills the chip.
+    ``groups``: Cin / Cout per group (the launch has groups x the channel tiles)."""
     if CONV3X3_ALGO != "auto" or not wino_supported(B, Cin, Cout, H, W):
         return False
     rw, rh = (32, 8) if (W % 32 == 0 and H % 8 == 0) else (16, 16)
-    return B * (H // rh) * (W // rw) * ((Cout + 63) // 64) * wino_ksplit(B, Cin, Cout, H, W) >= WINO_MIN_WORKGROUPS
+    tiles = groups * ((Cout + 63) // 64)
+    return B * (H // rh) * (W // rw) * tiles * wino_ksplit(B, Cin, groups * Cout, H, W) >= WINO_MIN_WORKGROUPS
 
 
 def wino_ksplit(B, Cin, Cout, H, W, want=0) -> int:
@@ -425,6 +427,21 @@ def pack_conv_weight_wino(weight: torch.Tensor, out=None, transpose_flip=False) 
 
 
 WINO_PACK_MAX = 32
+
+
+def pack_conv_weights_wino_into(weights, outs, transpose_flip=False):
+    """Winograd images of several [Cout,Cin,3,3] weights into the given buffers (views of one tensor for a grouped launch): one
+    spk_conv2d_pack_weights_wino_list launch per 32."""
+    for i in range(0, len(weights), WINO_PACK_MAX):
+        ws, os_ = weights[i:i + WINO_PACK_MAX], outs[i:i + WINO_PACK_MAX]
+        n = len(ws)
+        keep = [w.contiguous() for w in ws]
+        L.check(L.lib().spk_conv2d_pack_weights_wino_list((C.c_void_p * n)(*[L.dptr(w, "weight") for w in keep]),
+                                                          (C.c_void_p * n)(*[o.data_ptr() for o in os_]),
+                                                          (C.c_int * n)(*[w.shape[1] for w in ws]), (C.c_int * n)(*[w.shape[0] for w in ws]),
+                                                          (C.c_int * n)(*[1 if transpose_flip else 0] * n), n, L.stream_ptr()),
+                "spk_conv2d_pack_weights_wino_list")
+
 
 
 def prepack_wino(items):
@@ -465,12 +482,20 @@ def upsample2x(x, zero_border=False):
 
 def conv3x3_wino(x, w_packed, Cout, *, bias=None, noise_w=None, noise=None, style=None, style_stride=None, lrelu_slope=None,
                  out_scale=1.0, act_gain=1.0, out=None, out_pre=None, accumulate=False, out_scale_dev=None, batch_scale=None, demod=None,
-                 ksplit=0, rgb=None, rgb_out=None, store_out=True):
+                 ksplit=0, rgb=None, rgb_out=None, store_out=True, groups=1):
     """3x3 stride-1 pad-1 conv with the fused decoder epilogue as Winograd F(2x2, 3x3): fp32 throughout, 2.25x fewer matrix
     instructions than the direct form, 1e-6-class rel-L2 against it.  ``w_packed`` from ``pack_conv_weight_wino``.
     ``rgb`` = (weight [3,Cout,1,1], bias [3] | None): the 1x1 conv of styleganv1.py:607 inside the epilogue (Cout <= 64, unsliced);
-    returns (out, rgb image), and with ``store_out=False`` (None, rgb image) -- the activation is then never written."""
-    B, Cin, H, W = x.shape
+    returns (out, rgb image), and with ``store_out=False`` (None, rgb image) -- the activation is then never written.
+    ``groups`` > 1: that many independent convs in one launch (``Cout`` per group, x carries the groups' input channels side by side,
+    ``w_packed`` = the groups' images one after another); plain or ``accumulate`` only -- the encoders' data gradients."""
+    B, Cx, H, W = x.shape
+    G = int(groups)
+    if Cx % G:
+        raise L.SpkError(f"conv3x3_wino: {Cx} input channels do not split into {G} groups")
+    Cin = Cx // G
+    if G > 1 and any(t is not None for t in (bias, noise, style, out_pre, batch_scale, demod, rgb, lrelu_slope)):
+        raise L.SpkError("conv3x3_wino: a grouped launch is plain (accumulate allowed)")
     if rgb is not None:
         if Cout > 64 or out_pre is not None or accumulate or batch_scale is not None or tuple(rgb[0].shape[:2]) != (3, Cout):
             raise L.SpkError("conv3x3_wino: a fused toRGB needs Cout <= 64, weight [3,Cout,1,1], no out_pre / accumulate / modulation")
@@ -478,7 +503,7 @@ def conv3x3_wino(x, w_packed, Cout, *, bias=None, noise_w=None, noise=None, styl
             rgb_out = torch.empty((B, 3, H, W), device=x.device, dtype=torch.float32)
         ksplit = 1
     if out is None and (rgb is None or store_out):
-        out = torch.empty((B, Cout, H, W), device=x.device, dtype=torch.float32)
+        out = torch.empty((B, G * Cout, H, W), device=x.device, dtype=torch.float32)
     if noise is not None and (noise_w is None or noise.numel() != B * H * W):
         raise L.SpkError(f"conv3x3_wino: noise must be [B,1,H,W]={B, 1, H, W}, got {tuple(noise.shape)}")
     if style is not None and style_stride is None:
@@ -497,12 +522,12 @@ def conv3x3_wino(x, w_packed, Cout, *, bias=None, noise_w=None, noise=None, styl
                      y=L.dptr(out, "out"), y_pre=L.dptr(out_pre, "out_pre"), B=B, Cin=Cin, Cout=Cout, H=H, W=W, Hin=H, Win=W,
                      kh=3, kw=3, stride=1, style_stride=int(style_stride or 0), flags=flags,
                      lrelu_slope=float(lrelu_slope if lrelu_slope is not None else 1.0), out_scale=float(out_scale), config=-1,
-                     ksplit=int(ksplit), workspace=None, workspace_bytes=0, groups=1, group_in_stride=0, stats_slots=0,
+                     ksplit=int(ksplit), workspace=None, workspace_bytes=0, groups=G, group_in_stride=Cin if G > 1 else 0, stats_slots=0,
                      accum_half=None, out_scale_dev=L.dptr(out_scale_dev, "out_scale_dev"),
                      rgb_w=L.dptr(rgb[0].reshape(3, Cout), "rgb weight") if rgb is not None else None,
                      rgb_bias=L.dptr(rgb[1], "rgb bias") if rgb is not None and rgb[1] is not None else None,
                      rgb_y=L.dptr(rgb_out, "rgb_out") if rgb is not None else None, rgb_channels=3 if rgb is not None else 0)
-    ws_bytes = L.lib().spk_conv2d_wino_workspace_bytes(int(ksplit), B, Cin, Cout, H, W)
+    ws_bytes = L.lib().spk_conv2d_wino_workspace_bytes(int(ksplit), B, Cin, G * Cout, H, W)
     if ws_bytes > 0:                        # few regions: the contraction runs in slices, partial sums through the split-K workspace
         ws = _workspace(x.device, ws_bytes)
         d.workspace, d.workspace_bytes = ws.data_ptr(), ws.numel() * 4

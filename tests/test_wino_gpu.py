@@ -379,3 +379,25 @@ def test_wino_list_pack_equals_single_packs_bit_for_bit(ops):
     ws[1].mul_(2.0)
     ops.prepack_wino(items)
     assert pks[1]._cache[("wino", True)][1] is not before[1] and torch.equal(pks[1].get_wino(ws[1]), ops.pack_conv_weight_wino(ws[1]))
+
+
+@pytest.mark.parametrize("B,G,Cin,Cout,H,W,acc", [(2, 6, 64, 64, 16, 32, False), (1, 3, 128, 64, 16, 16, True), (2, 2, 64, 200, 8, 32, False)])
+def test_wino_grouped_launch_equals_per_group_convs(ops, B, G, Cin, Cout, H, W, acc):
+    """The encoders' 3x3 data gradients (model.py:60-62, :84-90: the G passes as groups of one launch): every group against its own fp64
+    convolution, with accumulate, whatever slicing the launch picks."""
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(B + G + Cin + Cout)
+    x = torch.randn(B, G * Cin, H, W, generator=g).to(dev)
+    ws = [(torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)).to(dev) for _ in range(G)]
+    n = ops.L.lib().spk_conv2d_packed_bytes_wino(Cin, Cout) // 4
+    wp = torch.empty(G * n, device=dev)
+    ops.pack_conv_weights_wino_into(ws, [wp[i * n:(i + 1) * n] for i in range(G)])
+    base = torch.randn(B, G * Cout, H, W, generator=g).to(dev)
+    y = ops.conv3x3_wino(x, wp, Cout, groups=G, out=base.clone() if acc else None, accumulate=acc)
+    ref = torch.cat([F.conv2d(x[:, q * Cin:(q + 1) * Cin].double(), ws[q].double(), padding=1) for q in range(G)], 1)
+    if acc:
+        ref = ref + base.double()
+    assert rel_l2(y, ref) < TOL, rel_l2(y, ref)
+    L = importlib.import_module("speak-hack_amd")._lib
+    with pytest.raises(L.SpkError):
+        ops.conv3x3_wino(x, wp, Cout, groups=G, lrelu_slope=0.2)
