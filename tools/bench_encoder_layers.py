@@ -67,6 +67,12 @@ def main():
         t_w = timeit(lambda: ops.conv2d_wgrad(g, x, Cout, Cin, k, s, in_affine=aff, groups=G, shared_input=first))
         if first:
             t_d = 0.0
+        elif k == 3 and s == 1 and ops.use_wino(B, Cout, Cin, H, H, groups=G):
+            # as encoder._GroupedConvBN.conv_bwd runs it: the G trunks as groups of one fp32 Winograd launch
+            nw = ops.L.lib().spk_conv2d_packed_bytes_wino(Cout, Cin) // 4
+            wtw = torch.empty(G * nw, device=dev)
+            ops.pack_conv_weights_wino_into(ws, [wtw[i * nw:(i + 1) * nw] for i in range(G)], transpose_flip=True)
+            t_d = timeit(lambda: ops.conv3x3_wino(g, wtw, Cin, groups=G))
         else:
             cfd, tf = ops.dgrad_plan(k, s, B, Cout, Cin, (H, H), (Ho, Ho))
             wt = torch.cat([ops.pack_conv_weight(w, cfd, tf) for w in ws])
