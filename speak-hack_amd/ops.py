@@ -460,7 +460,8 @@ def prepack_wino(items):
     for i in range(0, len(todo), WINO_PACK_MAX):
         part = todo[i:i + WINO_PACK_MAX]
         n = len(part)
-        ws = (C.c_void_p * n)(*[L.dptr(t[3].detach().contiguous(), "weight") for t in part])
+        keep = [t[3].detach().contiguous() for t in part]          # (alive until the launch is queued)
+        ws = (C.c_void_p * n)(*[L.dptr(w_, "weight") for w_ in keep])
         outs = (C.c_void_p * n)(*[t[5].data_ptr() for t in part])
         cin = (C.c_int * n)(*[t[3].shape[1] for t in part])
         cout = (C.c_int * n)(*[t[3].shape[0] for t in part])
