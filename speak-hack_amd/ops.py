@@ -503,6 +503,7 @@ def conv3x3_wino(x, w_packed, Cout, *, bias=None, noise_w=None, noise=None, styl
         if rgb_out is None:
             rgb_out = torch.empty((B, 3, H, W), device=x.device, dtype=torch.float32)
         ksplit = 1
+        rgb_w2d = rgb[0].detach().reshape(3, Cout).contiguous()      # (a local: alive until the launch is queued)
     if out is None and (rgb is None or store_out):
         out = torch.empty((B, G * Cout, H, W), device=x.device, dtype=torch.float32)
     if noise is not None and (noise_w is None or noise.numel() != B * H * W):
@@ -525,7 +526,7 @@ def conv3x3_wino(x, w_packed, Cout, *, bias=None, noise_w=None, noise=None, styl
                      lrelu_slope=float(lrelu_slope if lrelu_slope is not None else 1.0), out_scale=float(out_scale), config=-1,
                      ksplit=int(ksplit), workspace=None, workspace_bytes=0, groups=G, group_in_stride=Cin if G > 1 else 0, stats_slots=0,
                      accum_half=None, out_scale_dev=L.dptr(out_scale_dev, "out_scale_dev"),
-                     rgb_w=L.dptr(rgb[0].reshape(3, Cout), "rgb weight") if rgb is not None else None,
+                     rgb_w=L.dptr(rgb_w2d, "rgb weight") if rgb is not None else None,
                      rgb_bias=L.dptr(rgb[1], "rgb bias") if rgb is not None and rgb[1] is not None else None,
                      rgb_y=L.dptr(rgb_out, "rgb_out") if rgb is not None else None, rgb_channels=3 if rgb is not None else 0)
     ws_bytes = L.lib().spk_conv2d_wino_workspace_bytes(int(ksplit), B, Cin, G * Cout, H, W)
