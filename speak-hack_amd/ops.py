@@ -340,7 +340,8 @@ def train_conv_precision(precision: str):
 
 def train_bf16x3(B, Cin, Cout, H, W) -> bool:
     """Whether a 3x3 stride-1 conv with this OUTPUT shape takes the split-precision kernel under the training switch."""
-    return (TRAIN_CONV_PRECISION == "bf16x3" and B * H * W >= TRAIN_BF16X3_MIN_PIXELS and bf16x3_supported(B, Cin, Cout, H, W))
+    return (TRAIN_CONV_PRECISION == "bf16x3" and B * H * W >= TRAIN_BF16X3_MIN_PIXELS and bf16x3_supported(B, Cin, Cout, H, W)
+            and not (H * W <= 256 and use_wino(B, Cin, Cout, H, W)))      # (a <= 16^2 layer: the sliced fp32 Winograd launch is faster, and exact)
 
 
 def conv3x3_bf16x3(x, w_packed, Cout, *, bias=None, noise_w=None, noise=None, style=None, upsample=False, up_fir=False,

@@ -73,7 +73,9 @@ class LaunchPlan:
         ``precision`` "bf16x3": the opt-in split-precision kernel (include/spk.h SPK_CONV_BF16X3) where it serves the shape."""
         B, Cin, Hs, Ws = x.shape
         H, W = (2 * Hs, 2 * Ws) if upsample else (Hs, Ws)
-        if precision == "bf16x3" and B * H * W >= self.BF16X3_MIN_PIXELS and ops.bf16x3_supported(B, Cin, Cout, H, W):
+        # (bf16x3 where it is the FASTER form: a <= 16^2 layer runs quicker -- and exactly -- on the sliced fp32 Winograd kernel)
+        if (precision == "bf16x3" and B * H * W >= self.BF16X3_MIN_PIXELS and ops.bf16x3_supported(B, Cin, Cout, H, W)
+                and not (H * W <= 256 and ops.use_wino(B, Cin, Cout, H, W))):
             packed = torch.empty(L.lib().spk_conv2d_packed_bytes_bf16x3(Cin, Cout), device=self.device, dtype=torch.uint8)
             self.keep.append(packed)
             self._refreshers.append(lambda w=weight, p=packed: ops.pack_conv_weight_bf16x3(w.detach(), out=p))
@@ -292,8 +294,11 @@ class DecoderPlan(LaunchPlan):
                 y = pp[1 - cur][:B * Cout * H * H].view(B, Cout, H, H)
                 k = 1 + 2 * i + half
                 self.track(conv.bias, nmod.weight)
+                # the LAST conv (64 channels at full resolution): fp32 Winograd with toRGB in its epilogue beats the bf16x3 kernel + a toRGB pass
+                last_conv = i == len(s.layers) - 1 and half == 1 and FUSE_TORGB and Cout <= 64 and s.to_rgb.weight.shape[0] == 3 and \
+                    ops.use_wino(B, x.shape[1], Cout, H, H) and ops.wino_ksplit(B, x.shape[1], Cout, H, H) == 1
                 d = self.conv(x, conv.weight, Cout, bias=conv.bias, noise_w=nmod.weight, noise=self.noise_views[k],
-                              style=self.styles[k], upsample=up, slope=LRELU, out=y, precision=precision)
+                              style=self.styles[k], upsample=up, slope=LRELU, out=y, precision="f32" if last_conv else precision)
                 self.noise_ops.append(d)
                 x, cur = y, 1 - cur
         # ---- toRGB (styleganv1.py:607) ----

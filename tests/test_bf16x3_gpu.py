@@ -85,7 +85,9 @@ def test_decoder_end_to_end_within_the_north_star_bound(pkg, dev, golden):
     finally:
         g.synthesis.precision = "f32"
     print(f"bf16x3 decoder: rel-L2 {e1:.2e} vs the reference golden (B=1), {e8:.2e} vs the oracle (B=8); {n_fast} of 12 convs on the bf16 pipe")
-    assert n_fast >= 10                           # every layer from 16^2 up at B = 8
+    # the layers on which the split-precision kernel is the FASTER form: 32^2 and up, except the last conv (fp32 Winograd with toRGB in
+    # its epilogue beats bf16x3 + a toRGB pass); the 16^2 layers run quicker -- and exactly -- as sliced fp32 Winograd launches
+    assert n_fast >= 7
     assert e1 < 2e-4 and e8 < 2e-4, (e1, e8)
     with torch.no_grad():                         # the default path is untouched: exact fp32
         y_f32 = g(feats.to(dev), [n.to(dev) for n in noises])
